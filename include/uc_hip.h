@@ -1,0 +1,205 @@
+/*
+ * uc_hip.h — C ABI of libuc_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * UniCeption DUSt3R two-view pointmap hot path.
+ *
+ * Boundary rules:
+ *   - extern "C", plain pointers + explicit sizes/strides, no torch types.
+ *   - every entry point is asynchronous on the hipStream_t it is given, allocates
+ *     nothing, keeps no mutable global state (except the thread-local last-error text)
+ *     and returns 0 on success or a negative uc_status.
+ *   - all pointers are DEVICE pointers unless the name says "host".
+ *
+ * Each entry point cites the reference interface (file:line under the UniCeption tree)
+ * whose arithmetic it implements.
+ */
+#ifndef UC_HIP_H
+#define UC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* uc_stream_t; /* hipStream_t */
+
+enum uc_dtype { UC_F32 = 0, UC_BF16 = 1, UC_F16 = 2 };
+
+enum uc_status {
+    UC_OK = 0,
+    UC_ERR_BAD_ARG = -1,      /* rank / shape / stride / dtype the kernel does not support */
+    UC_ERR_UNSUPPORTED = -2,  /* valid request, not implemented for this dtype/shape        */
+    UC_ERR_LAUNCH = -3        /* hipGetLastError() != hipSuccess after the launch           */
+};
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* uc_last_error(void);
+/* ABI version; bumped when a signature changes. */
+int uc_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * RoPE-2D, in place — drop-in for the reference's only native entry point
+ *   curope.rope_2d(tokens[B,N,H,D], positions[B,N,2] int64, base, fwd)
+ *   (uniception/models/libs/croco/curope/curope.cpp:49-69, kernels.cu:17-108).
+ * tokens is addressed as tokens[b*sb + n*sn + h*sh + d] (element strides, d contiguous)
+ * so q/k views of a fused qkv buffer can be rotated in place.  fwd=+F0 rotates forward,
+ * fwd=-F0 applies the inverse rotation (the gradient path, curope2d.py:24-28).
+ * dtype: UC_F32 | UC_BF16 | UC_F16 (the reference has no bf16 dispatch).
+ * ---------------------------------------------------------------------------------- */
+int uc_rope2d(void* tokens, const int64_t* positions, int B, int N, int H, int D,
+              int64_t sb, int64_t sn, int64_t sh, float base, float fwd, int dtype,
+              uc_stream_t stream);
+
+/* cos/sin table used by the fused GEMM epilogue: table[p][i] = (cos, sin)(p * F0 * base^(-i/Q)),
+ * p in [0,npos), i in [0,Q), fp32 pairs.  Same angle formula as uc_rope2d. */
+int uc_rope_table(float* table, int npos, int Q, float base, float F0, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the last dim: y = (x-mean)/sqrt(var_biased+eps)*gamma+beta
+ *   (nn.LayerNorm(eps=1e-6): encoders/croco.py:32, info_sharing/cross_attention_transformer.py:42).
+ * x: [rows, C] (x_dtype f32|bf16), gamma/beta fp32 [C], y: [rows, C] (y_dtype f32|bf16).
+ * ---------------------------------------------------------------------------------- */
+int uc_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                 int y_dtype, int64_t rows, int C, float eps, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM family: C[M,N] = epilogue( A_op[M,K] . W[N,K]^T )
+ * One descriptor serves nn.Linear (blocks.py:80-129, transformer_blocks.py:219-256,345-386),
+ * the k=s patch-embed conv after im2col (patch_embed.py:47), 1x1 convs and — with
+ * a_mode=UC_A_CONV3X3 — the DPT 3x3 convolutions as implicit GEMMs over an NHWC input
+ * (dpt_block.py:21-80,156-177; dpt.py:107-178,271-277).
+ * ---------------------------------------------------------------------------------- */
+enum uc_a_mode { UC_A_DENSE = 0, UC_A_CONV3X3 = 1 };
+enum uc_act { UC_ACT_NONE = 0, UC_ACT_GELU_ERF = 1, UC_ACT_RELU = 2 };
+
+typedef struct uc_gemm_desc {
+    int compute_dtype;   /* UC_F32: A,W fp32, exact-fp32 FMA chain; UC_BF16: A,W bf16, MFMA, fp32 accumulate */
+    int a_mode;          /* uc_a_mode */
+    int relu_a;          /* apply ReLU to A elements while loading (DPT ResidualConvUnit pre-activation) */
+    const void* A;       /* dense: [M,K] row-major, leading dim lda.  conv: NHWC [B,H,W,Cin] */
+    int64_t lda;
+    const void* W;       /* [N,K] row-major (nn.Linear weight layout); conv: [N, 9*Cin] ordered (ky,kx,c) */
+    int64_t M, N, K;
+    /* conv3x3 (pad 1) geometry: M = B*Ho*Wo, K = 9*Cin */
+    int conv_B, conv_H, conv_W, conv_Cin, conv_stride, conv_Ho, conv_Wo;
+    /* epilogue */
+    const float* bias;   /* [N] fp32 or NULL */
+    int act;             /* uc_act, applied after bias */
+    const void* residual; /* [M,N] (ld = ldr) added after act, or NULL */
+    int res_dtype;
+    int64_t ldr;
+    /* fused RoPE-2D on output columns [0, rope_cols): columns are (head, d) with head_dim 64;
+       rows are tokens with positions rope_pos[m] = (y,x).  rope_table from uc_rope_table. */
+    int64_t rope_cols;
+    const int64_t* rope_pos;   /* [M,2] int64 */
+    const float* rope_table;   /* [npos][16][2] fp32 */
+    int rope_npos;
+    /* "VT" epilogue (bf16 path): output columns [vt_col0, N) are V channels (head-major, head_dim 64);
+       instead of C they are written transposed+permuted to vt_out [B,H,64,vt_npad] (see uc_attention_fwd).
+       Rows are tokens, vt_ntok per batch element (M = B*vt_ntok).  vt_col0 < 0 disables. */
+    int64_t vt_col0;
+    void* vt_out;
+    int vt_ntok, vt_npad;
+    void* C;             /* [M,N] row-major, leading dim ldc (only columns < vt_col0 are written when vt is on) */
+    int out_dtype;       /* UC_F32 | UC_BF16 */
+    int64_t ldc;
+} uc_gemm_desc;
+
+int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Scaled-dot-product attention, no mask, no dropout:  O = softmax(Q K^T * scale) V
+ *   (F.scaled_dot_product_attention call sites: libs/croco/blocks.py:123-125,
+ *    utils/transformer_blocks.py:244-246, 373-375).
+ * Element addressing (d contiguous):  Q[b*q_sb + n*q_sn + h*q_sh + d], same for K and O, so
+ * self-attention can pass views of a fused qkv buffer and cross-attention Nk != Nq.
+ *
+ * V comes in one of two layouts:
+ *   v_layout = UC_V_ROWMAJOR : V[b*v_sb + n*v_sn + h*v_sh + d]                    (UC_F32 path)
+ *   v_layout = UC_V_PACKED_T : "VT" — V transposed per head with the key index permuted inside
+ *       every group of 16 keys so that each lane's MFMA operand is one 16-byte LDS read:
+ *         VT[((b*H + h)*D + d) * Npad + 16*(n/16) + uc_vt_perm(n%16)],  Npad = roundup(Nk,64)
+ *         uc_vt_perm(w) = ((w>>2)&1)*8 + (w&3) + 4*(w>>3)
+ *       (required by the UC_BF16 MFMA path; produced by uc_gemm's vt epilogue or uc_vt_pack;
+ *        v_sb/v_sn/v_sh are ignored).
+ * UC_BF16 requires D == 64; UC_F32 supports D <= 64.
+ * ---------------------------------------------------------------------------------- */
+enum uc_v_layout { UC_V_ROWMAJOR = 0, UC_V_PACKED_T = 1 };
+
+int uc_attention_fwd(const void* Q, const void* K, const void* V, void* O, int dtype, int v_layout,
+                     int B, int H, int Nq, int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                     int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
+                     int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,
+                     uc_stream_t stream);
+
+/* Row-major bf16 V[b*v_sb + n*v_sn + h*v_sh + d] -> packed VT [B,H,D,Npad] (layout above). */
+int uc_vt_pack(const void* V, void* VT, int B, int H, int Nk, int D, int64_t v_sb, int64_t v_sn,
+               int64_t v_sh, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Patch gather for the k=s=P patch-embed conv (libs/croco/patch_embed.py:47,69-82):
+ * img fp32 NCHW [B,Cin,H,W] -> cols[B*(H/P)*(W/P), Cin*P*P] (out_dtype), column order
+ * (c,u,v) == Conv2d weight.view(D,-1) order, token order row-major (i,j).
+ * ---------------------------------------------------------------------------------- */
+int uc_patch_gather(const float* img, void* cols, int out_dtype, int B, int Cin, int H, int W,
+                    int P, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Layout/dtype conversion at the public BCHW boundary.
+ *   uc_nchw_to_nhwc: src [B,C,H,W] (src_dtype) -> dst [B,H,W,C] (dst_dtype)
+ *   uc_nhwc_to_nchw: src [B,H,W,C] -> dst [B,C,H,W]
+ * (reference hops: encoders/croco.py:177-180, info_sharing/cross_attention_transformer.py:428-431,497-503)
+ * ---------------------------------------------------------------------------------- */
+int uc_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C,
+                    int H, int W, uc_stream_t stream);
+int uc_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C,
+                    int H, int W, uc_stream_t stream);
+/* contiguous element-wise dtype conversion (n elements) */
+int uc_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
+               uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=True, NHWC (dpt_block.py:251-253 scale_factor=2; dpt.py:304 size=(H,W)).
+ * src [B,Hi,Wi,C] -> dst [B,Ho,Wo,C]; same dtype.  Optionally only the top-left (crop_h,crop_w)
+ * window of the resized image is produced (dpt.py:213: refinenet4 output cropped to level-2 size):
+ * dst is then [B,crop_h,crop_w,C].  Pass crop_h=Ho, crop_w=Wo for no crop.
+ * ---------------------------------------------------------------------------------- */
+int uc_bilinear_nhwc(const void* src, void* dst, int dtype, int B, int Hi, int Wi, int C, int Ho,
+                     int Wo, int crop_h, int crop_w, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pixel scatter after a GEMM with N = k*k*Cout columns ordered (u,v,o):
+ *   ConvTranspose2d(k=s, p=0) (dpt.py:116-140):  dst NHWC [B, k*h, k*w, Cout],
+ *   dst[b, k*i+u, k*j+v, o] = src[(b*h+i)*w+j, (u*k+v)*Cout + o]   (bias already added by the GEMM).
+ * ---------------------------------------------------------------------------------- */
+int uc_convt_scatter(const void* src, void* dst, int dtype, int B, int h, int w, int k, int Cout,
+                     uc_stream_t stream);
+
+/* F.pixel_shuffle(P) of the linear head (linear.py:81-82): src [B*h*w, Cout*P*P] row-major
+ * (column = c*P*P + u*P + v) -> dst fp32 NCHW [B,Cout,P*h,P*w]. */
+int uc_pixel_shuffle(const void* src, int src_dtype, float* dst, int B, int h, int w, int P,
+                     int Cout, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * PointMapWithConfidenceAdaptor("exp", "exp"; adaptors.py:337-342, 1080-1083) fused with the
+ * BCHW->BHWC permute of factory/dust3r.py:323-330.
+ *   in : x fp32, element (b,c,y,x) at x[b*x_sb + c*x_sc + (y*W+x)*x_sp]  (NCHW: sc=H*W, sp=1; NHWC: sc=1, sp=4)
+ *   out: pts [B,H,W,3] fp32, conf [B,H,W,1] fp32
+ *   pts = xyz / max(|xyz|,1e-8) * expm1(|xyz|);  conf = conf_vmin + min(exp(c), conf_vmax - conf_vmin)
+ * ---------------------------------------------------------------------------------- */
+int uc_pointmap_adaptor(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp, float* pts,
+                        float* conf, int B, int H, int W, float conf_vmin, float conf_vmax,
+                        uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * DPT regressor tail: ReLU'd features -> Conv1x1(Cin -> 4) + bias -> decoded channels
+ * (dpt.py:271-277 conv2[2]).  feat NHWC [npix, Cin] (dtype), w fp32 [4,Cin], b fp32 [4];
+ * out fp32 NHWC [npix,4].  Cin <= 256, multiple of 8.
+ * ---------------------------------------------------------------------------------- */
+int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const float* b, float* out,
+                   int64_t npix, int Cin, uc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UC_HIP_H */

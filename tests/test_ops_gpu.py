@@ -1,0 +1,377 @@
+"""Kernel-level parity: every C-ABI entry point against a plain fp32 PyTorch-CPU statement of the same op.
+
+fp32 kernels: 1e-5-class agreement.  bf16 MFMA kernels: inputs are rounded to bf16 first, the CPU
+reference runs in fp32 on the SAME rounded inputs, so the tolerance only has to absorb fp32
+accumulation order + the bf16 rounding of the output.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rope_ref(tokens_bnhd, pos, base, fwd):
+    """curope arithmetic (curope.cpp:21-46) in fp32 on [B,N,H,D]."""
+    t = tokens_bnhd.float().clone()
+    B, N, H, D = t.shape
+    Q = D // 4
+    inv = fwd / (base ** (torch.arange(Q, dtype=torch.float32) / Q))
+    for axis in range(2):
+        ang = pos[:, :, axis].float()[:, :, None] * inv[None, None, :]  # B,N,Q
+        c, s = ang.cos()[:, :, None, :], ang.sin()[:, :, None, :]
+        u = t[..., axis * 2 * Q: axis * 2 * Q + Q].clone()
+        v = t[..., axis * 2 * Q + Q: axis * 2 * Q + 2 * Q].clone()
+        t[..., axis * 2 * Q: axis * 2 * Q + Q] = u * c - v * s
+        t[..., axis * 2 * Q + Q: axis * 2 * Q + 2 * Q] = v * c + u * s
+    return t
+
+
+def grid_pos(B, h, w):
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    return torch.stack([ys.reshape(-1), xs.reshape(-1)], -1)[None].expand(B, -1, -1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
+@pytest.mark.parametrize("shape", [(2, 6, 9, 3, 64), (1, 2, 3, 2, 32), (1, 3, 5, 1, 20)])
+def test_rope2d_contiguous(gpu, dtype, tol, shape):
+    from uniception_amd import ops
+    B, h, w, H, D = shape
+    g = torch.Generator().manual_seed(1)
+    tok = torch.randn(B, h * w, H, D, generator=g).to(dtype)
+    pos = grid_pos(B, h, w)
+    ref = rope_ref(tok, pos, 100.0, 1.0)
+    t = tok.to(gpu)
+    ops.rope_2d_(t, pos.to(gpu), 100.0, 1.0)
+    assert rel_l2(t.cpu().float(), ref) < tol
+    # inverse rotation restores the input (the backward path of curope2d.py:24-28)
+    ops.rope_2d_(t, pos.to(gpu), 100.0, -1.0)
+    assert rel_l2(t.cpu().float(), tok.float()) < 2 * tol
+
+
+def test_rope2d_strided_qkv_view(gpu):
+    """q and k views of a fused qkv buffer rotated in place; v untouched (blocks.py:105-114)."""
+    from uniception_amd import ops
+    B, h, w, H, D = 2, 4, 7, 3, 64
+    N = h * w
+    g = torch.Generator().manual_seed(2)
+    qkv = torch.randn(B, N, 3, H, D, generator=g)
+    pos = grid_pos(B, h, w)
+    dev = qkv.to(gpu)
+    q, k = dev[:, :, 0], dev[:, :, 1]
+    ops.rope_2d_(q, pos.to(gpu), 100.0, 1.0)
+    ops.rope_2d_(k, pos.to(gpu), 100.0, 1.0)
+    out = dev.cpu()
+    assert rel_l2(out[:, :, 0], rope_ref(qkv[:, :, 0], pos, 100.0, 1.0)) < 2e-6
+    assert rel_l2(out[:, :, 1], rope_ref(qkv[:, :, 1], pos, 100.0, 1.0)) < 2e-6
+    assert torch.equal(out[:, :, 2], qkv[:, :, 2])
+
+
+def test_rope2d_error_behaviour(gpu):
+    from uniception_amd import ops
+    t = torch.zeros(1, 4, 2, 64, device=gpu)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d_(t[0], torch.zeros(1, 4, 2, dtype=torch.int64, device=gpu), 100.0, 1.0)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d_(t, torch.zeros(1, 5, 2, dtype=torch.int64, device=gpu), 100.0, 1.0)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d_(t, torch.zeros(1, 4, 3, dtype=torch.int64, device=gpu), 100.0, 1.0)
+    with pytest.raises(RuntimeError):  # CPU tensor: no fallback
+        ops.rope_2d_(torch.zeros(1, 4, 2, 64), torch.zeros(1, 4, 2, dtype=torch.int64), 100.0, 1.0)
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C", [64, 768, 1024, 100, 2052])
+@pytest.mark.parametrize("rows", [1, 7, 513])
+def test_layernorm(gpu, C, rows):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, C, generator=g) * 3 + 0.5
+    w = torch.randn(C, generator=g)
+    b = torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), w, b, 1e-6)
+    y = ops.layernorm(x.to(gpu), w.to(gpu), b.to(gpu), 1e-6, torch.float32)
+    assert rel_l2(y.cpu(), ref) < 3e-6
+    yb = ops.layernorm(x.to(gpu), w.to(gpu), b.to(gpu), 1e-6, torch.bfloat16)
+    assert rel_l2(yb.cpu().float(), ref) < 5e-3
+    xb = x.bfloat16()
+    yb2 = ops.layernorm(xb.to(gpu), w.to(gpu), b.to(gpu), 1e-6, torch.float32)
+    assert rel_l2(yb2.cpu(), F.layer_norm(xb.float(), (C,), w, b, 1e-6)) < 3e-6
+
+
+# ------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (130, 70, 96), (1, 4, 8), (777, 200, 864), (64, 3072, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_f32(gpu, M, N, K):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = F.gelu(a @ w.t() + bias) + res
+    out = ops.gemm(a.to(gpu), w.to(gpu), bias.to(gpu), act="gelu", residual=res.to(gpu))
+    assert rel_l2(out.cpu(), ref) < 3e-6
+    out2 = ops.gemm(a.to(gpu), w.to(gpu))
+    assert rel_l2(out2.cpu(), a @ w.t()) < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bf16(gpu, M, N, K):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(a.to(gpu), w.to(gpu), out_dtype=torch.float32)
+    assert rel_l2(out.cpu(), ref) < 2e-5, "asymmetric random operands: catches a transposed C write"
+    ref2 = F.gelu(ref + bias) + res
+    out2 = ops.gemm(a.to(gpu), w.to(gpu), bias.to(gpu), act="gelu", residual=res.to(gpu), out_dtype=torch.float32)
+    assert rel_l2(out2.cpu(), ref2) < 2e-5
+    out3 = ops.gemm(a.to(gpu), w.to(gpu), bias.to(gpu), act="relu", out_dtype=torch.bfloat16)
+    assert rel_l2(out3.cpu().float(), F.relu(ref + bias)) < 4e-3
+    # bf16 residual, strided A (row stride > K), in-place accumulate into the residual buffer
+    abig = torch.zeros(M, K + 8, dtype=torch.bfloat16)
+    abig[:, :K] = a
+    resb = res.bfloat16()
+    rdev = resb.to(gpu)
+    ops.gemm(abig.to(gpu)[:, :K], w.to(gpu), bias.to(gpu), residual=rdev, out=rdev)
+    assert rel_l2(rdev.cpu().float(), ref + bias + resb.float()) < 6e-3
+
+
+def test_gemm_bf16_rope_and_vt_epilogue(gpu):
+    """Fused QKV epilogue: RoPE on q,k columns, V written in the packed VT layout."""
+    from uniception_amd import ops
+    B, h, w, H = 2, 5, 7, 3   # N = 35 tokens: not a multiple of 16 -> general VT path
+    for (h, w) in [(5, 7), (8, 8)]:  # (8,8): N = 64, aligned fast path
+        N = h * w
+        Cd = H * 64
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(B * N, 128, generator=g).bfloat16()
+        wq = (torch.randn(3 * Cd, 128, generator=g) / math.sqrt(128)).bfloat16()
+        bias = torch.randn(3 * Cd, generator=g)
+        pos = grid_pos(B, h, w)
+        table = ops.rope_table(gpu, max(h, w), 100.0)
+        vt = ops.vt_buffer(B, H, N, gpu)
+        vt.zero_()
+        qk = ops.gemm(x.to(gpu), wq.to(gpu), bias.to(gpu), out_dtype=torch.bfloat16,
+                      rope=(pos.to(gpu).view(-1, 2), table, 2 * Cd), vt=(2 * Cd, vt, N))
+        assert qk.shape == (B * N, 2 * Cd)
+        full = (x.float() @ wq.float().t() + bias).view(B, N, 3, H, 64)
+        q_ref = rope_ref(full[:, :, 0], pos, 100.0, 1.0)
+        k_ref = rope_ref(full[:, :, 1], pos, 100.0, 1.0)
+        got = qk.cpu().float().view(B, N, 2, H, 64)
+        assert rel_l2(got[:, :, 0], q_ref) < 4e-3
+        assert rel_l2(got[:, :, 1], k_ref) < 4e-3
+        # VT layout: vt[b,h,d, 16*(n//16) + perm(n%16)] == v[b,n,h,d]
+        v_ref = full[:, :, 2]  # B,N,H,64
+        n = torch.arange(N)
+        wv = n % 16
+        posn = (n // 16) * 16 + ((wv >> 2) & 1) * 8 + (wv & 3) + 4 * (wv >> 3)
+        vt_cpu = vt.cpu().float()
+        got_v = vt_cpu[:, :, :, posn].permute(0, 3, 1, 2)  # B,N,H,64
+        assert rel_l2(got_v, v_ref) < 4e-3
+        # uc_vt_pack produces the same layout from a row-major V
+        packed = ops.vt_pack(v_ref.bfloat16().to(gpu))
+        assert torch.equal(packed.cpu()[:, :, :, posn], v_ref.bfloat16().permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(2, 9, 11, 16, 24, 1), (1, 37, 37, 32, 40, 2), (2, 8, 8, 96, 256, 1), (1, 6, 5, 8, 8, 2)])
+def test_conv3x3_implicit_gemm(gpu, dtype, geom):
+    """3x3 conv, pad 1, stride 1/2 (dpt_block.py:34-69, dpt.py:161-172) incl. the ReLU-on-load of the RCU."""
+    from uniception_amd import ops
+    B, H, W, Cin, Cout, s = geom
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dtype)
+    wt = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
+    bias = torch.randn(Cout, generator=g)
+    for relu_a in (False, True):
+        xin = F.relu(x.float()) if relu_a else x.float()
+        ref = F.conv2d(xin, wt.float(), bias, stride=s, padding=1)  # B,Cout,Ho,Wo
+        x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+        w_r = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(gpu)  # (ky,kx,c)
+        out = ops.gemm(x_nhwc, w_r, bias.to(gpu), conv=(B, H, W, Cin, s), relu_a=relu_a, out_dtype=torch.float32)
+        Ho, Wo = ref.shape[2:]
+        got = out.cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+        assert rel_l2(got, ref) < (3e-6 if dtype == torch.float32 else 2e-5)
+
+
+# ------------------------------------------------------------------------------------------
+def sdpa_ref(q, k, v, scale):
+    """q [B,Nq,H,D] etc. -> [B,Nq,H,D], fp32 softmax(QK^T*scale)V."""
+    qh, kh, vh = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (att @ vh).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 3, 50, 50, 64), (1, 2, 200, 77, 32), (1, 1, 1, 1, 64), (2, 2, 129, 300, 64)])
+def test_attention_f32(gpu, B, H, Nq, Nk, D):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(B, Nq, H, D, generator=g)
+    k = torch.randn(B, Nk, H, D, generator=g)
+    v = torch.randn(B, Nk, H, D, generator=g)
+    ref = sdpa_ref(q, k, v, D ** -0.5)
+    out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), D ** -0.5)
+    assert rel_l2(out.cpu(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 196, 196), (1, 2, 1024, 1024), (1, 2, 1369, 1369), (2, 1, 37, 300), (1, 1, 5, 3), (1, 2, 130, 64)])
+def test_attention_bf16(gpu, B, H, Nq, Nk):
+    from uniception_amd import ops
+    D = 64
+    g = torch.Generator().manual_seed(9)
+    q = (torch.randn(B, Nq, H, D, generator=g) * 1.5).bfloat16()
+    k = (torch.randn(B, Nk, H, D, generator=g) * 1.5).bfloat16()
+    v = torch.randn(B, Nk, H, D, generator=g).bfloat16()
+    ref = sdpa_ref(q, k, v, D ** -0.5)
+    vt = ops.vt_pack(v.to(gpu))
+    out = ops.attention(q.to(gpu), k.to(gpu), vt, D ** -0.5, v_packed=True)
+    # P is rounded to bf16 before PV and O to bf16 on store: ~2^-8 relative
+    assert rel_l2(out.cpu().float(), ref) < 8e-3
+    # strided views of a fused [B,N,2,H,D] q|k buffer (what the QKV GEMM produces)
+    if Nq == Nk:
+        qk = torch.stack([q, k], dim=2).to(gpu)
+        out2 = ops.attention(qk[:, :, 0], qk[:, :, 1], vt, D ** -0.5, v_packed=True)
+        assert torch.equal(out2, out)
+
+
+def test_attention_bf16_spiked_keys(gpu):
+    """One key dominating a late tile forces the running-max rescale branch (online softmax)."""
+    from uniception_amd import ops
+    B, H, N, D = 1, 1, 256, 64
+    g = torch.Generator().manual_seed(10)
+    q = torch.randn(B, N, H, D, generator=g).bfloat16()
+    k = torch.randn(B, N, H, D, generator=g).bfloat16()
+    v = torch.randn(B, N, H, D, generator=g).bfloat16()
+    k[0, 200, 0] = q[0, 17, 0] * 6  # spike: row 17 max jumps in tile 3
+    k[0, 70, 0] = q[0, 99, 0] * 4
+    ref = sdpa_ref(q, k, v, D ** -0.5)
+    out = ops.attention(q.to(gpu), k.to(gpu), ops.vt_pack(v.to(gpu)), D ** -0.5, v_packed=True)
+    assert (out.cpu().float() - ref).abs().max() < 3e-2
+    assert rel_l2(out.cpu().float(), ref) < 8e-3
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P,H,W", [(16, 32, 48), (14, 28, 42), (4, 8, 8)])
+def test_patch_gather(gpu, P, H, W):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(11)
+    if P % 4 != 0:
+        img = torch.randn(2, 3, H, W, generator=g)
+        with pytest.raises(Exception):
+            ops.patch_gather(img.to(gpu), P, torch.float32)
+        return
+    img = torch.randn(2, 3, H, W, generator=g)
+    ref = F.unfold(img, kernel_size=P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)  # (c,u,v) columns
+    out = ops.patch_gather(img.to(gpu), P, torch.float32)
+    assert torch.equal(out.cpu(), ref)
+    outb = ops.patch_gather(img.to(gpu), P, torch.bfloat16)
+    assert torch.equal(outb.cpu(), ref.bfloat16())
+
+
+def test_layout_conversions(gpu):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 70, 5, 9, generator=g)
+    y = ops.nchw_to_nhwc(x.to(gpu), torch.float32)
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    yb = ops.nchw_to_nhwc(x.to(gpu), torch.bfloat16)
+    assert torch.equal(yb.cpu(), x.permute(0, 2, 3, 1).contiguous().bfloat16())
+    z = ops.nhwc_to_nchw(yb, torch.float32)
+    assert torch.equal(z.cpu(), x.bfloat16().float())
+    assert torch.equal(ops.convert(x.to(gpu), torch.bfloat16).cpu(), x.bfloat16())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(2, 5, 7, 16, 10, 14, None), (1, 19, 19, 8, 38, 38, (37, 37)), (1, 37, 37, 8, 65, 65, None), (1, 1, 1, 8, 4, 4, None)])
+def test_bilinear(gpu, dtype, geom):
+    from uniception_amd import ops
+    B, Hi, Wi, C, Ho, Wo, crop = geom
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, C, Hi, Wi, generator=g).to(dtype)
+    ref = F.interpolate(x.float(), size=(Ho, Wo), mode="bilinear", align_corners=True)
+    if crop:
+        ref = ref[:, :, :crop[0], :crop[1]]
+    out = ops.bilinear_nhwc(x.permute(0, 2, 3, 1).contiguous().to(gpu), Ho, Wo, crop)
+    got = out.cpu().float().permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < (2e-6 if dtype == torch.float32 else 4e-3)
+
+
+def test_bilinear_scale2_matches_scale_factor(gpu):
+    """scale_factor=2, align_corners=True (dpt_block.py:251-253) == size=(2H,2W)."""
+    from uniception_amd import ops
+    x = torch.randn(1, 8, 6, 9)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    out = ops.bilinear_nhwc(x.permute(0, 2, 3, 1).contiguous().to(gpu), 12, 18)
+    assert rel_l2(out.cpu().permute(0, 3, 1, 2), ref) < 2e-6
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_convtranspose_as_gemm_plus_scatter(gpu, k):
+    """ConvTranspose2d(k=s) == GEMM with weight [(u,v,o), c] + pixel scatter (dpt.py:116-140)."""
+    from uniception_amd import ops
+    B, Cin, Cout, h, w = 2, 24, 16, 5, 6
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, Cin, h, w, generator=g)
+    wt = torch.randn(Cin, Cout, k, k, generator=g) / math.sqrt(Cin)
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x, wt, bias, stride=k)
+    a = x.permute(0, 2, 3, 1).reshape(B * h * w, Cin).contiguous().to(gpu)
+    wg = wt.permute(2, 3, 1, 0).reshape(k * k * Cout, Cin).contiguous().to(gpu)  # rows (u,v,o)
+    bg = bias.repeat(k * k).to(gpu)
+    y = ops.gemm(a, wg, bg)
+    out = ops.convt_scatter(y, B, h, w, k, Cout)
+    assert rel_l2(out.cpu().permute(0, 3, 1, 2), ref) < 3e-6
+
+
+def test_pixel_shuffle(gpu):
+    from uniception_amd import ops
+    B, h, w, P, Cout = 2, 3, 5, 4, 4
+    y = torch.randn(B, Cout * P * P, h, w)
+    ref = F.pixel_shuffle(y, P)
+    src = y.permute(0, 2, 3, 1).reshape(B * h * w, Cout * P * P).contiguous()
+    out = ops.pixel_shuffle(src.to(gpu), B, h, w, P, Cout)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_pointmap_adaptor(gpu):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(2, 4, 6, 7, generator=g) * 2
+    x[0, :3, 0, 0] = 0  # zero vector: d clipped at 1e-8
+    xyz, c = x[:, :3], x[:, 3:]
+    d = xyz.norm(dim=1, keepdim=True)
+    pts_ref = (xyz / d.clip(min=1e-8) * torch.expm1(d)).permute(0, 2, 3, 1)
+    conf_ref = (1 + c.exp().clip(max=float("inf"))).permute(0, 2, 3, 1)
+    pts, conf = ops.pointmap_adaptor(x.to(gpu), 1.0, float("inf"))
+    assert rel_l2(pts.cpu(), pts_ref) < 2e-6 and rel_l2(conf.cpu(), conf_ref) < 2e-6
+    # channels-last input (what the DPT tail produces) gives the same result
+    xcl = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).to(gpu)
+    pts2, conf2 = ops.pointmap_adaptor(xcl, 1.0, float("inf"))
+    assert torch.equal(pts2, pts) and torch.equal(conf2, conf)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv1x1_to4(gpu, dtype):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(16)
+    f = torch.randn(2, 5, 7, 128, generator=g).to(dtype)
+    w = torch.randn(4, 128, generator=g) / 11
+    b = torch.randn(4, generator=g)
+    ref = f.float() @ w.t() + b
+    out = ops.conv1x1_to4(f.to(gpu), w.to(gpu), b.to(gpu))
+    assert rel_l2(out.cpu(), ref) < 3e-6

@@ -1,0 +1,85 @@
+"""ctypes binding of libuc_hip.so (C ABI declared in include/uc_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the library is missing or a kernel call
+fails, an exception is raised (``UcHipError``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuc_hip.so")
+
+UC_F32, UC_BF16, UC_F16 = 0, 1, 2
+UC_A_DENSE, UC_A_CONV3X3 = 0, 1
+UC_ACT_NONE, UC_ACT_GELU_ERF, UC_ACT_RELU = 0, 1, 2
+UC_V_ROWMAJOR, UC_V_PACKED_T = 0, 1
+
+i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+
+class UcHipError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    # field order == struct uc_gemm_desc in include/uc_hip.h
+    _fields_ = [
+        ("compute_dtype", i32), ("a_mode", i32), ("relu_a", i32),
+        ("A", vp), ("lda", i64), ("W", vp), ("M", i64), ("N", i64), ("K", i64),
+        ("conv_B", i32), ("conv_H", i32), ("conv_W", i32), ("conv_Cin", i32), ("conv_stride", i32),
+        ("conv_Ho", i32), ("conv_Wo", i32),
+        ("bias", vp), ("act", i32), ("residual", vp), ("res_dtype", i32), ("ldr", i64),
+        ("rope_cols", i64), ("rope_pos", vp), ("rope_table", vp), ("rope_npos", i32),
+        ("vt_col0", i64), ("vt_out", vp), ("vt_ntok", i32), ("vt_npad", i32),
+        ("C", vp), ("out_dtype", i32), ("ldc", i64),
+    ]
+
+
+# name -> argtypes (every function returns int except uc_last_error)
+SIGNATURES = {
+    "uc_abi_version": [],
+    "uc_rope2d": [vp, vp, i32, i32, i32, i32, i64, i64, i64, f32, f32, i32, vp],
+    "uc_rope_table": [vp, i32, i32, f32, f32, vp],
+    "uc_layernorm": [vp, i32, vp, vp, vp, i32, i64, i32, f32, vp],
+    "uc_gemm": [C.POINTER(GemmDesc), vp],
+    "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp],
+    "uc_vt_pack": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
+    "uc_patch_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "uc_nchw_to_nhwc": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "uc_nhwc_to_nchw": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "uc_convert": [vp, i32, vp, i32, i64, vp],
+    "uc_bilinear_nhwc": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "uc_convt_scatter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "uc_pixel_shuffle": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "uc_pointmap_adaptor": [vp, i64, i64, i64, vp, vp, i32, i32, i32, f32, f32, vp],
+    "uc_conv1x1_to4": [vp, i32, vp, vp, vp, i64, i32, vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load libuc_hip.so (once). Raises UcHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UcHipError(
+            f"{LIB_PATH} not found: build it with `python -m uniception_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU/PyTorch fallback for the HIP path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.uc_last_error.restype = C.c_char_p
+    lib.uc_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = i32
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().uc_last_error().decode("utf-8", "replace")
+        raise UcHipError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,355 @@
+// Fused scaled-dot-product attention (no mask, no dropout) for gfx950.
+//
+// attn_bf16_kernel — flash-style, head_dim 64, v_mfma_f32_32x32x16_bf16.
+//   Workgroup = 4 wavefronts = 128 query rows of one (batch, head); each wave owns 32 queries.
+//   Per 64-key tile:   S^T[key,q] = K . Q^T   (A = K rows from LDS, B = Q^T held in registers)
+//   The swapped product puts a query's whole score column in ONE lane pair (lane, lane^32):
+//   row max / row sum are 31 in-register ops + one cross-half exchange; the running max,
+//   the rescale factor and the normaliser are lane-local scalars.
+//   P^T (bf16) in the S^T accumulator layout is directly the B operand of  O^T[d,q] += V^T . P^T
+//   when the key order inside each 16-key group is permuted the same way on the V side — which
+//   is what the "VT" layout (uc_hip.h) bakes into memory, so the A operand V^T[d, 8 keys] is one
+//   16-byte LDS read.  K and VT tiles are staged global -> VGPR -> LDS one tile ahead
+//   (double-buffered, XOR-swizzled 128-byte rows, one barrier per tile).
+//
+// attn_f32_kernel — verification mode: one thread per query row, fp32 FMA chains, expf.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct AttnParams {
+    const void* Q;
+    const void* K;
+    const void* V;
+    void* O;
+    int B, H, Nq, Nk, D;
+    int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
+    int npad;     // VT row length
+    float scale;
+};
+
+#define KV_TILE 64
+#define ATT_TILE_BYTES (KV_TILE * 128)  // 64 rows x 128 B
+
+__device__ __forceinline__ int att_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// key offset inside a 16-key group for VT position pp (inverse of uc_vt_perm)
+__device__ __forceinline__ int vt_key_of_pos(int pp) {
+    const int hi = pp >> 3, j = pp & 7;
+    return (j & 3) + 8 * (j >> 2) + 4 * hi;
+}
+
+__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE_BYTES];  // 2 stages x (K tile + VT tile)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const bf16_t* Qb = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const bf16_t* Kb = (const bf16_t*)p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const bf16_t* VTb = (const bf16_t*)p.V + ((int64_t)b * p.H + h) * 64 * (int64_t)p.npad;
+
+    // ---- Q^T fragments (B operand): lane (q = l31, hi) holds Q[q][16s + 8hi .. +7], s = 0..3 ----
+    bf16x8_t qf[4];
+    {
+        int q = q0 + l31;
+        if (q >= p.Nq) q = p.Nq - 1;  // clamp; rows beyond Nq are never stored
+        const bf16_t* qp = Qb + (int64_t)q * p.q_sn + hi * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+    }
+
+    // ---- staging assignment: 512 16-byte chunks per tile, 2 per thread ----
+    const int cc = tid & 7;     // chunk column
+    const int sr = tid >> 3;    // row 0..31 (+32)
+    uint4 rk0, rk1, rv0, rv1;   // named (not arrays) so they stay in VGPRs
+    auto load_k = [&](int k0, int row) -> uint4 {
+        int key = k0 + row;
+        if (key >= p.Nk) key = p.Nk - 1;  // clamped keys are masked in the softmax
+        return *reinterpret_cast<const uint4*>(Kb + (int64_t)key * p.k_sn + cc * 8);
+    };
+    auto load_v = [&](int k0, int row) -> uint4 {
+        // VT tile: row = channel d, 8 key positions [k0 + 8cc, +8)
+        uint4 v = *reinterpret_cast<const uint4*>(VTb + (int64_t)row * p.npad + k0 + cc * 8);
+        if (k0 + KV_TILE > p.Nk) {  // tail tile: zero positions whose key is out of range (0 * garbage guard)
+            const int gbase = k0 + ((cc * 8) & ~15);
+            const int pbase = (cc * 8) & 15;
+            unsigned m0 = 0xffffffffu, m1 = 0xffffffffu, m2 = 0xffffffffu, m3 = 0xffffffffu;
+            if (gbase + vt_key_of_pos(pbase + 0) >= p.Nk) m0 &= 0xffff0000u;
+            if (gbase + vt_key_of_pos(pbase + 1) >= p.Nk) m0 &= 0x0000ffffu;
+            if (gbase + vt_key_of_pos(pbase + 2) >= p.Nk) m1 &= 0xffff0000u;
+            if (gbase + vt_key_of_pos(pbase + 3) >= p.Nk) m1 &= 0x0000ffffu;
+            if (gbase + vt_key_of_pos(pbase + 4) >= p.Nk) m2 &= 0xffff0000u;
+            if (gbase + vt_key_of_pos(pbase + 5) >= p.Nk) m2 &= 0x0000ffffu;
+            if (gbase + vt_key_of_pos(pbase + 6) >= p.Nk) m3 &= 0xffff0000u;
+            if (gbase + vt_key_of_pos(pbase + 7) >= p.Nk) m3 &= 0x0000ffffu;
+            v.x &= m0; v.y &= m1; v.z &= m2; v.w &= m3;
+        }
+        return v;
+    };
+#define ATT_STAGE_LOAD(k0_)                 \
+    do {                                    \
+        rk0 = load_k((k0_), sr);            \
+        rk1 = load_k((k0_), sr + 32);       \
+        rv0 = load_v((k0_), sr);            \
+        rv1 = load_v((k0_), sr + 32);       \
+    } while (0)
+#define ATT_STAGE_WRITE(buf_)                                                          \
+    do {                                                                               \
+        char* sk_ = smem + (buf_) * 2 * ATT_TILE_BYTES;                                \
+        char* sv_ = sk_ + ATT_TILE_BYTES;                                              \
+        *reinterpret_cast<uint4*>(sk_ + att_swz(sr, cc)) = rk0;                        \
+        *reinterpret_cast<uint4*>(sk_ + att_swz(sr + 32, cc)) = rk1;                   \
+        *reinterpret_cast<uint4*>(sv_ + att_swz(sr, cc)) = rv0;                        \
+        *reinterpret_cast<uint4*>(sv_ + att_swz(sr + 32, cc)) = rv1;                   \
+    } while (0)
+
+    float16_t o[2];   // O^T accumulators: d-block x (16 regs): d = 32*db + (r&3) + 8*(r>>2) + 4*hi, q = l31
+    o[0] = (float16_t)(0.f);
+    o[1] = (float16_t)(0.f);
+    float m_run = -1e30f;   // running max of raw scores (shared by the lane pair)
+    float l_run = 0.f;      // lane-partial running sum
+    const float c = p.scale * 1.44269504088896340736f;  // scale * log2(e)
+
+    const int nt = (p.Nk + KV_TILE - 1) / KV_TILE;
+    ATT_STAGE_LOAD(0);
+    ATT_STAGE_WRITE(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        const int k0 = t * KV_TILE;
+        if (t + 1 < nt) ATT_STAGE_LOAD(k0 + KV_TILE);
+        const char* sk = smem + buf * 2 * ATT_TILE_BYTES;
+        const char* sv = sk + ATT_TILE_BYTES;
+
+        // ---- S^T = K . Q^T : two 32-key blocks, 4 k-steps (16 channels) each ----
+        float16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            s[kb] = (float16_t)(0.f);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + att_swz(kb * 32 + l31, 2 * st + hi));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- mask the tail ----
+        if (k0 + KV_TILE > p.Nk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.Nk) s[kb][r] = -1e30f;
+                }
+        }
+        // ---- online softmax (per query = per lane pair) ----
+        float mt = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8_t pf[4];   // P^T B-operand fragments: slab g = 2*kb + half, 8 key slots per lane
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    e[j] = __builtin_amdgcn_exp2f(fmaf(s[kb][hf * 8 + j], c, -mc));
+                    psum += e[j];
+                }
+                union { bf16x8_t v; unsigned u[4]; } pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk.u[j] = pack_bf16x2(e[2 * j], e[2 * j + 1]);
+                pf[kb * 2 + hf] = pk.v;
+            }
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- O^T += V^T . P^T : two 32-channel blocks x four 16-key slabs ----
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sv + att_swz(db * 32 + l31, 2 * g + hi));
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o[db], 0, 0, 0);
+            }
+
+        if (t + 1 < nt) ATT_STAGE_WRITE(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds 4 consecutive channels per (db, r>>2) ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < p.Nq) {
+        bf16_t* op = (bf16_t*)p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = db * 32 + 8 * g4 + 4 * hi;
+                uint2 pk;
+                pk.x = pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv);
+                pk.y = pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + d) = pk;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// row-major V -> VT packing (for callers that did not get VT from the GEMM epilogue)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__ V, bf16_t* __restrict__ VT, int H,
+                                                      int Nk, int D, int npad, int64_t v_sb, int64_t v_sn,
+                                                      int64_t v_sh) {
+    // block: (key tile of 64, head, batch); LDS transpose of a [64 keys][D] tile
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);  // [64][D+2]
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+    const int ld = D + 2;
+    const bf16_t* vb = V + (int64_t)b * v_sb + (int64_t)h * v_sh;
+    for (int idx = threadIdx.x; idx < 64 * D; idx += blockDim.x) {
+        const int key = idx / D, d = idx % D;
+        tile[key * ld + d] = (k0 + key < Nk) ? vb[(int64_t)(k0 + key) * v_sn + d] : (bf16_t)0;
+    }
+    __syncthreads();
+    bf16_t* out = VT + ((int64_t)b * H + h) * D * (int64_t)npad + k0;
+    for (int idx = threadIdx.x; idx < 64 * D; idx += blockDim.x) {
+        const int pos = idx & 63, d = idx >> 6;
+        const int key = (pos & ~15) + vt_key_of_pos(pos & 15);
+        out[(int64_t)d * npad + pos] = tile[key * ld + d];
+    }
+}
+
+extern "C" int uc_vt_pack(const void* V, void* VT, int B, int H, int Nk, int D, int64_t v_sb, int64_t v_sn,
+                          int64_t v_sh, uc_stream_t stream) {
+    UC_REQUIRE(V && VT, "uc_vt_pack: null pointer");
+    UC_REQUIRE(B > 0 && H > 0 && Nk > 0 && D > 0 && D <= 256, "uc_vt_pack: bad shape");
+    const int npad = (Nk + 63) / 64 * 64;
+    hipLaunchKernelGGL(vt_pack_kernel, dim3(npad / 64, H, B), dim3(256), (size_t)64 * (D + 2) * 2, (hipStream_t)stream,
+                       (const bf16_t*)V, (bf16_t*)VT, H, Nk, D, npad, v_sb, v_sn, v_sh);
+    UC_CHECK_LAUNCH("uc_vt_pack");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// fp32 verification kernel: one thread per query, 32-key tiles of K and V in LDS (broadcast reads)
+// ---------------------------------------------------------------------------------------
+#define F32_KT 32
+
+template <int DMAX>
+__global__ __launch_bounds__(128) void attn_f32_kernel(AttnParams p) {
+    __shared__ float Ks[F32_KT][DMAX];
+    __shared__ float Vs[F32_KT][DMAX];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 128 + threadIdx.x;
+    const int D = p.D;
+    const float* Qb = (const float*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const float* Kb = (const float*)p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const float* Vb = (const float*)p.V + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
+    const bool active = q < p.Nq;
+    float qr[DMAX], acc[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        qr[d] = (active && d < D) ? Qb[(int64_t)q * p.q_sn + d] : 0.f;
+        acc[d] = 0.f;
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int k0 = 0; k0 < p.Nk; k0 += F32_KT) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < F32_KT * DMAX; idx += blockDim.x) {
+            const int kk = idx / DMAX, d = idx % DMAX;
+            const bool ok = (k0 + kk < p.Nk) && d < D;
+            Ks[kk][d] = ok ? Kb[(int64_t)(k0 + kk) * p.k_sn + d] : 0.f;
+            Vs[kk][d] = ok ? Vb[(int64_t)(k0 + kk) * p.v_sn + d] : 0.f;
+        }
+        __syncthreads();
+        float s[F32_KT];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < F32_KT; ++kk) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) a = fmaf(qr[d], Ks[kk][d], a);
+            a *= p.scale;
+            s[kk] = (k0 + kk < p.Nk) ? a : -INFINITY;
+            mt = fmaxf(mt, s[kk]);
+        }
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) acc[d] *= alpha;
+#pragma unroll
+        for (int kk = 0; kk < F32_KT; ++kk) {
+            const float pw = (k0 + kk < p.Nk) ? expf(s[kk] - m_new) : 0.f;
+            l_run += pw;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) acc[d] = fmaf(pw, Vs[kk][d], acc[d]);
+        }
+        m_run = m_new;
+    }
+    if (active) {
+        float* op = (float*)p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+            if (d < D) op[d] = acc[d] * inv;
+    }
+}
+
+extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, void* O, int dtype, int v_layout,
+                                int B, int H, int Nq, int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                                int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                                int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale, uc_stream_t stream) {
+    UC_REQUIRE(Q && K && V && O, "uc_attention_fwd: null pointer");
+    UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && D > 0, "uc_attention_fwd: bad shape");
+    UC_REQUIRE(H <= 65535 && B <= 65535, "uc_attention_fwd: B and H must fit a grid dimension");
+    AttnParams p;
+    p.Q = Q; p.K = K; p.V = V; p.O = O; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.D = D;
+    p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
+    p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
+    p.npad = (Nk + 63) / 64 * 64;
+    p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UC_BF16) {
+        UC_REQUIRE(D == 64, "uc_attention_fwd(bf16): head_dim must be 64 (got %d)", D);
+        UC_REQUIRE(v_layout == UC_V_PACKED_T, "uc_attention_fwd(bf16): V must be in the packed VT layout (uc_vt_pack)");
+        UC_REQUIRE(q_sb % 8 == 0 && q_sn % 8 == 0 && q_sh % 8 == 0 && k_sb % 8 == 0 && k_sn % 8 == 0 && k_sh % 8 == 0,
+                   "uc_attention_fwd(bf16): Q/K strides must be multiples of 8 elements");
+        UC_REQUIRE(o_sb % 4 == 0 && o_sn % 4 == 0 && o_sh % 4 == 0, "uc_attention_fwd(bf16): O strides must be multiples of 4");
+        UC_REQUIRE(((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)O % 8 == 0),
+                   "uc_attention_fwd(bf16): pointer alignment");
+        hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
+    } else if (dtype == UC_F32) {
+        UC_REQUIRE(v_layout == UC_V_ROWMAJOR, "uc_attention_fwd(f32): V must be row-major");
+        UC_REQUIRE(D <= 64, "uc_attention_fwd(f32): head_dim must be <= 64 (got %d)", D);
+        const dim3 grid((Nq + 127) / 128, H, B);
+        if (D <= 32) hipLaunchKernelGGL((attn_f32_kernel<32>), grid, dim3(128), 0, st, p);
+        else hipLaunchKernelGGL((attn_f32_kernel<64>), grid, dim3(128), 0, st, p);
+    } else {
+        uc_set_error("uc_attention_fwd: unsupported dtype %d", dtype);
+        return UC_ERR_BAD_ARG;
+    }
+    UC_CHECK_LAUNCH("uc_attention_fwd");
+    return UC_OK;
+}

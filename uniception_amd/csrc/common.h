@@ -1,0 +1,91 @@
+// Internal helpers shared by the gfx950 kernels of libuc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/uc_hip.h"
+
+// ---------------------------------------------------------------------------------------
+// error plumbing (thread-local text, negative status codes)
+// ---------------------------------------------------------------------------------------
+void uc_set_error(const char* fmt, ...);
+
+#define UC_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            uc_set_error(__VA_ARGS__);        \
+            return UC_ERR_BAD_ARG;            \
+        }                                     \
+    } while (0)
+
+#define UC_CHECK_LAUNCH(name)                                                     \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            uc_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+            return UC_ERR_LAUNCH;                                                 \
+        }                                                                         \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// bf16 / f16 as raw 16-bit storage.  bf16 -> f32 is a shift; f32 -> bf16 rounds to nearest even
+// (same as torch's c10::BFloat16).
+// ---------------------------------------------------------------------------------------
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float f16_to_f32(unsigned short v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return (float)h;
+}
+__device__ __forceinline__ unsigned short f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    unsigned short v;
+    __builtin_memcpy(&v, &h, 2);
+    return v;
+}
+
+// element type tags so kernels can be written once
+struct F32Tag {
+    typedef float storage;
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+struct BF16Tag {
+    typedef bf16_t storage;
+    static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+struct F16Tag {
+    typedef unsigned short storage;
+    static __device__ __forceinline__ float load(const unsigned short* p) { return f16_to_f32(*p); }
+    static __device__ __forceinline__ void store(unsigned short* p, float v) { *p = f32_to_f16(v); }
+};
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef short short8_t __attribute__((ext_vector_type(8)));
+typedef short short4_t __attribute__((ext_vector_type(4)));
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,352 @@
+// HBM-bound data-movement kernels of the DUSt3R path for gfx950: patch gather, layout/dtype
+// conversion at the public BCHW boundary, bilinear resize (align_corners=True), the pixel scatters
+// behind ConvTranspose2d(k=s) / pixel_shuffle, the pointmap+confidence adaptor and the 1x1 head conv.
+// All are single-pass streaming kernels; channel-last (NHWC) tensors are moved 8 elements per lane
+// (16 B bf16 / 2x16 B fp32).
+#include "common.h"
+
+// ---- generic 8-element vector load/store with fp32 math in between --------------------------
+struct V8 { float v[8]; };
+
+template <typename Tag>
+__device__ __forceinline__ V8 load8(const typename Tag::storage* p);
+template <>
+__device__ __forceinline__ V8 load8<F32Tag>(const float* p) {
+    V8 r;
+    const float4_t a = *reinterpret_cast<const float4_t*>(p);
+    const float4_t b = *reinterpret_cast<const float4_t*>(p + 4);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+template <>
+__device__ __forceinline__ V8 load8<BF16Tag>(const bf16_t* p) {
+    V8 r;
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+template <typename Tag>
+__device__ __forceinline__ void store8(typename Tag::storage* p, const V8& r);
+template <>
+__device__ __forceinline__ void store8<F32Tag>(float* p, const V8& r) {
+    *reinterpret_cast<float4_t*>(p) = (float4_t){r.v[0], r.v[1], r.v[2], r.v[3]};
+    *reinterpret_cast<float4_t*>(p + 4) = (float4_t){r.v[4], r.v[5], r.v[6], r.v[7]};
+}
+template <>
+__device__ __forceinline__ void store8<BF16Tag>(bf16_t* p, const V8& r) {
+    uint4 u;
+    u.x = pack_bf16x2(r.v[0], r.v[1]); u.y = pack_bf16x2(r.v[2], r.v[3]);
+    u.z = pack_bf16x2(r.v[4], r.v[5]); u.w = pack_bf16x2(r.v[6], r.v[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+
+#define EW_GRID(n_items) ((unsigned)min((int64_t)65536 * 4, ceil_div64((n_items), 256)))
+
+// =======================================================================================
+// patch gather: img fp32 NCHW -> cols [B*h*w, Cin*P*P], columns (c,u,v).  One work item = 4 pixels of a patch row.
+// =======================================================================================
+template <typename TO>
+__global__ void patch_gather_kernel(const float* __restrict__ img, typename TO::storage* __restrict__ cols, int B,
+                                    int Cin, int H, int W, int P, int64_t items) {
+    const int h = H / P, w = W / P;
+    const int P4 = P / 4;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        // item index order == output order: (token, c, u, v4)
+        int64_t r = it;
+        const int v4 = (int)(r % P4); r /= P4;
+        const int u = (int)(r % P); r /= P;
+        const int c = (int)(r % Cin); r /= Cin;
+        const int j = (int)(r % w); r /= w;
+        const int i = (int)(r % h);
+        const int b = (int)(r / h);
+        const float4_t px = *reinterpret_cast<const float4_t*>(
+            img + (((int64_t)b * Cin + c) * H + (int64_t)i * P + u) * W + (int64_t)j * P + v4 * 4);
+        typename TO::storage* o = cols + it * 4;
+        TO::store(o + 0, px.x); TO::store(o + 1, px.y); TO::store(o + 2, px.z); TO::store(o + 3, px.w);
+    }
+}
+
+extern "C" int uc_patch_gather(const float* img, void* cols, int out_dtype, int B, int Cin, int H, int W, int P,
+                               uc_stream_t stream) {
+    UC_REQUIRE(img && cols, "uc_patch_gather: null pointer");
+    UC_REQUIRE(B > 0 && Cin > 0 && P > 0 && H % P == 0 && W % P == 0, "uc_patch_gather: H,W must be multiples of the patch size");
+    UC_REQUIRE(P % 4 == 0 && W % 4 == 0, "uc_patch_gather: patch size and width must be multiples of 4 (16-byte pixel quads)");
+    UC_REQUIRE((uintptr_t)img % 16 == 0, "uc_patch_gather: img must be 16-byte aligned");
+    const int64_t items = (int64_t)B * Cin * H * W / 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == UC_F32)
+        hipLaunchKernelGGL((patch_gather_kernel<F32Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, img, (float*)cols, B, Cin, H, W, P, items);
+    else if (out_dtype == UC_BF16)
+        hipLaunchKernelGGL((patch_gather_kernel<BF16Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, img, (bf16_t*)cols, B, Cin, H, W, P, items);
+    else { uc_set_error("uc_patch_gather: bad out_dtype %d", out_dtype); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_patch_gather");
+    return UC_OK;
+}
+
+// =======================================================================================
+// NCHW <-> NHWC with dtype conversion: LDS-tiled transpose of [C, HW] <-> [HW, C] per batch image.
+// =======================================================================================
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const typename TI::storage* __restrict__ src,
+                                                          typename TO::storage* __restrict__ dst, int R, int S) {
+    // per batch (blockIdx.z): src [R][S] -> dst [S][R]; 32x32 tiles, 256 threads (32 x 8)
+    __shared__ float tile[32][33];
+    const int64_t boff = (int64_t)blockIdx.z * R * S;
+    const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, s = s0 + tx;
+        if (r < R && s < S) tile[ty + 8 * k][tx] = TI::load(src + boff + (int64_t)r * S + s);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int s = s0 + ty + 8 * k, r = r0 + tx;
+        if (r < R && s < S) TO::store(dst + boff + (int64_t)s * R + r, tile[tx][ty + 8 * k]);
+    }
+}
+
+template <typename TI, typename TO>
+static void launch_transpose(const void* src, void* dst, int Bn, int R, int S, hipStream_t st) {
+    hipLaunchKernelGGL((transpose2d_kernel<TI, TO>), dim3((S + 31) / 32, (R + 31) / 32, Bn), dim3(256), 0, st,
+                       (const typename TI::storage*)src, (typename TO::storage*)dst, R, S);
+}
+
+static int dispatch_transpose(const char* name, const void* src, int sd, void* dst, int dd, int Bn, int R, int S,
+                              hipStream_t st) {
+    UC_REQUIRE(src && dst, "%s: null pointer", name);
+    UC_REQUIRE(Bn > 0 && R > 0 && S > 0 && Bn <= 65535 && (R + 31) / 32 <= 65535, "%s: bad shape", name);
+    if (sd == UC_F32 && dd == UC_F32) launch_transpose<F32Tag, F32Tag>(src, dst, Bn, R, S, st);
+    else if (sd == UC_F32 && dd == UC_BF16) launch_transpose<F32Tag, BF16Tag>(src, dst, Bn, R, S, st);
+    else if (sd == UC_BF16 && dd == UC_F32) launch_transpose<BF16Tag, F32Tag>(src, dst, Bn, R, S, st);
+    else if (sd == UC_BF16 && dd == UC_BF16) launch_transpose<BF16Tag, BF16Tag>(src, dst, Bn, R, S, st);
+    else { uc_set_error("%s: unsupported dtypes %d -> %d", name, sd, dd); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH(name);
+    return UC_OK;
+}
+
+extern "C" int uc_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H, int W,
+                               uc_stream_t stream) {
+    return dispatch_transpose("uc_nchw_to_nhwc", src, src_dtype, dst, dst_dtype, B, C, H * W, (hipStream_t)stream);
+}
+extern "C" int uc_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H, int W,
+                               uc_stream_t stream) {
+    return dispatch_transpose("uc_nhwc_to_nchw", src, src_dtype, dst, dst_dtype, B, H * W, C, (hipStream_t)stream);
+}
+
+template <typename TI, typename TO>
+__global__ void convert_kernel(const typename TI::storage* __restrict__ s, typename TO::storage* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        TO::store(d + i, TI::load(s + i));
+}
+
+extern "C" int uc_convert(const void* src, int sd, void* dst, int dd, int64_t n, uc_stream_t stream) {
+    UC_REQUIRE(src && dst && n >= 0, "uc_convert: bad argument");
+    if (n == 0) return UC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g(EW_GRID(n)), b(256);
+    if (sd == UC_F32 && dd == UC_BF16) hipLaunchKernelGGL((convert_kernel<F32Tag, BF16Tag>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == UC_BF16 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<BF16Tag, F32Tag>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<F32Tag, F32Tag>), g, b, 0, st, (const float*)src, (float*)dst, n);
+    else if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((convert_kernel<BF16Tag, BF16Tag>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else { uc_set_error("uc_convert: unsupported dtypes %d -> %d", sd, dd); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_convert");
+    return UC_OK;
+}
+
+// =======================================================================================
+// bilinear resize, align_corners=True, NHWC.  src = dst * (in-1)/(out-1); separable weights.
+// (torch: area_pixel_compute_scale -> (in-1)/(out-1) when out>1 else 0; index = scale*dst;
+//  i0 = floor, i1 = min(i0+1, in-1), lambda = index - i0.)  One work item = 8 channels of one output pixel.
+// =======================================================================================
+template <typename Tag>
+__global__ void bilinear_kernel(const typename Tag::storage* __restrict__ src, typename Tag::storage* __restrict__ dst,
+                                int B, int Hi, int Wi, int C, int Ho, int Wo, int ch, int cw, float sy, float sx,
+                                int64_t items) {
+    const int C8 = C / 8;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = it;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int ox = (int)(r % cw); r /= cw;
+        const int oy = (int)(r % ch);
+        const int b = (int)(r / ch);
+        const float fy = sy * (float)oy, fx = sx * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const typename Tag::storage* base = src + (int64_t)b * Hi * Wi * C + c8 * 8;
+        const V8 p00 = load8<Tag>(base + ((int64_t)y0 * Wi + x0) * C);
+        const V8 p01 = load8<Tag>(base + ((int64_t)y0 * Wi + x1) * C);
+        const V8 p10 = load8<Tag>(base + ((int64_t)y1 * Wi + x0) * C);
+        const V8 p11 = load8<Tag>(base + ((int64_t)y1 * Wi + x1) * C);
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o.v[e] = hy * (hx * p00.v[e] + lx * p01.v[e]) + ly * (hx * p10.v[e] + lx * p11.v[e]);
+        store8<Tag>(dst + it * 8, o);
+    }
+}
+
+extern "C" int uc_bilinear_nhwc(const void* src, void* dst, int dtype, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                int crop_h, int crop_w, uc_stream_t stream) {
+    UC_REQUIRE(src && dst, "uc_bilinear_nhwc: null pointer");
+    UC_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0, "uc_bilinear_nhwc: bad shape (C must be a multiple of 8)");
+    UC_REQUIRE(crop_h > 0 && crop_h <= Ho && crop_w > 0 && crop_w <= Wo, "uc_bilinear_nhwc: bad crop");
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const int64_t items = (int64_t)B * crop_h * crop_w * (C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UC_F32)
+        hipLaunchKernelGGL((bilinear_kernel<F32Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const float*)src, (float*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx, items);
+    else if (dtype == UC_BF16)
+        hipLaunchKernelGGL((bilinear_kernel<BF16Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx, items);
+    else { uc_set_error("uc_bilinear_nhwc: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_bilinear_nhwc");
+    return UC_OK;
+}
+
+// =======================================================================================
+// ConvTranspose2d(k=s) pixel scatter: src [B*h*w, k*k*Cout] (columns (u,v,o)) -> dst NHWC [B, k*h, k*w, Cout]
+// =======================================================================================
+template <typename Tag>
+__global__ void convt_scatter_kernel(const typename Tag::storage* __restrict__ src, typename Tag::storage* __restrict__ dst,
+                                     int B, int h, int w, int k, int Cout, int64_t items) {
+    const int C8 = Cout / 8;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        // iterate in destination order
+        int64_t r = it;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int X = (int)(r % (k * w)); r /= (k * w);
+        const int Y = (int)(r % (k * h));
+        const int b = (int)(r / (k * h));
+        const int i = Y / k, u = Y % k, j = X / k, v = X % k;
+        const int64_t srow = ((int64_t)b * h + i) * w + j;
+        const V8 x = load8<Tag>(src + srow * ((int64_t)k * k * Cout) + (int64_t)(u * k + v) * Cout + c8 * 8);
+        store8<Tag>(dst + it * 8, x);
+    }
+}
+
+extern "C" int uc_convt_scatter(const void* src, void* dst, int dtype, int B, int h, int w, int k, int Cout,
+                                uc_stream_t stream) {
+    UC_REQUIRE(src && dst, "uc_convt_scatter: null pointer");
+    UC_REQUIRE(B > 0 && h > 0 && w > 0 && k > 0 && Cout > 0 && Cout % 8 == 0, "uc_convt_scatter: bad shape (Cout must be a multiple of 8)");
+    const int64_t items = (int64_t)B * h * w * k * k * (Cout / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UC_F32)
+        hipLaunchKernelGGL((convt_scatter_kernel<F32Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const float*)src, (float*)dst, B, h, w, k, Cout, items);
+    else if (dtype == UC_BF16)
+        hipLaunchKernelGGL((convt_scatter_kernel<BF16Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, B, h, w, k, Cout, items);
+    else { uc_set_error("uc_convt_scatter: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_convt_scatter");
+    return UC_OK;
+}
+
+// =======================================================================================
+// pixel_shuffle(P): src [B*h*w, Cout*P*P] (column c*P*P + u*P + v) -> dst fp32 NCHW [B, Cout, P*h, P*w]
+// =======================================================================================
+template <typename Tag>
+__global__ void pixel_shuffle_kernel(const typename Tag::storage* __restrict__ src, float* __restrict__ dst, int B, int h,
+                                     int w, int P, int Cout, int64_t n) {
+    const int Wd = P * w, Hd = P * h;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n; it += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = it;
+        const int X = (int)(r % Wd); r /= Wd;
+        const int Y = (int)(r % Hd); r /= Hd;
+        const int c = (int)(r % Cout);
+        const int b = (int)(r / Cout);
+        const int i = Y / P, u = Y % P, j = X / P, v = X % P;
+        const int64_t srow = ((int64_t)b * h + i) * w + j;
+        dst[it] = Tag::load(src + srow * ((int64_t)Cout * P * P) + (int64_t)c * P * P + u * P + v);
+    }
+}
+
+extern "C" int uc_pixel_shuffle(const void* src, int src_dtype, float* dst, int B, int h, int w, int P, int Cout,
+                                uc_stream_t stream) {
+    UC_REQUIRE(src && dst && B > 0 && h > 0 && w > 0 && P > 0 && Cout > 0, "uc_pixel_shuffle: bad argument");
+    const int64_t n = (int64_t)B * Cout * P * h * P * w;
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == UC_F32)
+        hipLaunchKernelGGL((pixel_shuffle_kernel<F32Tag>), dim3(EW_GRID(n)), dim3(256), 0, st, (const float*)src, dst, B, h, w, P, Cout, n);
+    else if (src_dtype == UC_BF16)
+        hipLaunchKernelGGL((pixel_shuffle_kernel<BF16Tag>), dim3(EW_GRID(n)), dim3(256), 0, st, (const bf16_t*)src, dst, B, h, w, P, Cout, n);
+    else { uc_set_error("uc_pixel_shuffle: bad dtype %d", src_dtype); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_pixel_shuffle");
+    return UC_OK;
+}
+
+// =======================================================================================
+// pointmap + confidence adaptor ("exp","exp") fused with the BCHW -> BHWC permute
+// =======================================================================================
+__global__ void pointmap_adaptor_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sp,
+                                        float* __restrict__ pts, float* __restrict__ conf, int64_t HW, int64_t n,
+                                        float vmin, float vspan) {
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = it / HW, pix = it % HW;
+        const float* px = x + b * sb + pix * sp;
+        const float X = px[0], Y = px[sc], Z = px[2 * sc], Cf = px[3 * sc];
+        // torch.norm(dim=1): sqrt of the sum of squares
+        const float d = sqrtf(X * X + Y * Y + Z * Z);
+        const float s = expm1f(d) / fmaxf(d, 1e-8f);
+        pts[it * 3 + 0] = X * s;  // (xyz / clip(d)) * expm1(d); rounding differs from the reference only in op order
+        pts[it * 3 + 1] = Y * s;
+        pts[it * 3 + 2] = Z * s;
+        conf[it] = vmin + fminf(expf(Cf), vspan);
+    }
+}
+
+extern "C" int uc_pointmap_adaptor(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp, float* pts, float* conf,
+                                   int B, int H, int W, float conf_vmin, float conf_vmax, uc_stream_t stream) {
+    UC_REQUIRE(x && pts && conf && B > 0 && H > 0 && W > 0, "uc_pointmap_adaptor: bad argument");
+    const int64_t n = (int64_t)B * H * W;
+    hipLaunchKernelGGL(pointmap_adaptor_kernel, dim3(EW_GRID(n)), dim3(256), 0, (hipStream_t)stream, x, x_sb, x_sc, x_sp,
+                       pts, conf, (int64_t)H * W, n, conf_vmin, conf_vmax - conf_vmin);
+    UC_CHECK_LAUNCH("uc_pointmap_adaptor");
+    return UC_OK;
+}
+
+// =======================================================================================
+// 1x1 conv Cin -> 4 (+bias) on NHWC features: one thread per pixel, weights in LDS (broadcast reads)
+// =======================================================================================
+template <typename Tag>
+__global__ __launch_bounds__(256) void conv1x1_to4_kernel(const typename Tag::storage* __restrict__ feat,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int64_t npix, int Cin) {
+    __shared__ float ws[4][256];
+    for (int i = threadIdx.x; i < 4 * Cin; i += blockDim.x) ws[i / Cin][i % Cin] = w[i];
+    __syncthreads();
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+        float a0 = bias[0], a1 = bias[1], a2 = bias[2], a3 = bias[3];
+        const typename Tag::storage* f = feat + pix * Cin;
+        for (int c = 0; c < Cin; c += 8) {
+            const V8 x = load8<Tag>(f + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a0 = fmaf(x.v[e], ws[0][c + e], a0);
+                a1 = fmaf(x.v[e], ws[1][c + e], a1);
+                a2 = fmaf(x.v[e], ws[2][c + e], a2);
+                a3 = fmaf(x.v[e], ws[3][c + e], a3);
+            }
+        }
+        *reinterpret_cast<float4_t*>(out + pix * 4) = (float4_t){a0, a1, a2, a3};
+    }
+}
+
+extern "C" int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const float* b, float* out, int64_t npix,
+                              int Cin, uc_stream_t stream) {
+    UC_REQUIRE(feat && w && b && out && npix > 0, "uc_conv1x1_to4: bad argument");
+    UC_REQUIRE(Cin > 0 && Cin <= 256 && Cin % 8 == 0, "uc_conv1x1_to4: Cin must be a multiple of 8 and <= 256 (got %d)", Cin);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UC_F32)
+        hipLaunchKernelGGL((conv1x1_to4_kernel<F32Tag>), dim3(EW_GRID(npix)), dim3(256), 0, st, (const float*)feat, w, b, out, npix, Cin);
+    else if (dtype == UC_BF16)
+        hipLaunchKernelGGL((conv1x1_to4_kernel<BF16Tag>), dim3(EW_GRID(npix)), dim3(256), 0, st, (const bf16_t*)feat, w, b, out, npix, Cin);
+    else { uc_set_error("uc_conv1x1_to4: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_conv1x1_to4");
+    return UC_OK;
+}

@@ -1,0 +1,295 @@
+"""Tensor-level wrappers over the C ABI (include/uc_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every function below
+hands raw device pointers + sizes/strides to libuc_hip.so.  Nothing in this module computes with
+torch ops, and nothing falls back to the CPU: tensors must live on a HIP device.
+"""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (GemmDesc, UC_A_CONV3X3, UC_A_DENSE, UC_ACT_GELU_ERF, UC_ACT_NONE, UC_ACT_RELU, UC_BF16, UC_F16,
+                   UC_F32, UC_V_PACKED_T, UC_V_ROWMAJOR, UcHipError)
+
+_DT = {torch.float32: UC_F32, torch.bfloat16: UC_BF16, torch.float16: UC_F16}
+ACT = {None: UC_ACT_NONE, "none": UC_ACT_NONE, "gelu": UC_ACT_GELU_ERF, "relu": UC_ACT_RELU}
+
+
+def _dt(t: torch.dtype) -> int:
+    try:
+        return _DT[t]
+    except KeyError:
+        raise UcHipError(f"dtype {t} is not supported by the HIP kernels")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise UcHipError(
+                "uniception_amd kernels run on a HIP device only (got a CPU tensor); there is no CPU fallback. "
+                "Use the reference implementation or oracle/ for CPU execution."
+            )
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------------
+def rope_2d_(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
+    """In-place RoPE-2D on tokens [B,N,H,D] (any strides with stride(3)==1); positions [B,N,2] int64.
+    Same contract as curope.rope_2d (curope.cpp:49-69)."""
+    if tokens.dim() != 4:
+        raise RuntimeError("tokens must have 4 dimensions")
+    if positions.dim() != 3:
+        raise RuntimeError("positions must have 3 dimensions")
+    if tokens.size(0) != positions.size(0):
+        raise RuntimeError("batch size differs between tokens & positions")
+    if tokens.size(1) != positions.size(1):
+        raise RuntimeError("seq_length differs between tokens & positions")
+    if positions.size(2) != 2:
+        raise RuntimeError("positions.shape[2] must be equal to 2")
+    if tokens.is_cuda != positions.is_cuda:
+        raise RuntimeError("tokens and positions are not on the same device")
+    _need_gpu(tokens, positions)
+    if tokens.stride(3) != 1:
+        raise RuntimeError("tokens are not contiguous in the last dimension")
+    if positions.dtype != torch.int64 or not positions.is_contiguous():
+        raise RuntimeError("positions must be a contiguous int64 tensor")
+    B, N, H, D = tokens.shape
+    lib = _lib.load()
+    _lib.check(lib.uc_rope2d(tokens.data_ptr(), positions.data_ptr(), B, N, H, D, tokens.stride(0), tokens.stride(1),
+                             tokens.stride(2), float(base), float(fwd), _dt(tokens.dtype), _stream()), "uc_rope2d")
+
+
+_rope_tables = {}
+
+
+def rope_table(device, npos: int, base: float, F0: float = 1.0) -> torch.Tensor:
+    """[npos,16,2] fp32 cos/sin table for the fused GEMM epilogue (head_dim 64 -> Q=16); cached per device."""
+    npos = max(64, (npos + 63) // 64 * 64)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), npos, float(base), float(F0))
+    t = _rope_tables.get(key)
+    if t is None:
+        t = torch.empty(npos, 16, 2, dtype=torch.float32, device=device)
+        _lib.check(_lib.load().uc_rope_table(t.data_ptr(), npos, 16, float(base), float(F0), _stream()), "uc_rope_table")
+        _rope_tables[key] = t
+    return t
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, out_dtype: torch.dtype) -> torch.Tensor:
+    """x [..., C] contiguous (fp32|bf16) -> same shape in out_dtype."""
+    _need_gpu(x, weight, bias)
+    assert x.is_contiguous() and weight.dtype == torch.float32 and bias.dtype == torch.float32
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.load().uc_layernorm(x.data_ptr(), _dt(x.dtype), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                        _dt(out_dtype), rows, Cn, float(eps), _stream()), "uc_layernorm")
+    return y
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
+         residual: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+         out: Optional[torch.Tensor] = None, relu_a: bool = False,
+         rope: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
+         vt: Optional[Tuple[int, torch.Tensor, int]] = None,
+         conv: Optional[Tuple[int, int, int, int, int]] = None) -> torch.Tensor:
+    """C[M,N] = epilogue(A . W^T).
+
+    a    : dense [M,K] (row stride a.stride(0), unit column stride) or, with conv=(B,H,W,Cin,stride), an NHWC image.
+    w    : [N,K] contiguous, same dtype as a (fp32 -> exact fp32 kernel, bf16 -> MFMA kernel).
+    rope : (positions [M,2] int64, table, rope_cols) -> fused RoPE-2D on the first rope_cols columns (bf16 only).
+    vt   : (vt_col0, vt_out [B,H,64,Npad] bf16, ntok) -> V columns written in the packed VT layout (bf16 only).
+    """
+    _need_gpu(a, w, bias, residual)
+    assert a.dtype == w.dtype and w.is_contiguous() and w.dim() == 2
+    cd = _dt(a.dtype)
+    N, K = w.shape
+    d = GemmDesc()
+    d.compute_dtype = cd
+    d.relu_a = 1 if relu_a else 0
+    d.A, d.W = a.data_ptr(), w.data_ptr()
+    if conv is None:
+        assert a.dim() == 2 and a.stride(1) == 1 and a.shape[1] == K
+        M = a.shape[0]
+        d.a_mode, d.lda = UC_A_DENSE, a.stride(0)
+    else:
+        Bc, Hc, Wc, Cin, s = conv
+        assert a.is_contiguous() and a.numel() == Bc * Hc * Wc * Cin and K == 9 * Cin
+        Ho, Wo = (Hc - 1) // s + 1, (Wc - 1) // s + 1
+        M = Bc * Ho * Wo
+        d.a_mode, d.lda = UC_A_CONV3X3, 0
+        d.conv_B, d.conv_H, d.conv_W, d.conv_Cin, d.conv_stride, d.conv_Ho, d.conv_Wo = Bc, Hc, Wc, Cin, s, Ho, Wo
+    d.M, d.N, d.K = M, N, K
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
+    d.bias = _p(bias)
+    d.act = ACT[act]
+    if residual is not None:
+        assert residual.dim() == 2 and residual.stride(1) == 1 and residual.shape == (M, N)
+        d.residual, d.res_dtype, d.ldr = residual.data_ptr(), _dt(residual.dtype), residual.stride(0)
+    n_out = N
+    d.vt_col0 = -1
+    if vt is not None:
+        vt_col0, vt_out, ntok = vt
+        assert vt_out.dtype == torch.bfloat16 and vt_out.is_contiguous()
+        d.vt_col0, d.vt_out, d.vt_ntok, d.vt_npad = vt_col0, vt_out.data_ptr(), ntok, vt_out.shape[-1]
+        n_out = vt_col0
+    if rope is not None:
+        pos, table, rope_cols = rope
+        assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * M
+        d.rope_cols, d.rope_pos, d.rope_table, d.rope_npos = rope_cols, pos.data_ptr(), table.data_ptr(), table.shape[0]
+    if out is None:
+        out = torch.empty((M, n_out), dtype=out_dtype or a.dtype, device=a.device)
+    else:
+        assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] >= n_out
+    d.C, d.out_dtype, d.ldc = out.data_ptr(), _dt(out.dtype), out.stride(0)
+    _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
+    return out
+
+
+def vt_buffer(B: int, H: int, ntok: int, device) -> torch.Tensor:
+    npad = (ntok + 63) // 64 * 64
+    return torch.empty((B, H, 64, npad), dtype=torch.bfloat16, device=device)
+
+
+def vt_pack(v: torch.Tensor) -> torch.Tensor:
+    """v: [B,N,H,D] bf16 view (stride(3)==1) -> packed VT [B,H,D,Npad]."""
+    _need_gpu(v)
+    B, N, H, D = v.shape
+    assert v.dtype == torch.bfloat16 and v.stride(3) == 1
+    npad = (N + 63) // 64 * 64
+    out = torch.empty((B, H, D, npad), dtype=torch.bfloat16, device=v.device)
+    _lib.check(_lib.load().uc_vt_pack(v.data_ptr(), out.data_ptr(), B, H, N, D, v.stride(0), v.stride(1), v.stride(2),
+                                      _stream()), "uc_vt_pack")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, v_packed: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B,Nq,H,D], k [B,Nk,H,D] strided views (stride(3)==1); v same, or packed VT [B,H,D,Npad] when v_packed.
+    Returns O [B,Nq,H,D] contiguous (== [B,Nq,H*D])."""
+    _need_gpu(q, k, v)
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    assert q.stride(3) == 1 and k.stride(3) == 1 and q.dtype == k.dtype == v.dtype
+    if out is None:
+        out = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device)
+    if v_packed:
+        vs = (0, 0, 0)
+        assert v.is_contiguous() and v.shape[-1] == (Nk + 63) // 64 * 64
+    else:
+        assert v.stride(3) == 1
+        vs = (v.stride(0), v.stride(1), v.stride(2))
+    _lib.check(_lib.load().uc_attention_fwd(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _dt(q.dtype), UC_V_PACKED_T if v_packed else UC_V_ROWMAJOR,
+        B, H, Nq, Nk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), vs[0], vs[1], vs[2],
+        out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()), "uc_attention_fwd")
+    return out
+
+
+def patch_gather(img: torch.Tensor, P: int, out_dtype: torch.dtype) -> torch.Tensor:
+    _need_gpu(img)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4
+    B, Cin, H, W = img.shape
+    cols = torch.empty((B * (H // P) * (W // P), Cin * P * P), dtype=out_dtype, device=img.device)
+    _lib.check(_lib.load().uc_patch_gather(img.data_ptr(), cols.data_ptr(), _dt(out_dtype), B, Cin, H, W, P, _stream()),
+               "uc_patch_gather")
+    return cols
+
+
+def nchw_to_nhwc(x: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """x [B,C,H,W] contiguous -> [B,H,W,C] contiguous in out_dtype."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dim() == 4
+    B, Cn, H, W = x.shape
+    y = torch.empty((B, H, W, Cn), dtype=out_dtype, device=x.device)
+    _lib.check(_lib.load().uc_nchw_to_nhwc(x.data_ptr(), _dt(x.dtype), y.data_ptr(), _dt(out_dtype), B, Cn, H, W, _stream()),
+               "uc_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """x [B,H,W,C] contiguous -> [B,C,H,W] contiguous in out_dtype."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dim() == 4
+    B, H, W, Cn = x.shape
+    y = torch.empty((B, Cn, H, W), dtype=out_dtype, device=x.device)
+    _lib.check(_lib.load().uc_nhwc_to_nchw(x.data_ptr(), _dt(x.dtype), y.data_ptr(), _dt(out_dtype), B, Cn, H, W, _stream()),
+               "uc_nhwc_to_nchw")
+    return y
+
+
+def convert(x: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.is_contiguous()
+    if x.dtype == out_dtype:
+        return x
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.load().uc_convert(x.data_ptr(), _dt(x.dtype), y.data_ptr(), _dt(out_dtype), x.numel(), _stream()),
+               "uc_convert")
+    return y
+
+
+def bilinear_nhwc(x: torch.Tensor, Ho: int, Wo: int, crop: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """align_corners=True bilinear resize of NHWC x to (Ho,Wo), optionally keeping only the top-left crop."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dim() == 4
+    B, Hi, Wi, Cn = x.shape
+    ch, cw = crop if crop is not None else (Ho, Wo)
+    y = torch.empty((B, ch, cw, Cn), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().uc_bilinear_nhwc(x.data_ptr(), y.data_ptr(), _dt(x.dtype), B, Hi, Wi, Cn, Ho, Wo, ch, cw, _stream()),
+               "uc_bilinear_nhwc")
+    return y
+
+
+def convt_scatter(x: torch.Tensor, B: int, h: int, w: int, k: int, Cout: int) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.is_contiguous() and x.shape == (B * h * w, k * k * Cout)
+    y = torch.empty((B, k * h, k * w, Cout), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().uc_convt_scatter(x.data_ptr(), y.data_ptr(), _dt(x.dtype), B, h, w, k, Cout, _stream()),
+               "uc_convt_scatter")
+    return y
+
+
+def pixel_shuffle(x: torch.Tensor, B: int, h: int, w: int, P: int, Cout: int) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.is_contiguous() and x.shape == (B * h * w, Cout * P * P)
+    y = torch.empty((B, Cout, P * h, P * w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().uc_pixel_shuffle(x.data_ptr(), _dt(x.dtype), y.data_ptr(), B, h, w, P, Cout, _stream()),
+               "uc_pixel_shuffle")
+    return y
+
+
+def pointmap_adaptor(x: torch.Tensor, conf_vmin: float, conf_vmax: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x: fp32 4-channel map given as a BCHW-shaped tensor (contiguous NCHW or channels-last strides).
+    Returns (pts [B,H,W,3], conf [B,H,W,1]) fp32 contiguous."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 4
+    B, _, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    if sh != W * sw:
+        raise UcHipError("pointmap_adaptor: rows of the 4-channel map must be densely packed")
+    pts = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device)
+    conf = torch.empty((B, H, W, 1), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().uc_pointmap_adaptor(x.data_ptr(), sb, sc, sw, pts.data_ptr(), conf.data_ptr(), B, H, W,
+                                               float(conf_vmin), float(conf_vmax), _stream()), "uc_pointmap_adaptor")
+    return pts, conf
+
+
+def conv1x1_to4(feat: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """feat NHWC [B,H,W,Cin]; w fp32 [4,Cin]; b fp32 [4] -> fp32 NHWC [B,H,W,4]."""
+    _need_gpu(feat, w, b)
+    assert feat.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous() and w.shape[0] == 4
+    B, H, W, Cin = feat.shape
+    out = torch.empty((B, H, W, 4), dtype=torch.float32, device=feat.device)
+    _lib.check(_lib.load().uc_conv1x1_to4(feat.data_ptr(), _dt(feat.dtype), w.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                          B * H * W, Cin, _stream()), "uc_conv1x1_to4")
+    return out
