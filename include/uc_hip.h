@@ -86,6 +86,7 @@ typedef struct uc_gemm_desc {
     const float* bias;   /* [N] fp32 or NULL */
     int act;             /* uc_act, applied after bias */
     const void* residual; /* [M,N] (ld = ldr) added after act, or NULL */
+    const void* residual2; /* optional second addend, same dtype and ld as residual (DPT fusion: path + RCU(skip)) */
     int res_dtype;
     int64_t ldr;
     /* fused RoPE-2D on output columns [0, rope_cols): columns are (head, d) with head_dim 64;

@@ -1,0 +1,67 @@
+"""CPU: the C-ABI shared library loads and exports every entry point include/uc_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "uc_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(uc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_hot_path_entry_points():
+    syms = declared_symbols()
+    for must in ("uc_rope2d", "uc_layernorm", "uc_gemm", "uc_attention_fwd", "uc_patch_gather", "uc_bilinear_nhwc",
+                 "uc_convt_scatter", "uc_pixel_shuffle", "uc_pointmap_adaptor", "uc_conv1x1_to4", "uc_vt_pack"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from uniception_amd import _lib, build
+
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in uc_hip.h but not exported: {missing}"
+    # the ctypes signature table covers the same set
+    assert sorted(list(_lib.SIGNATURES.keys()) + ["uc_last_error"]) == declared_symbols()
+    loaded = _lib.load()
+    assert loaded.uc_abi_version() == 1
+    assert loaded.uc_last_error() is not None
+
+
+def test_gemm_descriptor_layout_matches_header():
+    """Field order of the ctypes mirror == field order of struct uc_gemm_desc."""
+    from uniception_amd._lib import GemmDesc
+
+    text = open(HEADER).read()
+    body = re.search(r"typedef struct uc_gemm_desc \{(.*?)\} uc_gemm_desc;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(void|float|int64_t|int)\s*\*?\s*", "", decl)
+        names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
+    assert names == [f[0] for f in GemmDesc._fields_]
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    from uniception_amd import ops
+    from uniception_amd._lib import UcHipError
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(UcHipError):
+        ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-6, torch.float32)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d_(torch.zeros(1, 2, 1, 64), torch.zeros(1, 2, 2, dtype=torch.int64), 100.0, 1.0)

@@ -1,0 +1,117 @@
+"""GPU parity of the nn.Module mirror against the golden vectors of the real reference.
+
+fp32 mode (exact-fp32 kernels) must meet the north-star bar: 1e-3 relative on every captured tensor (it lands
+around 1e-6..1e-5).  bf16 mode (MFMA operands bf16, fp32 accumulate, fp32 residual stream) is held to the error the
+reference itself shows under bf16 autocast (~1e-2 rel-L2 on encoder/decoder features)."""
+import pytest
+import torch
+
+from tests.golden.cases import CASES
+from tests.helpers import build_case_model, case_images, compare_to_golden, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-3
+# bf16: encoder/decoder features ~1e-2; decoded channels pass through exp/expm1, which amplifies absolute error
+BF16_TOL = {"default": 4e-2}
+
+
+def run_case(name, gpu, mode):
+    from uniception_amd import engine
+
+    model, c = build_case_model(name)
+    model = model.to(gpu)
+    img1, img2 = (t.to(gpu) for t in case_images(c))
+    collect = {}
+    with torch.no_grad(), engine.precision(mode):
+        if c.get("factory"):
+            v1 = {"img": img1, "instance": [str(i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+            v2 = {"img": img2, "instance": [str(100 + i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+            r1, r2 = model(v1, v2)
+        else:
+            r1, r2 = model(img1, img2, collect)
+    torch.cuda.synchronize()
+    tensors = dict(collect)
+    tensors.update(pts3d_1=r1["pts3d"], conf_1=r1["conf"], pts3d_2=r2["pts3d_in_other_view"], conf_2=r2["conf"])
+    for k in ("pts3d_1", "pts3d_2"):
+        assert tensors[k].shape == (c["B"], c["img"][0], c["img"][1], 3) and tensors[k].is_contiguous()
+    for k in ("conf_1", "conf_2"):
+        assert tensors[k].shape == (c["B"], c["img"][0], c["img"][1], 1) and tensors[k].is_contiguous()
+    return tensors, c
+
+
+@pytest.mark.parametrize("name", list(CASES.keys()))
+def test_fp32_parity_1e3(gpu, name):
+    tensors, c = run_case(name, gpu, "fp32")
+    report = {}
+    worst = compare_to_golden(load_golden(name), tensors, c, tol=FP32_TOL, report=report)
+    print(f"\n[fp32] {name}: worst {worst[0]} {worst[1]:.2e}")
+
+
+@pytest.mark.parametrize("name", list(CASES.keys()))
+def test_bf16_parity(gpu, name):
+    tensors, c = run_case(name, gpu, "bf16")
+    report = {}
+    worst = compare_to_golden(load_golden(name), tensors, c, tol=BF16_TOL["default"], report=report)
+    print(f"\n[bf16] {name}: worst {worst[0]} {worst[1]:.2e}; " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(report.items())))
+
+
+def test_autocast_selects_bf16_and_heads_follow_reference_policy(gpu):
+    """Under torch.autocast the transformer runs the bf16 MFMA path; results equal engine.precision('bf16')."""
+    from uniception_amd import engine
+
+    model, c = build_case_model("tiny_linear")
+    model = model.to(gpu)
+    img1, img2 = (t.to(gpu) for t in case_images(c))
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert engine.compute_dtype() == torch.bfloat16
+            a1, _ = model(img1, img2, {})
+        assert engine.compute_dtype() == torch.float32
+        with engine.precision("bf16"):
+            b1, _ = model(img1, img2, {})
+    assert torch.equal(a1["pts3d"], b1["pts3d"])
+
+
+def test_symmetrized_batch_shortcut(gpu):
+    """(a,b),(b,a) batches encode each image once and interleave (factory/dust3r.py:227-238): same outputs."""
+    from uniception_amd.models.factory import DUSt3R
+    from oracle import dust3r_oracle as O
+    from tests.golden.cases import GAINS
+
+    model = DUSt3R(name="s", img_size=(32, 48), pred_head_type="linear").eval()
+    # shrink: keep the test light by using only the first blocks
+    model.encoder.enc_blocks = model.encoder.enc_blocks[:2]
+    model.info_sharing.depth = 2
+    O.fill_state_dict_(model.state_dict(), gains=GAINS)
+    model = model.to(gpu)
+    a, b = O.make_images(5, 1, 32, 48)
+    img1 = torch.cat([a, b]).to(gpu)
+    img2 = torch.cat([b, a]).to(gpu)
+    sym1 = {"img": img1, "instance": ["p", "q"], "data_norm_type": "dust3r"}
+    sym2 = {"img": img2, "instance": ["q", "p"], "data_norm_type": "dust3r"}
+    ns1 = {"img": img1, "instance": ["p", "q"], "data_norm_type": "dust3r"}
+    ns2 = {"img": img2, "instance": ["x", "y"], "data_norm_type": "dust3r"}
+    with torch.no_grad():
+        s1, s2 = model(sym1, sym2)
+        n1, n2 = model(ns1, ns2)
+    assert torch.allclose(s1["pts3d"], n1["pts3d"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(s2["conf"], n2["conf"], rtol=1e-5, atol=1e-6)
+
+
+def test_contiguous_nchw_inputs_are_accepted(gpu):
+    """Decoder and heads accept plain contiguous NCHW tensors (what reference-style callers pass) as well as the
+    channels-last views produced by the HIP encoder."""
+    from uniception_amd.models.info_sharing.base import MultiViewTransformerInput
+
+    model, c = build_case_model("tiny_linear")
+    model = model.to(gpu)
+    img1, img2 = (t.to(gpu) for t in case_images(c))
+    from uniception_amd.models.encoders.base import ViTEncoderInput
+    with torch.no_grad():
+        f = model.encoder(ViTEncoderInput(image=torch.cat([img1, img2]), data_norm_type="dust3r")).features
+        f1, f2 = f.chunk(2)
+        a = model.info_sharing(MultiViewTransformerInput(features=[f1, f2]))
+        b = model.info_sharing(MultiViewTransformerInput(features=[f1.contiguous(), f2.contiguous()]))
+    assert torch.equal(a.features[0], b.features[0]) and torch.equal(a.features[1], b.features[1])
+    assert not f1.is_contiguous() and f1.contiguous().is_contiguous()

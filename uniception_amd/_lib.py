@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("A", vp), ("lda", i64), ("W", vp), ("M", i64), ("N", i64), ("K", i64),
         ("conv_B", i32), ("conv_H", i32), ("conv_W", i32), ("conv_Cin", i32), ("conv_stride", i32),
         ("conv_Ho", i32), ("conv_Wo", i32),
-        ("bias", vp), ("act", i32), ("residual", vp), ("res_dtype", i32), ("ldr", i64),
+        ("bias", vp), ("act", i32), ("residual", vp), ("residual2", vp), ("res_dtype", i32), ("ldr", i64),
         ("rope_cols", i64), ("rope_pos", vp), ("rope_table", vp), ("rope_npos", i32),
         ("vt_col0", i64), ("vt_out", vp), ("vt_ntok", i32), ("vt_npad", i32),
         ("C", vp), ("out_dtype", i32), ("ldc", i64),

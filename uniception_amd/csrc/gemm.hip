@@ -30,6 +30,7 @@ struct GemmParams {
     const float* bias;
     int act;
     const void* residual;
+    const void* residual2;
     int res_dtype;
     int64_t ldr;
     int64_t rope_cols;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
                 if (n >= p.N) continue;
                 float o = v[j];
                 if (p.residual) o += load_res(p.residual, p.res_dtype, m * p.ldr + n);
+                if (p.residual2) o += load_res(p.residual2, p.res_dtype, m * p.ldr + n);
                 store_out(p.C, p.out_dtype, m * p.ldc + n, o);
             }
         }
@@ -411,6 +413,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             float v = acc[i][j] + (p.bias ? p.bias[n] : 0.f);
             v = apply_act(v, p.act);
             if (p.residual) v += load_res(p.residual, p.res_dtype, m * p.ldr + n);
+            if (p.residual2) v += load_res(p.residual2, p.res_dtype, m * p.ldr + n);
             store_out(p.C, p.out_dtype, m * p.ldc + n, v);
         }
     }
@@ -425,6 +428,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     UC_REQUIRE(d->a_mode == UC_A_DENSE || d->a_mode == UC_A_CONV3X3, "uc_gemm: bad a_mode %d", d->a_mode);
     UC_REQUIRE(d->out_dtype == UC_F32 || d->out_dtype == UC_BF16, "uc_gemm: bad out_dtype %d", d->out_dtype);
     UC_REQUIRE(d->act >= UC_ACT_NONE && d->act <= UC_ACT_RELU, "uc_gemm: bad act %d", d->act);
+    UC_REQUIRE(d->residual || !d->residual2, "uc_gemm: residual2 without residual");
     if (d->residual)
         UC_REQUIRE(d->res_dtype == UC_F32 || d->res_dtype == UC_BF16, "uc_gemm: bad res_dtype %d", d->res_dtype);
     if (d->M == 0) return UC_OK;
@@ -433,7 +437,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     p.A = d->A; p.lda = d->lda; p.W = d->W; p.M = d->M; p.N = d->N; p.K = d->K; p.relu_a = d->relu_a;
     p.cB = d->conv_B; p.cH = d->conv_H; p.cW = d->conv_W; p.cCin = d->conv_Cin; p.cStride = d->conv_stride;
     p.cHo = d->conv_Ho; p.cWo = d->conv_Wo;
-    p.bias = d->bias; p.act = d->act; p.residual = d->residual; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
+    p.bias = d->bias; p.act = d->act; p.residual = d->residual; p.residual2 = d->residual2; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
     p.rope_cols = d->rope_cols; p.rope_pos = d->rope_pos; p.rope_table = (const float2*)d->rope_table;
     p.rope_npos = d->rope_npos; p.vt_col0 = d->vt_col0; p.vt_out = (bf16_t*)d->vt_out; p.vt_ntok = d->vt_ntok;
     p.vt_npad = d->vt_npad; p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;

@@ -1,0 +1,313 @@
+"""Execution engine of the DUSt3R hot path: precision policy, prepared-weight cache and the fused
+token-stream / NHWC pipelines that the nn.Module shells in ``uniception_amd.models`` call.
+
+Data layout in HBM
+  * token stream  : [B*N, C] row-major ("NLC"), residual stream fp32 (as the reference keeps it under autocast:
+                    LayerNorm outputs fp32, residual adds promote to fp32), GEMM operands in the compute dtype.
+  * q|k buffer    : [B*N, 2C] compute dtype, RoPE already applied by the QKV GEMM epilogue (bf16 mode);
+                    V is written by the same GEMM in the packed "VT" layout [B,H,64,Npad] the attention kernel wants.
+  * dense maps    : NHWC in the compute dtype inside the DPT head; BCHW-shaped tensors at the public API are
+                    channels-last *views* of the same memory (no transposes), contiguous NCHW inputs are converted once.
+
+Precision: fp32 ("verification mode", exact-fp32 kernels) unless CUDA autocast is active or
+``precision("bf16")`` is in force, in which case GEMM/attention operands are bf16 with fp32 accumulation.
+"""
+import contextlib
+import os
+import weakref
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import UcHipError
+
+_forced_dtype: Optional[torch.dtype] = None
+_head_mode: str = os.environ.get("UNICEPTION_AMD_HEAD_PRECISION", "follow")  # "follow" | "fp32"
+ROPE_TABLE_NPOS = 1024  # positions covered by the fused-epilogue cos/sin table (16k px at patch 16)
+
+
+@contextlib.contextmanager
+def precision(name: Optional[str]):
+    """Force the compute dtype of the transformer GEMMs/attention: "fp32" | "bf16" | None (follow autocast)."""
+    global _forced_dtype
+    prev = _forced_dtype
+    _forced_dtype = {None: None, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                     "bfloat16": torch.bfloat16}[name]
+    try:
+        yield
+    finally:
+        _forced_dtype = prev
+
+
+def set_head_precision(mode: str) -> None:
+    """"follow": prediction heads use the compute dtype; "fp32": heads always run the exact-fp32 kernels
+    (what the reference does by disabling autocast around them, factory/dust3r.py:309)."""
+    global _head_mode
+    assert mode in ("follow", "fp32")
+    _head_mode = mode
+
+
+def compute_dtype() -> torch.dtype:
+    if _forced_dtype is not None:
+        return _forced_dtype
+    if torch.is_autocast_enabled("cuda"):
+        # fp16 autocast (the reference's profile_dust3r.py default) is served by the bf16 MFMA path
+        return torch.bfloat16
+    return torch.float32
+
+
+def head_dtype() -> torch.dtype:
+    return torch.float32 if _head_mode == "fp32" else compute_dtype()
+
+
+def require_inference(*tensors) -> None:
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise UcHipError(
+            "uniception_amd: the HIP backward kernels are not implemented yet; run the forward under torch.no_grad() "
+            "(inputs/parameters requiring grad were passed with grad mode enabled)."
+        )
+
+
+# ---------------------------------------------------------------------------------------------
+# prepared weights: compute-dtype copies / re-laid-out tensors derived from nn.Parameters, cached per
+# (owner module, tag) and invalidated when any source parameter is modified or replaced.
+# ---------------------------------------------------------------------------------------------
+_prep_cache = weakref.WeakKeyDictionary()
+
+
+def prepared(owner: nn.Module, tag, sources: Sequence[Optional[torch.Tensor]], build):
+    stamp = tuple((s.data_ptr(), s._version, s.device, s.dtype) if s is not None else None for s in sources)
+    slot = _prep_cache.setdefault(owner, {})
+    hit = slot.get(tag)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    with torch.no_grad():
+        val = build()
+    slot[tag] = (stamp, val)
+    return val
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.detach().float().contiguous()
+
+
+def lin_weights(lin: nn.Linear, dtype: torch.dtype):
+    """(W [N,K] in dtype, bias fp32|None) of an nn.Linear."""
+    return prepared(lin, ("lin", dtype), (lin.weight, lin.bias),
+                    lambda: (lin.weight.detach().to(dtype).contiguous(), _f32c(lin.bias)))
+
+
+def kv_weights(projk: nn.Linear, projv: nn.Linear, dtype: torch.dtype):
+    """Concatenated [Wk; Wv] so K and V of the other view come out of one GEMM."""
+    def build():
+        w = torch.cat([projk.weight.detach(), projv.weight.detach()], 0).to(dtype).contiguous()
+        if projk.bias is None and projv.bias is None:
+            b = None
+        else:
+            zk = projk.bias.detach() if projk.bias is not None else torch.zeros_like(projk.weight[:, 0])
+            zv = projv.bias.detach() if projv.bias is not None else torch.zeros_like(projv.weight[:, 0])
+            b = torch.cat([zk, zv]).float().contiguous()
+        return w, b
+    return prepared(projk, ("kv", dtype), (projk.weight, projk.bias, projv.weight, projv.bias), build)
+
+
+def conv1x1_weights(conv: nn.Conv2d, dtype: torch.dtype):
+    return prepared(conv, ("c1", dtype), (conv.weight, conv.bias),
+                    lambda: (conv.weight.detach().reshape(conv.out_channels, -1).to(dtype).contiguous(), _f32c(conv.bias)))
+
+
+def conv3x3_weights(conv: nn.Conv2d, dtype: torch.dtype):
+    """[Cout, 9*Cin] with K ordered (ky,kx,c) to match the NHWC implicit-GEMM gather."""
+    return prepared(conv, ("c3", dtype), (conv.weight, conv.bias),
+                    lambda: (conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.out_channels, -1).to(dtype).contiguous(),
+                             _f32c(conv.bias)))
+
+
+def convt_weights(ct: nn.ConvTranspose2d, dtype: torch.dtype):
+    """ConvTranspose2d(k=s): weight [Cin,Cout,k,k] -> GEMM weight [(u,v,o), Cin]; bias repeated per (u,v)."""
+    k = ct.kernel_size[0]
+
+    def build():
+        w = ct.weight.detach().permute(2, 3, 1, 0).reshape(k * k * ct.out_channels, ct.in_channels).to(dtype).contiguous()
+        b = None if ct.bias is None else ct.bias.detach().float().repeat(k * k).contiguous()
+        return w, b
+    return prepared(ct, ("ct", dtype), (ct.weight, ct.bias), build)
+
+
+def patch_weights(conv: nn.Conv2d, dtype: torch.dtype):
+    return prepared(conv, ("pe", dtype), (conv.weight, conv.bias),
+                    lambda: (conv.weight.detach().reshape(conv.out_channels, -1).to(dtype).contiguous(), _f32c(conv.bias)))
+
+
+def ln_params(ln: nn.LayerNorm):
+    return prepared(ln, "ln", (ln.weight, ln.bias), lambda: (_f32c(ln.weight), _f32c(ln.bias)))
+
+
+# ---------------------------------------------------------------------------------------------
+# layout helpers at the public BCHW boundary
+# ---------------------------------------------------------------------------------------------
+def nlc_as_bchw(x2d: torch.Tensor, B: int, h: int, w: int) -> torch.Tensor:
+    """[B*h*w, C] -> BCHW-shaped channels-last view (no copy)."""
+    return x2d.view(B, h, w, x2d.shape[-1]).permute(0, 3, 1, 2)
+
+
+def bchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """BCHW-shaped tensor -> contiguous NHWC tensor in `dtype` (free when it already is a channels-last view)."""
+    B, C, H, W = feat.shape
+    nhwc = feat.permute(0, 2, 3, 1)
+    if nhwc.is_contiguous():
+        return nhwc if nhwc.dtype == dtype else ops.convert(nhwc, dtype)
+    if not feat.is_contiguous():
+        feat = feat.contiguous()
+    return ops.nchw_to_nhwc(feat, dtype)
+
+
+def layernorm(x: torch.Tensor, ln: nn.LayerNorm, out_dtype: torch.dtype) -> torch.Tensor:
+    g, b = ln_params(ln)
+    return ops.layernorm(x, g, b, ln.eps, out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# RoPE plumbing
+# ---------------------------------------------------------------------------------------------
+def is_native_rope(rope) -> bool:
+    return rope is not None and getattr(rope, "_uc_native_rope", False)
+
+
+def _rope_epilogue(rope, pos2d: torch.Tensor, cols: int):
+    table = ops.rope_table(pos2d.device, ROPE_TABLE_NPOS, rope.base, rope.F0)
+    return (pos2d, table, cols)
+
+
+def _pos2d(pos: torch.Tensor) -> torch.Tensor:
+    if pos.dtype != torch.int64:
+        pos = pos.long()
+    return pos.reshape(-1, 2).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# attention sub-graphs on the token stream.  x2d: [B*N, C]; returns the attention-branch output
+# (proj applied) with `residual` added by the proj GEMM epilogue when given.
+# ---------------------------------------------------------------------------------------------
+def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.Linear, num_heads: int, rope, pos,
+                   scale: float, residual: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+    dtype = h2d.dtype
+    M, Cd = h2d.shape
+    Dh = Cd // num_heads
+    wq, bq = lin_weights(qkv, dtype)
+    wp, bp = lin_weights(proj, dtype)
+    native = rope is None or is_native_rope(rope)
+    if dtype == torch.bfloat16 and Dh == 64 and native:
+        vt = ops.vt_buffer(B, num_heads, N, h2d.device)
+        ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
+        qk = ops.gemm(h2d, wq, bq, rope=ep, vt=(2 * Cd, vt, N))
+        qk5 = qk.view(B, N, 2, num_heads, Dh)
+        o = ops.attention(qk5[:, :, 0], qk5[:, :, 1], vt, scale, v_packed=True)
+    else:
+        if dtype == torch.bfloat16 and Dh != 64:
+            raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh}); use fp32 precision for this model")
+        t = ops.gemm(h2d, wq, bq).view(B, N, 3, num_heads, Dh)
+        q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
+        q, k = _apply_rope(rope, q, k, pos, pos)
+        o = _attention_generic(q, k, v, scale)
+    return ops.gemm(o.view(M, Cd), wp, bp, residual=residual, out_dtype=out_dtype)
+
+
+def _apply_rope(rope, q, k, qpos, kpos):
+    """q,k: [B,N,H,D] views.  Native rope rotates in place; a foreign callable gets the reference's [B,H,N,D] view."""
+    if rope is None:
+        return q, k
+    if is_native_rope(rope):
+        ops.rope_2d_(q, qpos.contiguous(), rope.base, rope.F0)
+        ops.rope_2d_(k, kpos.contiguous(), rope.base, rope.F0)
+        return q, k
+    return rope(q.transpose(1, 2), qpos).transpose(1, 2), rope(k.transpose(1, 2), kpos).transpose(1, 2)
+
+
+def _attention_generic(q, k, v, scale):
+    if q.dtype == torch.bfloat16:
+        q = q if q.stride(3) == 1 else q.contiguous()
+        k = k if k.stride(3) == 1 else k.contiguous()
+        v = v if v.stride(3) == 1 else v.contiguous()
+        return ops.attention(q, k, ops.vt_pack(v), scale, v_packed=True)
+    q = q if q.stride(3) == 1 else q.contiguous()
+    k = k if k.stride(3) == 1 else k.contiguous()
+    v = v if v.stride(3) == 1 else v.contiguous()
+    return ops.attention(q, k, v, scale)
+
+
+def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk: int, projq: nn.Linear, projk: nn.Linear,
+                    projv: nn.Linear, proj: nn.Linear, num_heads: int, rope, qpos, kpos, scale: float,
+                    residual: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+    dtype = hq2d.dtype
+    Cd = hq2d.shape[1]
+    Dh = Cd // num_heads
+    wq, bq = lin_weights(projq, dtype)
+    wkv, bkv = kv_weights(projk, projv, dtype)
+    wp, bp = lin_weights(proj, dtype)
+    native = rope is None or is_native_rope(rope)
+    if dtype == torch.bfloat16 and Dh == 64 and native:
+        vt = ops.vt_buffer(B, num_heads, Nk, hq2d.device)
+        epq = _rope_epilogue(rope, _pos2d(qpos), Cd) if rope is not None else None
+        epk = _rope_epilogue(rope, _pos2d(kpos), Cd) if rope is not None else None
+        q = ops.gemm(hq2d, wq, bq, rope=epq).view(B, Nq, num_heads, Dh)
+        k = ops.gemm(hkv2d, wkv, bkv, rope=epk, vt=(Cd, vt, Nk)).view(B, Nk, num_heads, Dh)
+        o = ops.attention(q, k, vt, scale, v_packed=True)
+    else:
+        if dtype == torch.bfloat16 and Dh != 64:
+            raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh}); use fp32 precision for this model")
+        q = ops.gemm(hq2d, wq, bq).view(B, Nq, num_heads, Dh)
+        kv = ops.gemm(hkv2d, wkv, bkv).view(B, Nk, 2, num_heads, Dh)
+        k, v = kv[:, :, 0], kv[:, :, 1]
+        q, k = _apply_rope(rope, q, k, qpos, kpos)
+        o = _attention_generic(q, k, v, scale)
+    return ops.gemm(o.reshape(B * Nq, Cd), wp, bp, residual=residual, out_dtype=out_dtype)
+
+
+def mlp(h2d: torch.Tensor, fc1: nn.Linear, fc2: nn.Linear, act: str, residual: Optional[torch.Tensor],
+        out_dtype: torch.dtype) -> torch.Tensor:
+    w1, b1 = lin_weights(fc1, h2d.dtype)
+    w2, b2 = lin_weights(fc2, h2d.dtype)
+    g = ops.gemm(h2d, w1, b1, act=act)
+    return ops.gemm(g, w2, b2, residual=residual, out_dtype=out_dtype)
+
+
+def act_name(act_module: nn.Module) -> str:
+    if isinstance(act_module, nn.GELU) and getattr(act_module, "approximate", "none") == "none":
+        return "gelu"
+    if isinstance(act_module, nn.ReLU):
+        return "relu"
+    if isinstance(act_module, nn.Identity):
+        return "none"
+    raise UcHipError(f"activation {type(act_module).__name__} has no fused HIP epilogue (supported: GELU(erf), ReLU)")
+
+
+# ---------------------------------------------------------------------------------------------
+# DPT pieces on NHWC maps
+# ---------------------------------------------------------------------------------------------
+def conv1x1(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    B, H, W, Cin = x.shape
+    w, b = conv1x1_weights(conv, x.dtype)
+    return ops.gemm(x.view(-1, Cin), w, b).view(B, H, W, -1)
+
+
+def conv3x3(x: torch.Tensor, conv: nn.Conv2d, relu_in: bool = False, act=None, residual: Optional[torch.Tensor] = None,
+            residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, H, W, Cin = x.shape
+    s = conv.stride[0]
+    w, b = conv3x3_weights(conv, x.dtype)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    r1 = None if residual is None else residual.reshape(-1, residual.shape[-1])
+    r2 = None if residual2 is None else residual2.reshape(-1, residual2.shape[-1])
+    y = ops.gemm(x, w, b, act=act, residual=r1, residual2=r2, relu_a=relu_in, conv=(B, H, W, Cin, s))
+    return y.view(B, Ho, Wo, -1)
+
+
+def conv_transpose_ks(x: torch.Tensor, ct: nn.ConvTranspose2d) -> torch.Tensor:
+    B, H, W, Cin = x.shape
+    k = ct.kernel_size[0]
+    w, b = convt_weights(ct, x.dtype)
+    y = ops.gemm(x.view(-1, Cin), w, b)
+    return ops.convt_scatter(y, B, H, W, k, ct.out_channels)

@@ -1,0 +1,103 @@
+"""DPT building blocks (reference: libs/croco/dpt_block.py:17-289) on NHWC maps and implicit-GEMM convolutions.
+
+Public modules keep the reference's parameters/state_dict keys.  `forward` accepts BCHW-shaped tensors like the
+reference; the fused head pipeline calls the `_nhwc` methods directly and never leaves channel-last layout.
+"""
+import torch
+import torch.nn as nn
+
+from .... import engine, ops
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def make_scratch(in_shape, out_shape, groups=1, expand=False):
+    """Four bias-free 3x3 projections to the fusion width (dpt_block.py:21-80), registered under both
+    `layerK_rn` and `layer_rn.(K-1)` like the reference (aliased state_dict entries)."""
+    if groups != 1:
+        raise engine.UcHipError("grouped convolutions are not supported by the HIP DPT head")
+    scratch = nn.Module()
+    outs = [out_shape * m for m in ((1, 2, 4, 8) if expand else (1, 1, 1, 1))]
+    for i in range(4):
+        setattr(scratch, f"layer{i + 1}_rn", nn.Conv2d(in_shape[i], outs[i], kernel_size=3, stride=1, padding=1, bias=False, groups=groups))
+    scratch.layer_rn = nn.ModuleList([scratch.layer1_rn, scratch.layer2_rn, scratch.layer3_rn, scratch.layer4_rn])
+    return scratch
+
+
+def make_nonlinearity(nonlinearity, dim=None, on_channels=False):
+    if nonlinearity == "relu":
+        return nn.ReLU(False)
+    raise engine.UcHipError(f"nonlinearity '{nonlinearity}' has no fused HIP epilogue (DUSt3R uses 'relu')")
+
+
+def _to_nhwc(x):
+    return engine.bchw_to_nhwc(x, engine.head_dtype())
+
+
+def _to_bchw_view(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+class ResidualConvUnit_custom(nn.Module):
+    """x + conv2(act(conv1(act(x)))) — 3x3 convs, activation applied on load inside the implicit GEMM."""
+
+    def __init__(self, features, activation, bn):
+        super().__init__()
+        if bn:
+            raise engine.UcHipError("BatchNorm in the DPT head is not supported by the HIP path (DUSt3R uses use_bn=False)")
+        self.bn = bn
+        self.groups = 1
+        self.conv1 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True, groups=1)
+        self.conv2 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True, groups=1)
+        self.activation = activation
+
+    def _nhwc(self, x, extra=None):
+        """RCU(x) (+ extra), both residual adds fused into conv2's epilogue."""
+        if not isinstance(self.activation, nn.ReLU):
+            raise engine.UcHipError("only ReLU is fused into the HIP residual conv unit")
+        t = engine.conv3x3(x, self.conv1, relu_in=True)
+        return engine.conv3x3(t, self.conv2, relu_in=True, residual=x, residual2=extra)
+
+    def forward(self, x):
+        engine.require_inference(x, self.conv1.weight)
+        return _to_bchw_view(self._nhwc(_to_nhwc(x)))
+
+
+class FeatureFusionBlock_custom(nn.Module):
+    """(path + RCU1(skip)) -> RCU2 -> x2 bilinear (align_corners=True) -> 1x1 conv (dpt_block.py:180-255)."""
+
+    def __init__(self, features, activation, deconv=False, bn=False, expand=False, align_corners=True, width_ratio=1):
+        super().__init__()
+        if width_ratio != 1:
+            raise engine.UcHipError("width_ratio != 1 is not supported by the HIP DPT head")
+        if not align_corners:
+            raise engine.UcHipError("align_corners=False is not supported by the HIP DPT head")
+        self.width_ratio = width_ratio
+        self.deconv = deconv
+        self.align_corners = align_corners
+        self.groups = 1
+        self.expand = expand
+        out_features = features // 2 if expand else features
+        self.out_conv = nn.Conv2d(features, out_features, kernel_size=1, stride=1, padding=0, bias=True, groups=1)
+        self.resConfUnit1 = ResidualConvUnit_custom(features, activation, bn)
+        self.resConfUnit2 = ResidualConvUnit_custom(features, activation, bn)
+
+    def _nhwc(self, path, skip=None, crop=None):
+        out = path if skip is None else self.resConfUnit1._nhwc(skip, extra=path)
+        out = self.resConfUnit2._nhwc(out)
+        B, H, W, _ = out.shape
+        out = ops.bilinear_nhwc(out, 2 * H, 2 * W, crop)
+        return engine.conv1x1(out, self.out_conv)
+
+    def forward(self, *xs):
+        engine.require_inference(xs[0], self.out_conv.weight)
+        path = _to_nhwc(xs[0])
+        skip = _to_nhwc(xs[1]) if len(xs) == 2 else None
+        return _to_bchw_view(self._nhwc(path, skip))
+
+
+def make_fusion_block(features, use_bn, width_ratio=1, nonlinearity="relu"):
+    return FeatureFusionBlock_custom(features, make_nonlinearity(nonlinearity, features, on_channels=True), deconv=False,
+                                     bn=use_bn, expand=False, align_corners=True, width_ratio=width_ratio)

@@ -1,0 +1,151 @@
+"""DPT pointmap head (reference: prediction_heads/dpt.py:23-311) as an NHWC implicit-GEMM pipeline.
+
+DPTFeature   : 4 token maps -> [1x1 conv (+ConvT k=s as GEMM+scatter | + 3x3 s2 conv)] -> 3x3 projection to
+               feature_dim -> 4 fusion blocks (residual conv units with ReLU-on-load, x2 bilinear, 1x1 conv).
+DPTRegressionProcessor : conv3x3 -> bilinear to (H,W) -> conv3x3+ReLU -> conv1x1 (Cin -> 4, fp32 output).
+All intermediate maps are NHWC in the head compute dtype; BCHW tensors at the API are channels-last views.
+"""
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ... import engine, ops
+from ..libs.croco.dpt_block import make_fusion_block, make_nonlinearity, make_scratch, pair
+from .base import PixelTaskOutput, PredictionHeadLayeredInput
+
+
+@dataclass
+class DPTFeatureInput:
+    features_upsampled_8x: Tensor  # [batch, dpt_output_feat_dim, 8*feat_height, 8*feat_width]
+    target_output_shape: Tuple[int, int]
+
+
+class DPTFeature(nn.Module):
+    "DPT feature head: list of 4 BCHW token maps -> 8x upsampled fused feature map."
+
+    def __init__(self, patch_size: Union[int, Tuple[int, int]] = 16, main_tasks: Iterable[str] = ("rgb",),
+                 hooks: List[int] = [2, 5, 8, 11], input_feature_dims: Optional[Union[int, List[int]]] = 768,
+                 layer_dims: List[int] = [96, 192, 384, 768], feature_dim: int = 256, use_bn: bool = False,
+                 output_width_ratio=1, pretrained_checkpoint_path: str = None, checkpoint_gradient: bool = False,
+                 nonlinearity: str = "relu", *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.patch_size = pair(patch_size)
+        self.main_tasks = main_tasks
+        self.hooks = hooks
+        self.layer_dims = layer_dims
+        self.feature_dim = feature_dim
+        self.checkpoint_gradient = checkpoint_gradient
+        if isinstance(input_feature_dims, int):
+            input_feature_dims = 4 * [input_feature_dims]
+        else:
+            assert isinstance(input_feature_dims, List) and len(input_feature_dims) == 4
+        self.input_feature_dims = input_feature_dims
+
+        self.scratch = make_scratch(layer_dims, feature_dim, groups=1, expand=False)
+        for i in (1, 2, 3, 4):
+            setattr(self.scratch, f"refinenet{i}", make_fusion_block(feature_dim, use_bn, output_width_ratio, nonlinearity=nonlinearity))
+        # unused in forward (refinenet4 has no skip input); the reference deletes it for DDP (dpt.py:82-83)
+        del self.scratch.refinenet4.resConfUnit1
+        if self.input_feature_dims is not None:
+            self.init(input_feature_dims=input_feature_dims)
+        self.pretrained_checkpoint_path = pretrained_checkpoint_path
+        if pretrained_checkpoint_path is not None:
+            print(f"Loading pretrained DPT dense feature head from {pretrained_checkpoint_path}")
+            ckpt = torch.load(pretrained_checkpoint_path, weights_only=False)
+            print(self.load_state_dict(ckpt["model"]))
+
+    def init(self, input_feature_dims: Union[int, List[int]] = 768):
+        "Build the reassemble layers that depend on the token width (dpt.py:94-178)."
+        if isinstance(input_feature_dims, int):
+            input_feature_dims = 4 * [input_feature_dims]
+        self.input_feature_dims = [dt * len(self.main_tasks) for dt in input_feature_dims]
+        d, L = self.input_feature_dims, self.layer_dims
+        act_postprocess = [
+            nn.Sequential(nn.Conv2d(d[0], L[0], kernel_size=1, stride=1, padding=0),
+                          nn.ConvTranspose2d(L[0], L[0], kernel_size=4, stride=4, padding=0, bias=True, dilation=1, groups=1)),
+            nn.Sequential(nn.Conv2d(d[1], L[1], kernel_size=1, stride=1, padding=0),
+                          nn.ConvTranspose2d(L[1], L[1], kernel_size=2, stride=2, padding=0, bias=True, dilation=1, groups=1)),
+            nn.Sequential(nn.Conv2d(d[2], L[2], kernel_size=1, stride=1, padding=0)),
+            nn.Sequential(nn.Conv2d(d[3], L[3], kernel_size=1, stride=1, padding=0),
+                          nn.Conv2d(L[3], L[3], kernel_size=3, stride=2, padding=1)),
+        ]
+        self.input_process = nn.ModuleList(
+            [nn.Sequential(act_, layer_rn_) for act_, layer_rn_ in zip(act_postprocess, self.scratch.layer_rn)])
+
+    def _reassemble(self, idx: int, x: Tensor) -> Tensor:
+        act, layer_rn = self.input_process[idx][0], self.input_process[idx][1]
+        x = engine.conv1x1(x, act[0])
+        if idx in (0, 1):
+            x = engine.conv_transpose_ks(x, act[1])
+        elif idx == 3:
+            x = engine.conv3x3(x, act[1])
+        return engine.conv3x3(x, layer_rn)
+
+    def _nhwc(self, layered: List[Tensor]) -> Tensor:
+        layers = [self._reassemble(i, x) for i, x in enumerate(layered)]
+        s = self.scratch
+        path4 = s.refinenet4._nhwc(layers[3], None, crop=(layers[2].shape[1], layers[2].shape[2]))
+        path3 = s.refinenet3._nhwc(path4, layers[2])
+        path2 = s.refinenet2._nhwc(path3, layers[1])
+        return s.refinenet1._nhwc(path2, layers[0])
+
+    def forward(self, dpt_input: PredictionHeadLayeredInput) -> DPTFeatureInput:
+        assert self.input_feature_dims is not None, "Need to call init(input_feature_dims) function first"
+        feats = dpt_input.list_features
+        for hook_idx, hook in enumerate(self.hooks):
+            assert feats[hook].shape[1] == self.input_feature_dims[hook_idx], (
+                f"Input feature dimension mismatch at hook {hook}. Expected BCHW")
+        engine.require_inference(*feats, self.scratch.layer1_rn.weight)
+        dt = engine.head_dtype()
+        out = self._nhwc([engine.bchw_to_nhwc(feats[hook], dt) for hook in self.hooks])
+        return DPTFeatureInput(features_upsampled_8x=out.permute(0, 3, 1, 2), target_output_shape=dpt_input.target_output_shape)
+
+
+class DPTRegressionProcessor(nn.Module):
+    "8x-upsampled DPT features -> regression channels at the target resolution (dpt.py:238-311)."
+
+    def __init__(self, input_feature_dim: int, output_dim: int, hidden_dims: Optional[List[int]] = None,
+                 pretrained_checkpoint_path: str = None, checkpoint_gradient: bool = False, nonlinearity: str = "relu",
+                 *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if hidden_dims is None:
+            hidden_dims = [input_feature_dim // 2] * 2
+        else:
+            assert isinstance(hidden_dims, List) and len(hidden_dims) == 2
+        self.checkpoint_gradient = checkpoint_gradient
+        self.conv1 = nn.Conv2d(input_feature_dim, hidden_dims[0], kernel_size=3, stride=1, padding=1)
+        self.conv2 = nn.Sequential(
+            nn.Conv2d(hidden_dims[0], hidden_dims[1], kernel_size=3, stride=1, padding=1),
+            make_nonlinearity(nonlinearity),
+            nn.Conv2d(hidden_dims[1], output_dim, kernel_size=1, stride=1, padding=0),
+        )
+        self.pretrained_checkpoint_path = pretrained_checkpoint_path
+        if pretrained_checkpoint_path is not None:
+            print(f"Loading pretrained DPT regression processor from {pretrained_checkpoint_path}")
+            ckpt = torch.load(pretrained_checkpoint_path, weights_only=False)
+            print(self.load_state_dict(ckpt["model"]))
+
+    def forward(self, dpt_processor_input: DPTFeatureInput):
+        x = dpt_processor_input.features_upsampled_8x
+        H, W = dpt_processor_input.target_output_shape
+        engine.require_inference(x, self.conv1.weight)
+        dt = engine.head_dtype()
+        x = engine.bchw_to_nhwc(x, dt)
+        x = engine.conv3x3(x, self.conv1)
+        x = ops.bilinear_nhwc(x, H, W)
+        x = engine.conv3x3(x, self.conv2[0], act="relu")
+        last = self.conv2[2]
+        if last.out_channels == 4 and last.in_channels <= 256 and last.in_channels % 8 == 0:
+            w = engine.prepared(last, "c1x4", (last.weight, last.bias),
+                                lambda: (last.weight.detach().reshape(4, -1).float().contiguous(),
+                                         last.bias.detach().float().contiguous() if last.bias is not None
+                                         else torch.zeros(4, device=last.weight.device)))
+            out = ops.conv1x1_to4(x, w[0], w[1])  # fp32 NHWC [B,H,W,4]
+        else:
+            wl, bl = engine.conv1x1_weights(last, dt)
+            B, Hh, Ww, Cin = x.shape
+            out = ops.gemm(x.view(-1, Cin), wl, bl, out_dtype=torch.float32).view(B, Hh, Ww, -1)
+        return PixelTaskOutput(decoded_channels=out.permute(0, 3, 1, 2))

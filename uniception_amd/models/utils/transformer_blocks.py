@@ -1,0 +1,206 @@
+"""Decoder transformer blocks (reference: utils/transformer_blocks.py:38-89, 136-412, 517-647) on the HIP kernels.
+
+CrossAttentionBlock.forward(x, y, xpos, ypos):
+    x += proj(SDPA(rope(q), rope(k), v))              q,k,v = qkv(norm1(x))
+    x += proj(SDPA(rope(projq(norm2(x)), xpos), rope(projk(norm_y(y)), ypos), projv(norm_y(y))))
+    x += fc2(gelu(fc1(norm3(x))))
+Each line is: LayerNorm kernel -> GEMM(s) with fused bias/RoPE/VT epilogues -> flash attention ->
+GEMM with fused bias+residual.  K and V of the other view share one GEMM (weights concatenated once).
+"""
+import math
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import engine
+from ..libs.croco.blocks import DropPath, Mlp, _as_2d, _check_no_dropout, to_2tuple  # noqa: F401
+from .config import use_fused_attn
+
+
+def _softmax_scale_multiplier(module, n_tokens: int) -> float:
+    """The reference's optional q-scalings are scalar multipliers of q, i.e. of the softmax scale
+    (transformer_blocks.py:231-241, 360-370)."""
+    m = 1.0
+    if module.use_scalable_softmax:
+        m *= math.log(n_tokens)
+    if module.use_entropy_scaling:
+        m *= math.sqrt(module.entropy_scaling_growth_factor * math.log(n_tokens)
+                       / math.log(module.base_token_count_for_entropy_scaling))
+    return m
+
+
+class Attention(nn.Module):
+    "Self-Attention Layer"
+
+    def __init__(self, dim: int, latent_attn_dim: Optional[int] = None, num_heads: int = 8, qkv_bias: bool = False,
+                 qk_norm: bool = False, attn_drop: float = 0.0, proj_drop: float = 0.0, norm_layer: nn.Module = nn.LayerNorm,
+                 custom_positional_encoding: Callable = None, use_scalable_softmax: bool = False,
+                 use_entropy_scaling: bool = False, base_token_count_for_entropy_scaling: int = 444,
+                 entropy_scaling_growth_factor: float = 1.4):
+        super().__init__()
+        if latent_attn_dim is not None:
+            raise engine.UcHipError("latent_attn_dim is not supported by the HIP attention path")
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        self.latent_attn = False
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim**-0.5
+        self.fused_attn = use_fused_attn()
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.q_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.custom_positional_encoding = custom_positional_encoding
+        self.use_scalable_softmax = use_scalable_softmax
+        self.use_entropy_scaling = use_entropy_scaling
+        self.base_token_count_for_entropy_scaling = base_token_count_for_entropy_scaling
+        self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
+
+    def _run(self, h2d, B, N, xpos, residual, out_dtype):
+        _check_no_dropout(self, self.attn_drop.p, self.proj_drop.p)
+        if not isinstance(self.q_norm, nn.Identity):
+            raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
+        if self.custom_positional_encoding is not None:
+            assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
+        scale = self.scale * _softmax_scale_multiplier(self, N)
+        return engine.self_attention(h2d, B, N, self.qkv, self.proj, self.num_heads, self.custom_positional_encoding, xpos,
+                                     scale, residual, out_dtype)
+
+    def forward(self, x: torch.Tensor, xpos: torch.Tensor = None) -> torch.Tensor:
+        engine.require_inference(x, self.qkv.weight)
+        B, N, C = x.shape
+        dt = engine.compute_dtype()
+        x2 = _as_2d(x)
+        h = x2 if x2.dtype == dt else engine.ops.convert(x2, dt)
+        return self._run(h, B, N, xpos, None, dt).view(B, N, C)
+
+
+class CrossAttention(nn.Module):
+    "Cross-Attention Layer"
+
+    def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = False, qk_norm: bool = False, attn_drop: float = 0.0,
+                 proj_drop: float = 0.0, norm_layer: nn.Module = nn.LayerNorm, custom_positional_encoding: Callable = None,
+                 use_scalable_softmax: bool = False, use_entropy_scaling: bool = False,
+                 base_token_count_for_entropy_scaling: int = 444, entropy_scaling_growth_factor: float = 1.4):
+        super().__init__()
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim**-0.5
+        self.fused_attn = use_fused_attn()
+        self.projq = nn.Linear(dim, dim, bias=qkv_bias)
+        self.projk = nn.Linear(dim, dim, bias=qkv_bias)
+        self.projv = nn.Linear(dim, dim, bias=qkv_bias)
+        self.q_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.custom_positional_encoding = custom_positional_encoding
+        self.use_scalable_softmax = use_scalable_softmax
+        self.use_entropy_scaling = use_entropy_scaling
+        self.base_token_count_for_entropy_scaling = base_token_count_for_entropy_scaling
+        self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
+
+    def _run(self, hq2d, hkv2d, B, Nq, Nk, qpos, kpos, residual, out_dtype):
+        _check_no_dropout(self, self.attn_drop.p, self.proj_drop.p)
+        if not isinstance(self.q_norm, nn.Identity):
+            raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
+        if self.custom_positional_encoding is not None:
+            assert qpos is not None, "Positions of queries (qpos) are a required input when using custom positional encoding"
+            assert kpos is not None, "Positions of keys (kpos) are a required input when using custom positional encoding"
+        scale = self.scale * _softmax_scale_multiplier(self, Nq)
+        return engine.cross_attention(hq2d, hkv2d, B, Nq, Nk, self.projq, self.projk, self.projv, self.proj, self.num_heads,
+                                      self.custom_positional_encoding, qpos, kpos, scale, residual, out_dtype)
+
+    def forward(self, query, key, value, qpos=None, kpos=None):
+        engine.require_inference(query, key, value, self.projq.weight)
+        if value is not key:
+            raise engine.UcHipError("the HIP cross-attention computes K and V from one tensor (key is value), as DUSt3R does")
+        B, Nq, C = query.shape
+        Nk = key.shape[1]
+        dt = engine.compute_dtype()
+        q2, k2 = _as_2d(query), _as_2d(key)
+        hq = q2 if q2.dtype == dt else engine.ops.convert(q2, dt)
+        hk = k2 if k2.dtype == dt else engine.ops.convert(k2, dt)
+        return self._run(hq, hk, B, Nq, Nk, qpos, kpos, None, dt).view(B, Nq, C)
+
+
+class LayerScale(nn.Module):
+    "Per-channel scale; parameter container only — the fused HIP path requires init_values=None (as DUSt3R uses)."
+
+    def __init__(self, dim: int, init_values: float = 1e-5, inplace: bool = False):
+        super().__init__()
+        self.inplace = inplace
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise engine.UcHipError("LayerScale (init_values != None) is not supported by the HIP path")
+
+
+class CrossAttentionBlock(nn.Module):
+    "Cross-Attention Block"
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float = 4.0, qkv_bias: bool = False, qk_norm: bool = False,
+                 proj_drop: float = 0.0, attn_drop: float = 0.0, init_values: Optional[float] = None, drop_path: float = 0.0,
+                 act_layer: nn.Module = nn.GELU, norm_layer: nn.Module = nn.LayerNorm, mlp_layer: nn.Module = Mlp,
+                 custom_positional_encoding: Callable = None, norm_cross_tokens: bool = True,
+                 use_scalable_softmax: bool = False, use_entropy_scaling: bool = False,
+                 base_token_count_for_entropy_scaling: int = 444, entropy_scaling_growth_factor: float = 1.4):
+        super().__init__()
+        akw = dict(num_heads=num_heads, qkv_bias=qkv_bias, qk_norm=qk_norm, attn_drop=attn_drop, proj_drop=proj_drop,
+                   norm_layer=norm_layer, custom_positional_encoding=custom_positional_encoding,
+                   use_scalable_softmax=use_scalable_softmax, use_entropy_scaling=use_entropy_scaling,
+                   base_token_count_for_entropy_scaling=base_token_count_for_entropy_scaling,
+                   entropy_scaling_growth_factor=entropy_scaling_growth_factor)
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, **akw)
+        self.ls1 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.drop_path1 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm_y = norm_layer(dim) if norm_cross_tokens else nn.Identity()
+        self.custom_positional_encoding = custom_positional_encoding
+        self.norm2 = norm_layer(dim)
+        self.cross_attn = CrossAttention(dim, **akw)
+        self.ls2 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.drop_path2 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm3 = norm_layer(dim)
+        self.mlp = mlp_layer(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=proj_drop)
+        self.ls3 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.drop_path3 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def _check_supported(self):
+        for ls in (self.ls1, self.ls2, self.ls3):
+            if not isinstance(ls, nn.Identity):
+                raise engine.UcHipError("LayerScale (init_values != None) is not supported by the HIP path")
+        for dp in (self.drop_path1, self.drop_path2, self.drop_path3):
+            if isinstance(dp, DropPath) and dp.drop_prob > 0 and self.training:
+                raise engine.UcHipError("DropPath with drop_prob > 0 in training mode is not supported by the HIP path")
+        if not isinstance(self.mlp, Mlp):
+            raise engine.UcHipError("only the standard Mlp layer has a fused HIP pipeline")
+
+    def forward_tokens(self, x2d, y2d, B, Nx, Ny, xpos, ypos, dt):
+        """x2d [B*Nx, C] residual stream, y2d [B*Ny, C] other-view tokens (previous depth) -> new x2d."""
+        self._check_supported()
+        if self.custom_positional_encoding is not None:
+            assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
+            assert ypos is not None, "Positions of cross tokens (ypos) are a required input when using custom positional encoding"
+        h = engine.layernorm(x2d, self.norm1, dt)
+        x2d = self.attn._run(h, B, Nx, xpos, x2d, x2d.dtype)
+        if isinstance(self.norm_y, nn.Identity):
+            yn = y2d if y2d.dtype == dt else engine.ops.convert(y2d, dt)
+        else:
+            yn = engine.layernorm(y2d, self.norm_y, dt)
+        h = engine.layernorm(x2d, self.norm2, dt)
+        x2d = self.cross_attn._run(h, yn, B, Nx, Ny, xpos, ypos, x2d, x2d.dtype)
+        h = engine.layernorm(x2d, self.norm3, dt)
+        return self.mlp._run(h, x2d, x2d.dtype)
+
+    def forward(self, x, y, xpos=None, ypos=None):
+        engine.require_inference(x, y, self.norm1.weight)
+        B, Nx, C = x.shape
+        Ny = y.shape[1]
+        out = self.forward_tokens(_as_2d(x), _as_2d(y), B, Nx, Ny, xpos, ypos, engine.compute_dtype())
+        return out.view(B, Nx, C)

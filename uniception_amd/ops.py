@@ -96,7 +96,8 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
-         residual: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+         residual: Optional[torch.Tensor] = None, residual2: Optional[torch.Tensor] = None,
+         out_dtype: Optional[torch.dtype] = None,
          out: Optional[torch.Tensor] = None, relu_a: bool = False,
          rope: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
          vt: Optional[Tuple[int, torch.Tensor, int]] = None,
@@ -135,6 +136,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if residual is not None:
         assert residual.dim() == 2 and residual.stride(1) == 1 and residual.shape == (M, N)
         d.residual, d.res_dtype, d.ldr = residual.data_ptr(), _dt(residual.dtype), residual.stride(0)
+        if residual2 is not None:
+            assert residual2.shape == residual.shape and residual2.stride() == residual.stride() and residual2.dtype == residual.dtype
+            d.residual2 = residual2.data_ptr()
     n_out = N
     d.vt_col0 = -1
     if vt is not None:
