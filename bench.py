@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Headline benchmark: image-pairs/s of the DUSt3R two-view forward, ViT-L/16 encoder + 12-block CroCo
+cross-attention decoder + DPT pointmap heads + adaptor, 512x512 pairs, bf16 MFMA operands (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; every rank runs `--pairs` independent image pairs per step (weak scaling, no data-path
+collective: pairs are independent in the forward).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md §Chip-level parameters)
+# forward GFLOP per 512x512 pair, encoder+decoder and the two DPT heads
+GFLOP_ENC_DEC_512, GFLOP_DPT_512 = 2068.0, 497.9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=8, help="image pairs per GPU per step")
+    ap.add_argument("--img", type=int, default=512)
+    ap.add_argument("--head", default="dpt", choices=["dpt", "linear"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-max-s", type=float, default=30.0)
+    return ap.parse_args()
+
+
+def make_views(B, H, W, rank, dev):
+    g = torch.Generator().manual_seed(1000 + rank)
+    img1 = torch.randn(B, 3, H, W, generator=g).to(dev)
+    img2 = torch.randn(B, 3, H, W, generator=g).to(dev)
+    v1 = {"img": img1, "instance": [f"a{rank}_{i}" for i in range(B)], "data_norm_type": "dust3r"}
+    v2 = {"img": img2, "instance": [f"b{rank}_{i}" for i in range(B)], "data_norm_type": "dust3r"}  # not symmetrized
+    return v1, v2
+
+
+def roofline_pass(model, v1, v2, precision, steps):
+    """Bracket every dense bf16 GEMM launch (the dominant kernel: gemm_bf16_kernel<dense>) with HIP events on the
+    launch stream and relate its algorithmic FLOPs to the measured launch time."""
+    from uniception_amd import engine, ops
+
+    records = []
+    orig = ops.gemm
+
+    def timed_gemm(a, w, *args, **kw):
+        if kw.get("conv") is not None or a.dtype != torch.bfloat16:
+            return orig(a, w, *args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(a, w, *args, **kw)
+        e1.record()
+        records.append((e0, e1, 2.0 * a.shape[0] * w.shape[0] * w.shape[1]))
+        return out
+
+    ops.gemm = timed_gemm
+    try:
+        with torch.no_grad(), engine.precision(precision):
+            for _ in range(steps):
+                model(v1, v2)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = orig
+    t = sum(e0.elapsed_time(e1) for e0, e1, _ in records) * 1e-3
+    fl = sum(f for _, _, f in records)
+    n = len(records)
+    return {"bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "gemm_bf16_kernel<dense>",
+            "launches_per_step": n // steps, "avg_launch_us": round(t / n * 1e6, 2),
+            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2)}
+
+
+def cpu_baseline(model, H, W, head, max_s):
+    """The oracle (CPU restatement of the reference path, validated against the real reference in tests/golden) timed on
+    the host cores with torch.utils.benchmark-style repeats on ONE pair (bounded sample of the same workload)."""
+    from oracle import dust3r_oracle as O
+
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    img1, img2 = O.make_images(7, 1, H, W)
+    cores = torch.get_num_threads()
+    times = []
+    t_start = time.time()
+    with torch.no_grad():
+        while len(times) < 3 and (time.time() - t_start) < max_s:
+            t0 = time.time()
+            O.dust3r_forward(sd, img1, img2, head=head)
+            times.append(time.time() - t0)
+    best = min(times)
+    return {"value": round(1.0 / best, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 pair (2x{H}x{W}) fp32 forward incl. heads, best of {len(times)} runs, {best:.2f}s each, torch CPU {cores} threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from uniception_amd import _lib, engine
+    from uniception_amd.models.factory import DUSt3R
+
+    _lib.load()  # fail loudly if the HIP extension is missing
+    torch.manual_seed(0)
+    model = DUSt3R(name="bench", img_size=(args.img, args.img), pred_head_type=args.head).eval().to(dev)
+    v1, v2 = make_views(args.pairs, args.img, args.img, rank, dev)
+
+    def step():
+        with torch.no_grad(), engine.precision(args.precision):
+            return model(v1, v2)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out[0]["pts3d"]).all()
+
+    pairs_total = world * args.pairs * args.steps
+    value = pairs_total / dt
+    gflop_pair = GFLOP_ENC_DEC_512 * (args.img / 512) ** 2  # informational (exact only at 512)
+    line = {
+        "metric": "image-pairs/sec fwd, ViT-L/16 two-view 512x512 (encoder + CroCo decoder + DPT heads + adaptor)",
+        "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: ViT-L/16 encoder + 12-block CroCo decoder + {args.head} head, "
+                               f"{args.img}x{args.img} pairs, forward, random-init weights",
+                   "pairs_per_gpu": args.pairs, "global_pairs_per_step": world * args.pairs, "img": args.img,
+                   "head": args.head, "parallelism": f"dp{world} (independent pairs per rank, no data-path collective)"},
+        "enc_dec_mfma_frac": round(value / world * gflop_pair / 1e3 / PEAK_BF16_TFLOPS, 4),
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline and args.precision == "bf16":
+            line["roofline"] = roofline_pass(model, v1, v2, args.precision, min(args.steps, 3))
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, args.img, args.img, args.head, args.cpu_baseline_max_s)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
