@@ -17,6 +17,8 @@
 // aligned to a 64-wide head, the RoPE partner of channel d (< 16) is channel d+16 of the same
 // row: fragment ni and ni+1 of the SAME lane and register, so the rotation needs no cross-lane traffic.
 #include "common.h"
+#include "gemm_glds.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
@@ -474,6 +476,36 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             UC_REQUIRE(d->act == UC_ACT_NONE && !d->residual, "uc_gemm: vt epilogue cannot be combined with act/residual");
             UC_REQUIRE(d->rope_cols <= d->vt_col0, "uc_gemm: rope columns overlap vt columns");
             UC_REQUIRE((uintptr_t)d->vt_out % 8 == 0, "uc_gemm: vt_out must be 8-byte aligned");
+        }
+        // dense operands with K % 64 == 0 take the direct-to-LDS kernel (gemm_glds.hip)
+        static int forced_variant = -2;
+        if (forced_variant == -2) {
+            const char* e = getenv("UC_GEMM_VARIANT");
+            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..2: glds tile variants
+        }
+        if (d->a_mode == UC_A_DENSE && !d->relu_a && d->K % 64 == 0 && forced_variant != -1) {
+            GldsParams g;
+            g.A = (const bf16_t*)d->A; g.lda = d->lda; g.W = (const bf16_t*)d->W; g.M = d->M; g.N = d->N; g.K = d->K;
+            g.bias = d->bias; g.act = d->act; g.residual = d->residual; g.residual2 = d->residual2; g.res_dtype = d->res_dtype;
+            g.ldr = d->ldr; g.rope_cols = d->rope_cols; g.rope_pos = d->rope_pos; g.rope_table = (const float2*)d->rope_table;
+            g.rope_npos = d->rope_npos; g.vt_col0 = d->vt_col0; g.vt_out = (bf16_t*)d->vt_out; g.vt_ntok = d->vt_ntok;
+            g.vt_npad = d->vt_npad; g.C = d->C; g.out_dtype = d->out_dtype; g.ldc = d->ldc; g.tiles_m = g.tiles_n = 0;
+            const bool c_ok = ((uintptr_t)d->C % 16 == 0) && (d->ldc % 8 == 0);
+            const bool b_ok = !d->bias || ((uintptr_t)d->bias % 16 == 0);
+            const bool r_ok = !d->residual || (((uintptr_t)d->residual % 16 == 0) && (d->ldr % 4 == 0) &&
+                                               (!d->residual2 || (uintptr_t)d->residual2 % 16 == 0));
+            g.vec_ok = (c_ok && b_ok && r_ok) ? 1 : 0;
+            int variant = forced_variant;
+            if (variant < 0) {
+                // tile choice: the 256x256 tile (16 waves) has the best steady state (least LDS fill per flop) but needs
+                // enough tiles to cover the 256 CUs; smaller problems fall back to 256x128 / 128x128 tiles.
+                const int64_t t256 = ceil_div64(d->M, 256) * ceil_div64(d->N, 256);
+                const int64_t t256x128 = ceil_div64(d->M, 256) * ceil_div64(d->N, 128);
+                variant = t256 >= 192 ? 2 : (t256x128 >= 160 ? 1 : 0);
+            }
+            uc_launch_gemm_glds(g, variant, st);
+            UC_CHECK_LAUNCH("uc_gemm(glds)");
+            return UC_OK;
         }
         p.tiles_m = (int)ceil_div64(d->M, BM);
         p.tiles_n = (int)ceil_div64(d->N, BN);

@@ -1,0 +1,31 @@
+// Parameters / launcher of the direct-to-LDS dense bf16 GEMM (gemm_glds.hip), shared with the uc_gemm dispatcher.
+#pragma once
+#include "common.h"
+
+struct GldsParams {
+    const bf16_t* A;
+    int64_t lda;
+    const bf16_t* W;
+    int64_t M, N, K;
+    const float* bias;
+    int act;
+    const void* residual;
+    const void* residual2;
+    int res_dtype;
+    int64_t ldr;
+    int64_t rope_cols;
+    const int64_t* rope_pos;
+    const float2* rope_table;
+    int rope_npos;
+    int64_t vt_col0;
+    bf16_t* vt_out;
+    int vt_ntok, vt_npad;
+    void* C;
+    int out_dtype;
+    int64_t ldc;
+    int tiles_m, tiles_n;
+    int vec_ok;   // C / residual / bias satisfy the alignment needed by the 4-wide vector epilogue
+};
+
+// variant: 0 = 128x128 tile (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
+int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st);

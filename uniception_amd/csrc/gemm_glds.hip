@@ -1,0 +1,333 @@
+// Dense bf16 GEMM for gfx950 with direct global->LDS staging (global_load_lds_dwordx4, 1 KiB per wave-instruction).
+//
+//   C[M,N] = epilogue(A[M,K] . W[N,K]^T),  K % 64 == 0, A/W bf16 row-major.
+//
+// Tile geometry: BM x BN x 64 per workgroup, every wavefront owns a 64x64 sub-tile (4x4 MFMA 16x16x32 fragments).
+// LDS image of a stage: (BM + BN) rows x 128 B.  The DMA writes lane-linear (wave base + lane*16), so the
+// XOR swizzle that makes the ds_read_b128 fragment loads conflict-free (chunk ^= (row>>1)&7) is applied to the
+// per-lane SOURCE address; the fragment reads apply the same involution.  Two stages; the loads of K-step t+1
+// are issued before the MFMAs of step t and drained by the barrier that ends the step.
+//
+// Operand orientation: for ordinary tiles the MFMA computes C^T fragments (first operand = W rows), so a lane owns
+// 4 CONSECUTIVE output columns of one row: bias/residual/stores are 8/16-byte vector accesses and, with the W-row
+// permutation 16*(a>>2)+4j+(a&3), a lane's 16 values are 16 consecutive columns.  Tiles that take the RoPE epilogue
+// keep the identity column map (partner channel d+16 = next fragment, same lane/register); V tiles that are written
+// in the packed VT layout use the un-swapped orientation (a lane owns 4 consecutive TOKENS of one channel).
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+#include "gemm_glds.h"
+#include <type_traits>
+
+__device__ __forceinline__ float glds_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float glds_act(float v, int act) {
+    if (act == UC_ACT_GELU_ERF) return glds_gelu(v);
+    if (act == UC_ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ int glds_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// BM_ x BN_ workgroup tile, WAVES_M x WAVES_N wavefronts; a wave owns (16*FA) x 64 outputs, FA = BM_/WAVES_M/16.
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(GldsParams p) {
+    static_assert(BN_ / WAVES_N == 64, "a wave owns 64 output columns (one 64-wide head)");
+    constexpr int WTM = BM_ / WAVES_M;
+    constexpr int FA = WTM / 16;          // A-row fragments per wave (4 or 8)
+    static_assert(WTM % 16 == 0 && (FA == 4 || FA == 8), "wave tile rows");
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int STAGE_BYTES = (BM_ + BN_) * 128;
+    constexpr int NI = (BM_ + BN_) / 8;   // 1-KiB DMA instructions per stage
+    constexpr int PER = NI / NW;          // per wave
+    static_assert(NI % NW == 0, "DMA instructions must split evenly over the waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int t = glds_xcd_remap(blockIdx.x, nwg);
+    const int tm = t / p.tiles_n, tn = t % p.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM_;
+    const int64_t n0 = (int64_t)tn * BN_;
+    const int64_t wave_m = m0 + wr * WTM;
+    const int64_t wave_n = n0 + wc * 64;
+
+    // ---- per-wave epilogue mode (wave-uniform) ----
+    const bool is_vt = p.vt_col0 >= 0 && wave_n >= p.vt_col0;
+    const bool is_rope = !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
+    const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
+
+    // ---- DMA source pointers: instruction I = wave*PER + q covers combined-tile rows [8I, 8I+8) ----
+    const bf16_t* src[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int rr = (wave * PER + q) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((rr >> 1) & 7);   // logical chunk stored at physical chunk (lane&7) of row rr
+        if (rr < BM_) {
+            int64_t m = m0 + rr;
+            if (m >= p.M) m = p.M - 1;
+            src[q] = p.A + m * p.lda + c * 8;
+        } else {
+            int64_t n = n0 + (rr - BM_);
+            if (n >= p.N) n = p.N - 1;
+            src[q] = p.W + n * p.K + c * 8;
+        }
+    }
+    auto issue_stage = [&](int stage, int64_t k0) {
+        char* base = smem + stage * STAGE_BYTES + wave * (PER * 1024);
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[q] + k0), (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addressing (identity row maps: conflict-free under the (row>>1)&7 chunk swizzle) ----
+    const int frow = lane & 15;
+    const int fk = lane >> 4;
+    int a_off[FA], a_sw[FA], w_off[4], w_sw[4];
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const int row = wr * WTM + 16 * i + frow;
+        a_off[i] = row * 128; a_sw[i] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = BM_ + wc * 64 + 16 * j + frow;
+        w_off[j] = row * 128; w_sw[j] = (row >> 1) & 7;
+    }
+
+    float4_t acc[FA][4];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(p.K / 64);
+    // SWAP: first MFMA operand = W rows -> C^T fragments (lane owns 4 consecutive columns of one row);
+    // !SWAP (VT tiles): first operand = A rows (lane owns 4 consecutive tokens of one channel).
+    auto compute_stage = [&](const char* st, auto swap_tag) {
+        constexpr bool SWAP = decltype(swap_tag)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 4 + fk;
+            bf16x8_t af[FA], wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_off[j] + ((chunk ^ w_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < FA; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(st + a_off[i] + ((chunk ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    auto main_loop = [&](auto swap_tag) {
+        if constexpr (STAGES == 2) {
+            issue_stage(0, 0);
+            __syncthreads();
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) issue_stage((kt + 1) & 1, (int64_t)(kt + 1) * 64);
+                compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag);
+                __syncthreads();   // drains the DMA of stage kt+1 (pending LDS writes) and fences the reads of stage kt
+            }
+        } else {
+            // 3-stage ring, DMA two K-steps ahead, counted vmcnt + raw barrier: the loads of step kt+1 stay in flight
+            // across the barrier that publishes step kt (a __syncthreads() would drain them: it implies vmcnt(0)).
+            issue_stage(0, 0);
+            if (nk > 1) issue_stage(1, 64);
+            int cur = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // this wave's DMA of step kt has landed
+                __builtin_amdgcn_s_barrier();                                 // ... and every other wave's; reads of step kt-1 done
+                int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
+                if (kt + 2 < nk) issue_stage(nxt, (int64_t)(kt + 2) * 64);
+                compute_stage(smem + cur * STAGE_BYTES, swap_tag);
+                cur = (cur == 2) ? 0 : cur + 1;
+            }
+        }
+    };
+    if (mode == 2) main_loop(std::false_type{}); else main_loop(std::true_type{});
+
+    // =============================== epilogue ===============================
+    const int g = lane >> 4;
+    if (wave_n >= p.N) return;
+
+    if (mode == 2) {
+        // acc[i][j][r]: token row m = wave_m + 16i + 4g + r, channel column wave_n + 16j + frow
+        const int head = (int)((wave_n - p.vt_col0) >> 6);
+        const int nheads = (int)((p.N - p.vt_col0) >> 6);
+        const bool aligned = (p.vt_ntok & 15) == 0;
+        float bcol[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bcol[j] = p.bias ? p.bias[wave_n + 16 * j + frow] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int64_t mb = wave_m + 16 * i + 4 * g;
+            if (aligned) {
+                if (mb >= p.M) continue;
+                const int b = (int)(mb / p.vt_ntok);
+                const int tok = (int)(mb % p.vt_ntok);
+                const int pos = (tok & ~15) + ((g & 1) << 3) + ((g >> 1) << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = 16 * j + frow;
+                    bf16_t* dst = p.vt_out + (((int64_t)b * nheads + head) * 64 + d) * p.vt_npad + pos;
+                    uint2 pk;
+                    pk.x = pack_bf16x2(acc[i][j][0] + bcol[j], acc[i][j][1] + bcol[j]);
+                    pk.y = pack_bf16x2(acc[i][j][2] + bcol[j], acc[i][j][3] + bcol[j]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = mb + r;
+                    if (m >= p.M) continue;
+                    const int b = (int)(m / p.vt_ntok);
+                    const int tok = (int)(m % p.vt_ntok);
+                    const int w = tok & 15;
+                    const int pos = (tok & ~15) + (((w >> 2) & 1) << 3) + (w & 3) + ((w >> 3) << 2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        p.vt_out[(((int64_t)b * nheads + head) * 64 + 16 * j + frow) * p.vt_npad + pos] =
+                            f32_to_bf16(acc[i][j][r] + bcol[j]);
+                }
+            }
+        }
+        return;
+    }
+
+    // swapped modes: acc[i][j][r]: row m = wave_m + 16i + frow; 4 consecutive columns wave_n + 16j + 4g + r
+    float b4[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t nb = wave_n + 16 * j + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[j][r] = 0.f;
+        if (p.bias) {
+            if (p.vec_ok && nb + 3 < p.N) {
+                const float4_t bb = *reinterpret_cast<const float4_t*>(p.bias + nb);
+                b4[j][0] = bb.x; b4[j][1] = bb.y; b4[j][2] = bb.z; b4[j][3] = bb.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[j][r] = (nb + r < p.N) ? p.bias[nb + r] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const int64_t m = wave_m + 16 * i + frow;
+        if (m >= p.M) continue;
+        float v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j][r] = glds_act(acc[i][j][r] + b4[j][r], p.act);
+        if (mode == 1) {
+            int py = (int)p.rope_pos[m * 2 + 0];
+            int px = (int)p.rope_pos[m * 2 + 1];
+            py = min(max(py, 0), p.rope_npos - 1);
+            px = min(max(px, 0), p.rope_npos - 1);
+            const float4_t* ty = reinterpret_cast<const float4_t*>(p.rope_table + py * 16 + 4 * g);
+            const float4_t* tx = reinterpret_cast<const float4_t*>(p.rope_table + px * 16 + 4 * g);
+            const float4_t cy0 = ty[0], cy1 = ty[1], cx0 = tx[0], cx1 = tx[1];  // (cos,sin) x 4
+            const float cyc[4] = {cy0.x, cy0.z, cy1.x, cy1.z}, cys[4] = {cy0.y, cy0.w, cy1.y, cy1.w};
+            const float cxc[4] = {cx0.x, cx0.z, cx1.x, cx1.z}, cxs[4] = {cx0.y, cx0.w, cx1.y, cx1.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u0 = v[0][r], w0 = v[1][r], u1 = v[2][r], w1 = v[3][r];
+                v[0][r] = u0 * cyc[r] - w0 * cys[r];
+                v[1][r] = w0 * cyc[r] + u0 * cys[r];
+                v[2][r] = u1 * cxc[r] - w1 * cxs[r];
+                v[3][r] = w1 * cxc[r] + u1 * cxs[r];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t nb = wave_n + 16 * j + 4 * g;
+            if (nb >= p.N) continue;
+            const bool full = p.vec_ok && nb + 3 < p.N;
+            if (p.residual) {
+                if (full && p.res_dtype == UC_F32) {
+                    const float4_t r4 = *reinterpret_cast<const float4_t*>((const float*)p.residual + m * p.ldr + nb);
+                    v[j][0] += r4.x; v[j][1] += r4.y; v[j][2] += r4.z; v[j][3] += r4.w;
+                    if (p.residual2) {
+                        const float4_t s4 = *reinterpret_cast<const float4_t*>((const float*)p.residual2 + m * p.ldr + nb);
+                        v[j][0] += s4.x; v[j][1] += s4.y; v[j][2] += s4.z; v[j][3] += s4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (nb + r >= p.N) continue;
+                        const int64_t idx = m * p.ldr + nb + r;
+                        v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual)[idx] : bf16_to_f32(((const bf16_t*)p.residual)[idx]);
+                        if (p.residual2)
+                            v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual2)[idx] : bf16_to_f32(((const bf16_t*)p.residual2)[idx]);
+                    }
+                }
+            }
+            if (full) {
+                if (p.out_dtype == UC_F32) {
+                    *reinterpret_cast<float4_t*>((float*)p.C + m * p.ldc + nb) = (float4_t){v[j][0], v[j][1], v[j][2], v[j][3]};
+                } else {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[j][0], v[j][1]);
+                    pk.y = pack_bf16x2(v[j][2], v[j][3]);
+                    *reinterpret_cast<uint2*>((bf16_t*)p.C + m * p.ldc + nb) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nb + r >= p.N) continue;
+                    if (p.out_dtype == UC_F32) ((float*)p.C)[m * p.ldc + nb + r] = v[j][r];
+                    else ((bf16_t*)p.C)[m * p.ldc + nb + r] = f32_to_bf16(v[j][r]);
+                }
+            }
+        }
+    }
+}
+
+template <int BM_, int BN_, int WM_, int WN_, int STAGES>
+static void launch_variant(GldsParams p, hipStream_t st) {
+    p.tiles_m = (int)ceil_div64(p.M, BM_);
+    p.tiles_n = (int)ceil_div64(p.N, BN_);
+    auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES>;
+    constexpr int smem = STAGES * (BM_ + BN_) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(WM_ * WN_ * 64), smem, st, p);
+}
+
+// variant: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2 of 64x64), 2 = 256x256 (4x4 of 64x64),
+//          3 = 256x128 3-stage ring, 4 = 256x256 (2x4 waves of 128x64), 5 = 256x128 (2x2 waves of 128x64),
+//          6 = 128x256 (1x4 waves of 128x64)
+int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
+    switch (variant) {
+        case 1: launch_variant<256, 128, 4, 2, 2>(p, st); break;
+        case 2: launch_variant<256, 256, 4, 4, 2>(p, st); break;
+        case 3: launch_variant<256, 128, 4, 2, 3>(p, st); break;
+        case 4: launch_variant<256, 256, 2, 4, 2>(p, st); break;
+        case 5: launch_variant<256, 128, 2, 2, 2>(p, st); break;
+        case 6: launch_variant<128, 256, 1, 4, 2>(p, st); break;
+        default: launch_variant<128, 128, 2, 2, 2>(p, st); break;
+    }
+    return 0;
+}
