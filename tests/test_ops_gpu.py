@@ -189,7 +189,8 @@ def test_gemm_bf16_rope_and_vt_epilogue(gpu):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("geom", [(2, 9, 11, 16, 24, 1), (1, 37, 37, 32, 40, 2), (2, 8, 8, 96, 256, 1), (1, 6, 5, 8, 8, 2)])
+@pytest.mark.parametrize("geom", [(2, 9, 11, 16, 24, 1), (1, 37, 37, 32, 40, 2), (2, 8, 8, 96, 256, 1), (1, 6, 5, 8, 8, 2),
+                                  (1, 9, 11, 64, 72, 1), (2, 10, 7, 128, 40, 2), (3, 19, 23, 64, 300, 1)])
 def test_conv3x3_implicit_gemm(gpu, dtype, geom):
     """3x3 conv, pad 1, stride 1/2 (dpt_block.py:34-69, dpt.py:161-172) incl. the ReLU-on-load of the RCU."""
     from uniception_amd import ops

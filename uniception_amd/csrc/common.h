@@ -37,16 +37,18 @@ typedef unsigned short bf16_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// f32 -> bf16 through the gfx950 hardware conversion (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved);
+// a hand-rolled integer rounding costs ~6 VALU + a NaN branch per element and was the top VALU item of the
+// attention softmax.
+typedef __bf16 bf16x2v_t __attribute__((ext_vector_type(2)));
+typedef float float2v_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    const float2v_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v_t));
 }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float f16_to_f32(unsigned short v) {
     _Float16 h;

@@ -483,7 +483,10 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const char* e = getenv("UC_GEMM_VARIANT");
             forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..2: glds tile variants
         }
-        if (d->a_mode == UC_A_DENSE && !d->relu_a && d->K % 64 == 0 && forced_variant != -1) {
+        const bool glds_dense = d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a;
+        const bool glds_conv = d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 == 0 &&
+                               (int64_t)d->conv_B * d->conv_H * d->conv_W < (int64_t)1 << 30;
+        if ((glds_dense || glds_conv) && forced_variant != -1) {
             GldsParams g;
             g.A = (const bf16_t*)d->A; g.lda = d->lda; g.W = (const bf16_t*)d->W; g.M = d->M; g.N = d->N; g.K = d->K;
             g.bias = d->bias; g.act = d->act; g.residual = d->residual; g.residual2 = d->residual2; g.res_dtype = d->res_dtype;
@@ -495,6 +498,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const bool r_ok = !d->residual || (((uintptr_t)d->residual % 16 == 0) && (d->ldr % 4 == 0) &&
                                                (!d->residual2 || (uintptr_t)d->residual2 % 16 == 0));
             g.vec_ok = (c_ok && b_ok && r_ok) ? 1 : 0;
+            g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
+            g.cStride = d->conv_stride; g.cHo = d->conv_Ho; g.cWo = d->conv_Wo;
             int variant = forced_variant;
             if (variant < 0) {
                 // tile choice: the 256x256 tile (16 waves) has the best steady state (least LDS fill per flop) but needs

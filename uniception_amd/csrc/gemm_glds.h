@@ -25,6 +25,9 @@ struct GldsParams {
     int64_t ldc;
     int tiles_m, tiles_n;
     int vec_ok;   // C / residual / bias satisfy the alignment needed by the 4-wide vector epilogue
+    // implicit-GEMM 3x3 convolution over an NHWC image (a_mode == UC_A_CONV3X3): K = 9*Cin, Cin % 64 == 0
+    int a_mode, relu_a;
+    int cH, cW, cCin, cStride, cHo, cWo;
 };
 
 // variant: 0 = 128x128 tile (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)

@@ -36,11 +36,24 @@ __device__ __forceinline__ int glds_xcd_remap(int bid, int nwg) {
     return base + k;
 }
 
+// 128 zero bytes: DMA source for im2col positions that fall into the convolution's zero padding
+__device__ uint4 g_zero_chunk[8];
+
+__device__ __forceinline__ uint4 glds_relu_bf16x8(uint4 v) {
+    unsigned* q = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned neg = (q[i] >> 15) & 0x00010001u;
+        q[i] &= ~(neg * 0xffffu);
+    }
+    return v;
+}
+
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 // BM_ x BN_ workgroup tile, WAVES_M x WAVES_N wavefronts; a wave owns (16*FA) x 64 outputs, FA = BM_/WAVES_M/16.
-template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES>
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES, int A_MODE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(GldsParams p) {
     static_assert(BN_ / WAVES_N == 64, "a wave owns 64 output columns (one 64-wide head)");
     constexpr int WTM = BM_ / WAVES_M;
@@ -72,15 +85,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
 
     // ---- DMA source pointers: instruction I = wave*PER + q covers combined-tile rows [8I, 8I+8) ----
+    // dense: src[q] + k0.   conv: A rows are gathered per K-step from the 3x3 window (one tap per 64-channel K-step,
+    // because Cin % 64 == 0); positions inside the zero padding read from g_zero_chunk instead.
     const bf16_t* src[PER];
+    int c_iy0[PER], c_ix0[PER], c_pix[PER], c_c8[PER];
+    bool is_a[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int rr = (wave * PER + q) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((rr >> 1) & 7);   // logical chunk stored at physical chunk (lane&7) of row rr
+        is_a[q] = (wave * PER + q) * 8 < BM_;         // wave-uniform: an instruction is all-A or all-W
+        c_iy0[q] = c_ix0[q] = c_pix[q] = 0;
+        c_c8[q] = c * 8;
         if (rr < BM_) {
             int64_t m = m0 + rr;
             if (m >= p.M) m = p.M - 1;
-            src[q] = p.A + m * p.lda + c * 8;
+            if (A_MODE == UC_A_DENSE) {
+                src[q] = p.A + m * p.lda + c * 8;
+            } else {
+                const int ox = (int)(m % p.cWo);
+                const int oy = (int)((m / p.cWo) % p.cHo);
+                const int b = (int)(m / ((int64_t)p.cWo * p.cHo));
+                c_iy0[q] = oy * p.cStride - 1;
+                c_ix0[q] = ox * p.cStride - 1;
+                c_pix[q] = b * p.cH * p.cW;
+                src[q] = p.A;
+            }
         } else {
             int64_t n = n0 + (rr - BM_);
             if (n >= p.N) n = p.N - 1;
@@ -89,9 +119,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     }
     auto issue_stage = [&](int stage, int64_t k0) {
         char* base = smem + stage * STAGE_BYTES + wave * (PER * 1024);
+        int ky = 0, kx = 0, ch0 = 0;
+        if (A_MODE != UC_A_DENSE) {
+            const int tap = (int)(k0 / p.cCin);
+            ch0 = (int)(k0 % p.cCin);
+            ky = tap / 3; kx = tap - 3 * ky;
+        }
 #pragma unroll
-        for (int q = 0; q < PER; ++q)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[q] + k0), (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+        for (int q = 0; q < PER; ++q) {
+            const bf16_t* g;
+            if (A_MODE != UC_A_DENSE && is_a[q]) {
+                const int iy = c_iy0[q] + ky, ix = c_ix0[q] + kx;
+                const bool ok = iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+                g = ok ? p.A + ((int64_t)(c_pix[q] + iy * p.cW + ix) * p.cCin + ch0 + c_c8[q])
+                       : reinterpret_cast<const bf16_t*>(g_zero_chunk) + c_c8[q];
+            } else {
+                g = src[q] + k0;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+        }
     };
 
     // ---- fragment addressing (identity row maps: conflict-free under the (row>>1)&7 chunk swizzle) ----
@@ -127,7 +173,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
 #pragma unroll
             for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_off[j] + ((chunk ^ w_sw[j]) << 4));
 #pragma unroll
-            for (int i = 0; i < FA; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(st + a_off[i] + ((chunk ^ a_sw[i]) << 4));
+            for (int i = 0; i < FA; ++i) {
+                uint4 raw = *reinterpret_cast<const uint4*>(st + a_off[i] + ((chunk ^ a_sw[i]) << 4));
+                if constexpr (A_MODE != UC_A_DENSE) {
+                    if (p.relu_a) raw = glds_relu_bf16x8(raw);   // uniform flag: ReLU of the DPT residual conv unit, applied on load
+                }
+                af[i] = __builtin_bit_cast(bf16x8_t, raw);
+            }
 #pragma unroll
             for (int i = 0; i < FA; ++i)
 #pragma unroll
@@ -302,11 +354,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     }
 }
 
-template <int BM_, int BN_, int WM_, int WN_, int STAGES>
-static void launch_variant(GldsParams p, hipStream_t st) {
+template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE>
+static void launch_variant_mode(GldsParams p, hipStream_t st) {
     p.tiles_m = (int)ceil_div64(p.M, BM_);
     p.tiles_n = (int)ceil_div64(p.N, BN_);
-    auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES>;
+    auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES, A_MODE>;
     constexpr int smem = STAGES * (BM_ + BN_) * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -316,17 +368,22 @@ static void launch_variant(GldsParams p, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(WM_ * WN_ * 64), smem, st, p);
 }
 
+template <int BM_, int BN_, int WM_, int WN_, int STAGES>
+static void launch_variant(const GldsParams& p, hipStream_t st) {
+    if (p.a_mode == UC_A_CONV3X3) launch_variant_mode<BM_, BN_, WM_, WN_, STAGES, UC_A_CONV3X3>(p, st);
+    else launch_variant_mode<BM_, BN_, WM_, WN_, STAGES, UC_A_DENSE>(p, st);
+}
+
 // variant: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2 of 64x64), 2 = 256x256 (4x4 of 64x64),
-//          3 = 256x128 3-stage ring, 4 = 256x256 (2x4 waves of 128x64), 5 = 256x128 (2x2 waves of 128x64),
-//          6 = 128x256 (1x4 waves of 128x64)
+//          3 = 256x128 3-stage ring
 int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
     switch (variant) {
         case 1: launch_variant<256, 128, 4, 2, 2>(p, st); break;
-        case 2: launch_variant<256, 256, 4, 4, 2>(p, st); break;
+        case 2:
+            if (p.a_mode == UC_A_CONV3X3) launch_variant<256, 128, 4, 2, 2>(p, st);   // the 16-wave tile has no registers for the gather
+            else launch_variant_mode<256, 256, 4, 4, 2, UC_A_DENSE>(p, st);
+            break;
         case 3: launch_variant<256, 128, 4, 2, 3>(p, st); break;
-        case 4: launch_variant<256, 256, 2, 4, 2>(p, st); break;
-        case 5: launch_variant<256, 128, 2, 2, 2>(p, st); break;
-        case 6: launch_variant<128, 256, 1, 4, 2>(p, st); break;
         default: launch_variant<128, 128, 2, 2, 2>(p, st); break;
     }
     return 0;
