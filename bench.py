@@ -79,7 +79,8 @@ def roofline_pass(model, v1, v2, precision, steps):
     fl = sum(f for _, _, f in records)
     n = len(records)
     return {"bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "gemm_bf16_kernel<dense>",
+            "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_bf16_glds_kernel (dense bf16 MFMA GEMM, all tile variants)",
             "launches_per_step": n // steps, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2)}
 
@@ -144,9 +145,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        from uniception_amd.distributed import max_over_ranks
+        dt = max_over_ranks(dt, dev)
     assert torch.isfinite(out[0]["pts3d"]).all()
 
     pairs_total = world * args.pairs * args.steps
