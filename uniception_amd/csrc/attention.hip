@@ -98,15 +98,19 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
         rv0 = load_v((k0_), sr);            \
         rv1 = load_v((k0_), sr + 32);       \
     } while (0)
+    // loop-invariant LDS byte offsets: rows r and r+32 share the swizzle key, so one offset + an immediate serves both
+    const int w_off = att_swz(sr, cc);
 #define ATT_STAGE_WRITE(buf_)                                                          \
     do {                                                                               \
-        char* sk_ = smem + (buf_) * 2 * ATT_TILE_BYTES;                                \
-        char* sv_ = sk_ + ATT_TILE_BYTES;                                              \
-        *reinterpret_cast<uint4*>(sk_ + att_swz(sr, cc)) = rk0;                        \
-        *reinterpret_cast<uint4*>(sk_ + att_swz(sr + 32, cc)) = rk1;                   \
-        *reinterpret_cast<uint4*>(sv_ + att_swz(sr, cc)) = rv0;                        \
-        *reinterpret_cast<uint4*>(sv_ + att_swz(sr + 32, cc)) = rv1;                   \
+        char* sk_ = smem + (buf_) * 2 * ATT_TILE_BYTES + w_off;                        \
+        *reinterpret_cast<uint4*>(sk_) = rk0;                                          \
+        *reinterpret_cast<uint4*>(sk_ + 32 * 128) = rk1;                               \
+        *reinterpret_cast<uint4*>(sk_ + ATT_TILE_BYTES) = rv0;                         \
+        *reinterpret_cast<uint4*>(sk_ + ATT_TILE_BYTES + 32 * 128) = rv1;              \
     } while (0)
+    int r_off[4];   // fragment read offsets: row l31 (+32 via immediate), chunk 2*st+hi, st = 0..3 (K and VT tiles alike)
+#pragma unroll
+    for (int st = 0; st < 4; ++st) r_off[st] = att_swz(l31, 2 * st + hi);
 
     float16_t o[2];   // O^T accumulators: d-block x (16 regs): d = 32*db + (r&3) + 8*(r>>2) + 4*hi, q = l31
     o[0] = (float16_t)(0.f);
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
             s[kb] = (float16_t)(0.f);
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + att_swz(kb * 32 + l31, 2 * st + hi));
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + r_off[st] + kb * (32 * 128));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kb], 0, 0, 0);
             }
         }
@@ -155,10 +159,20 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
+        // Deferred rescale: keep the old running max while no query of the wave grew by more than 2^RESCALE_LOG2 in the
+        // exp2 domain (P stays <= 2^8, exact in the final O/l ratio); the O/l rescale then runs on a wave-uniform branch.
+        const bool grow = (mt - m_run) * c > 8.0f;
+        if (__any(grow)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float mc = m_run * c;
         float psum = 0.f;
         bf16x8_t pf[4];   // P^T B-operand fragments: slab g = 2*kb + half, 8 key slots per lane
 #pragma unroll
@@ -177,18 +191,14 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
                 pf[kb * 2 + hf] = pk.v;
             }
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T . P^T : two 32-channel blocks x four 16-key slabs ----
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sv + att_swz(db * 32 + l31, 2 * g + hi));
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sv + r_off[g] + db * (32 * 128));
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o[db], 0, 0, 0);
             }
 

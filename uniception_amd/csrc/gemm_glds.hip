@@ -52,6 +52,149 @@ __device__ __forceinline__ uint4 glds_relu_bf16x8(uint4 v) {
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
+// Shared epilogue: bias -> activation -> fused RoPE-2D -> residual(s) -> store, or the packed-VT store of V tiles.
+template <int FA>
+__device__ __forceinline__ void glds_epilogue(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                              int64_t wave_n, int lane) {
+    const int frow = lane & 15;
+    // =============================== epilogue ===============================
+    const int g = lane >> 4;
+    if (wave_n >= p.N) return;
+
+    if (mode == 2) {
+        // acc[i][j][r]: token row m = wave_m + 16i + 4g + r, channel column wave_n + 16j + frow
+        const int head = (int)((wave_n - p.vt_col0) >> 6);
+        const int nheads = (int)((p.N - p.vt_col0) >> 6);
+        const bool aligned = (p.vt_ntok & 15) == 0;
+        float bcol[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bcol[j] = p.bias ? p.bias[wave_n + 16 * j + frow] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int64_t mb = wave_m + 16 * i + 4 * g;
+            if (aligned) {
+                if (mb >= p.M) continue;
+                const int b = (int)(mb / p.vt_ntok);
+                const int tok = (int)(mb % p.vt_ntok);
+                const int pos = (tok & ~15) + ((g & 1) << 3) + ((g >> 1) << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = 16 * j + frow;
+                    bf16_t* dst = p.vt_out + (((int64_t)b * nheads + head) * 64 + d) * p.vt_npad + pos;
+                    uint2 pk;
+                    pk.x = pack_bf16x2(acc[i][j][0] + bcol[j], acc[i][j][1] + bcol[j]);
+                    pk.y = pack_bf16x2(acc[i][j][2] + bcol[j], acc[i][j][3] + bcol[j]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = mb + r;
+                    if (m >= p.M) continue;
+                    const int b = (int)(m / p.vt_ntok);
+                    const int tok = (int)(m % p.vt_ntok);
+                    const int w = tok & 15;
+                    const int pos = (tok & ~15) + (((w >> 2) & 1) << 3) + (w & 3) + ((w >> 3) << 2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        p.vt_out[(((int64_t)b * nheads + head) * 64 + 16 * j + frow) * p.vt_npad + pos] =
+                            f32_to_bf16(acc[i][j][r] + bcol[j]);
+                }
+            }
+        }
+        return;
+    }
+
+    // swapped modes: acc[i][j][r]: row m = wave_m + 16i + frow; 4 consecutive columns wave_n + 16j + 4g + r
+    float b4[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t nb = wave_n + 16 * j + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[j][r] = 0.f;
+        if (p.bias) {
+            if (p.vec_ok && nb + 3 < p.N) {
+                const float4_t bb = *reinterpret_cast<const float4_t*>(p.bias + nb);
+                b4[j][0] = bb.x; b4[j][1] = bb.y; b4[j][2] = bb.z; b4[j][3] = bb.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[j][r] = (nb + r < p.N) ? p.bias[nb + r] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const int64_t m = wave_m + 16 * i + frow;
+        if (m >= p.M) continue;
+        float v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j][r] = glds_act(acc[i][j][r] + b4[j][r], p.act);
+        if (mode == 1) {
+            int py = (int)p.rope_pos[m * 2 + 0];
+            int px = (int)p.rope_pos[m * 2 + 1];
+            py = min(max(py, 0), p.rope_npos - 1);
+            px = min(max(px, 0), p.rope_npos - 1);
+            const float4_t* ty = reinterpret_cast<const float4_t*>(p.rope_table + py * 16 + 4 * g);
+            const float4_t* tx = reinterpret_cast<const float4_t*>(p.rope_table + px * 16 + 4 * g);
+            const float4_t cy0 = ty[0], cy1 = ty[1], cx0 = tx[0], cx1 = tx[1];  // (cos,sin) x 4
+            const float cyc[4] = {cy0.x, cy0.z, cy1.x, cy1.z}, cys[4] = {cy0.y, cy0.w, cy1.y, cy1.w};
+            const float cxc[4] = {cx0.x, cx0.z, cx1.x, cx1.z}, cxs[4] = {cx0.y, cx0.w, cx1.y, cx1.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u0 = v[0][r], w0 = v[1][r], u1 = v[2][r], w1 = v[3][r];
+                v[0][r] = u0 * cyc[r] - w0 * cys[r];
+                v[1][r] = w0 * cyc[r] + u0 * cys[r];
+                v[2][r] = u1 * cxc[r] - w1 * cxs[r];
+                v[3][r] = w1 * cxc[r] + u1 * cxs[r];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t nb = wave_n + 16 * j + 4 * g;
+            if (nb >= p.N) continue;
+            const bool full = p.vec_ok && nb + 3 < p.N;
+            if (p.residual) {
+                if (full && p.res_dtype == UC_F32) {
+                    const float4_t r4 = *reinterpret_cast<const float4_t*>((const float*)p.residual + m * p.ldr + nb);
+                    v[j][0] += r4.x; v[j][1] += r4.y; v[j][2] += r4.z; v[j][3] += r4.w;
+                    if (p.residual2) {
+                        const float4_t s4 = *reinterpret_cast<const float4_t*>((const float*)p.residual2 + m * p.ldr + nb);
+                        v[j][0] += s4.x; v[j][1] += s4.y; v[j][2] += s4.z; v[j][3] += s4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (nb + r >= p.N) continue;
+                        const int64_t idx = m * p.ldr + nb + r;
+                        v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual)[idx] : bf16_to_f32(((const bf16_t*)p.residual)[idx]);
+                        if (p.residual2)
+                            v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual2)[idx] : bf16_to_f32(((const bf16_t*)p.residual2)[idx]);
+                    }
+                }
+            }
+            if (full) {
+                if (p.out_dtype == UC_F32) {
+                    *reinterpret_cast<float4_t*>((float*)p.C + m * p.ldc + nb) = (float4_t){v[j][0], v[j][1], v[j][2], v[j][3]};
+                } else {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[j][0], v[j][1]);
+                    pk.y = pack_bf16x2(v[j][2], v[j][3]);
+                    *reinterpret_cast<uint2*>((bf16_t*)p.C + m * p.ldc + nb) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nb + r >= p.N) continue;
+                    if (p.out_dtype == UC_F32) ((float*)p.C)[m * p.ldc + nb + r] = v[j][r];
+                    else ((bf16_t*)p.C)[m * p.ldc + nb + r] = f32_to_bf16(v[j][r]);
+                }
+            }
+        }
+    }
+}
+
 // BM_ x BN_ workgroup tile, WAVES_M x WAVES_N wavefronts; a wave owns (16*FA) x 64 outputs, FA = BM_/WAVES_M/16.
 template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES, int A_MODE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(GldsParams p) {
@@ -216,142 +359,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     };
     if (mode == 2) main_loop(std::false_type{}); else main_loop(std::true_type{});
 
-    // =============================== epilogue ===============================
-    const int g = lane >> 4;
-    if (wave_n >= p.N) return;
-
-    if (mode == 2) {
-        // acc[i][j][r]: token row m = wave_m + 16i + 4g + r, channel column wave_n + 16j + frow
-        const int head = (int)((wave_n - p.vt_col0) >> 6);
-        const int nheads = (int)((p.N - p.vt_col0) >> 6);
-        const bool aligned = (p.vt_ntok & 15) == 0;
-        float bcol[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bcol[j] = p.bias ? p.bias[wave_n + 16 * j + frow] : 0.f;
-#pragma unroll
-        for (int i = 0; i < FA; ++i) {
-            const int64_t mb = wave_m + 16 * i + 4 * g;
-            if (aligned) {
-                if (mb >= p.M) continue;
-                const int b = (int)(mb / p.vt_ntok);
-                const int tok = (int)(mb % p.vt_ntok);
-                const int pos = (tok & ~15) + ((g & 1) << 3) + ((g >> 1) << 2);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int d = 16 * j + frow;
-                    bf16_t* dst = p.vt_out + (((int64_t)b * nheads + head) * 64 + d) * p.vt_npad + pos;
-                    uint2 pk;
-                    pk.x = pack_bf16x2(acc[i][j][0] + bcol[j], acc[i][j][1] + bcol[j]);
-                    pk.y = pack_bf16x2(acc[i][j][2] + bcol[j], acc[i][j][3] + bcol[j]);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t m = mb + r;
-                    if (m >= p.M) continue;
-                    const int b = (int)(m / p.vt_ntok);
-                    const int tok = (int)(m % p.vt_ntok);
-                    const int w = tok & 15;
-                    const int pos = (tok & ~15) + (((w >> 2) & 1) << 3) + (w & 3) + ((w >> 3) << 2);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        p.vt_out[(((int64_t)b * nheads + head) * 64 + 16 * j + frow) * p.vt_npad + pos] =
-                            f32_to_bf16(acc[i][j][r] + bcol[j]);
-                }
-            }
-        }
-        return;
-    }
-
-    // swapped modes: acc[i][j][r]: row m = wave_m + 16i + frow; 4 consecutive columns wave_n + 16j + 4g + r
-    float b4[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t nb = wave_n + 16 * j + 4 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b4[j][r] = 0.f;
-        if (p.bias) {
-            if (p.vec_ok && nb + 3 < p.N) {
-                const float4_t bb = *reinterpret_cast<const float4_t*>(p.bias + nb);
-                b4[j][0] = bb.x; b4[j][1] = bb.y; b4[j][2] = bb.z; b4[j][3] = bb.w;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b4[j][r] = (nb + r < p.N) ? p.bias[nb + r] : 0.f;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < FA; ++i) {
-        const int64_t m = wave_m + 16 * i + frow;
-        if (m >= p.M) continue;
-        float v[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[j][r] = glds_act(acc[i][j][r] + b4[j][r], p.act);
-        if (mode == 1) {
-            int py = (int)p.rope_pos[m * 2 + 0];
-            int px = (int)p.rope_pos[m * 2 + 1];
-            py = min(max(py, 0), p.rope_npos - 1);
-            px = min(max(px, 0), p.rope_npos - 1);
-            const float4_t* ty = reinterpret_cast<const float4_t*>(p.rope_table + py * 16 + 4 * g);
-            const float4_t* tx = reinterpret_cast<const float4_t*>(p.rope_table + px * 16 + 4 * g);
-            const float4_t cy0 = ty[0], cy1 = ty[1], cx0 = tx[0], cx1 = tx[1];  // (cos,sin) x 4
-            const float cyc[4] = {cy0.x, cy0.z, cy1.x, cy1.z}, cys[4] = {cy0.y, cy0.w, cy1.y, cy1.w};
-            const float cxc[4] = {cx0.x, cx0.z, cx1.x, cx1.z}, cxs[4] = {cx0.y, cx0.w, cx1.y, cx1.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float u0 = v[0][r], w0 = v[1][r], u1 = v[2][r], w1 = v[3][r];
-                v[0][r] = u0 * cyc[r] - w0 * cys[r];
-                v[1][r] = w0 * cyc[r] + u0 * cys[r];
-                v[2][r] = u1 * cxc[r] - w1 * cxs[r];
-                v[3][r] = w1 * cxc[r] + u1 * cxs[r];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t nb = wave_n + 16 * j + 4 * g;
-            if (nb >= p.N) continue;
-            const bool full = p.vec_ok && nb + 3 < p.N;
-            if (p.residual) {
-                if (full && p.res_dtype == UC_F32) {
-                    const float4_t r4 = *reinterpret_cast<const float4_t*>((const float*)p.residual + m * p.ldr + nb);
-                    v[j][0] += r4.x; v[j][1] += r4.y; v[j][2] += r4.z; v[j][3] += r4.w;
-                    if (p.residual2) {
-                        const float4_t s4 = *reinterpret_cast<const float4_t*>((const float*)p.residual2 + m * p.ldr + nb);
-                        v[j][0] += s4.x; v[j][1] += s4.y; v[j][2] += s4.z; v[j][3] += s4.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (nb + r >= p.N) continue;
-                        const int64_t idx = m * p.ldr + nb + r;
-                        v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual)[idx] : bf16_to_f32(((const bf16_t*)p.residual)[idx]);
-                        if (p.residual2)
-                            v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual2)[idx] : bf16_to_f32(((const bf16_t*)p.residual2)[idx]);
-                    }
-                }
-            }
-            if (full) {
-                if (p.out_dtype == UC_F32) {
-                    *reinterpret_cast<float4_t*>((float*)p.C + m * p.ldc + nb) = (float4_t){v[j][0], v[j][1], v[j][2], v[j][3]};
-                } else {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(v[j][0], v[j][1]);
-                    pk.y = pack_bf16x2(v[j][2], v[j][3]);
-                    *reinterpret_cast<uint2*>((bf16_t*)p.C + m * p.ldc + nb) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (nb + r >= p.N) continue;
-                    if (p.out_dtype == UC_F32) ((float*)p.C)[m * p.ldc + nb + r] = v[j][r];
-                    else ((bf16_t*)p.C)[m * p.ldc + nb + r] = f32_to_bf16(v[j][r]);
-                }
-            }
-        }
-    }
+    glds_epilogue<FA>(p, acc, mode, wave_m, wave_n, lane);
 }
 
 template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE>

@@ -154,6 +154,49 @@ __device__ __forceinline__ void ln_store4<BF16Tag>(bf16_t* p, float4_t v) {
     *reinterpret_cast<uint2*>(p) = r;
 }
 
+// Exact-width variant: C == NV*256, no per-chunk predicates, so all NV 16-byte loads of a row are issued back to back
+// (the predicated generic kernel below serialises them behind exec-mask branches: 2.8 TB/s vs 7+ TB/s cache-hot).
+template <typename TI, typename TO, int NV>
+__global__ __launch_bounds__(256) void layernorm_exact_kernel(const typename TI::storage* __restrict__ x,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              typename TO::storage* __restrict__ y, int64_t rows, float eps) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const typename TI::storage* xr = x + row * C;
+    float4_t v[NV], g[NV], bb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ln_load4<TI>(xr + (i * 64 + lane) * 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *reinterpret_cast<const float4_t*>(gamma + (i * 64 + lane) * 4);
+        bb[i] = *reinterpret_cast<const float4_t*>(beta + (i * 64 + lane) * 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s) * (1.0f / (float)C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+        q += (a * a + b * b) + (d * d + e * e);
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / (float)C) + eps);
+    typename TO::storage* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float4_t o;
+        o.x = (v[i].x - mean) * rstd * g[i].x + bb[i].x;
+        o.y = (v[i].y - mean) * rstd * g[i].y + bb[i].y;
+        o.z = (v[i].z - mean) * rstd * g[i].z + bb[i].z;
+        o.w = (v[i].w - mean) * rstd * g[i].w + bb[i].w;
+        ln_store4<TO>(yr + (i * 64 + lane) * 4, o);
+    }
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const typename TI::storage* __restrict__ x,
                                                             const float* __restrict__ gamma,
@@ -236,7 +279,18 @@ static void launch_ln(const void* x, const float* g, const float* b, void* y, in
     const bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV) && ((uintptr_t)x % 16 == 0) &&
                      ((uintptr_t)y % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)b % 16 == 0) &&
                      (((int64_t)C * sizeof(SI)) % (4 * sizeof(SI)) == 0);
-    if (vec)
+    const bool exact = vec && (C % 256 == 0);
+#define UC_LN_EXACT(NV_)                                                                                             \
+    hipLaunchKernelGGL((layernorm_exact_kernel<TI, TO, NV_>), dim3(grid), dim3(256), 0, st, (const SI*)x, g, b, (SO*)y, \
+                       rows, eps)
+    if (exact && C == 256) UC_LN_EXACT(1);
+    else if (exact && C == 512) UC_LN_EXACT(2);
+    else if (exact && C == 768) UC_LN_EXACT(3);
+    else if (exact && C == 1024) UC_LN_EXACT(4);
+    else if (exact && C == 1536) UC_LN_EXACT(6);
+    else if (exact && C == 2048) UC_LN_EXACT(8);
+#undef UC_LN_EXACT
+    else if (vec)
         hipLaunchKernelGGL((layernorm_vec_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const SI*)x, g, b,
                            (SO*)y, rows, C, eps);
     else
