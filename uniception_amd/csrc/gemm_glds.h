@@ -26,6 +26,7 @@ struct GldsParams {
     int tiles_m, tiles_n;
     int vec_ok;   // C / residual / bias satisfy the alignment needed by the 4-wide vector epilogue
     // implicit-GEMM 3x3 convolution over an NHWC image (a_mode == UC_A_CONV3X3): K = 9*Cin, Cin % 64 == 0
+    int dbg;      // diagnostics only (UC_GEMM_DBG): bit0 skip the in-loop DMA, bit1 skip the in-loop barrier
     int a_mode, relu_a;
     int cH, cW, cCin, cStride, cHo, cWo;
 };

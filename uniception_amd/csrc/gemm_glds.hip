@@ -49,6 +49,25 @@ __device__ __forceinline__ uint4 glds_relu_bf16x8(uint4 v) {
     return v;
 }
 
+// One 1-KiB LDS-DMA piece issued through inline asm.  With the __builtin form hipcc tracks the DMA as an LDS write it
+// cannot disambiguate from the fragment ds_reads of the OTHER stage buffer and inserts `s_waitcnt vmcnt(0)` in front of
+// them — the whole global->LDS latency is then exposed in every K-step (measured: matrix pipe 39 % busy, 57 % of wave
+// cycles parked).  The asm form is invisible to that pass; completion is enforced by hand with counted s_waitcnt
+// vmcnt(N) + s_barrier (see the K-loops).  M0 carries the wave-uniform LDS byte address; it is compiler-reserved, so it
+// is saved and restored inside the statement; s_nop 0 covers the M0-write -> LDS-DMA hazard.
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
+
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
@@ -260,8 +279,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
             src[q] = p.W + n * p.K + c * 8;
         }
     }
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;   // LDS byte address of the dynamic region
     auto issue_stage = [&](int stage, int64_t k0) {
-        char* base = smem + stage * STAGE_BYTES + wave * (PER * 1024);
         int ky = 0, kx = 0, ch0 = 0;
         if (A_MODE != UC_A_DENSE) {
             const int tap = (int)(k0 / p.cCin);
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
             } else {
                 g = src[q] + k0;
             }
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+            dma16_to_lds(g, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE_BYTES + wave * (PER * 1024) + q * 1024)));
         }
     };
 
@@ -334,22 +353,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     };
     auto main_loop = [&](auto swap_tag) {
         if constexpr (STAGES == 2) {
+            // 2-stage ring: the DMA of step kt+1 is in flight while the MFMAs of step kt run.
             issue_stage(0, 0);
-            __syncthreads();
             for (int kt = 0; kt < nk; ++kt) {
-                if (kt + 1 < nk) issue_stage((kt + 1) & 1, (int64_t)(kt + 1) * 64);
+                wait_vmcnt<0>();                 // this wave's pieces of stage kt have landed
+                __builtin_amdgcn_s_barrier();    // ... and everyone else's; every wave is done reading stage kt-1
+                asm volatile("" ::: "memory");
+                if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, (int64_t)(kt + 1) * 64);
                 compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag);
-                __syncthreads();   // drains the DMA of stage kt+1 (pending LDS writes) and fences the reads of stage kt
             }
         } else {
-            // 3-stage ring, DMA two K-steps ahead, counted vmcnt + raw barrier: the loads of step kt+1 stay in flight
-            // across the barrier that publishes step kt (a __syncthreads() would drain them: it implies vmcnt(0)).
+            // 3-stage ring, DMA two K-steps ahead: the loads of step kt+1 stay in flight across the barrier of step kt.
             issue_stage(0, 0);
             if (nk > 1) issue_stage(1, 64);
             int cur = 0;
             for (int kt = 0; kt < nk; ++kt) {
-                if (kt + 1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // this wave's DMA of step kt has landed
-                __builtin_amdgcn_s_barrier();                                 // ... and every other wave's; reads of step kt-1 done
+                if (kt + 1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
                 int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
                 if (kt + 2 < nk) issue_stage(nxt, (int64_t)(kt + 2) * 64);
                 compute_stage(smem + cur * STAGE_BYTES, swap_tag);
@@ -392,6 +413,7 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
             else launch_variant_mode<256, 256, 4, 4, 2, UC_A_DENSE>(p, st);
             break;
         case 3: launch_variant<256, 128, 4, 2, 3>(p, st); break;
+        case 4: if (p.a_mode == UC_A_DENSE) launch_variant_mode<256, 256, 2, 4, 2, UC_A_DENSE>(p, st); else launch_variant<256, 128, 4, 2, 2>(p, st); break;
         default: launch_variant<128, 128, 2, 2, 2>(p, st); break;
     }
     return 0;
