@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=16, help="image pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=32, help="image pairs per GPU per step")
     ap.add_argument("--img", type=int, default=512)
     ap.add_argument("--head", default="dpt", choices=["dpt", "linear"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])

@@ -51,6 +51,14 @@ def main():
         t = timeit(lambda: ops.attention(q, k, vt, 0.125, v_packed=True, out=o))
         fl = 4 * Bq * H * N * N * 64
         print(f"attn {name:10s} B={Bq} H={H} N={N}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TFLOP/s")
+    # DPT 3x3 convolutions (implicit GEMM over NHWC): (H=W, Cin, Cout, relu_a)
+    for name, Hh, Cin, Cout in [("rcu 128^2 256->256", 128, 256, 256), ("rcu 64^2 256->256", 64, 256, 256),
+                                ("reg conv1 256^2 256->128", 256, 256, 128), ("reg conv2 512^2 128->128", 512, 128, 128)]:
+        xi = (torch.randn(B, Hh, Hh, Cin, device=dev) * 0.5).bfloat16()
+        wc = (torch.randn(Cout, 9 * Cin, device=dev) / math.sqrt(9 * Cin)).bfloat16()
+        for relu_a in (False, True):
+            t = timeit(lambda: ops.gemm(xi, wc, conv=(B, Hh, Hh, Cin, 1), relu_a=relu_a), iters=10)
+            print(f"conv {name:26s} relu_a={int(relu_a)}: {t*1e6:9.1f} us  {2*B*Hh*Hh*9*Cin*Cout/t/1e12:7.1f} TFLOP/s")
     x = torch.randn(2 * B * N, 1024, device=dev)
     g = torch.ones(1024, device=dev)
     bb = torch.zeros(1024, device=dev)

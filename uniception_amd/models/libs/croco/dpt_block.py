@@ -57,8 +57,11 @@ class ResidualConvUnit_custom(nn.Module):
         """RCU(x) (+ extra), both residual adds fused into conv2's epilogue."""
         if not isinstance(self.activation, nn.ReLU):
             raise engine.UcHipError("only ReLU is fused into the HIP residual conv unit")
-        t = engine.conv3x3(x, self.conv1, relu_in=True)
-        return engine.conv3x3(t, self.conv2, relu_in=True, residual=x, residual2=extra)
+        # conv1's output is only ever consumed through the second ReLU, so that ReLU runs in conv1's epilogue and conv2
+        # loads plain operands (ReLU-on-load costs ~14 % of an implicit-GEMM conv); x itself is needed un-activated for
+        # the residual, so its ReLU stays on the load path of conv1.
+        t = engine.conv3x3(x, self.conv1, relu_in=True, act="relu")
+        return engine.conv3x3(t, self.conv2, relu_in=False, residual=x, residual2=extra)
 
     def forward(self, x):
         engine.require_inference(x, self.conv1.weight)
