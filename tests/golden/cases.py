@@ -14,6 +14,8 @@ CASES = {
     "tiny_linear": dict(_TINY, head="linear", img=(64, 96), B=2, seed=12),
     # odd 5x7 token grid: N=35 (attention/VT tails), DPT stride-2 level 3x4 -> x2 -> crop to 5x7
     "tiny_dpt_odd": dict(_TINY, head="dpt", img=(80, 112), B=1, seed=13),
+    # patch 14 (BASELINE config 4's grid class): 5x7 tokens, 8x DPT map 40x56 -> non-integer bilinear resize to 70x98
+    "tiny_dpt_p14": dict(_TINY, head="dpt", img=(70, 98), B=1, seed=14, patch=14),
     # BASELINE config 0: ViT-B/16 encoder + 6-block decoder + linear head, 224x224, batch 2
     "cfg1_vitb_linear_224": dict(patch=16, enc_dim=768, enc_depth=12, enc_heads=12, dec_dim=768, dec_depth=6, dec_heads=12,
                                  indices=(), head="linear", img=(224, 224), B=2, seed=21, store="samples"),

@@ -150,6 +150,55 @@ def run_case(name, c):
           f"{len(save)} arrays, total {time.time() - t0:.1f}s", flush=True)
 
 
+def run_module_cases():
+    """Module-level goldens (tests/golden/modules.npz): pieces of the interface that the two-view cases do not reach."""
+    from uniception.models.encoders.croco import CroCoIntermediateFeatureReturner
+    from uniception.models.libs.croco.blocks import Attention as EncAttention, Mlp as EncMlp
+    from uniception.models.libs.croco.patch_embed import ManyAR_PatchEmbed
+    from uniception.models.utils.transformer_blocks import CrossAttention
+
+    out = {}
+
+    def rnd(seed, *shape):
+        rng = np.random.Generator(np.random.Philox(key=seed))
+        return torch.from_numpy(rng.standard_normal(size=shape, dtype=np.float32))
+
+    with torch.no_grad():
+        # m1: three views, K/V = concatenation of the two other views (cross_attention_transformer.py:246-256)
+        m = MultiViewCrossAttentionTransformer(name="mv3", input_embed_dim=128, num_views=3, depth=2, dim=128, num_heads=2,
+                                               custom_positional_encoding=RoPE2D(freq=100.0)).eval()
+        O.fill_state_dict_(m.state_dict())
+        feats = [rnd(100 + v, 2, 128, 3, 4) for v in range(3)]
+        r = m(MultiViewTransformerInput(features=feats))
+        for v in range(3):
+            out[f"mv3_out{v}"] = r.features[v].numpy()
+        # m2: encoder with intermediate feature return
+        e = CroCoIntermediateFeatureReturner(name="ifr", data_norm_type="dust3r", img_size=(32, 48), enc_embed_dim=128, enc_depth=3,
+                                             enc_num_heads=2, indices=[0, 2], norm_intermediate=True, intermediates_only=False).eval()
+        O.fill_state_dict_(e.state_dict())
+        fin, inter = e(ViTEncoderInput(image=rnd(110, 2, 3, 32, 48), data_norm_type="dust3r"))
+        out["ifr_final"] = fin.features.numpy()
+        out["ifr_inter0"], out["ifr_inter1"] = inter[0].features.numpy(), inter[1].features.numpy()
+        # m3: mixed landscape / portrait batch
+        pe = ManyAR_PatchEmbed((32, 48), 16, 3, 64).eval()
+        O.fill_state_dict_(pe.state_dict())
+        x, pos = pe(rnd(120, 2, 3, 32, 48), true_shape=torch.tensor([[32, 48], [48, 32]]))
+        out["manyar_x"], out["manyar_pos"] = x.numpy(), pos.numpy()
+        # m4: stand-alone layers
+        att = EncAttention(128, rope=RoPE2D(freq=100.0), num_heads=2, qkv_bias=True).eval()
+        O.fill_state_dict_(att.state_dict())
+        out["att_out"] = att(rnd(130, 2, 12, 128), O.grid_positions(2, 3, 4)).numpy()
+        ca = CrossAttention(128, num_heads=2, qkv_bias=True, custom_positional_encoding=RoPE2D(freq=100.0)).eval()
+        O.fill_state_dict_(ca.state_dict())
+        y = rnd(141, 2, 20, 128)
+        out["ca_out"] = ca(rnd(140, 2, 12, 128), y, y, O.grid_positions(2, 3, 4), O.grid_positions(2, 4, 5)).numpy()
+        mlp = EncMlp(128, 256).eval()
+        O.fill_state_dict_(mlp.state_dict())
+        out["mlp_out"] = mlp(rnd(150, 2, 12, 128)).numpy()
+    np.savez_compressed(os.path.join(HERE, "modules.npz"), **out)
+    print("modules:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     torch.set_num_threads(8)
@@ -157,3 +206,5 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         run_case(name, c)
+    if not only or "modules" in only:
+        run_module_cases()

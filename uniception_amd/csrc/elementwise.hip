@@ -70,19 +70,44 @@ __global__ void patch_gather_kernel(const float* __restrict__ img, typename TO::
     }
 }
 
+// any patch size (e.g. 14): one element per work item, output-ordered
+template <typename TO>
+__global__ void patch_gather_scalar_kernel(const float* __restrict__ img, typename TO::storage* __restrict__ cols, int B,
+                                           int Cin, int H, int W, int P, int64_t n) {
+    const int h = H / P, w = W / P;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n; it += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = it;
+        const int v = (int)(r % P); r /= P;
+        const int u = (int)(r % P); r /= P;
+        const int c = (int)(r % Cin); r /= Cin;
+        const int j = (int)(r % w); r /= w;
+        const int i = (int)(r % h);
+        const int b = (int)(r / h);
+        TO::store(cols + it, img[(((int64_t)b * Cin + c) * H + (int64_t)i * P + u) * W + (int64_t)j * P + v]);
+    }
+}
+
 extern "C" int uc_patch_gather(const float* img, void* cols, int out_dtype, int B, int Cin, int H, int W, int P,
                                uc_stream_t stream) {
     UC_REQUIRE(img && cols, "uc_patch_gather: null pointer");
     UC_REQUIRE(B > 0 && Cin > 0 && P > 0 && H % P == 0 && W % P == 0, "uc_patch_gather: H,W must be multiples of the patch size");
-    UC_REQUIRE(P % 4 == 0 && W % 4 == 0, "uc_patch_gather: patch size and width must be multiples of 4 (16-byte pixel quads)");
-    UC_REQUIRE((uintptr_t)img % 16 == 0, "uc_patch_gather: img must be 16-byte aligned");
-    const int64_t items = (int64_t)B * Cin * H * W / 4;
+    UC_REQUIRE(out_dtype == UC_F32 || out_dtype == UC_BF16, "uc_patch_gather: bad out_dtype %d", out_dtype);
     hipStream_t st = (hipStream_t)stream;
+    const bool quad = (P % 4 == 0) && (W % 4 == 0) && ((uintptr_t)img % 16 == 0);   // 16-byte pixel quads
+    if (!quad) {
+        const int64_t n = (int64_t)B * Cin * H * W;
+        if (out_dtype == UC_F32)
+            hipLaunchKernelGGL((patch_gather_scalar_kernel<F32Tag>), dim3(EW_GRID(n)), dim3(256), 0, st, img, (float*)cols, B, Cin, H, W, P, n);
+        else
+            hipLaunchKernelGGL((patch_gather_scalar_kernel<BF16Tag>), dim3(EW_GRID(n)), dim3(256), 0, st, img, (bf16_t*)cols, B, Cin, H, W, P, n);
+        UC_CHECK_LAUNCH("uc_patch_gather");
+        return UC_OK;
+    }
+    const int64_t items = (int64_t)B * Cin * H * W / 4;
     if (out_dtype == UC_F32)
         hipLaunchKernelGGL((patch_gather_kernel<F32Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, img, (float*)cols, B, Cin, H, W, P, items);
-    else if (out_dtype == UC_BF16)
+    else
         hipLaunchKernelGGL((patch_gather_kernel<BF16Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, img, (bf16_t*)cols, B, Cin, H, W, P, items);
-    else { uc_set_error("uc_patch_gather: bad out_dtype %d", out_dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_patch_gather");
     return UC_OK;
 }

@@ -39,6 +39,8 @@ class PatchEmbedCroCo(nn.Module):
         B, C, H, W = x.shape
         P = self.patch_size[0]
         dt = engine.compute_dtype()
+        if (C * P * P) % 8 != 0:
+            dt = torch.float32   # e.g. patch 14: K = 588 is not a multiple of the 16-byte bf16 chunk; this GEMM is 0.1 % of the FLOPs
         img = x.float().contiguous() if (x.dtype != torch.float32 or not x.is_contiguous()) else x
         cols = ops.patch_gather(img, P, dt)
         w, b = engine.patch_weights(self.proj, dt)
