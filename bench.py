@@ -75,11 +75,20 @@ def roofline_pass(model, v1, v2, precision, steps):
         torch.cuda.synchronize()
     finally:
         ops.gemm = orig
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes (profiles/), only when they were taken on this workload
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        c = pmc["config"]
+        if (c["pairs_per_gpu"], c["img"], c["precision"]) == (v1["img"].shape[0], v1["img"].shape[-1], precision):
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     t = sum(e0.elapsed_time(e1) for e0, e1, _ in records) * 1e-3
     fl = sum(f for _, _, f in records)
     n = len(records)
     return {"bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "kernel": "gemm_bf16_glds_kernel (dense bf16 MFMA GEMM, all tile variants)",
             "launches_per_step": n // steps, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2)}

@@ -498,6 +498,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const bool r_ok = !d->residual || (((uintptr_t)d->residual % 16 == 0) && (d->ldr % 4 == 0) &&
                                                (!d->residual2 || (uintptr_t)d->residual2 % 16 == 0));
             g.vec_ok = (c_ok && b_ok && r_ok) ? 1 : 0;
+            { static int gm = -1; if (gm < 0) { const char* e = getenv("UC_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } g.group_m = gm; }
             { static int dbg = -1; if (dbg < 0) { const char* e = getenv("UC_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
             g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
             g.cStride = d->conv_stride; g.cHo = d->conv_Ho; g.cWo = d->conv_Wo;

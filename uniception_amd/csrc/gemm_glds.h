@@ -24,6 +24,7 @@ struct GldsParams {
     int out_dtype;
     int64_t ldc;
     int tiles_m, tiles_n;
+    int group_m;  // row panels per L2-sharing tile group (tile traversal order)
     int vec_ok;   // C / residual / bias satisfy the alignment needed by the 4-wide vector epilogue
     // implicit-GEMM 3x3 convolution over an NHWC image (a_mode == UC_A_CONV3X3): K = 9*Cin, Cin % 64 == 0
     int dbg;      // diagnostics only (UC_GEMM_DBG): bit0 skip the in-loop DMA, bit1 skip the in-loop barrier

@@ -235,7 +235,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int t = glds_xcd_remap(blockIdx.x, nwg);
-    const int tm = t / p.tiles_n, tn = t % p.tiles_n;
+    // Tile order inside an XCD's run: groups of GM row panels swept column by column, so the ~32 tiles an XCD runs
+    // concurrently form a GM x (32/GM) block that shares GM A-panels and 32/GM W-panels in its L2 (a plain row-major
+    // order shares 2 A-panels but streams ALL of W through every pair of row panels: 2.4x algorithmic fetch traffic).
+    int tm, tn;
+    {
+        const int GM = p.group_m;
+        const int per_group = GM * p.tiles_n;
+        const int grp = t / per_group, within = t - grp * per_group;
+        const int first_m = grp * GM;
+        const int gsz = min(GM, p.tiles_m - first_m);
+        tm = first_m + within % gsz;
+        tn = within / gsz;
+    }
     const int64_t m0 = (int64_t)tm * BM_;
     const int64_t n0 = (int64_t)tn * BN_;
     const int64_t wave_m = m0 + wr * WTM;
