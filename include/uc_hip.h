@@ -101,6 +101,14 @@ typedef struct uc_gemm_desc {
     int64_t vt_col0;
     void* vt_out;
     int vt_ntok, vt_npad;
+    /* training-path extras (bf16 path):
+       preact_out: if non-NULL, the value BEFORE the activation (acc + bias) is also stored there, same dtype/ld as C
+                   (saved for the activation's backward);
+       split_k   : > 1 splits the K loop over that many workgroup groups whose partial products are accumulated into
+                   C with fp32 atomic adds — C must be fp32 and zero-initialised; no bias/act/residual/rope/vt.
+                   Used by the weight-gradient GEMMs (few output tiles, very long K). */
+    void* preact_out;
+    int split_k;
     void* C;             /* [M,N] row-major, leading dim ldc (only columns < vt_col0 are written when vt is on) */
     int out_dtype;       /* UC_F32 | UC_BF16 */
     int64_t ldc;
@@ -131,6 +139,7 @@ int uc_attention_fwd(const void* Q, const void* K, const void* V, void* O, int d
                      int B, int H, int Nq, int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh,
                      int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
                      int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,
+                     float* lse /* optional fp32 [B,H,Nq]: log-sum-exp of the scaled scores, saved for the backward */,
                      uc_stream_t stream);
 
 /* Row-major bf16 V[b*v_sb + n*v_sn + h*v_sh + d] -> packed VT [B,H,D,Npad] (layout above). */
@@ -199,6 +208,55 @@ int uc_pointmap_adaptor(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp
  * ---------------------------------------------------------------------------------- */
 int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const float* b, float* out,
                    int64_t npix, int Cin, uc_stream_t stream);
+
+/* ====================================================================================
+ * Training path (backward of the same hot path; config 3 of BASELINE.json).
+ * The reference has no hand-written backward: it relies on PyTorch autograd over the modules cited above, so each
+ * entry point below states the forward expression it differentiates.
+ * ==================================================================================== */
+
+/* LayerNorm backward (forward: uc_layernorm).  x fp32 [rows,C], dy [rows,C] (dy_dtype f32|bf16), gamma fp32 [C].
+ *   dx[r,:]  = rstd*(a - mean(a) - xhat*mean(a*xhat)) (+ dres[r,:] if dres != NULL),  a = dy*gamma, xhat = (x-mean)*rstd
+ *   dgamma[c] += sum_r dy*xhat, dbeta[c] += sum_r dy     (fp32 atomic accumulation: zero them first)
+ * C must be a multiple of 256 and <= 2048. */
+int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
+                     float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream);
+
+/* Column sums (bias gradients): out[n] += sum_m src[m*ld + n]; out fp32, zero-initialised by the caller. */
+int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, float* out, uc_stream_t stream);
+
+/* Activation backward: du = dg * act'(u), u = saved pre-activation (uc_gemm preact_out).  act: UC_ACT_GELU_ERF | UC_ACT_RELU. */
+int uc_act_bwd(const void* dg, const void* u, void* du, int dtype, int act, int64_t n, uc_stream_t stream);
+
+/* Plain 2-D transpose src[R,S] -> dst[S,R] (row-major, same dtype f32|bf16, or f32 -> bf16), used to put the reduction
+ * dimension of the weight-gradient GEMMs (dW = dY^T X) on the contiguous axis. */
+int uc_transpose2d(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t R, int64_t S, uc_stream_t stream);
+
+/* Fused adaptor + loss, forward and backward in one pass over the decoded channels of one view
+ * (forward: uc_pointmap_adaptor; loss = mean over pixels of conf*|pts-gt| - alpha*log(conf), the DUSt3R confidence loss).
+ *   x fp32 4-channel map addressed like uc_pointmap_adaptor; gt fp32 [B,H,W,3];
+ *   loss_sum[0] += sum over pixels (caller divides by the pixel count); dx gets d(loss_sum)/dx * grad_scale, same addressing as x. */
+int uc_pointmap_loss(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp, const float* gt, float alpha,
+                     float grad_scale, float* loss_sum, float* dx, int B, int H, int W, uc_stream_t stream);
+
+/* Inverse of uc_pixel_shuffle for gradients: src fp32 NCHW [B,Cout,P*h,P*w] -> dst [B*h*w, Cout*P*P] (dst_dtype). */
+int uc_pixel_unshuffle(const float* src, void* dst, int dst_dtype, int B, int h, int w, int P, int Cout, uc_stream_t stream);
+
+/* AdamW step on flat fp32 buffers: p, g, m, v of n elements (decoupled weight decay).  step >= 1. */
+int uc_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int step, float grad_scale, uc_stream_t stream);
+
+/* Attention backward (forward: uc_attention_fwd, which must have been called with a non-NULL lse).
+ *   inputs : Q,K,V,O,dO as [B,N,H,64] strided views (bf16), LSE fp32 [B,H,Nq] (natural log of the softmax denominator of
+ *            the scaled scores), plus the packed transposes (layout of uc_vt_pack) QT, dOT [B,H,64,Nq_pad] and KT [B,H,64,Nk_pad];
+ *   outputs: dQ [B,Nq,H,64], dK, dV [B,Nk,H,64] bf16 (strided like the inputs).
+ *   delta fp32 [B,H,Nq] is scratch for rowsum(dO*O). */
+int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                     const void* QT, const void* dOT, const void* KT, void* dQ, void* dK, void* dV, float* delta, int B,
+                     int H, int Nq, int Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
+                     int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                     int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
+                     int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream);
 
 #ifdef __cplusplus
 }

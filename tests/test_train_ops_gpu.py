@@ -1,0 +1,221 @@
+"""Backward-kernel parity: every training-path C-ABI entry point against torch autograd on the CPU (fp32) of the forward
+expression the header says it differentiates.  The reference has no hand-written backward — autograd over its modules IS
+the reference behaviour — so an autograd gradient of the same expression on the same (bf16-rounded where the kernel
+takes bf16) inputs is the oracle here.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C", [256, 768, 1024])
+@pytest.mark.parametrize("dy_dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-5)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_bwd(gpu, C, dy_dtype, tol, with_res):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(C)
+    rows = 777
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    dy = torch.randn(rows, C, generator=g).to(dy_dtype)
+    dres = torch.randn(rows, C, generator=g) if with_res else None
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-6)
+    y.backward(dy.float())
+    dx_ref = x.grad + (dres if with_res else 0)
+    dgam = torch.zeros(C, device=gpu)
+    dbet = torch.zeros(C, device=gpu)
+    dx = ops.layernorm_bwd(x.detach().to(gpu), gamma.detach().to(gpu), dy.to(gpu), 1e-6, dgam, dbet,
+                           dres.to(gpu) if with_res else None)
+    assert rel_l2(dx.cpu(), dx_ref) < tol
+    assert rel_l2(dgam.cpu(), gamma.grad) < tol
+    assert rel_l2(dbet.cpu(), beta.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,ld", [(1000, 768, 768), (5, 1024, 3072), (2049, 30, 32), (1, 4, 4)])
+def test_colsum(gpu, dtype, M, N, ld):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    full = torch.randn(M, ld, generator=g).to(dtype)
+    src = full[:, :N]
+    out = torch.full((N,), 0.5, device=gpu)
+    ops.colsum_(full.to(gpu)[:, :N], out)
+    ref = src.double().sum(0) + 0.5
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, math.sqrt(M))
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 5e-3)])
+def test_act_bwd(gpu, act, dtype, tol):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(3)
+    u = (torch.randn(513, 300, generator=g) * 2).to(dtype)
+    dg = torch.randn(513, 300, generator=g).to(dtype)
+    uu = u.float().requires_grad_(True)
+    (F.gelu(uu) if act == "gelu" else F.relu(uu)).backward(dg.float())
+    du = ops.act_bwd(dg.to(gpu), u.to(gpu), act)
+    assert du.dtype == dtype
+    assert rel_l2(du.cpu().float(), uu.grad) < tol
+
+
+@pytest.mark.parametrize("R,S", [(64, 64), (197, 1000), (3, 5), (1024, 3072)])
+@pytest.mark.parametrize("src,dst", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                     (torch.float32, torch.bfloat16)])
+def test_transpose2d(gpu, R, S, src, dst):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(R)
+    x = torch.randn(R, S, generator=g).to(src)
+    y = ops.transpose2d(x.to(gpu), dst)
+    assert y.shape == (S, R) and y.dtype == dst
+    assert torch.equal(y.cpu(), x.t().contiguous().to(dst))
+
+
+@pytest.mark.parametrize("P,Cout,h,w", [(16, 4, 3, 5), (14, 4, 2, 2), (2, 3, 4, 4)])
+def test_pixel_unshuffle_is_inverse_of_pixel_shuffle(gpu, P, Cout, h, w):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(P)
+    B = 2
+    rows = torch.randn(B * h * w, Cout * P * P, generator=g)
+    img = ops.pixel_shuffle(rows.to(gpu), B, h, w, P, Cout)
+    ref = F.pixel_shuffle(rows.view(B, h, w, -1).permute(0, 3, 1, 2), P)
+    assert torch.equal(img.cpu(), ref)
+    back = ops.pixel_unshuffle(img, P, torch.float32)
+    assert torch.equal(back.cpu(), rows)
+    # and it is the autograd gradient of pixel_shuffle
+    gimg = torch.randn(B, Cout, P * h, P * w, generator=g)
+    rr = rows.clone().requires_grad_(True)
+    F.pixel_shuffle(rr.view(B, h, w, -1).permute(0, 3, 1, 2), P).backward(gimg)
+    assert torch.equal(ops.pixel_unshuffle(gimg.to(gpu), P, torch.float32).cpu(), rr.grad)
+
+
+# ------------------------------------------------------------------------------------------
+def _adaptor_loss_ref(x, gt, alpha):
+    """x [B,4,H,W]; the adaptor of adaptors.py:337-342,1080-1083 followed by the confidence-weighted regression loss."""
+    xyz = x[:, :3].permute(0, 2, 3, 1)
+    d = xyz.norm(dim=-1, keepdim=True)
+    pts = xyz / d.clamp(min=1e-8) * torch.expm1(d)
+    conf = 1 + x[:, 3].exp()
+    r = (pts - gt).norm(dim=-1)
+    return (conf * r - alpha * conf.log()).sum()
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_pointmap_loss_forward_backward(gpu, layout):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 24, 40
+    x = torch.randn(B, 4, H, W, generator=g, dtype=torch.float64) * 0.7
+    x[0, :3, 0, :5] *= 1e-3       # tiny-norm pixels exercise the series branch of s'(d)
+    gt = torch.randn(B, H, W, 3, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    loss_ref = _adaptor_loss_ref(xr, gt, 0.2)
+    loss_ref.backward()
+    xd = x.float().to(gpu)
+    if layout == "nhwc":
+        xd = xd.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    loss = torch.zeros(1, device=gpu)
+    dx = ops.pointmap_loss(xd, gt.float().to(gpu), 0.2, 0.5, loss)
+    assert dx.stride() == xd.stride()
+    assert abs(float(loss.cpu()) - float(loss_ref.detach())) / abs(float(loss_ref.detach())) < 1e-5
+    assert rel_l2(dx.cpu(), 0.5 * xr.grad) < 1e-5
+
+
+def test_adamw_matches_torch(gpu):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n = 100_003
+    p0 = torch.randn(n, generator=g)
+    pref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pref], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    p, m, v = p0.to(gpu), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g)
+        pref.grad = grad.clone()
+        opt.step()
+        ops.adamw_(p, (grad * 4).to(gpu), m, v, 1e-3, 0.9, 0.95, 1e-8, 0.05, step, grad_scale=0.25)
+    assert rel_l2(p.cpu(), pref.detach()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,sk", [(768, 768, 6272, 8), (1024, 3072, 4096, 4), (200, 72, 1024, 3)])
+def test_gemm_split_k(gpu, M, N, K, sk):
+    """weight-gradient shape: few output tiles, long K; fp32 atomic accumulation into a zeroed C."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = torch.randn(N, K, generator=g).bfloat16()
+    c = torch.zeros(M, N, device=gpu)
+    ops.gemm(a.to(gpu), w.to(gpu), out=c, out_dtype=torch.float32, split_k=sk)
+    ref = a.float() @ w.float().t()
+    assert rel_l2(c.cpu(), ref) < 2e-5
+
+
+def test_gemm_preact_out(gpu):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 300, 512, 256
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / 16).bfloat16()
+    b = torch.randn(N, generator=g)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=gpu)
+    y = ops.gemm(a.to(gpu), w.to(gpu), bias=b.to(gpu), act="gelu", out_dtype=torch.bfloat16, preact_out=pre)
+    u = a.float() @ w.float().t() + b
+    assert rel_l2(pre.cpu().float(), u) < 4e-3
+    assert rel_l2(y.cpu().float(), F.gelu(u)) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 196, 196), (1, 2, 64, 64), (1, 1, 77, 130), (2, 12, 1024, 1024), (1, 2, 33, 300)])
+def test_attention_lse_and_backward(gpu, B, H, Nq, Nk):
+    from uniception_amd import ops
+    D = 64
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    q = torch.randn(B, Nq, H, D, generator=g).bfloat16()
+    k = torch.randn(B, Nk, H, D, generator=g).bfloat16()
+    v = torch.randn(B, Nk, H, D, generator=g).bfloat16()
+    do = torch.randn(B, Nq, H, D, generator=g).bfloat16()
+    scale = D ** -0.5
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qf, kf) * scale
+    o_ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vf)
+    o_ref.backward(do.float())
+    lse_ref = s.logsumexp(-1)
+
+    qd, kd, vd = q.to(gpu), k.to(gpu), v.to(gpu)
+    lse = torch.empty(B, H, Nq, dtype=torch.float32, device=gpu)
+    o = ops.attention(qd, kd, ops.vt_pack(vd), scale, v_packed=True, lse=lse)
+    assert rel_l2(o.cpu().float(), o_ref.detach()) < 6e-3
+    assert float((lse.cpu() - lse_ref.detach()).abs().max()) < 2e-3
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, o, do.to(gpu), lse, scale)
+    assert rel_l2(dv.cpu().float(), vf.grad) < 1e-2
+    assert rel_l2(dq.cpu().float(), qf.grad) < 1.5e-2
+    assert rel_l2(dk.cpu().float(), kf.grad) < 1.5e-2
+
+
+def test_attention_backward_on_fused_qkv_views(gpu):
+    """self-attention layout of the encoder: q/k/v are strided views of one [B,N,3,H,D] buffer."""
+    from uniception_amd import ops
+    B, N, H, D = 2, 100, 4, 64
+    g = torch.Generator().manual_seed(21)
+    qkv = torch.randn(B, N, 3, H, D, generator=g).bfloat16()
+    do = torch.randn(B, N, H, D, generator=g).bfloat16()
+    qf, kf, vf = (qkv[:, :, i].float().requires_grad_(True) for i in range(3))
+    F.scaled_dot_product_attention(qf.transpose(1, 2), kf.transpose(1, 2), vf.transpose(1, 2)).transpose(1, 2).backward(do.float())
+    dev = qkv.to(gpu)
+    qd, kd, vd = dev[:, :, 0], dev[:, :, 1], dev[:, :, 2]
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=gpu)
+    o = ops.attention(qd, kd, ops.vt_pack(vd), D ** -0.5, v_packed=True, lse=lse)
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, o, do.to(gpu), lse, D ** -0.5)
+    for got, ref in ((dq, qf.grad), (dk, kf.grad), (dv, vf.grad)):
+        assert rel_l2(got.cpu().float(), ref) < 1.5e-2

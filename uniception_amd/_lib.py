@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("bias", vp), ("act", i32), ("residual", vp), ("residual2", vp), ("res_dtype", i32), ("ldr", i64),
         ("rope_cols", i64), ("rope_pos", vp), ("rope_table", vp), ("rope_npos", i32),
         ("vt_col0", i64), ("vt_out", vp), ("vt_ntok", i32), ("vt_npad", i32),
+        ("preact_out", vp), ("split_k", i32),
         ("C", vp), ("out_dtype", i32), ("ldc", i64),
     ]
 
@@ -42,7 +43,7 @@ SIGNATURES = {
     "uc_rope_table": [vp, i32, i32, f32, f32, vp],
     "uc_layernorm": [vp, i32, vp, vp, vp, i32, i64, i32, f32, vp],
     "uc_gemm": [C.POINTER(GemmDesc), vp],
-    "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp],
+    "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
     "uc_vt_pack": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
     "uc_patch_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_nchw_to_nhwc": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
@@ -53,6 +54,14 @@ SIGNATURES = {
     "uc_pixel_shuffle": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "uc_pointmap_adaptor": [vp, i64, i64, i64, vp, vp, i32, i32, i32, f32, f32, vp],
     "uc_conv1x1_to4": [vp, i32, vp, vp, vp, i64, i32, vp],
+    "uc_layernorm_bwd": [vp, vp, vp, i32, vp, vp, vp, vp, i64, i32, f32, vp],
+    "uc_colsum": [vp, i32, i64, i64, i64, vp, vp],
+    "uc_act_bwd": [vp, vp, vp, i32, i32, i64, vp],
+    "uc_transpose2d": [vp, i32, vp, i32, i64, i64, vp],
+    "uc_pointmap_loss": [vp, i64, i64, i64, vp, f32, f32, vp, vp, i32, i32, i32, vp],
+    "uc_pixel_unshuffle": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "uc_adamw": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
+    "uc_attention_bwd": [vp] * 13 + [i32] * 4 + [i64] * 21 + [f32, vp],
 }
 
 _lib = None

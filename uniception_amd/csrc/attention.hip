@@ -26,6 +26,7 @@ struct AttnParams {
     int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
     int npad;     // VT row length
     float scale;
+    float* lse;   // optional [B,H,Nq]: log-sum-exp of the scaled scores (saved for the backward)
 };
 
 #define KV_TILE 64
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
+    if (p.lse && q < p.Nq && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + q] = m_run * p.scale + logf(l_tot);
     if (q < p.Nq) {
         bf16_t* op = (bf16_t*)p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
 #pragma unroll
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(AttnParams p) {
         m_run = m_new;
     }
     if (active) {
+        if (p.lse) p.lse[((int64_t)b * p.H + h) * p.Nq + q] = m_run + logf(l_run);
         float* op = (float*)p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
         const float inv = 1.0f / l_run;
 #pragma unroll
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(AttnParams p) {
 extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, void* O, int dtype, int v_layout,
                                 int B, int H, int Nq, int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh,
                                 int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh,
-                                int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale, uc_stream_t stream) {
+                                int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale, float* lse, uc_stream_t stream) {
     UC_REQUIRE(Q && K && V && O, "uc_attention_fwd: null pointer");
     UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && D > 0, "uc_attention_fwd: bad shape");
     UC_REQUIRE(H <= 65535 && B <= 65535, "uc_attention_fwd: B and H must fit a grid dimension");
@@ -340,6 +343,7 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
     p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
     p.npad = (Nk + 63) / 64 * 64;
     p.scale = scale;
+    p.lse = lse;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UC_BF16) {
         UC_REQUIRE(D == 64, "uc_attention_fwd(bf16): head_dim must be 64 (got %d)", D);

@@ -1,0 +1,349 @@
+// Attention backward for gfx950 (bf16, head_dim 64, v_mfma_f32_32x32x16_bf16), flash-style recomputation.
+//
+//   S = scale Q K^T,  P = exp(S - LSE),  dV = P^T dO,  dP = dO V^T,  D = rowsum(dO * O),
+//   dS = P * (dP - D),  dQ = scale dS K,  dK = scale dS^T Q.
+//
+// Two kernels, no atomics:
+//  * attn_bwd_dq_kernel  — a workgroup owns 128 queries (4 waves x 32) and streams KV tiles.  Swapped products keep a
+//    query in one lane pair: S^T = K Q^T, dP^T = V dO^T (A operands = K / V rows from LDS, B operands = Q^T / dO^T in
+//    registers); dS^T in accumulator layout is the B operand of  dQ^T += K^T dS^T  with K^T read from the packed "KT" tile.
+//  * attn_bwd_dkv_kernel — a workgroup owns 128 keys and streams Q tiles.  Un-swapped products keep a KEY in one lane
+//    pair: S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS, B = K^T / V^T in registers); P and dS in accumulator layout
+//    are the B operands of  dV^T += dO^T P  and  dK^T += Q^T dS  with dO^T / Q^T read from the packed "dOT"/"QT" tiles.
+// The packed-transposed tensors use the VT layout of the forward (uc_hip.h): inside each group of 16 positions the index
+// is permuted so that the accumulator register order IS the MFMA k-slot order.
+// LDS tiles are 64 rows x 128 B with the (row>>1)&7 chunk swizzle (conflict-free ds_read_b128), single-buffered.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct AttnBwdParams {
+    const bf16_t *Q, *K, *V, *O, *dO, *QT, *dOT, *KT;
+    const float* LSE;
+    float* delta;
+    bf16_t *dQ, *dK, *dV;
+    int B, H, Nq, Nk, nq_pad, nk_pad;
+    int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
+    int64_t dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh;
+    float scale;
+};
+
+#define TB (64 * 128)   // bytes of one 64-row tile
+
+__device__ __forceinline__ int bswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ int key_of_pos16(int pp) {  // inverse of uc_vt_perm inside a 16-group
+    const int hi = pp >> 3, j = pp & 7;
+    return (j & 3) + 8 * (j >> 2) + 4 * hi;
+}
+
+// zero the packed-transposed positions whose source index is >= n_valid (tail tile), chunk = 8 positions starting at p0
+__device__ __forceinline__ uint4 mask_packed_chunk(uint4 v, int p0_in_tile, int tile0, int n_valid) {
+    const int gbase = tile0 + (p0_in_tile & ~15);
+    const int pbase = p0_in_tile & 15;
+    unsigned m[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (gbase + key_of_pos16(pbase + j) >= n_valid) m[j >> 1] &= (j & 1) ? 0x0000ffffu : 0xffff0000u;
+    v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+    return v;
+}
+
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+__global__ void attn_delta_kernel(AttnBwdParams p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.H * p.Nq;
+    if (idx >= total) return;
+    const int q = (int)(idx % p.Nq);
+    const int h = (int)((idx / p.Nq) % p.H);
+    const int b = (int)(idx / ((int64_t)p.Nq * p.H));
+    const bf16_t* o = p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
+    const bf16_t* d = p.dO + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint4 a = *reinterpret_cast<const uint4*>(o + c * 8);
+        const uint4 g = *reinterpret_cast<const uint4*>(d + c * 8);
+        const unsigned* au = reinterpret_cast<const unsigned*>(&a);
+        const unsigned* gu = reinterpret_cast<const unsigned*>(&g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s += __uint_as_float(au[e] << 16) * __uint_as_float(gu[e] << 16);
+            s += __uint_as_float(au[e] & 0xffff0000u) * __uint_as_float(gu[e] & 0xffff0000u);
+        }
+    }
+    p.delta[idx] = s;
+}
+
+// =================================================================================================================
+// dQ
+// =================================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * TB];   // K rows | V rows | KT
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    int q = q0 + l31;
+    const bool q_ok = q < p.Nq;
+    if (!q_ok) q = p.Nq - 1;
+
+    const bf16_t* Kb = p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const bf16_t* Vb = p.V + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
+    const bf16_t* KTb = p.KT + ((int64_t)b * p.H + h) * 64 * (int64_t)p.nk_pad;
+
+    bf16x8_t qf[4], dof[4];
+    {
+        const bf16_t* qp = p.Q + (int64_t)b * p.q_sb + (int64_t)q * p.q_sn + (int64_t)h * p.q_sh + hi * 8;
+        const bf16_t* dp = p.dO + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh + hi * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+            dof[s] = *reinterpret_cast<const bf16x8_t*>(dp + 16 * s);
+        }
+    }
+    const float c = p.scale * 1.44269504088896340736f;
+    const float lse2 = p.LSE[((int64_t)b * p.H + h) * p.Nq + q] * 1.44269504088896340736f;
+    const float dlt = p.delta[((int64_t)b * p.H + h) * p.Nq + q];
+
+    float16_t dq[2];
+    dq[0] = (float16_t)(0.f);
+    dq[1] = (float16_t)(0.f);
+
+    const int cc = tid & 7, sr = tid >> 3;
+    int r_off[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) r_off[st] = bswz(l31, 2 * st + hi);
+    const int w_off = bswz(sr, cc);
+
+    const int nt = (p.Nk + 63) / 64;
+    for (int t = 0; t < nt; ++t) {
+        const int k0 = t * 64;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = sr + 32 * i;
+            int key = k0 + row;
+            if (key >= p.Nk) key = p.Nk - 1;
+            *reinterpret_cast<uint4*>(smem + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * p.k_sn + cc * 8);
+            *reinterpret_cast<uint4*>(smem + TB + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * p.v_sn + cc * 8);
+            uint4 kt = *reinterpret_cast<const uint4*>(KTb + (int64_t)row * p.nk_pad + k0 + cc * 8);
+            if (k0 + 64 > p.Nk) kt = mask_packed_chunk(kt, cc * 8, k0, p.Nk);
+            *reinterpret_cast<uint4*>(smem + 2 * TB + w_off + i * 32 * 128) = kt;
+        }
+        __syncthreads();
+
+        bf16x8_t dsf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float16_t s = (float16_t)(0.f), dp = (float16_t)(0.f);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + r_off[st] + kb * (32 * 128));
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(smem + TB + r_off[st] + kb * (32 * 128));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[st], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = hf * 8 + j;
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float pv = (key < p.Nk) ? __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2)) : 0.f;
+                    e[j] = pv * (dp[r] - dlt);
+                }
+                union { bf16x8_t v; unsigned u[4]; } pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk.u[j] = pack_bf16x2(e[2 * j], e[2 * j + 1]);
+                dsf[kb * 2 + hf] = pk.v;
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x8_t ktf = *reinterpret_cast<const bf16x8_t*>(smem + 2 * TB + r_off[g] + db * (32 * 128));
+                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[g], dq[db], 0, 0, 0);
+            }
+    }
+    if (q_ok) {
+        bf16_t* op = p.dQ + (int64_t)b * p.dq_sb + (int64_t)q * p.dq_sn + (int64_t)h * p.dq_sh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = db * 32 + 8 * g4 + 4 * hi;
+                uint2 pk;
+                pk.x = pack_bf16x2(dq[db][g4 * 4 + 0] * p.scale, dq[db][g4 * 4 + 1] * p.scale);
+                pk.y = pack_bf16x2(dq[db][g4 * 4 + 2] * p.scale, dq[db][g4 * 4 + 3] * p.scale);
+                *reinterpret_cast<uint2*>(op + d) = pk;
+            }
+    }
+}
+
+// =================================================================================================================
+// dK, dV
+// =================================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TB + 512];   // Q rows | dO rows | QT | dOT | lse2[64] delta[64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int key0 = blockIdx.x * 128 + wave * 32;
+    int key = key0 + l31;
+    const bool key_ok = key < p.Nk;
+    if (!key_ok) key = p.Nk - 1;
+
+    const bf16_t* Qb = p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const bf16_t* dOb = p.dO + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
+    const bf16_t* QTb = p.QT + ((int64_t)b * p.H + h) * 64 * (int64_t)p.nq_pad;
+    const bf16_t* dOTb = p.dOT + ((int64_t)b * p.H + h) * 64 * (int64_t)p.nq_pad;
+    const float* lse_b = p.LSE + ((int64_t)b * p.H + h) * p.Nq;
+    const float* dl_b = p.delta + ((int64_t)b * p.H + h) * p.Nq;
+    float* s_lse = reinterpret_cast<float*>(smem + 4 * TB);
+    float* s_dl = s_lse + 64;
+
+    bf16x8_t kf[4], vf[4];   // B operands: lane key = l31, channels 16s + 8hi .. +7
+    {
+        const bf16_t* kp = p.K + (int64_t)b * p.k_sb + (int64_t)key * p.k_sn + (int64_t)h * p.k_sh + hi * 8;
+        const bf16_t* vp = p.V + (int64_t)b * p.v_sb + (int64_t)key * p.v_sn + (int64_t)h * p.v_sh + hi * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * s);
+            vf[s] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * s);
+        }
+    }
+    const float c = p.scale * 1.44269504088896340736f;
+    float16_t dk[2], dv[2];
+    dk[0] = (float16_t)(0.f); dk[1] = (float16_t)(0.f);
+    dv[0] = (float16_t)(0.f); dv[1] = (float16_t)(0.f);
+
+    const int cc = tid & 7, sr = tid >> 3;
+    int r_off[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) r_off[st] = bswz(l31, 2 * st + hi);
+    const int w_off = bswz(sr, cc);
+
+    const int nt = (p.Nq + 63) / 64;
+    for (int t = 0; t < nt; ++t) {
+        const int q0 = t * 64;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = sr + 32 * i;
+            int q = q0 + row;
+            if (q >= p.Nq) q = p.Nq - 1;
+            *reinterpret_cast<uint4*>(smem + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Qb + (int64_t)q * p.q_sn + cc * 8);
+            *reinterpret_cast<uint4*>(smem + TB + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(dOb + (int64_t)q * p.o_sn + cc * 8);
+            uint4 qt = *reinterpret_cast<const uint4*>(QTb + (int64_t)row * p.nq_pad + q0 + cc * 8);
+            uint4 dt = *reinterpret_cast<const uint4*>(dOTb + (int64_t)row * p.nq_pad + q0 + cc * 8);
+            if (q0 + 64 > p.Nq) {
+                qt = mask_packed_chunk(qt, cc * 8, q0, p.Nq);
+                dt = mask_packed_chunk(dt, cc * 8, q0, p.Nq);
+            }
+            *reinterpret_cast<uint4*>(smem + 2 * TB + w_off + i * 32 * 128) = qt;
+            *reinterpret_cast<uint4*>(smem + 3 * TB + w_off + i * 32 * 128) = dt;
+        }
+        if (tid < 64) {
+            const int q = q0 + tid;
+            s_lse[tid] = (q < p.Nq) ? lse_b[q] * 1.44269504088896340736f : 0.f;
+            s_dl[tid] = (q < p.Nq) ? dl_b[q] : 0.f;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float16_t s = (float16_t)(0.f), dp = (float16_t)(0.f);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(smem + r_off[st] + qb * (32 * 128));
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(smem + TB + r_off[st] + qb * (32 * 128));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[st], s, 0, 0, 0);     // S[q rows, key cols]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[st], dp, 0, 0, 0);   // dP[q rows, key cols]
+            }
+            bf16x8_t pfr[2], dsfr[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float pe[8], de[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = hf * 8 + j;
+                    const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;   // query index inside the tile
+                    const float pv = (q0 + ql < p.Nq) ? __builtin_amdgcn_exp2f(fmaf(s[r], c, -s_lse[ql])) : 0.f;
+                    pe[j] = pv;
+                    de[j] = pv * (dp[r] - s_dl[ql]);
+                }
+                union { bf16x8_t v; unsigned u[4]; } a, d2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a.u[j] = pack_bf16x2(pe[2 * j], pe[2 * j + 1]);
+                    d2.u[j] = pack_bf16x2(de[2 * j], de[2 * j + 1]);
+                }
+                pfr[hf] = a.v;
+                dsfr[hf] = d2.v;
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int g = qb * 2 + hf;   // 16-query slab inside the tile -> chunks 2g, 2g+1
+                    const bf16x8_t dota = *reinterpret_cast<const bf16x8_t*>(smem + 3 * TB + r_off[g] + db * (32 * 128));
+                    const bf16x8_t qta = *reinterpret_cast<const bf16x8_t*>(smem + 2 * TB + r_off[g] + db * (32 * 128));
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dota, pfr[hf], dv[db], 0, 0, 0);   // dV^T[d, key]
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsfr[hf], dk[db], 0, 0, 0);   // dK^T[d, key]
+                }
+        }
+    }
+    if (key_ok) {
+        bf16_t* kp = p.dK + (int64_t)b * p.dk_sb + (int64_t)key * p.dk_sn + (int64_t)h * p.dk_sh;
+        bf16_t* vp = p.dV + (int64_t)b * p.dv_sb + (int64_t)key * p.dv_sn + (int64_t)h * p.dv_sh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = db * 32 + 8 * g4 + 4 * hi;
+                uint2 a, v;
+                a.x = pack_bf16x2(dk[db][g4 * 4 + 0] * p.scale, dk[db][g4 * 4 + 1] * p.scale);
+                a.y = pack_bf16x2(dk[db][g4 * 4 + 2] * p.scale, dk[db][g4 * 4 + 3] * p.scale);
+                v.x = pack_bf16x2(dv[db][g4 * 4 + 0], dv[db][g4 * 4 + 1]);
+                v.y = pack_bf16x2(dv[db][g4 * 4 + 2], dv[db][g4 * 4 + 3]);
+                *reinterpret_cast<uint2*>(kp + d) = a;
+                *reinterpret_cast<uint2*>(vp + d) = v;
+            }
+    }
+}
+
+extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                const void* QT, const void* dOT, const void* KT, void* dQ, void* dK, void* dV, float* delta,
+                                int B, int H, int Nq, int Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb,
+                                int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
+                                int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn,
+                                int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream) {
+    UC_REQUIRE(Q && K && V && O && dO && LSE && QT && dOT && KT && dQ && dK && dV && delta, "uc_attention_bwd: null pointer");
+    UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B <= 65535 && H <= 65535, "uc_attention_bwd: bad shape");
+    UC_REQUIRE(q_sn % 8 == 0 && k_sn % 8 == 0 && v_sn % 8 == 0 && o_sn % 8 == 0 && q_sh % 8 == 0 && k_sh % 8 == 0 && v_sh % 8 == 0 &&
+                   o_sh % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0,
+               "uc_attention_bwd: input strides must be multiples of 8 elements");
+    UC_REQUIRE(dq_sn % 4 == 0 && dk_sn % 4 == 0 && dv_sn % 4 == 0 && dq_sh % 4 == 0 && dk_sh % 4 == 0 && dv_sh % 4 == 0 &&
+                   dq_sb % 4 == 0 && dk_sb % 4 == 0 && dv_sb % 4 == 0,
+               "uc_attention_bwd: output strides must be multiples of 4 elements");
+    AttnBwdParams p;
+    p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (const bf16_t*)O; p.dO = (const bf16_t*)dO;
+    p.QT = (const bf16_t*)QT; p.dOT = (const bf16_t*)dOT; p.KT = (const bf16_t*)KT; p.LSE = LSE; p.delta = delta;
+    p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.nq_pad = (Nq + 63) / 64 * 64; p.nk_pad = (Nk + 63) / 64 * 64;
+    p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh; p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh;
+    p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh; p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.dk_sb = dk_sb; p.dk_sn = dk_sn;
+    p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh; p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * H * Nq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 0, st, p);
+    UC_CHECK_LAUNCH("uc_attention_bwd");
+    return UC_OK;
+}

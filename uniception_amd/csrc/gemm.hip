@@ -483,6 +483,14 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const char* e = getenv("UC_GEMM_VARIANT");
             forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..2: glds tile variants
         }
+        if (d->split_k > 1) {
+            UC_REQUIRE(d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a, "uc_gemm: split_k needs a dense operand with K %% 64 == 0");
+            UC_REQUIRE(d->out_dtype == UC_F32 && !d->bias && d->act == UC_ACT_NONE && !d->residual && d->rope_cols <= 0 && d->vt_col0 < 0 && !d->preact_out,
+                       "uc_gemm: split_k accumulates raw fp32 partial products only (no epilogue options)");
+            UC_REQUIRE(d->split_k <= 1024, "uc_gemm: split_k too large");
+        }
+        if (d->preact_out) UC_REQUIRE(d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a && d->vt_col0 < 0 && d->rope_cols <= 0,
+                                      "uc_gemm: preact_out is implemented on the dense direct-to-LDS kernel only");
         const bool glds_dense = d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a;
         const bool glds_conv = d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 == 0 &&
                                (int64_t)d->conv_B * d->conv_H * d->conv_W < (int64_t)1 << 30;
@@ -498,6 +506,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const bool r_ok = !d->residual || (((uintptr_t)d->residual % 16 == 0) && (d->ldr % 4 == 0) &&
                                                (!d->residual2 || (uintptr_t)d->residual2 % 16 == 0));
             g.vec_ok = (c_ok && b_ok && r_ok) ? 1 : 0;
+            g.preact = d->preact_out; g.split_k = d->split_k > 1 ? d->split_k : 1;
             { static int gm = -1; if (gm < 0) { const char* e = getenv("UC_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } g.group_m = gm; }
             { static int dbg = -1; if (dbg < 0) { const char* e = getenv("UC_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
             g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
@@ -508,7 +517,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 // enough tiles to cover the 256 CUs; smaller problems fall back to 256x128 / 128x128 tiles.
                 const int64_t t256 = ceil_div64(d->M, 256) * ceil_div64(d->N, 256);
                 const int64_t t256x128 = ceil_div64(d->M, 256) * ceil_div64(d->N, 128);
-                variant = t256 >= 192 ? 2 : (t256x128 >= 160 ? 1 : 0);
+                const int64_t sk = d->split_k > 1 ? d->split_k : 1;
+                variant = t256 * sk >= 192 ? 2 : (t256x128 * sk >= 160 ? 1 : 0);
             }
             uc_launch_gemm_glds(g, variant, st);
             UC_CHECK_LAUNCH("uc_gemm(glds)");
@@ -523,6 +533,10 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         else
             hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_CONV3X3>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);
     } else if (d->compute_dtype == UC_F32) {
+        if (d->split_k > 1 || d->preact_out) {
+            uc_set_error("uc_gemm(f32): split_k / preact_out are only implemented for the bf16 MFMA path");
+            return UC_ERR_UNSUPPORTED;
+        }
         if (d->vt_col0 >= 0) {
             uc_set_error("uc_gemm(f32): vt epilogue is only implemented for the bf16 MFMA path");
             return UC_ERR_UNSUPPORTED;

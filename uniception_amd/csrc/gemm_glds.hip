@@ -146,6 +146,29 @@ __device__ __forceinline__ void glds_epilogue(const GldsParams& p, float4_t (&ac
         const int64_t m = wave_m + 16 * i + frow;
         if (m >= p.M) continue;
         float v[4][4];
+        if (p.split_k > 1) {   // partial product of one K slice: fp32 atomic accumulation, nothing else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t nb = wave_n + 16 * j + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nb + r < p.N) unsafeAtomicAdd((float*)p.C + m * p.ldc + nb + r, acc[i][j][r]);
+            }
+            continue;
+        }
+        if (p.preact) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t nb = wave_n + 16 * j + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nb + r >= p.N) continue;
+                    const float u = acc[i][j][r] + b4[j][r];
+                    if (p.out_dtype == UC_F32) ((float*)p.preact)[m * p.ldc + nb + r] = u;
+                    else ((bf16_t*)p.preact)[m * p.ldc + nb + r] = f32_to_bf16(u);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -234,7 +257,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int t = glds_xcd_remap(blockIdx.x, nwg);
+    const int ksplit = (int)blockIdx.x / nwg;                 // split-K slice (0 when split_k == 1)
+    const int t = glds_xcd_remap((int)blockIdx.x - ksplit * nwg, nwg);
     // Tile order inside an XCD's run: groups of GM row panels swept column by column, so the ~32 tiles an XCD runs
     // concurrently form a GM x (32/GM) block that shares GM A-panels and 32/GM W-panels in its L2 (a plain row-major
     // order shares 2 A-panels but streams ALL of W through every pair of row panels: 2.4x algorithmic fetch traffic).
@@ -335,7 +359,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (int)(p.K / 64);
+    // K range of this workgroup (whole K unless split_k > 1)
+    const int nk_total = (int)(p.K / 64);
+    const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
+    const int kt0 = ksplit * nk_per;
+    const int nk = max(0, min(nk_per, nk_total - kt0));
+    const int64_t kbase = (int64_t)kt0 * 64;
     // SWAP: first MFMA operand = W rows -> C^T fragments (lane owns 4 consecutive columns of one row);
     // !SWAP (VT tiles): first operand = A rows (lane owns 4 consecutive tokens of one channel).
     auto compute_stage = [&](const char* st, auto swap_tag) {
@@ -366,25 +395,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     auto main_loop = [&](auto swap_tag) {
         if constexpr (STAGES == 2) {
             // 2-stage ring: the DMA of step kt+1 is in flight while the MFMAs of step kt run.
-            issue_stage(0, 0);
+            if (nk > 0) issue_stage(0, kbase);
             for (int kt = 0; kt < nk; ++kt) {
                 wait_vmcnt<0>();                 // this wave's pieces of stage kt have landed
                 __builtin_amdgcn_s_barrier();    // ... and everyone else's; every wave is done reading stage kt-1
                 asm volatile("" ::: "memory");
-                if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, (int64_t)(kt + 1) * 64);
+                if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * 64);
                 compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag);
             }
         } else {
             // 3-stage ring, DMA two K-steps ahead: the loads of step kt+1 stay in flight across the barrier of step kt.
-            issue_stage(0, 0);
-            if (nk > 1) issue_stage(1, 64);
+            if (nk > 0) issue_stage(0, kbase);
+            if (nk > 1) issue_stage(1, kbase + 64);
             int cur = 0;
             for (int kt = 0; kt < nk; ++kt) {
                 if (kt + 1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
-                if (kt + 2 < nk) issue_stage(nxt, (int64_t)(kt + 2) * 64);
+                if (kt + 2 < nk) issue_stage(nxt, kbase + (int64_t)(kt + 2) * 64);
                 compute_stage(smem + cur * STAGE_BYTES, swap_tag);
                 cur = (cur == 2) ? 0 : cur + 1;
             }
@@ -406,7 +435,7 @@ static void launch_variant_mode(GldsParams p, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(WM_ * WN_ * 64), smem, st, p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n * (unsigned)p.split_k), dim3(WM_ * WN_ * 64), smem, st, p);
 }
 
 template <int BM_, int BN_, int WM_, int WN_, int STAGES>

@@ -1,0 +1,357 @@
+// Backward / training-step kernels of the DUSt3R path that are HBM-bound: LayerNorm backward, column sums (bias
+// gradients), activation backward, 2-D transpose (puts the reduction axis of the weight-gradient GEMMs on the
+// contiguous dimension), fused adaptor+loss forward/backward, pixel un-shuffle, AdamW.
+// The reference has no hand-written backward (it is PyTorch autograd over the modules); each kernel cites the forward
+// expression it differentiates in include/uc_hip.h.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  One wavefront per row, exact width C = NV*256 (all loads of a row issued back to back), rows
+// distributed grid-stride so each wave also accumulates its share of dgamma/dbeta in registers and issues ONE atomic
+// per column at the end.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TD>
+__device__ __forceinline__ float4_t tr_load4(const typename TD::storage* p);
+template <>
+__device__ __forceinline__ float4_t tr_load4<F32Tag>(const float* p) { return *reinterpret_cast<const float4_t*>(p); }
+template <>
+__device__ __forceinline__ float4_t tr_load4<BF16Tag>(const bf16_t* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    float4_t v;
+    v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
+    v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
+    return v;
+}
+
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+}
+
+template <typename TD, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const typename TD::storage* __restrict__ dy,
+                                                            const float* __restrict__ dres, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int64_t rows, float eps) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    float4_t g[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *reinterpret_cast<const float4_t*>(gamma + (i * 64 + lane) * 4);
+        dg[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        db[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const float invC = 1.0f / (float)C;
+    for (int64_t row = wave_id; row < rows; row += nwaves) {
+        float4_t v[NV], d[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4_t*>(x + row * C + (i * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) d[i] = tr_load4<TD>(dy + row * C + (i * 64 + lane) * 4);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;   // xhat
+            dg[i].x += d[i].x * v[i].x; dg[i].y += d[i].y * v[i].y; dg[i].z += d[i].z * v[i].z; dg[i].w += d[i].w * v[i].w;
+            db[i].x += d[i].x; db[i].y += d[i].y; db[i].z += d[i].z; db[i].w += d[i].w;
+            d[i].x *= g[i].x; d[i].y *= g[i].y; d[i].z *= g[i].z; d[i].w *= g[i].w;               // a = dy*gamma
+            s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+            s2 += (d[i].x * v[i].x + d[i].y * v[i].y) + (d[i].z * v[i].z + d[i].w * v[i].w);
+        }
+        wave_sum2(s1, s2);
+        s1 *= invC; s2 *= invC;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float4_t o;
+            o.x = rstd * (d[i].x - s1 - v[i].x * s2);
+            o.y = rstd * (d[i].y - s1 - v[i].y * s2);
+            o.z = rstd * (d[i].z - s1 - v[i].z * s2);
+            o.w = rstd * (d[i].w - s1 - v[i].w * s2);
+            if (dres) {
+                const float4_t r = *reinterpret_cast<const float4_t*>(dres + row * C + (i * 64 + lane) * 4);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4_t*>(dx + row * C + (i * 64 + lane) * 4) = o;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        unsafeAtomicAdd(dgamma + c + 0, dg[i].x); unsafeAtomicAdd(dgamma + c + 1, dg[i].y);
+        unsafeAtomicAdd(dgamma + c + 2, dg[i].z); unsafeAtomicAdd(dgamma + c + 3, dg[i].w);
+        unsafeAtomicAdd(dbeta + c + 0, db[i].x); unsafeAtomicAdd(dbeta + c + 1, db[i].y);
+        unsafeAtomicAdd(dbeta + c + 2, db[i].z); unsafeAtomicAdd(dbeta + c + 3, db[i].w);
+    }
+}
+
+extern "C" int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
+                                float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream) {
+    UC_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "uc_layernorm_bwd: null pointer");
+    UC_REQUIRE(rows >= 0 && C > 0 && C % 256 == 0 && C <= 2048, "uc_layernorm_bwd: C must be a multiple of 256 and <= 2048 (got %d)", C);
+    UC_REQUIRE(dy_dtype == UC_F32 || dy_dtype == UC_BF16, "uc_layernorm_bwd: bad dy dtype %d", dy_dtype);
+    if (rows == 0) return UC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)min((int64_t)512, ceil_div64(rows, 4));
+#define UC_LNB(TD_, NV_)                                                                                                \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TD_, NV_>), dim3(grid), dim3(256), 0, st, x, gamma,                            \
+                       (const typename TD_::storage*)dy, dres, dx, dgamma, dbeta, rows, eps)
+#define UC_LNB_NV(TD_)                      \
+    switch (C / 256) {                      \
+        case 1: UC_LNB(TD_, 1); break;      \
+        case 2: UC_LNB(TD_, 2); break;      \
+        case 3: UC_LNB(TD_, 3); break;      \
+        case 4: UC_LNB(TD_, 4); break;      \
+        case 6: UC_LNB(TD_, 6); break;      \
+        case 8: UC_LNB(TD_, 8); break;      \
+        default: uc_set_error("uc_layernorm_bwd: unsupported width %d", C); return UC_ERR_UNSUPPORTED; \
+    }
+    if (dy_dtype == UC_F32) { UC_LNB_NV(F32Tag) } else { UC_LNB_NV(BF16Tag) }
+#undef UC_LNB_NV
+#undef UC_LNB
+    UC_CHECK_LAUNCH("uc_layernorm_bwd");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// column sums: block = 64 column-lanes (4 columns each) x 4 row-lanes; grid.y slabs of rows; one atomic per column per block
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Tag>
+__global__ __launch_bounds__(256) void colsum_kernel(const typename Tag::storage* __restrict__ src, int64_t M, int64_t N,
+                                                     int64_t ld, float* __restrict__ out, int64_t rows_per_block) {
+    __shared__ float red[4][64][4];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t)blockIdx.x * 64 + cl) * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + 3 < N && (ld % 4 == 0)) {
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            const float4_t v = tr_load4<Tag>(src + r * ld + c0);
+            a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+        }
+    } else {
+        for (int64_t r = r0 + rl; r < r1; r += 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < N) a[e] += Tag::load(src + r * ld + c0 + e);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rl][cl][e] = a[e];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = red[0][cl][e] + red[1][cl][e] + red[2][cl][e] + red[3][cl][e];
+            if (c0 + e < N) unsafeAtomicAdd(out + c0 + e, s);
+        }
+    }
+}
+
+extern "C" int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, float* out, uc_stream_t stream) {
+    UC_REQUIRE(src && out && M >= 0 && N > 0 && ld >= N, "uc_colsum: bad argument");
+    if (M == 0) return UC_OK;
+    const int64_t rows_per_block = 512;
+    dim3 grid((unsigned)ceil_div64(N, 256), (unsigned)min((int64_t)65535, ceil_div64(M, rows_per_block)));
+    const int64_t rpb = ceil_div64(M, grid.y);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UC_F32) hipLaunchKernelGGL((colsum_kernel<F32Tag>), grid, dim3(256), 0, st, (const float*)src, M, N, ld, out, rpb);
+    else if (dtype == UC_BF16) hipLaunchKernelGGL((colsum_kernel<BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, M, N, ld, out, rpb);
+    else { uc_set_error("uc_colsum: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_colsum");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// activation backward
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Tag>
+__global__ void act_bwd_kernel(const typename Tag::storage* __restrict__ dg, const typename Tag::storage* __restrict__ u,
+                               typename Tag::storage* __restrict__ du, int act, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = Tag::load(u + i), g = Tag::load(dg + i);
+        float d;
+        if (act == UC_ACT_GELU_ERF) {
+            // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x exp(-x^2/2) / sqrt(2 pi)
+            d = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+        } else {
+            d = x > 0.f ? 1.f : 0.f;
+        }
+        Tag::store(du + i, g * d);
+    }
+}
+
+extern "C" int uc_act_bwd(const void* dg, const void* u, void* du, int dtype, int act, int64_t n, uc_stream_t stream) {
+    UC_REQUIRE(dg && u && du && n >= 0, "uc_act_bwd: bad argument");
+    UC_REQUIRE(act == UC_ACT_GELU_ERF || act == UC_ACT_RELU, "uc_act_bwd: bad act %d", act);
+    if (n == 0) return UC_OK;
+    const unsigned grid = (unsigned)min((int64_t)65536 * 4, ceil_div64(n, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UC_F32) hipLaunchKernelGGL((act_bwd_kernel<F32Tag>), dim3(grid), dim3(256), 0, st, (const float*)dg, (const float*)u, (float*)du, act, n);
+    else if (dtype == UC_BF16) hipLaunchKernelGGL((act_bwd_kernel<BF16Tag>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dg, (const bf16_t*)u, (bf16_t*)du, act, n);
+    else { uc_set_error("uc_act_bwd: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_act_bwd");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2-D transpose, 64x64 tiles through LDS (pitch 65 floats: conflict-free both ways)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose64_kernel(const typename TI::storage* __restrict__ src,
+                                                          typename TO::storage* __restrict__ dst, int64_t R, int64_t S) {
+    __shared__ float tile[64][65];
+    const int64_t s0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t r = r0 + ty + 4 * k, s = s0 + tx;
+        if (r < R && s < S) tile[ty + 4 * k][tx] = TI::load(src + r * S + s);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t s = s0 + ty + 4 * k, r = r0 + tx;
+        if (r < R && s < S) TO::store(dst + s * R + r, tile[tx][ty + 4 * k]);
+    }
+}
+
+extern "C" int uc_transpose2d(const void* src, int sd, void* dst, int dd, int64_t R, int64_t S, uc_stream_t stream) {
+    UC_REQUIRE(src && dst && R > 0 && S > 0, "uc_transpose2d: bad argument");
+    UC_REQUIRE((R + 63) / 64 <= 65535, "uc_transpose2d: too many rows");
+    dim3 grid((unsigned)ceil_div64(S, 64), (unsigned)ceil_div64(R, 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<BF16Tag, BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, R, S);
+    else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((transpose64_kernel<F32Tag, F32Tag>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, R, S);
+    else if (sd == UC_F32 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<F32Tag, BF16Tag>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, R, S);
+    else { uc_set_error("uc_transpose2d: unsupported dtypes %d -> %d", sd, dd); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_transpose2d");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused adaptor + confidence-weighted regression loss, forward and backward
+//   pts = xyz * s(d), s(d) = expm1(d)/max(d,1e-8), d = |xyz|;  conf = 1 + exp(c)
+//   L = conf * r - alpha * log(conf),  r = |pts - gt|
+//   dL/dpts = conf * (pts-gt)/max(r,1e-12);  dL/dc = (r - alpha/conf) * exp(c)
+//   dpts_i/dxyz_j = s delta_ij + xyz_i xyz_j s'(d)/d,  s'(d) = (exp(d) d - expm1(d)) / d^2
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pointmap_loss_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sp,
+                                     const float* __restrict__ gt, float alpha, float gscale, float* __restrict__ loss_sum,
+                                     float* __restrict__ dx, int64_t HW, int64_t n) {
+    float local = 0.f;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = it / HW, pix = it % HW;
+        const int64_t base = b * sb + pix * sp;
+        const float X = x[base], Y = x[base + sc], Z = x[base + 2 * sc], Cf = x[base + 3 * sc];
+        const float d = sqrtf(X * X + Y * Y + Z * Z);
+        const float dc = fmaxf(d, 1e-8f);
+        const float em1 = expm1f(d);
+        const float s = em1 / dc;
+        const float px = X * s, py = Y * s, pz = Z * s;
+        const float ec = expf(Cf);
+        const float conf = 1.0f + ec;
+        const float ex = px - gt[it * 3 + 0], ey = py - gt[it * 3 + 1], ez = pz - gt[it * 3 + 2];
+        const float r = sqrtf(ex * ex + ey * ey + ez * ez);
+        local += conf * r - alpha * logf(conf);
+        const float ir = conf / fmaxf(r, 1e-12f);
+        const float gx = ex * ir, gy = ey * ir, gz = ez * ir;          // dL/dpts
+        // s'(d) = (e^d d - expm1(d)) / d^2, series 1/2 + d/3 near 0 (the closed form cancels catastrophically there)
+        const float sprime = (d > 1e-2f) ? ((em1 + 1.0f) * d - em1) / (d * d) : 0.5f + d * (1.0f / 3.0f);
+        const float sprime_over_d = sprime / dc;
+        const float dot = X * gx + Y * gy + Z * gz;
+        const float k = dot * sprime_over_d;
+        dx[base] = (s * gx + X * k) * gscale;
+        dx[base + sc] = (s * gy + Y * k) * gscale;
+        dx[base + 2 * sc] = (s * gz + Z * k) * gscale;
+        dx[base + 3 * sc] = (r - alpha / conf) * ec * gscale;
+    }
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(loss_sum, local);
+}
+
+extern "C" int uc_pointmap_loss(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp, const float* gt, float alpha,
+                                float grad_scale, float* loss_sum, float* dx, int B, int H, int W, uc_stream_t stream) {
+    UC_REQUIRE(x && gt && loss_sum && dx && B > 0 && H > 0 && W > 0, "uc_pointmap_loss: bad argument");
+    const int64_t n = (int64_t)B * H * W;
+    const unsigned grid = (unsigned)min((int64_t)4096, ceil_div64(n, 256));
+    hipLaunchKernelGGL(pointmap_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, x_sb, x_sc, x_sp, gt, alpha,
+                       grad_scale, loss_sum, dx, (int64_t)H * W, n);
+    UC_CHECK_LAUNCH("uc_pointmap_loss");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pixel un-shuffle (gradient of the linear head's pixel_shuffle)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void pixel_unshuffle_kernel(const float* __restrict__ src, typename TO::storage* __restrict__ dst, int B, int h, int w,
+                                       int P, int Cout, int64_t n) {
+    const int Wd = P * w, Hd = P * h, CPP = Cout * P * P;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n; it += (int64_t)gridDim.x * blockDim.x) {
+        // destination order: (token row, column c*P*P + u*P + v)
+        const int col = (int)(it % CPP);
+        const int64_t tok = it / CPP;
+        const int v = col % P, u = (col / P) % P, c = col / (P * P);
+        const int j = (int)(tok % w), i = (int)((tok / w) % h), b = (int)(tok / ((int64_t)w * h));
+        TO::store(dst + it, src[(((int64_t)b * Cout + c) * Hd + (int64_t)i * P + u) * Wd + (int64_t)j * P + v]);
+    }
+}
+
+extern "C" int uc_pixel_unshuffle(const float* src, void* dst, int dst_dtype, int B, int h, int w, int P, int Cout, uc_stream_t stream) {
+    UC_REQUIRE(src && dst && B > 0 && h > 0 && w > 0 && P > 0 && Cout > 0, "uc_pixel_unshuffle: bad argument");
+    const int64_t n = (int64_t)B * h * w * Cout * P * P;
+    const unsigned grid = (unsigned)min((int64_t)65536 * 4, ceil_div64(n, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dst_dtype == UC_F32) hipLaunchKernelGGL((pixel_unshuffle_kernel<F32Tag>), dim3(grid), dim3(256), 0, st, src, (float*)dst, B, h, w, P, Cout, n);
+    else if (dst_dtype == UC_BF16) hipLaunchKernelGGL((pixel_unshuffle_kernel<BF16Tag>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, B, h, w, P, Cout, n);
+    else { uc_set_error("uc_pixel_unshuffle: bad dtype %d", dst_dtype); return UC_ERR_BAD_ARG; }
+    UC_CHECK_LAUNCH("uc_pixel_unshuffle");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AdamW on flat fp32 buffers (decoupled weight decay, bias-corrected moments)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             int64_t n, float lr, float b1, float b2, float eps, float wd, float c1, float c2, float gs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float upd = (mi * c1) / (sqrtf(vi * c2) + eps);
+        p[i] = p[i] * (1.f - lr * wd) - lr * upd;
+    }
+}
+
+extern "C" int uc_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, uc_stream_t stream) {
+    UC_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "uc_adamw: bad argument");
+    if (n == 0) return UC_OK;
+    const float c1 = 1.0f / (1.0f - powf(beta1, (float)step));
+    const float c2 = 1.0f / (1.0f - powf(beta2, (float)step));
+    const unsigned grid = (unsigned)min((int64_t)65536, ceil_div64(n, 256));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, c1, c2, grad_scale);
+    UC_CHECK_LAUNCH("uc_adamw");
+    return UC_OK;
+}

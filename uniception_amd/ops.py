@@ -101,7 +101,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          out: Optional[torch.Tensor] = None, relu_a: bool = False,
          rope: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
          vt: Optional[Tuple[int, torch.Tensor, int]] = None,
-         conv: Optional[Tuple[int, int, int, int, int]] = None) -> torch.Tensor:
+         conv: Optional[Tuple[int, int, int, int, int]] = None, preact_out: Optional[torch.Tensor] = None,
+         split_k: int = 1) -> torch.Tensor:
     """C[M,N] = epilogue(A . W^T).
 
     a    : dense [M,K] (row stride a.stride(0), unit column stride) or, with conv=(B,H,W,Cin,stride), an NHWC image.
@@ -155,6 +156,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     else:
         assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] >= n_out
     d.C, d.out_dtype, d.ldc = out.data_ptr(), _dt(out.dtype), out.stride(0)
+    if preact_out is not None:
+        assert preact_out.shape == out.shape and preact_out.stride() == out.stride() and preact_out.dtype == out.dtype
+        d.preact_out = preact_out.data_ptr()
+    d.split_k = int(split_k)
     _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
     return out
 
@@ -177,7 +182,7 @@ def vt_pack(v: torch.Tensor) -> torch.Tensor:
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, v_packed: bool = False,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [B,Nq,H,D], k [B,Nk,H,D] strided views (stride(3)==1); v same, or packed VT [B,H,D,Npad] when v_packed.
     Returns O [B,Nq,H,D] contiguous (== [B,Nq,H*D])."""
     _need_gpu(q, k, v)
@@ -195,7 +200,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, v
     _lib.check(_lib.load().uc_attention_fwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _dt(q.dtype), UC_V_PACKED_T if v_packed else UC_V_ROWMAJOR,
         B, H, Nq, Nk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), vs[0], vs[1], vs[2],
-        out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()), "uc_attention_fwd")
+        out.stride(0), out.stride(1), out.stride(2), float(scale), _p(lse), _stream()), "uc_attention_fwd")
     return out
 
 
@@ -297,3 +302,108 @@ def conv1x1_to4(feat: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.T
     _lib.check(_lib.load().uc_conv1x1_to4(feat.data_ptr(), _dt(feat.dtype), w.data_ptr(), b.data_ptr(), out.data_ptr(),
                                           B * H * W, Cin, _stream()), "uc_conv1x1_to4")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# training path
+# --------------------------------------------------------------------------------------------
+def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float, dgamma: torch.Tensor,
+                  dbeta: torch.Tensor, dres: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx (fp32) of y = LN(x); dgamma/dbeta are accumulated into (fp32, caller-zeroed). dres: gradient of a parallel
+    residual branch to add into dx."""
+    _need_gpu(x, gamma, dy, dgamma, dbeta, dres)
+    assert x.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    dx = torch.empty_like(x)
+    if dres is not None:
+        assert dres.dtype == torch.float32 and dres.is_contiguous() and dres.shape == x.shape
+    _lib.check(_lib.load().uc_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy.dtype), _p(dres), dx.data_ptr(),
+                                            dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn, float(eps), _stream()), "uc_layernorm_bwd")
+    return dx
+
+
+def colsum_(src: torch.Tensor, out: torch.Tensor) -> None:
+    """out[n] += sum_m src[m, n] (out fp32)."""
+    _need_gpu(src, out)
+    assert src.dim() == 2 and src.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == src.shape[1]
+    _lib.check(_lib.load().uc_colsum(src.data_ptr(), _dt(src.dtype), src.shape[0], src.shape[1], src.stride(0), out.data_ptr(),
+                                     _stream()), "uc_colsum")
+
+
+def act_bwd(dg: torch.Tensor, u: torch.Tensor, act: str) -> torch.Tensor:
+    _need_gpu(dg, u)
+    assert dg.is_contiguous() and u.is_contiguous() and dg.shape == u.shape and dg.dtype == u.dtype
+    du = torch.empty_like(dg)
+    _lib.check(_lib.load().uc_act_bwd(dg.data_ptr(), u.data_ptr(), du.data_ptr(), _dt(dg.dtype), ACT[act], dg.numel(), _stream()),
+               "uc_act_bwd")
+    return du
+
+
+def transpose2d(x: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """[R,S] contiguous -> [S,R] contiguous."""
+    _need_gpu(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((x.shape[1], x.shape[0]), dtype=out_dtype, device=x.device)
+    _lib.check(_lib.load().uc_transpose2d(x.data_ptr(), _dt(x.dtype), y.data_ptr(), _dt(out_dtype), x.shape[0], x.shape[1],
+                                          _stream()), "uc_transpose2d")
+    return y
+
+
+def pointmap_loss(x: torch.Tensor, gt: torch.Tensor, alpha: float, grad_scale: float, loss_sum: torch.Tensor) -> torch.Tensor:
+    """x: fp32 4-channel BCHW-shaped map (dense rows); gt [B,H,W,3] fp32. Adds the summed loss into loss_sum[0] and
+    returns d(loss_sum)/dx * grad_scale with the memory layout of x."""
+    _need_gpu(x, gt, loss_sum)
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 4 and gt.is_contiguous() and gt.dtype == torch.float32
+    B, _, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    assert sh == W * sw
+    dx = torch.empty_strided(x.shape, x.stride(), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().uc_pointmap_loss(x.data_ptr(), sb, sc, sw, gt.data_ptr(), float(alpha), float(grad_scale),
+                                            loss_sum.data_ptr(), dx.data_ptr(), B, H, W, _stream()), "uc_pointmap_loss")
+    return dx
+
+
+def pixel_unshuffle(g: torch.Tensor, P: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """g fp32 NCHW [B,Cout,P*h,P*w] contiguous -> [B*h*w, Cout*P*P]."""
+    _need_gpu(g)
+    assert g.dtype == torch.float32 and g.is_contiguous()
+    B, Cout, Hd, Wd = g.shape
+    h, w = Hd // P, Wd // P
+    y = torch.empty((B * h * w, Cout * P * P), dtype=out_dtype, device=g.device)
+    _lib.check(_lib.load().uc_pixel_unshuffle(g.data_ptr(), y.data_ptr(), _dt(out_dtype), B, h, w, P, Cout, _stream()),
+               "uc_pixel_unshuffle")
+    return y
+
+
+def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
+           weight_decay: float, step: int, grad_scale: float = 1.0) -> None:
+    _need_gpu(p, g, m, v)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    _lib.check(_lib.load().uc_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
+                                    float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream()), "uc_adamw")
+
+
+def attention_bwd(q, k, v, o, do, lse, scale: float):
+    """q,o,do [B,Nq,H,64]; k,v [B,Nk,H,64] bf16 views (unit last stride); lse fp32 [B,H,Nq].
+    Returns dq, dk, dv (contiguous [B,N,H,64] bf16)."""
+    _need_gpu(q, k, v, o, do, lse)
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    assert D == 64 and q.dtype == torch.bfloat16 and lse.dtype == torch.float32 and lse.is_contiguous()
+    if do.stride() != o.stride() or o.stride(3) != 1:
+        o, do = o.contiguous(), do.contiguous()
+    qt, dot, kt = vt_pack(q), vt_pack(do), vt_pack(k)
+    dq = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
+    dk = torch.empty((B, Nk, H, D), dtype=torch.bfloat16, device=q.device)
+    dv = torch.empty((B, Nk, H, D), dtype=torch.bfloat16, device=q.device)
+    delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().uc_attention_bwd(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), qt.data_ptr(), dot.data_ptr(),
+        kt.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk,
+        q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
+        o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1), dk.stride(2),
+        dv.stride(0), dv.stride(1), dv.stride(2), float(scale), _stream()), "uc_attention_bwd")
+    return dq, dk, dv
