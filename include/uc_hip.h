@@ -218,7 +218,7 @@ int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const float* b, 
 /* LayerNorm backward (forward: uc_layernorm).  x fp32 [rows,C], dy [rows,C] (dy_dtype f32|bf16), gamma fp32 [C].
  *   dx[r,:]  = rstd*(a - mean(a) - xhat*mean(a*xhat)) (+ dres[r,:] if dres != NULL),  a = dy*gamma, xhat = (x-mean)*rstd
  *   dgamma[c] += sum_r dy*xhat, dbeta[c] += sum_r dy     (fp32 atomic accumulation: zero them first)
- * C must be a multiple of 256 and <= 2048. */
+ * Any C; widths 256*{1,2,3,4,6,8} take the register-resident kernel. */
 int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
                      float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream);
 
@@ -228,9 +228,23 @@ int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, floa
 /* Activation backward: du = dg * act'(u), u = saved pre-activation (uc_gemm preact_out).  act: UC_ACT_GELU_ERF | UC_ACT_RELU. */
 int uc_act_bwd(const void* dg, const void* u, void* du, int dtype, int act, int64_t n, uc_stream_t stream);
 
-/* Plain 2-D transpose src[R,S] -> dst[S,R] (row-major, same dtype f32|bf16, or f32 -> bf16), used to put the reduction
- * dimension of the weight-gradient GEMMs (dW = dY^T X) on the contiguous axis. */
-int uc_transpose2d(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t R, int64_t S, uc_stream_t stream);
+/* 2-D transpose src[R,S] -> dst[S, ld_dst] (row-major; f32->f32, bf16->bf16 or f32->bf16), used to put the reduction
+ * dimension of the weight-gradient GEMMs (dW = dY^T X) on the contiguous axis.  ld_dst in [R, R+64): columns R..ld_dst-1
+ * are written as zeros so the GEMM K dimension can be padded to a multiple of 64.  If rowmajor_copy != NULL the
+ * converted (dst dtype) un-transposed [R,S] matrix is written there in the same pass. */
+int uc_transpose2d(const void* src, int src_dtype, void* dst, int dst_dtype, void* rowmajor_copy, int64_t R, int64_t S,
+                   int64_t ld_dst, uc_stream_t stream);
+
+/* Backward of uc_pointmap_adaptor for an arbitrary downstream loss: dpts [B,H,W,3], dconf [B,H,W,1] (either may be
+ * NULL = zero) -> dx addressed like x.  The confidence clamp at conf_vmax passes no gradient. */
+int uc_pointmap_adaptor_bwd(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp, const float* dpts,
+                            const float* dconf, float conf_vmin, float conf_vmax, float* dx, int B, int H, int W,
+                            uc_stream_t stream);
+
+/* Confidence-weighted regression loss on adaptor outputs (the DUSt3R training objective; the reference ships no loss):
+ *   loss_sum[0] += sum_pix conf*|pts-gt| - alpha*log(conf);  dpts, dconf = its gradients * grad_scale. */
+int uc_conf_loss(const float* pts, const float* conf, const float* gt, float alpha, float grad_scale, float* loss_sum,
+                 float* dpts, float* dconf, int64_t npix, uc_stream_t stream);
 
 /* Fused adaptor + loss, forward and backward in one pass over the decoded channels of one view
  * (forward: uc_pointmap_adaptor; loss = mean over pixels of conf*|pts-gt| - alpha*log(conf), the DUSt3R confidence loss).
@@ -257,6 +271,15 @@ int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O,
                      int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
                      int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
                      int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream);
+
+/* fp32 verification-mode attention backward: same math, row-major fp32 operands (head_dim D <= 64), no packed
+ * transposes needed.  delta fp32 [B,H,Nq] is scratch. */
+int uc_attention_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                         const float* LSE, float* dQ, float* dK, float* dV, float* delta, int B, int H, int Nq, int Nk,
+                         int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                         int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                         int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
+                         int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream);
 
 #ifdef __cplusplus
 }

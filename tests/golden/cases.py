@@ -32,3 +32,18 @@ def sample_indices(numel: int, n: int = 4096) -> np.ndarray:
     if numel <= n:
         return np.arange(numel, dtype=np.int64)
     return (np.arange(n, dtype=np.int64) * (numel - 1)) // (n - 1)
+
+
+# cases that also have a gradient fixture (<case>__grads.npz, written by make_golden_grads.py)
+GRAD_CASES = ("tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224")
+
+
+def grad_targets(c):
+    """Seeded synthetic pointmap targets [B,H,W,3] for the two views of case dict `c`."""
+    import torch
+    H, W = c["img"]
+    out = []
+    for v in (0, 1):
+        rng = np.random.Generator(np.random.Philox(key=7000 + 10 * c["seed"] + v))
+        out.append(torch.from_numpy(rng.standard_normal(size=(c["B"], H, W, 3), dtype=np.float32)))
+    return out

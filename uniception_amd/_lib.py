@@ -57,11 +57,14 @@ SIGNATURES = {
     "uc_layernorm_bwd": [vp, vp, vp, i32, vp, vp, vp, vp, i64, i32, f32, vp],
     "uc_colsum": [vp, i32, i64, i64, i64, vp, vp],
     "uc_act_bwd": [vp, vp, vp, i32, i32, i64, vp],
-    "uc_transpose2d": [vp, i32, vp, i32, i64, i64, vp],
+    "uc_transpose2d": [vp, i32, vp, i32, vp, i64, i64, i64, vp],
+    "uc_pointmap_adaptor_bwd": [vp, i64, i64, i64, vp, vp, f32, f32, vp, i32, i32, i32, vp],
+    "uc_conf_loss": [vp, vp, vp, f32, f32, vp, vp, vp, i64, vp],
     "uc_pointmap_loss": [vp, i64, i64, i64, vp, f32, f32, vp, vp, i32, i32, i32, vp],
     "uc_pixel_unshuffle": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_adamw": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
     "uc_attention_bwd": [vp] * 13 + [i32] * 4 + [i64] * 21 + [f32, vp],
+    "uc_attention_bwd_f32": [vp] * 10 + [i32] * 5 + [i64] * 21 + [f32, vp],
 }
 
 _lib = None

@@ -1,0 +1,433 @@
+"""Training path of the DUSt3R hot path: ``torch.autograd.Function``s whose forward AND backward are the HIP kernels.
+
+The reference trains through PyTorch autograd over its modules (it ships no hand-written backward); here autograd only
+wires the graph (residual stream, the Jacobi update between the two views, the view ops at the BCHW boundary) while every
+sub-layer's backward is one Function calling uc_hip entry points:
+
+    pre-LN sub-layer  x_out = x + f(LN(x)):   backward gets d(x_out) and returns
+        dx = LN_bwd(x, gamma, df/dh) + d(x_out)              (residual add fused into uc_layernorm_bwd)
+    linear y = h W^T + b:
+        dW = dy^T h   -> uc_transpose2d (both operands, K padded to 64) + split-K uc_gemm with fp32 atomics
+        db = uc_colsum(dy),   dh = uc_gemm(dy, W^T)          (W^T prepared once per weight version)
+    attention: uc_attention_fwd saves LSE; uc_attention_bwd recomputes P tile by tile (dQ kernel + dK/dV kernel)
+    RoPE: gradients of the rotated q/k are rotated back in place with the inverse angle (curope2d.py:24-28)
+
+Precision follows the forward: bf16 operands with fp32 accumulation, fp32 residual stream, fp32 weight gradients; in
+fp32 verification mode every kernel is the exact-fp32 variant.
+"""
+import math
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import engine, ops
+from ._lib import UcHipError
+
+KPAD = 64  # the weight-gradient GEMMs reduce over tokens: pad that axis to the direct-to-LDS kernel's K granule
+
+
+def grad_needed(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _c(g: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if g is None else (g if g.is_contiguous() else g.contiguous())
+
+
+def _tp(x2d: torch.Tensor, dt: torch.dtype, with_copy: bool = False):
+    return ops.transpose2d(x2d, dt, pad_to=KPAD, with_copy=with_copy)
+
+
+def _wgrad(dyT: torch.Tensor, xT: torch.Tensor) -> torch.Tensor:
+    """dW [N,K] fp32 = dy^T x with both operands already transposed ([N,Mp], [K,Mp]; Mp = tokens padded to 64)."""
+    N, Mp = dyT.shape
+    K = xT.shape[0]
+    if dyT.dtype == torch.bfloat16:
+        tiles = ((N + 255) // 256) * ((K + 255) // 256)
+        sk = max(1, min(Mp // 256, -(-768 // tiles)))
+        if sk > 1:
+            out = torch.zeros((N, K), dtype=torch.float32, device=dyT.device)
+            ops.gemm(dyT, xT, out=out, out_dtype=torch.float32, split_k=sk)
+            return out
+    return ops.gemm(dyT, xT, out_dtype=torch.float32)
+
+
+def _colsum(src2d: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros(src2d.shape[1], dtype=torch.float32, device=src2d.device)
+    ops.colsum_(src2d, out)
+    return out
+
+
+def _w_t(owner, tag, weight2d_sources, build_2d, dt):
+    """W^T [K,N] in dt of a [N,K] fp32 weight, cached per weight version."""
+    return engine.prepared(owner, (tag, "T", dt), weight2d_sources, lambda: ops.transpose2d(build_2d(), dt))
+
+
+def lin_weight_t(lin, dt):
+    return _w_t(lin, "lin", (lin.weight,), lambda: lin.weight.detach().float().reshape(lin.weight.shape[0], -1).contiguous(), dt)
+
+
+def kv_weight_t(projk, projv, dt):
+    return _w_t(projk, "kv", (projk.weight, projv.weight),
+                lambda: torch.cat([projk.weight.detach(), projv.weight.detach()], 0).float().contiguous(), dt)
+
+
+def _check_rope(rope):
+    if rope is not None and not engine.is_native_rope(rope):
+        raise UcHipError("training through a foreign positional-encoding callable is not supported; use RoPE2D / cuRoPE2D")
+
+
+def _rope_inverse_(t4, pos, rope):
+    if rope is not None:
+        ops.rope_2d_(t4, pos.contiguous(), rope.base, -rope.F0)
+
+
+def _attention_fwd(q, k, v, scale, lse):
+    if q.dtype == torch.bfloat16:
+        if q.shape[-1] != 64:
+            raise UcHipError(f"bf16 attention needs head_dim 64 (got {q.shape[-1]})")
+        return ops.attention(q, k, ops.vt_pack(v), scale, v_packed=True, lse=lse)
+    return ops.attention(q, k, v, scale, lse=lse)
+
+
+# =================================================================================================================
+# LayerNorm alone (encoder / decoder final norms, intermediate norms)
+# =================================================================================================================
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, eps, out_dtype):
+        x2d = _c(x2d)
+        if x2d.dtype != torch.float32:
+            raise UcHipError("training keeps the residual stream in fp32")
+        g, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        ctx.save_for_backward(x2d, g)
+        ctx.eps = eps
+        return ops.layernorm(x2d, g, b, eps, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, g = ctx.saved_tensors
+        dy = _c(dy)
+        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        dx = ops.layernorm_bwd(x2d, g, dy, ctx.eps, dg, db)
+        return dx, dg, db, None, None
+
+
+def layer_norm(x2d, ln, out_dtype):
+    return LayerNormFn.apply(x2d, ln.weight, ln.bias, ln.eps, out_dtype)
+
+
+# =================================================================================================================
+# Linear (proj_embed, the linear head's 1x1 conv, patch embedding GEMM)
+# =================================================================================================================
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, owner, dt, out_dtype):
+        x2d = _c(x2d)
+        xb = x2d if x2d.dtype == dt else ops.convert(x2d, dt)
+        w, b = engine.prepared(owner, ("lin2d", dt), (weight, bias),
+                               lambda: (weight.detach().reshape(weight.shape[0], -1).to(dt).contiguous(),
+                                        None if bias is None else bias.detach().float().contiguous()))
+        ctx.save_for_backward(xb)
+        ctx.owner, ctx.dt, ctx.x_dtype, ctx.wshape, ctx.has_bias = owner, dt, x2d.dtype, weight.shape, bias is not None
+        ctx.weight = weight
+        return ops.gemm(xb, w, b, out_dtype=out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xb,) = ctx.saved_tensors
+        dt = ctx.dt
+        dy = _c(dy)
+        need_dx = ctx.needs_input_grad[0]
+        if need_dx:
+            dyT, dyb = _tp(dy, dt, with_copy=True)
+        else:
+            dyT, dyb = _tp(dy, dt), None
+        dW = _wgrad(dyT, _tp(xb, dt)).view(ctx.wshape)
+        db = _colsum(dy) if ctx.has_bias else None
+        dx = None
+        if need_dx:
+            wT = _w_t(ctx.owner, "lin2d", (ctx.weight,),
+                      lambda: ctx.weight.detach().float().reshape(ctx.wshape[0], -1).contiguous(), dt)
+            dx = ops.gemm(dyb, wT, out_dtype=ctx.x_dtype)
+        return dx, dW, db, None, None, None
+
+
+def linear(x2d, weight, bias, owner, dt, out_dtype):
+    return LinearFn.apply(x2d, weight, bias, owner, dt, out_dtype)
+
+
+class PatchEmbedFn(Function):
+    """tokens = gather(img) . W^T + b (libs/croco/patch_embed.py:47,69-82); the image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, owner, P, dt):
+        cols = ops.patch_gather(img, P, dt)
+        w, b = engine.patch_weights(owner, dt)
+        ctx.save_for_backward(cols)
+        ctx.dt, ctx.wshape, ctx.has_bias = dt, weight.shape, bias is not None
+        return ops.gemm(cols, w, b, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        (cols,) = ctx.saved_tensors
+        dtok = _c(dtok)
+        dW = _wgrad(_tp(dtok, ctx.dt), _tp(cols, ctx.dt)).view(ctx.wshape)
+        db = _colsum(dtok) if ctx.has_bias else None
+        return None, dW, db, None, None, None
+
+
+def patch_embed(img, conv, P, dt):
+    if img.requires_grad:
+        raise UcHipError("gradients w.r.t. the input images are not implemented")
+    return PatchEmbedFn.apply(img, conv.weight, conv.bias, conv, P, dt)
+
+
+# =================================================================================================================
+# pre-LN sub-layers of the transformer blocks
+# =================================================================================================================
+class SelfAttnSubLayerFn(Function):
+    """x + proj(SDPA(rope(q), rope(k), v)),  q,k,v = qkv(LN(x))   (blocks.py:105-125,154-158; transformer_blocks.py:214-260)."""
+
+    @staticmethod
+    def forward(ctx, x2d, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, ln, qkv, proj, B, N, H, rope, pos, scale, dt):
+        x2d = _c(x2d)
+        M, C = x2d.shape
+        Dh = C // H
+        _check_rope(rope)
+        g, bta = engine.ln_params(ln)
+        h = ops.layernorm(x2d, g, bta, ln.eps, dt)
+        wq, bq = engine.lin_weights(qkv, dt)
+        wp, bp = engine.lin_weights(proj, dt)
+        if dt == torch.bfloat16 and rope is not None:
+            if Dh != 64:
+                raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh})")
+            t = ops.gemm(h, wq, bq, rope=engine._rope_epilogue(rope, engine._pos2d(pos), 2 * C))
+            t5 = t.view(B, N, 3, H, Dh)
+        else:
+            t = ops.gemm(h, wq, bq)
+            t5 = t.view(B, N, 3, H, Dh)
+            if rope is not None:
+                ops.rope_2d_(t5[:, :, 0], pos.contiguous(), rope.base, rope.F0)
+                ops.rope_2d_(t5[:, :, 1], pos.contiguous(), rope.base, rope.F0)
+        lse = torch.empty((B, H, N), dtype=torch.float32, device=x2d.device)
+        o = _attention_fwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], scale, lse)
+        out = ops.gemm(o.view(M, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
+        ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0))
+        ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dxo):
+        x2d, g, h, t, o, lse, pos = ctx.saved_tensors
+        ln, qkv, proj, B, N, H, rope, scale, dt, has_bq, has_bp = ctx.meta
+        M, C = x2d.shape
+        Dh = C // H
+        dxo = _c(dxo)
+        dyT, dyb = _tp(dxo, dt, with_copy=True)
+        dWp = _wgrad(dyT, _tp(o.view(M, C), dt))
+        dbp = _colsum(dyb) if has_bp else None
+        do = ops.gemm(dyb, lin_weight_t(proj, dt))
+        dt3 = torch.empty_like(t)
+        d5, t5 = dt3.view(B, N, 3, H, Dh), t.view(B, N, 3, H, Dh)
+        ops.attention_bwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale,
+                          out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]))
+        _rope_inverse_(d5[:, :, 0], pos, rope)
+        _rope_inverse_(d5[:, :, 1], pos, rope)
+        dWq = _wgrad(_tp(dt3, dt), _tp(h, dt))
+        dbq = _colsum(dt3) if has_bq else None
+        dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
+        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)
+        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10
+
+
+def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt):
+    return SelfAttnSubLayerFn.apply(x2d, ln.weight, ln.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, ln, qkv, proj,
+                                    B, N, H, rope, pos, scale, dt)
+
+
+class CrossAttnSubLayerFn(Function):
+    """x + proj(SDPA(rope(projq(LN2(x)), xpos), rope(projk(LNy(y)), ypos), projv(LNy(y))))  (transformer_blocks.py:329-412,604-647)."""
+
+    @staticmethod
+    def forward(ctx, x2d, y2d, ln_w, ln_b, lny_w, lny_b, wq_, bq_, wk_, bk_, wv_, bv_, wp_, bp_, ln, lny, projq, projk, projv, proj,
+                B, Nq, Nk, H, rope, qpos, kpos, scale, dt):
+        x2d, y2d = _c(x2d), _c(y2d)
+        Mq, C = x2d.shape
+        Dh = C // H
+        _check_rope(rope)
+        g, bta = engine.ln_params(ln)
+        hq = ops.layernorm(x2d, g, bta, ln.eps, dt)
+        if lny is not None:
+            gy, by = engine.ln_params(lny)
+            hy = ops.layernorm(y2d, gy, by, lny.eps, dt)
+        else:
+            gy = torch.empty(0, device=x2d.device)
+            hy = y2d if y2d.dtype == dt else ops.convert(y2d, dt)
+        wq, bq = engine.lin_weights(projq, dt)
+        wkv, bkv = engine.kv_weights(projk, projv, dt)
+        wp, bp = engine.lin_weights(proj, dt)
+        if dt == torch.bfloat16 and rope is not None:
+            if Dh != 64:
+                raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh})")
+            q = ops.gemm(hq, wq, bq, rope=engine._rope_epilogue(rope, engine._pos2d(qpos), C))
+            kv = ops.gemm(hy, wkv, bkv, rope=engine._rope_epilogue(rope, engine._pos2d(kpos), C))
+        else:
+            q = ops.gemm(hq, wq, bq)
+            kv = ops.gemm(hy, wkv, bkv)
+            if rope is not None:
+                ops.rope_2d_(q.view(B, Nq, H, Dh), qpos.contiguous(), rope.base, rope.F0)
+                ops.rope_2d_(kv.view(B, Nk, 2, H, Dh)[:, :, 0], kpos.contiguous(), rope.base, rope.F0)
+        kv5 = kv.view(B, Nk, 2, H, Dh)
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=x2d.device)
+        o = _attention_fwd(q.view(B, Nq, H, Dh), kv5[:, :, 0], kv5[:, :, 1], scale, lse)
+        out = ops.gemm(o.view(Mq, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
+        e = torch.empty(0)
+        ctx.save_for_backward(x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos if qpos is not None else e, kpos if kpos is not None else e)
+        ctx.meta = (ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt,
+                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dxo):
+        x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos, kpos = ctx.saved_tensors
+        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp = ctx.meta
+        Mq, C = x2d.shape
+        Dh = C // H
+        dxo = _c(dxo)
+        dyT, dyb = _tp(dxo, dt, with_copy=True)
+        dWp = _wgrad(dyT, _tp(o.view(Mq, C), dt))
+        dbp = _colsum(dyb) if has_bp else None
+        do = ops.gemm(dyb, lin_weight_t(proj, dt))
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        kv5, dkv5 = kv.view(B, Nk, 2, H, Dh), dkv.view(B, Nk, 2, H, Dh)
+        ops.attention_bwd(q.view(B, Nq, H, Dh), kv5[:, :, 0], kv5[:, :, 1], o, do.view(B, Nq, H, Dh), lse, scale,
+                          out=(dq.view(B, Nq, H, Dh), dkv5[:, :, 0], dkv5[:, :, 1]))
+        _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
+        _rope_inverse_(dkv5[:, :, 0], kpos, rope)
+        # query side
+        dWq = _wgrad(_tp(dq, dt), _tp(hq, dt))
+        dbq = _colsum(dq) if has_bq else None
+        dhq = ops.gemm(dq, lin_weight_t(projq, dt))
+        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        dx = ops.layernorm_bwd(x2d, g, dhq, ln.eps, dg, db, dres=dxo)
+        # key/value side (the other view's tokens)
+        dWkv = _wgrad(_tp(dkv, dt), _tp(hy, dt))
+        dbkv = _colsum(dkv) if (has_bk or has_bv) else None
+        dhy = ops.gemm(dkv, kv_weight_t(projk, projv, dt), out_dtype=dt if lny is not None else torch.float32)
+        if lny is not None:
+            dgy, dby = torch.zeros_like(gy), torch.zeros_like(gy)
+            dy = ops.layernorm_bwd(y2d, gy, dhy, lny.eps, dgy, dby)
+        else:
+            dgy = dby = None
+            dy = dhy
+        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWkv[:C], dbkv[:C] if has_bk else None, dWkv[C:],
+                dbkv[C:] if has_bv else None, dWp, dbp) + (None,) * 15
+
+
+def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt):
+    lw, lb = (lny.weight, lny.bias) if lny is not None else (None, None)
+    return CrossAttnSubLayerFn.apply(x2d, y2d, ln.weight, ln.bias, lw, lb, ca.projq.weight, ca.projq.bias, ca.projk.weight,
+                                     ca.projk.bias, ca.projv.weight, ca.projv.bias, ca.proj.weight, ca.proj.bias, ln, lny,
+                                     ca.projq, ca.projk, ca.projv, ca.proj, B, Nq, Nk, H, rope, qpos, kpos, scale, dt)
+
+
+class MlpSubLayerFn(Function):
+    """x + fc2(act(fc1(LN(x))))   (blocks.py:64-86,159; transformer_blocks.py:517-560)."""
+
+    @staticmethod
+    def forward(ctx, x2d, ln_w, ln_b, w1_, b1_, w2_, b2_, ln, fc1, fc2, act, dt):
+        x2d = _c(x2d)
+        g, bta = engine.ln_params(ln)
+        h = ops.layernorm(x2d, g, bta, ln.eps, dt)
+        w1, b1 = engine.lin_weights(fc1, dt)
+        w2, b2 = engine.lin_weights(fc2, dt)
+        u = torch.empty((x2d.shape[0], w1.shape[0]), dtype=dt, device=x2d.device)
+        a = ops.gemm(h, w1, b1, act=act, preact_out=u)
+        out = ops.gemm(a, w2, b2, residual=x2d, out_dtype=x2d.dtype)
+        ctx.save_for_backward(x2d, g, h, u, a)
+        ctx.meta = (ln, fc1, fc2, act, dt, b1_ is not None, b2_ is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dxo):
+        x2d, g, h, u, a = ctx.saved_tensors
+        ln, fc1, fc2, act, dt, has_b1, has_b2 = ctx.meta
+        dxo = _c(dxo)
+        dyT, dyb = _tp(dxo, dt, with_copy=True)
+        dW2 = _wgrad(dyT, _tp(a, dt))
+        db2 = _colsum(dyb) if has_b2 else None
+        da = ops.gemm(dyb, lin_weight_t(fc2, dt))
+        du = ops.act_bwd(da, u, act) if act != "none" else da
+        dW1 = _wgrad(_tp(du, dt), _tp(h, dt))
+        db1 = _colsum(du) if has_b1 else None
+        dh = ops.gemm(du, lin_weight_t(fc1, dt))
+        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)
+        return (dx, dg, db, dW1, db1, dW2, db2) + (None,) * 5
+
+
+def mlp_sublayer(x2d, ln, fc1, fc2, act, dt):
+    return MlpSubLayerFn.apply(x2d, ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln, fc1, fc2, act, dt)
+
+
+# =================================================================================================================
+# heads: pixel shuffle, adaptor, loss
+# =================================================================================================================
+class PixelShuffleFn(Function):
+    @staticmethod
+    def forward(ctx, rows, B, h, w, P, Cout):
+        ctx.P = P
+        return ops.pixel_shuffle(_c(rows), B, h, w, P, Cout)
+
+    @staticmethod
+    def backward(ctx, dimg):
+        return ops.pixel_unshuffle(_c(dimg), ctx.P, torch.float32), None, None, None, None, None
+
+
+def pixel_shuffle(rows, B, h, w, P, Cout):
+    return PixelShuffleFn.apply(rows, B, h, w, P, Cout)
+
+
+class PointmapAdaptorFn(Function):
+    @staticmethod
+    def forward(ctx, x, vmin, vmax):
+        ctx.save_for_backward(x)
+        ctx.v = (vmin, vmax)
+        pts, conf = ops.pointmap_adaptor(x, vmin, vmax)
+        return pts, conf
+
+    @staticmethod
+    def backward(ctx, dpts, dconf):
+        (x,) = ctx.saved_tensors
+        return ops.pointmap_adaptor_bwd(x, _c(dpts), _c(dconf), *ctx.v), None, None
+
+
+def pointmap_adaptor(x, vmin, vmax):
+    return PointmapAdaptorFn.apply(x, vmin, vmax)
+
+
+class ConfLossFn(Function):
+    """mean_pix(conf * |pts - gt|) - alpha * mean_pix(log conf): the DUSt3R confidence-weighted regression objective
+    (the reference ships no loss; SURVEY §8d names this one).  One kernel computes the loss and both gradients."""
+
+    @staticmethod
+    def forward(ctx, pts, conf, gt, alpha):
+        pts, conf, gt = _c(pts), _c(conf), _c(gt)
+        npix = conf.numel()
+        acc = torch.zeros(1, dtype=torch.float32, device=pts.device)
+        dpts, dconf = ops.conf_loss(pts, conf, gt, alpha, 1.0 / npix, acc)
+        ctx.save_for_backward(dpts, dconf)
+        return acc[0] / npix
+
+    @staticmethod
+    def backward(ctx, g):
+        dpts, dconf = ctx.saved_tensors
+        return dpts * g, dconf * g, None, None
+
+
+def conf_loss(pts, conf, gt, alpha: float = 0.2):
+    return ConfLossFn.apply(pts, conf, gt.float(), alpha)

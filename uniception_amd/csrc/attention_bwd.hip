@@ -347,3 +347,178 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     UC_CHECK_LAUNCH("uc_attention_bwd");
     return UC_OK;
 }
+
+// =================================================================================================================
+// fp32 verification-mode backward (head_dim <= 64): one thread per query row (dQ) / per key row (dK, dV), the other
+// side streamed through LDS in 32-row tiles; plain fp32 FMA chains and expf, no atomics.
+// =================================================================================================================
+struct AttnBwdF32Params {
+    const float *Q, *K, *V, *O, *dO, *LSE;
+    float *dQ, *dK, *dV, *delta;
+    int B, H, Nq, Nk, D;
+    int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
+    int64_t dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh;
+    float scale;
+};
+
+#define BF_T 32
+
+__global__ void attn_delta_f32_kernel(AttnBwdF32Params p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.H * p.Nq;
+    if (idx >= total) return;
+    const int q = (int)(idx % p.Nq);
+    const int h = (int)((idx / p.Nq) % p.H);
+    const int b = (int)(idx / ((int64_t)p.Nq * p.H));
+    const float* o = p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
+    const float* d = p.dO + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
+    float s = 0.f;
+    for (int c = 0; c < p.D; ++c) s = fmaf(o[c], d[c], s);
+    p.delta[idx] = s;
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(AttnBwdF32Params p) {
+    __shared__ float Ks[BF_T][DMAX];
+    __shared__ float Vs[BF_T][DMAX];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 128 + threadIdx.x;
+    const int D = p.D;
+    const bool active = q < p.Nq;
+    const int qc = active ? q : p.Nq - 1;
+    const float* qp = p.Q + (int64_t)b * p.q_sb + (int64_t)qc * p.q_sn + (int64_t)h * p.q_sh;
+    const float* dp_ = p.dO + (int64_t)b * p.o_sb + (int64_t)qc * p.o_sn + (int64_t)h * p.o_sh;
+    const float* Kb = p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const float* Vb = p.V + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
+    float qr[DMAX], dor[DMAX], acc[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        qr[d] = d < D ? qp[d] : 0.f;
+        dor[d] = d < D ? dp_[d] : 0.f;
+        acc[d] = 0.f;
+    }
+    const float lse = p.LSE[((int64_t)b * p.H + h) * p.Nq + qc];
+    const float dlt = p.delta[((int64_t)b * p.H + h) * p.Nq + qc];
+    for (int k0 = 0; k0 < p.Nk; k0 += BF_T) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < BF_T * DMAX; idx += blockDim.x) {
+            const int kk = idx / DMAX, d = idx % DMAX;
+            const bool ok = (k0 + kk < p.Nk) && d < D;
+            Ks[kk][d] = ok ? Kb[(int64_t)(k0 + kk) * p.k_sn + d] : 0.f;
+            Vs[kk][d] = ok ? Vb[(int64_t)(k0 + kk) * p.v_sn + d] : 0.f;
+        }
+        __syncthreads();
+        for (int kk = 0; kk < BF_T; ++kk) {
+            if (k0 + kk >= p.Nk) break;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                s = fmaf(qr[d], Ks[kk][d], s);
+                dp = fmaf(dor[d], Vs[kk][d], dp);
+            }
+            const float pw = expf(s * p.scale - lse);
+            const float ds = pw * (dp - dlt);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) acc[d] = fmaf(ds, Ks[kk][d], acc[d]);
+        }
+    }
+    if (active) {
+        float* op = p.dQ + (int64_t)b * p.dq_sb + (int64_t)q * p.dq_sn + (int64_t)h * p.dq_sh;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+            if (d < D) op[d] = acc[d] * p.scale;
+    }
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(AttnBwdF32Params p) {
+    __shared__ float Qs[BF_T][DMAX];
+    __shared__ float Ds[BF_T][DMAX];
+    __shared__ float Ls[BF_T], Dl[BF_T];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int key = blockIdx.x * 128 + threadIdx.x;
+    const int D = p.D;
+    const bool active = key < p.Nk;
+    const int kc = active ? key : p.Nk - 1;
+    const float* kp = p.K + (int64_t)b * p.k_sb + (int64_t)kc * p.k_sn + (int64_t)h * p.k_sh;
+    const float* vp = p.V + (int64_t)b * p.v_sb + (int64_t)kc * p.v_sn + (int64_t)h * p.v_sh;
+    const float* Qb = p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const float* dOb = p.dO + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
+    float kr[DMAX], vr[DMAX], dk[DMAX], dv[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        kr[d] = d < D ? kp[d] : 0.f;
+        vr[d] = d < D ? vp[d] : 0.f;
+        dk[d] = 0.f;
+        dv[d] = 0.f;
+    }
+    for (int q0 = 0; q0 < p.Nq; q0 += BF_T) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < BF_T * DMAX; idx += blockDim.x) {
+            const int qq = idx / DMAX, d = idx % DMAX;
+            const bool ok = (q0 + qq < p.Nq) && d < D;
+            Qs[qq][d] = ok ? Qb[(int64_t)(q0 + qq) * p.q_sn + d] : 0.f;
+            Ds[qq][d] = ok ? dOb[(int64_t)(q0 + qq) * p.o_sn + d] : 0.f;
+        }
+        if (threadIdx.x < BF_T) {
+            const int qq = q0 + threadIdx.x;
+            Ls[threadIdx.x] = qq < p.Nq ? p.LSE[((int64_t)b * p.H + h) * p.Nq + qq] : 0.f;
+            Dl[threadIdx.x] = qq < p.Nq ? p.delta[((int64_t)b * p.H + h) * p.Nq + qq] : 0.f;
+        }
+        __syncthreads();
+        for (int qq = 0; qq < BF_T; ++qq) {
+            if (q0 + qq >= p.Nq) break;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                s = fmaf(Qs[qq][d], kr[d], s);
+                dp = fmaf(Ds[qq][d], vr[d], dp);
+            }
+            const float pw = expf(s * p.scale - Ls[qq]);
+            const float ds = pw * (dp - Dl[qq]);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                dv[d] = fmaf(pw, Ds[qq][d], dv[d]);
+                dk[d] = fmaf(ds, Qs[qq][d], dk[d]);
+            }
+        }
+    }
+    if (active) {
+        float* okp = p.dK + (int64_t)b * p.dk_sb + (int64_t)key * p.dk_sn + (int64_t)h * p.dk_sh;
+        float* ovp = p.dV + (int64_t)b * p.dv_sb + (int64_t)key * p.dv_sn + (int64_t)h * p.dv_sh;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+            if (d < D) {
+                okp[d] = dk[d] * p.scale;
+                ovp[d] = dv[d];
+            }
+    }
+}
+
+extern "C" int uc_attention_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                                    const float* LSE, float* dQ, float* dK, float* dV, float* delta, int B, int H, int Nq,
+                                    int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
+                                    int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
+                                    int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn,
+                                    int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream) {
+    UC_REQUIRE(Q && K && V && O && dO && LSE && dQ && dK && dV && delta, "uc_attention_bwd_f32: null pointer");
+    UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && D > 0 && D <= 64 && B <= 65535 && H <= 65535, "uc_attention_bwd_f32: bad shape (head_dim <= 64)");
+    AttnBwdF32Params p;
+    p.Q = Q; p.K = K; p.V = V; p.O = O; p.dO = dO; p.LSE = LSE; p.dQ = dQ; p.dK = dK; p.dV = dV; p.delta = delta;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.D = D;
+    p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh; p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh;
+    p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh; p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.dk_sb = dk_sb; p.dk_sn = dk_sn;
+    p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh; p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * H * Nq;
+    hipLaunchKernelGGL(attn_delta_f32_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, p);
+    if (D <= 32) {
+        hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<32>), dim3((Nq + 127) / 128, H, B), dim3(128), 0, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<32>), dim3((Nk + 127) / 128, H, B), dim3(128), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<64>), dim3((Nq + 127) / 128, H, B), dim3(128), 0, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<64>), dim3((Nk + 127) / 128, H, B), dim3(128), 0, st, p);
+    }
+    UC_CHECK_LAUNCH("uc_attention_bwd_f32");
+    return UC_OK;
+}

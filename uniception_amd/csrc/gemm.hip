@@ -46,6 +46,7 @@ struct GemmParams {
     int out_dtype;
     int64_t ldc;
     int tiles_m, tiles_n;
+    void* preact;   // fp32 kernel only (the bf16 path carries it in GldsParams)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const int64_t n = n0 + tx * 4 + j;
             if (n >= p.N) continue;
             float v = acc[i][j] + (p.bias ? p.bias[n] : 0.f);
+            if (p.preact) store_out(p.preact, p.out_dtype, m * p.ldc + n, v);
             v = apply_act(v, p.act);
             if (p.residual) v += load_res(p.residual, p.res_dtype, m * p.ldr + n);
             if (p.residual2) v += load_res(p.residual2, p.res_dtype, m * p.ldr + n);
@@ -442,7 +444,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     p.bias = d->bias; p.act = d->act; p.residual = d->residual; p.residual2 = d->residual2; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
     p.rope_cols = d->rope_cols; p.rope_pos = d->rope_pos; p.rope_table = (const float2*)d->rope_table;
     p.rope_npos = d->rope_npos; p.vt_col0 = d->vt_col0; p.vt_out = (bf16_t*)d->vt_out; p.vt_ntok = d->vt_ntok;
-    p.vt_npad = d->vt_npad; p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
+    p.vt_npad = d->vt_npad; p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc; p.preact = nullptr;
 
     if (d->a_mode == UC_A_CONV3X3) {
         UC_REQUIRE(d->conv_B > 0 && d->conv_H > 0 && d->conv_W > 0 && d->conv_Cin > 0 && d->conv_stride > 0,
@@ -533,10 +535,11 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         else
             hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_CONV3X3>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);
     } else if (d->compute_dtype == UC_F32) {
-        if (d->split_k > 1 || d->preact_out) {
-            uc_set_error("uc_gemm(f32): split_k / preact_out are only implemented for the bf16 MFMA path");
+        if (d->split_k > 1) {
+            uc_set_error("uc_gemm(f32): split_k is only implemented for the bf16 MFMA path");
             return UC_ERR_UNSUPPORTED;
         }
+        p.preact = d->preact_out;
         if (d->vt_col0 >= 0) {
             uc_set_error("uc_gemm(f32): vt epilogue is only implemented for the bf16 MFMA path");
             return UC_ERR_UNSUPPORTED;

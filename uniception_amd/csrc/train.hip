@@ -102,13 +102,57 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// any width: one wavefront per row, three strided passes, per-element atomics for dgamma/dbeta (small models only)
+template <typename TD>
+__global__ __launch_bounds__(256) void layernorm_bwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                    const typename TD::storage* __restrict__ dy,
+                                                                    const float* __restrict__ dres, float* __restrict__ dx,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    const typename TD::storage* dr = dy + row * C;
+    const float invC = 1.0f / (float)C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) * invC;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, a = TD::load(dr + c) * gamma[c];
+        s1 += a; s2 += a * xh;
+    }
+    wave_sum2(s1, s2);
+    s1 *= invC; s2 *= invC;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, d = TD::load(dr + c);
+        float o = rstd * (d * gamma[c] - s1 - xh * s2);
+        if (dres) o += dres[row * C + c];
+        dx[row * C + c] = o;
+        unsafeAtomicAdd(dgamma + c, d * xh);
+        unsafeAtomicAdd(dbeta + c, d);
+    }
+}
+
 extern "C" int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
                                 float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream) {
     UC_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "uc_layernorm_bwd: null pointer");
-    UC_REQUIRE(rows >= 0 && C > 0 && C % 256 == 0 && C <= 2048, "uc_layernorm_bwd: C must be a multiple of 256 and <= 2048 (got %d)", C);
+    UC_REQUIRE(rows >= 0 && C > 0, "uc_layernorm_bwd: bad shape");
     UC_REQUIRE(dy_dtype == UC_F32 || dy_dtype == UC_BF16, "uc_layernorm_bwd: bad dy dtype %d", dy_dtype);
     if (rows == 0) return UC_OK;
     hipStream_t st = (hipStream_t)stream;
+    const int nv = C / 256;
+    if (C % 256 != 0 || !(nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8)) {
+        const unsigned g = (unsigned)ceil_div64(rows, 4);
+        if (dy_dtype == UC_F32) hipLaunchKernelGGL((layernorm_bwd_generic_kernel<F32Tag>), dim3(g), dim3(256), 0, st, x, gamma, (const float*)dy, dres, dx, dgamma, dbeta, rows, C, eps);
+        else hipLaunchKernelGGL((layernorm_bwd_generic_kernel<BF16Tag>), dim3(g), dim3(256), 0, st, x, gamma, (const bf16_t*)dy, dres, dx, dgamma, dbeta, rows, C, eps);
+        UC_CHECK_LAUNCH("uc_layernorm_bwd");
+        return UC_OK;
+    }
     const unsigned grid = (unsigned)min((int64_t)512, ceil_div64(rows, 4));
 #define UC_LNB(TD_, NV_)                                                                                                \
     hipLaunchKernelGGL((layernorm_bwd_kernel<TD_, NV_>), dim3(grid), dim3(256), 0, st, x, gamma,                            \
@@ -216,31 +260,40 @@ extern "C" int uc_act_bwd(const void* dg, const void* u, void* du, int dtype, in
 // ---------------------------------------------------------------------------------------------------------------
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void transpose64_kernel(const typename TI::storage* __restrict__ src,
-                                                          typename TO::storage* __restrict__ dst, int64_t R, int64_t S) {
+                                                          typename TO::storage* __restrict__ dst,
+                                                          typename TO::storage* __restrict__ copy, int64_t R, int64_t S,
+                                                          int64_t ld_dst) {
     __shared__ float tile[64][65];
     const int64_t s0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int64_t r = r0 + ty + 4 * k, s = s0 + tx;
-        if (r < R && s < S) tile[ty + 4 * k][tx] = TI::load(src + r * S + s);
+        float v = 0.f;
+        if (r < R && s < S) {
+            v = TI::load(src + r * S + s);
+            if (copy) TO::store(copy + r * S + s, v);
+        }
+        tile[ty + 4 * k][tx] = v;   // rows >= R read back as the zero padding of dst
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int64_t s = s0 + ty + 4 * k, r = r0 + tx;
-        if (r < R && s < S) TO::store(dst + s * R + r, tile[tx][ty + 4 * k]);
+        if (r < ld_dst && s < S) TO::store(dst + s * ld_dst + r, tile[tx][ty + 4 * k]);
     }
 }
 
-extern "C" int uc_transpose2d(const void* src, int sd, void* dst, int dd, int64_t R, int64_t S, uc_stream_t stream) {
+extern "C" int uc_transpose2d(const void* src, int sd, void* dst, int dd, void* rowmajor_copy, int64_t R, int64_t S,
+                              int64_t ld_dst, uc_stream_t stream) {
     UC_REQUIRE(src && dst && R > 0 && S > 0, "uc_transpose2d: bad argument");
-    UC_REQUIRE((R + 63) / 64 <= 65535, "uc_transpose2d: too many rows");
-    dim3 grid((unsigned)ceil_div64(S, 64), (unsigned)ceil_div64(R, 64));
+    UC_REQUIRE(ld_dst >= R && ld_dst < R + 64, "uc_transpose2d: ld_dst must be in [R, R+64)");
+    UC_REQUIRE((ld_dst + 63) / 64 <= 65535, "uc_transpose2d: too many rows");
+    dim3 grid((unsigned)ceil_div64(S, 64), (unsigned)ceil_div64(ld_dst, 64));
     hipStream_t st = (hipStream_t)stream;
-    if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<BF16Tag, BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, R, S);
-    else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((transpose64_kernel<F32Tag, F32Tag>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, R, S);
-    else if (sd == UC_F32 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<F32Tag, BF16Tag>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, R, S);
+    if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<BF16Tag, BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, (bf16_t*)rowmajor_copy, R, S, ld_dst);
+    else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((transpose64_kernel<F32Tag, F32Tag>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, (float*)rowmajor_copy, R, S, ld_dst);
+    else if (sd == UC_F32 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<F32Tag, BF16Tag>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, (bf16_t*)rowmajor_copy, R, S, ld_dst);
     else { uc_set_error("uc_transpose2d: unsupported dtypes %d -> %d", sd, dd); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_transpose2d");
     return UC_OK;
@@ -295,6 +348,74 @@ extern "C" int uc_pointmap_loss(const float* x, int64_t x_sb, int64_t x_sc, int6
     hipLaunchKernelGGL(pointmap_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, x_sb, x_sc, x_sp, gt, alpha,
                        grad_scale, loss_sum, dx, (int64_t)H * W, n);
     UC_CHECK_LAUNCH("uc_pointmap_loss");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// adaptor backward alone (arbitrary downstream loss): dx from (dpts, dconf)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pointmap_adaptor_bwd_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sp,
+                                            const float* __restrict__ dpts, const float* __restrict__ dconf, float cspan,
+                                            float* __restrict__ dx, int64_t HW, int64_t n) {
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = it / HW, pix = it % HW;
+        const int64_t base = b * sb + pix * sp;
+        const float X = x[base], Y = x[base + sc], Z = x[base + 2 * sc], Cf = x[base + 3 * sc];
+        const float d = sqrtf(X * X + Y * Y + Z * Z);
+        const float dc = fmaxf(d, 1e-8f);
+        const float em1 = expm1f(d);
+        const float s = em1 / dc;
+        const float sprime = (d > 1e-2f) ? ((em1 + 1.0f) * d - em1) / (d * d) : 0.5f + d * (1.0f / 3.0f);
+        const float gx = dpts ? dpts[it * 3 + 0] : 0.f, gy = dpts ? dpts[it * 3 + 1] : 0.f, gz = dpts ? dpts[it * 3 + 2] : 0.f;
+        const float k = (X * gx + Y * gy + Z * gz) * sprime / dc;
+        dx[base] = s * gx + X * k;
+        dx[base + sc] = s * gy + Y * k;
+        dx[base + 2 * sc] = s * gz + Z * k;
+        const float ec = expf(Cf);
+        // conf = vmin + min(exp(c), vmax - vmin): gradient passes only below the clamp
+        dx[base + 3 * sc] = (dconf && ec < cspan) ? dconf[it] * ec : 0.f;
+    }
+}
+
+extern "C" int uc_pointmap_adaptor_bwd(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp, const float* dpts,
+                                       const float* dconf, float conf_vmin, float conf_vmax, float* dx, int B, int H, int W,
+                                       uc_stream_t stream) {
+    UC_REQUIRE(x && dx && B > 0 && H > 0 && W > 0, "uc_pointmap_adaptor_bwd: bad argument");
+    const int64_t n = (int64_t)B * H * W;
+    const unsigned grid = (unsigned)min((int64_t)8192, ceil_div64(n, 256));
+    hipLaunchKernelGGL(pointmap_adaptor_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, x_sb, x_sc, x_sp, dpts,
+                       dconf, conf_vmax - conf_vmin, dx, (int64_t)H * W, n);
+    UC_CHECK_LAUNCH("uc_pointmap_adaptor_bwd");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// confidence-weighted regression loss on adaptor outputs: sum_pix conf*|pts-gt| - alpha*log(conf), with both gradients
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void conf_loss_kernel(const float* __restrict__ pts, const float* __restrict__ conf, const float* __restrict__ gt,
+                                 float alpha, float gscale, float* __restrict__ loss_sum, float* __restrict__ dpts,
+                                 float* __restrict__ dconf, int64_t n) {
+    float local = 0.f;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n; it += (int64_t)gridDim.x * blockDim.x) {
+        const float ex = pts[it * 3 + 0] - gt[it * 3 + 0], ey = pts[it * 3 + 1] - gt[it * 3 + 1], ez = pts[it * 3 + 2] - gt[it * 3 + 2];
+        const float r = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float c = conf[it];
+        local += c * r - alpha * logf(c);
+        const float ir = gscale * c / fmaxf(r, 1e-12f);
+        dpts[it * 3 + 0] = ex * ir; dpts[it * 3 + 1] = ey * ir; dpts[it * 3 + 2] = ez * ir;
+        dconf[it] = gscale * (r - alpha / c);
+    }
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(loss_sum, local);
+}
+
+extern "C" int uc_conf_loss(const float* pts, const float* conf, const float* gt, float alpha, float grad_scale,
+                            float* loss_sum, float* dpts, float* dconf, int64_t npix, uc_stream_t stream) {
+    UC_REQUIRE(pts && conf && gt && loss_sum && dpts && dconf && npix > 0, "uc_conf_loss: bad argument");
+    const unsigned grid = (unsigned)min((int64_t)8192, ceil_div64(npix, 256));
+    hipLaunchKernelGGL(conf_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pts, conf, gt, alpha, grad_scale,
+                       loss_sum, dpts, dconf, npix);
+    UC_CHECK_LAUNCH("uc_conf_loss");
     return UC_OK;
 }
 

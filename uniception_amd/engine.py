@@ -65,8 +65,8 @@ def head_dtype() -> torch.dtype:
 def require_inference(*tensors) -> None:
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise UcHipError(
-            "uniception_amd: the HIP backward kernels are not implemented yet; run the forward under torch.no_grad() "
-            "(inputs/parameters requiring grad were passed with grad mode enabled)."
+            "uniception_amd: this module has no HIP backward yet (the transformer blocks, patch embedding, linear head, "
+            "adaptor and loss do); run it under torch.no_grad() or freeze it (requires_grad_(False))."
         )
 
 
@@ -165,6 +165,10 @@ def bchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def layernorm(x: torch.Tensor, ln: nn.LayerNorm, out_dtype: torch.dtype) -> torch.Tensor:
+    if torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad):
+        from . import autograd
+        x2 = x.reshape(-1, x.shape[-1])
+        return autograd.layer_norm(x2, ln, out_dtype).view(x.shape)
     g, b = ln_params(ln)
     return ops.layernorm(x, g, b, ln.eps, out_dtype)
 

@@ -11,7 +11,7 @@ from typing import Callable, List, Optional, Tuple, Type, Union
 import torch
 import torch.nn as nn
 
-from ... import engine, ops
+from ... import autograd, engine, ops
 from ..utils.intermediate_feature_return import IntermediateFeatureReturner, feature_take_indices
 from ..utils.positional_encoding import PositionGetter
 from ..utils.transformer_blocks import CrossAttentionBlock, Mlp
@@ -99,7 +99,6 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
         assert len(feats) == self.num_views, f"Expected {self.num_views} views, got {len(feats)}"
         assert all(f.shape[1] == self.input_embed_dim for f in feats), f"All views must have input dimension {self.input_embed_dim}"
         assert all(f.ndim == 4 for f in feats), "All views must have 4 dimensions (N, C, H, W)"
-        engine.require_inference(*feats, self.norm.weight)
 
     def _run(self, model_input, take_indices, norm_intermediate):
         feats = model_input.features
@@ -109,7 +108,15 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
         V = self.num_views
         # NCHW -> NLC (free for channels-last views), then proj_embed
         xs = []
+        train = autograd.grad_needed(*feats, self.norm.weight)
         for f in feats:
+            if train:
+                # differentiable layout hop (a view for the channels-last features the encoder returns)
+                x2d = f.float().permute(0, 2, 3, 1).reshape(B * N, self.input_embed_dim)
+                if not isinstance(self.proj_embed, nn.Identity):
+                    x2d = autograd.linear(x2d, self.proj_embed.weight, self.proj_embed.bias, self.proj_embed, dt, torch.float32)
+                xs.append(x2d)
+                continue
             nlc = engine.bchw_to_nhwc(f, torch.float32 if isinstance(self.proj_embed, nn.Identity) else dt)
             x2d = nlc.reshape(B * N, self.input_embed_dim)
             if not isinstance(self.proj_embed, nn.Identity):

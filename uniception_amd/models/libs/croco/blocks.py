@@ -11,7 +11,7 @@ from itertools import repeat
 import torch
 import torch.nn as nn
 
-from .... import engine
+from .... import autograd, engine
 from ...utils.config import use_fused_attn
 
 use_torch_attn = use_fused_attn()
@@ -133,12 +133,16 @@ class Block(nn.Module):
         """[B*N, C] residual stream in, new residual stream out (same dtype)."""
         if isinstance(self.drop_path, DropPath):
             self.drop_path(x2d)  # raises in training with rate > 0
+        if autograd.grad_needed(x2d, self.norm1.weight, self.mlp.fc1.weight):
+            _check_no_dropout(self, self.attn.dropout_p, self.attn.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
+            x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads,
+                                              self.attn.rope, xpos, self.attn.scale, dt)
+            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt)
         h = engine.layernorm(x2d, self.norm1, dt)
         x2d = self.attn._run(h, B, N, xpos, x2d, x2d.dtype)
         h = engine.layernorm(x2d, self.norm2, dt)
         return self.mlp._run(h, x2d, x2d.dtype)
 
     def forward(self, x, xpos):
-        engine.require_inference(x, self.norm1.weight)
         B, N, C = x.shape
         return self.forward_tokens(_as_2d(x), B, N, xpos, engine.compute_dtype()).view(B, N, C)

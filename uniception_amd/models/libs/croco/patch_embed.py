@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from .... import engine, ops
+from .... import autograd, engine, ops
 from ...utils.positional_encoding import PositionGetter  # noqa: F401  (same helper as the reference's local copy)
 from .blocks import to_2tuple
 
@@ -31,7 +31,6 @@ class PatchEmbedCroCo(nn.Module):
 
     def _embed(self, x):
         """[B,3,H,W] -> (tokens fp32 [B,N,D], pos)."""
-        engine.require_inference(x, self.proj.weight)
         if self.patch_size[0] != self.patch_size[1]:
             raise engine.UcHipError("non-square patches are not supported by the HIP patch gather")
         if not self.flatten:
@@ -42,12 +41,19 @@ class PatchEmbedCroCo(nn.Module):
         if (C * P * P) % 8 != 0:
             dt = torch.float32   # e.g. patch 14: K = 588 is not a multiple of the 16-byte bf16 chunk; this GEMM is 0.1 % of the FLOPs
         img = x.float().contiguous() if (x.dtype != torch.float32 or not x.is_contiguous()) else x
-        cols = ops.patch_gather(img, P, dt)
-        w, b = engine.patch_weights(self.proj, dt)
-        tok = ops.gemm(cols, w, b, out_dtype=torch.float32).view(B, (H // P) * (W // P), -1)
+        train = autograd.grad_needed(x, self.proj.weight)
+        if train:
+            tok = autograd.patch_embed(img, self.proj, P, dt).view(B, (H // P) * (W // P), -1)
+        else:
+            cols = ops.patch_gather(img, P, dt)
+            w, b = engine.patch_weights(self.proj, dt)
+            tok = ops.gemm(cols, w, b, out_dtype=torch.float32).view(B, (H // P) * (W // P), -1)
         pos = self.position_getter(B, H // P, W // P, x.device)
         if not isinstance(self.norm, nn.Identity):
-            tok = engine.layernorm(tok, self.norm, torch.float32)
+            if train:
+                tok = autograd.layer_norm(tok.view(-1, tok.shape[-1]), self.norm, torch.float32).view(tok.shape)
+            else:
+                tok = engine.layernorm(tok, self.norm, torch.float32)
         return tok, pos
 
     def forward(self, x, **kw):

@@ -10,7 +10,7 @@ from math import isfinite
 import numpy as np
 import torch
 
-from ... import engine, ops
+from ... import autograd, engine, ops
 from .base import AdaptorInput, RegressionAdaptorOutput, RegressionWithConfidenceAdaptorOutput, UniCeptionAdaptorBase
 
 
@@ -65,8 +65,10 @@ class ValueWithConfidenceAdaptor(UniCeptionAdaptorBase):
             raise engine.UcHipError("the HIP adaptor kernel implements pointmap_mode='exp' without bounds and confidence_type='exp'")
         x = adaptor_input.adaptor_feature
         assert x.shape[1] == 4, "pointmap + confidence needs 4 channels"
-        engine.require_inference(x)
-        pts, conf = ops.pointmap_adaptor(_as_f32_map(x), float(ca.vmin), float(ca.vmax))
+        if autograd.grad_needed(x):
+            pts, conf = autograd.pointmap_adaptor(_as_f32_map(x), float(ca.vmin), float(ca.vmax))
+        else:
+            pts, conf = ops.pointmap_adaptor(_as_f32_map(x), float(ca.vmin), float(ca.vmax))
         return RegressionWithConfidenceAdaptorOutput(value=pts.permute(0, 3, 1, 2), confidence=conf.permute(0, 3, 1, 2))
 
 

@@ -3,7 +3,7 @@ followed by pixel_shuffle(P) (one scatter kernel)."""
 import torch
 import torch.nn as nn
 
-from ... import engine, ops
+from ... import autograd, engine, ops
 from .base import PixelTaskOutput, PredictionHeadInput
 
 
@@ -27,9 +27,12 @@ class LinearFeature(nn.Module):
     def forward(self, feature_input: PredictionHeadInput):
         x = feature_input.last_feature
         assert x.shape[1] == self.input_feature_dim, f"Input feature dimension mismatch: {x.shape[1]} != {self.input_feature_dim}"
-        engine.require_inference(x, self.linear.weight)
         B, C, h, w = x.shape
         dt = engine.head_dtype()
+        if autograd.grad_needed(x, self.linear.weight):
+            tok = x.float().permute(0, 2, 3, 1).reshape(B * h * w, C)
+            y = autograd.linear(tok, self.linear.weight, self.linear.bias, self.linear, dt, torch.float32)
+            return PixelTaskOutput(decoded_channels=autograd.pixel_shuffle(y, B, h, w, self.patch_size, self.output_dim))
         tok = engine.bchw_to_nhwc(x, dt).reshape(B * h * w, C)
         wl, bl = engine.conv1x1_weights(self.linear, dt)
         y = ops.gemm(tok, wl, bl, out_dtype=torch.float32)

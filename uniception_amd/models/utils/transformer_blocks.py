@@ -13,7 +13,7 @@ from typing import Callable, Optional
 import torch
 import torch.nn as nn
 
-from ... import engine
+from ... import autograd, engine
 from ..libs.croco.blocks import DropPath, Mlp, _as_2d, _check_no_dropout, to_2tuple  # noqa: F401
 from .config import use_fused_attn
 
@@ -187,6 +187,8 @@ class CrossAttentionBlock(nn.Module):
         if self.custom_positional_encoding is not None:
             assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
             assert ypos is not None, "Positions of cross tokens (ypos) are a required input when using custom positional encoding"
+        if autograd.grad_needed(x2d, y2d, self.norm1.weight, self.mlp.fc1.weight):
+            return self._forward_tokens_train(x2d, y2d, B, Nx, Ny, xpos, ypos, dt)
         h = engine.layernorm(x2d, self.norm1, dt)
         x2d = self.attn._run(h, B, Nx, xpos, x2d, x2d.dtype)
         if isinstance(self.norm_y, nn.Identity):
@@ -198,8 +200,22 @@ class CrossAttentionBlock(nn.Module):
         h = engine.layernorm(x2d, self.norm3, dt)
         return self.mlp._run(h, x2d, x2d.dtype)
 
+    def _forward_tokens_train(self, x2d, y2d, B, Nx, Ny, xpos, ypos, dt):
+        """Same three sub-layers as autograd Functions (HIP forward + HIP backward)."""
+        sa, ca = self.attn, self.cross_attn
+        _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, ca.attn_drop.p, ca.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
+        for m in (sa, ca):
+            if not isinstance(m.q_norm, nn.Identity):
+                raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
+        rope = self.custom_positional_encoding
+        x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, Nx, sa.num_heads, rope, xpos,
+                                          sa.scale * _softmax_scale_multiplier(sa, Nx), dt)
+        lny = None if isinstance(self.norm_y, nn.Identity) else self.norm_y
+        x2d = autograd.cross_attn_sublayer(x2d, y2d, self.norm2, lny, ca, B, Nx, Ny, ca.num_heads, rope, xpos, ypos,
+                                           ca.scale * _softmax_scale_multiplier(ca, Nx), dt)
+        return autograd.mlp_sublayer(x2d, self.norm3, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt)
+
     def forward(self, x, y, xpos=None, ypos=None):
-        engine.require_inference(x, y, self.norm1.weight)
         B, Nx, C = x.shape
         Ny = y.shape[1]
         out = self.forward_tokens(_as_2d(x), _as_2d(y), B, Nx, Ny, xpos, ypos, engine.compute_dtype())

@@ -340,15 +340,48 @@ def act_bwd(dg: torch.Tensor, u: torch.Tensor, act: str) -> torch.Tensor:
     return du
 
 
-def transpose2d(x: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """[R,S] contiguous -> [S,R] contiguous."""
+def transpose2d(x: torch.Tensor, out_dtype: Optional[torch.dtype] = None, pad_to: int = 1, with_copy: bool = False):
+    """[R,S] contiguous -> [S,Rp] contiguous, Rp = R rounded up to `pad_to` (<= 64; pad columns are zeros).
+    with_copy: also return the un-transposed matrix converted to out_dtype (one pass over the source)."""
     _need_gpu(x)
-    assert x.dim() == 2 and x.is_contiguous()
+    assert x.dim() == 2 and x.is_contiguous() and 1 <= pad_to <= 64
     out_dtype = out_dtype or x.dtype
-    y = torch.empty((x.shape[1], x.shape[0]), dtype=out_dtype, device=x.device)
-    _lib.check(_lib.load().uc_transpose2d(x.data_ptr(), _dt(x.dtype), y.data_ptr(), _dt(out_dtype), x.shape[0], x.shape[1],
-                                          _stream()), "uc_transpose2d")
-    return y
+    R, S = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    y = torch.empty((S, Rp), dtype=out_dtype, device=x.device)
+    c = torch.empty((R, S), dtype=out_dtype, device=x.device) if with_copy else None
+    _lib.check(_lib.load().uc_transpose2d(x.data_ptr(), _dt(x.dtype), y.data_ptr(), _dt(out_dtype), _p(c), R, S, Rp, _stream()),
+               "uc_transpose2d")
+    return (y, c) if with_copy else y
+
+
+def pointmap_adaptor_bwd(x: torch.Tensor, dpts: Optional[torch.Tensor], dconf: Optional[torch.Tensor], conf_vmin: float,
+                         conf_vmax: float) -> torch.Tensor:
+    _need_gpu(x, dpts, dconf)
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 4
+    B, _, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    assert sh == W * sw
+    for t in (dpts, dconf):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    dx = torch.empty_strided(x.shape, x.stride(), dtype=torch.float32, device=x.device)
+    vmax = conf_vmax if conf_vmax != float("inf") else 3.0e38
+    _lib.check(_lib.load().uc_pointmap_adaptor_bwd(x.data_ptr(), sb, sc, sw, _p(dpts), _p(dconf), float(conf_vmin), float(vmax),
+                                                   dx.data_ptr(), B, H, W, _stream()), "uc_pointmap_adaptor_bwd")
+    return dx
+
+
+def conf_loss(pts: torch.Tensor, conf: torch.Tensor, gt: torch.Tensor, alpha: float, grad_scale: float,
+              loss_sum: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _need_gpu(pts, conf, gt, loss_sum)
+    for t in (pts, conf, gt):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    npix = conf.numel()
+    assert pts.numel() == 3 * npix and gt.numel() == 3 * npix
+    dpts, dconf = torch.empty_like(pts), torch.empty_like(conf)
+    _lib.check(_lib.load().uc_conf_loss(pts.data_ptr(), conf.data_ptr(), gt.data_ptr(), float(alpha), float(grad_scale),
+                                        loss_sum.data_ptr(), dpts.data_ptr(), dconf.data_ptr(), npix, _stream()), "uc_conf_loss")
+    return dpts, dconf
 
 
 def pointmap_loss(x: torch.Tensor, gt: torch.Tensor, alpha: float, grad_scale: float, loss_sum: torch.Tensor) -> torch.Tensor:
@@ -386,20 +419,37 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, l
                                     float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream()), "uc_adamw")
 
 
-def attention_bwd(q, k, v, o, do, lse, scale: float):
+def attention_bwd(q, k, v, o, do, lse, scale: float, out=None):
     """q,o,do [B,Nq,H,64]; k,v [B,Nk,H,64] bf16 views (unit last stride); lse fp32 [B,H,Nq].
-    Returns dq, dk, dv (contiguous [B,N,H,64] bf16)."""
+    Returns dq, dk, dv ([B,N,H,64] bf16): fresh contiguous tensors, or the three views passed as `out`
+    (e.g. slices of one fused dqkv buffer)."""
     _need_gpu(q, k, v, o, do, lse)
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
-    assert D == 64 and q.dtype == torch.bfloat16 and lse.dtype == torch.float32 and lse.is_contiguous()
+    dt = q.dtype
+    if not ((dt == torch.bfloat16 and D == 64) or (dt == torch.float32 and D <= 64)):
+        raise UcHipError("attention backward needs bf16 with head_dim 64, or fp32 with head_dim <= 64")
+    assert lse.dtype == torch.float32 and lse.is_contiguous()
     if do.stride() != o.stride() or o.stride(3) != 1:
         o, do = o.contiguous(), do.contiguous()
-    qt, dot, kt = vt_pack(q), vt_pack(do), vt_pack(k)
-    dq = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
-    dk = torch.empty((B, Nk, H, D), dtype=torch.bfloat16, device=q.device)
-    dv = torch.empty((B, Nk, H, D), dtype=torch.bfloat16, device=q.device)
+    if out is None:
+        dq = torch.empty((B, Nq, H, D), dtype=dt, device=q.device)
+        dk = torch.empty((B, Nk, H, D), dtype=dt, device=q.device)
+        dv = torch.empty((B, Nk, H, D), dtype=dt, device=q.device)
+    else:
+        dq, dk, dv = out
+        assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+        assert all(t.dtype == dt and t.stride(3) == 1 for t in out)
     delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    if dt == torch.float32:
+        _lib.check(_lib.load().uc_attention_bwd_f32(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+            dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D,
+            q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
+            o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1),
+            dk.stride(2), dv.stride(0), dv.stride(1), dv.stride(2), float(scale), _stream()), "uc_attention_bwd_f32")
+        return dq, dk, dv
+    qt, dot, kt = vt_pack(q), vt_pack(do), vt_pack(k)
     _lib.check(_lib.load().uc_attention_bwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), qt.data_ptr(), dot.data_ptr(),
         kt.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk,
