@@ -86,8 +86,15 @@ def test_no_silent_cpu_compute():
 
 
 def test_training_inputs_are_rejected_not_mishandled():
+    """Modules without a HIP backward refuse inputs that need gradients (no silent CPU/ATen fallback); modules with
+    one go to the HIP autograd path, which needs a device."""
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    enc = encoder_factory("croco", name="e", data_norm_type="dust3r", img_size=(32, 32), enc_embed_dim=64, enc_depth=1, enc_num_heads=1)
+    from uniception_amd.models.prediction_heads.dpt import DPTRegressionProcessor
+    from uniception_amd.models.prediction_heads.dpt import DPTFeatureInput
+    reg = DPTRegressionProcessor(input_feature_dim=32, output_dim=4)
     with pytest.raises(UcHipError, match="backward"):
+        reg(DPTFeatureInput(features_upsampled_8x=torch.zeros(1, 32, 8, 8), target_output_shape=(16, 16)))
+    enc = encoder_factory("croco", name="e", data_norm_type="dust3r", img_size=(32, 32), enc_embed_dim=64, enc_depth=1, enc_num_heads=1)
+    with pytest.raises(UcHipError, match="HIP device only"):
         enc(ViTEncoderInput(image=torch.zeros(1, 3, 32, 32), data_norm_type="dust3r"))

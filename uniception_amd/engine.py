@@ -75,10 +75,18 @@ def require_inference(*tensors) -> None:
 # (owner module, tag) and invalidated when any source parameter is modified or replaced.
 # ---------------------------------------------------------------------------------------------
 _prep_cache = weakref.WeakKeyDictionary()
+_weight_epoch = 0
+
+
+def bump_weight_epoch() -> None:
+    """Invalidate every prepared weight: call after parameters were modified through raw pointers (uc_adamw on the flat
+    buffer, a broadcast into it) — such writes do not advance the tensors' autograd version counters."""
+    global _weight_epoch
+    _weight_epoch += 1
 
 
 def prepared(owner: nn.Module, tag, sources: Sequence[Optional[torch.Tensor]], build):
-    stamp = tuple((s.data_ptr(), s._version, s.device, s.dtype) if s is not None else None for s in sources)
+    stamp = (_weight_epoch,) + tuple((s.data_ptr(), s._version, s.device, s.dtype) if s is not None else None for s in sources)
     slot = _prep_cache.setdefault(owner, {})
     hit = slot.get(tag)
     if hit is not None and hit[0] == stamp:
