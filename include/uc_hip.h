@@ -272,6 +272,27 @@ int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O,
                      int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
                      int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * DPT head backward helpers (forward ops: uc_bilinear_nhwc, uc_convt_scatter, uc_gemm conv mode, uc_conv1x1_to4).
+ * ---------------------------------------------------------------------------------- */
+/* Adjoint of uc_bilinear_nhwc: dy [B,crop_h,crop_w,C] -> dx [B,Hi,Wi,C] (same dtype), identical index/clamp rules. */
+int uc_bilinear_nhwc_bwd(const void* dy, void* dx, int dtype, int B, int Hi, int Wi, int C, int Ho, int Wo, int crop_h,
+                         int crop_w, uc_stream_t stream);
+/* Inverse of uc_convt_scatter: src NHWC [B,k*h,k*w,Cout] -> dst [B*h*w, k*k*Cout] (columns (u,v,o)). */
+int uc_convt_gather(const void* src, void* dst, int dtype, int B, int h, int w, int k, int Cout, uc_stream_t stream);
+/* Transposed im2col of a 3x3/pad-1 conv input for the weight-gradient GEMM:
+ *   dst[(ky*3+kx)*Cin + c, p] = act(x[b, oy*stride-1+ky, ox*stride-1+kx, c]),  p = (b*Ho+oy)*Wo+ox,
+ * zero outside the image and for p in [B*Ho*Wo, ld); act = ReLU when relu != 0 (the conv's ReLU-on-load). */
+int uc_im2col_t(const void* x, void* dst, int dtype, int B, int H, int W, int Cin, int stride, int relu, int64_t ld,
+                uc_stream_t stream);
+/* Zero-stuffing (data gradient of a strided conv): dst [B,H,W,C] = src [B,h,w,C] placed at multiples of `stride`. */
+int uc_dilate_nhwc(const void* src, void* dst, int dtype, int B, int h, int w, int H, int W, int C, int stride,
+                   uc_stream_t stream);
+/* Backward of uc_conv1x1_to4: dfeat[p,c] = sum_o dout[p,o] w[o,c] (dtype of feat); dw [4,Cin] and db [4] are
+ * accumulated with fp32 atomics (zero them first). */
+int uc_conv1x1_to4_bwd(const void* feat, int dtype, const float* w, const float* dout, void* dfeat, float* dw, float* db,
+                       int64_t npix, int Cin, uc_stream_t stream);
+
 /* fp32 verification-mode attention backward: same math, row-major fp32 operands (head_dim D <= 64), no packed
  * transposes needed.  delta fp32 [B,H,Nq] is scratch. */
 int uc_attention_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO,

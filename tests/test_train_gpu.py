@@ -23,8 +23,6 @@ def train_step(name, gpu, mode):
 
     model, c = build_case_model(name)
     model = model.to(gpu).train()
-    if c["head"] == "dpt":
-        pytest.skip("DPT head backward not wired yet")
     img1, img2 = (t.to(gpu) for t in case_images(c))
     gt1, gt2 = (t.to(gpu) for t in grad_targets(c))
     with engine.precision(mode):
@@ -40,7 +38,7 @@ def load_grads(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + "__grads.npz")))
 
 
-@pytest.mark.parametrize("name", ["tiny_linear", "cfg1_vitb_linear_224"])
+@pytest.mark.parametrize("name", ["tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224"])
 def test_fp32_gradients_match_reference_autograd(gpu, name):
     loss, grads = train_step(name, gpu, "fp32")
     gold = load_grads(name)
@@ -60,7 +58,7 @@ def test_fp32_gradients_match_reference_autograd(gpu, name):
     print(f"\n[fp32 grads] {name}: loss {loss:.6f}, worst {worst[0]} {worst[1]:.2e}")
 
 
-@pytest.mark.parametrize("name", ["tiny_linear", "cfg1_vitb_linear_224"])
+@pytest.mark.parametrize("name", ["tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224"])
 def test_bf16_gradients_track_reference_autograd(gpu, name):
     loss, grads = train_step(name, gpu, "bf16")
     gold = load_grads(name)

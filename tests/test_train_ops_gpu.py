@@ -219,3 +219,81 @@ def test_attention_backward_on_fused_qkv_views(gpu):
     dq, dk, dv = ops.attention_bwd(qd, kd, vd, o, do.to(gpu), lse, D ** -0.5)
     for got, ref in ((dq, qf.grad), (dk, kf.grad), (dv, vf.grad)):
         assert rel_l2(got.cpu().float(), ref) < 1.5e-2
+
+
+# ------------------------------------------------------------------------------------------
+# DPT head backward helpers
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)])
+@pytest.mark.parametrize("geom", [(5, 7, 10, 14, None), (3, 4, 6, 8, (5, 7)), (37, 37, 64, 50, None), (8, 8, 8, 8, None), (1, 1, 2, 2, None)])
+def test_bilinear_backward_is_the_adjoint(gpu, dtype, tol, geom):
+    from uniception_amd import ops
+    Hi, Wi, Ho, Wo, crop = geom
+    g = torch.Generator().manual_seed(Hi * 31 + Wo)
+    B, C = 2, 16
+    x = torch.randn(B, C, Hi, Wi, generator=g).to(dtype).float().requires_grad_(True)
+    y = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    if crop is not None:
+        y = y[:, :, :crop[0], :crop[1]]
+    dy = torch.randn(y.shape, generator=g).to(dtype)
+    y.backward(dy.float())
+    dx = ops.bilinear_nhwc_bwd(dy.permute(0, 2, 3, 1).contiguous().to(gpu), Hi, Wi, Ho, Wo)
+    assert dx.shape == (B, Hi, Wi, C)
+    assert rel_l2(dx.float().cpu().permute(0, 3, 1, 2), x.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k", [2, 4])
+def test_convt_gather_inverts_scatter(gpu, dtype, k):
+    from uniception_amd import ops
+    B, h, w, Cout = 2, 3, 5, 16
+    g = torch.Generator().manual_seed(k)
+    rows = torch.randn(B * h * w, k * k * Cout, generator=g).to(dtype).to(gpu)
+    img = ops.convt_scatter(rows, B, h, w, k, Cout)
+    assert torch.equal(ops.convt_gather(img, k), rows)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride,relu,H,W,Cin", [(1, False, 6, 9, 16), (1, True, 5, 7, 72), (2, False, 5, 7, 16), (2, True, 8, 8, 64)])
+def test_im2col_t_matches_unfold(gpu, dtype, stride, relu, H, W, Cin):
+    from uniception_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dtype)
+    out = ops.im2col_t(x.to(gpu), stride, relu)
+    xa = x.float().relu() if relu else x.float()
+    cols = F.unfold(xa.permute(0, 3, 1, 2), kernel_size=3, padding=1, stride=stride)      # [B, Cin*9, L], rows (c, ky, kx)
+    L = cols.shape[-1]
+    ref = cols.view(B, Cin, 9, L).permute(2, 1, 0, 3).reshape(9 * Cin, B * L)              # rows (tap, c), cols (b, oy, ox)
+    npix = B * L
+    assert out.shape[0] == 9 * Cin and out.shape[1] % 64 == 0 and out.shape[1] >= npix
+    assert torch.equal(out[:, :npix].float().cpu(), ref.to(dtype).float())
+    assert float(out[:, npix:].abs().sum()) == 0.0
+
+
+def test_dilate_nhwc(gpu):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(1)
+    src = torch.randn(2, 3, 4, 8, generator=g)
+    out = ops.dilate_nhwc(src.to(gpu), 5, 7, 2).cpu()
+    ref = torch.zeros(2, 5, 7, 8)
+    ref[:, ::2, ::2] = src
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-6), (torch.bfloat16, 6e-3)])
+@pytest.mark.parametrize("Cin", [128, 16, 72])
+def test_conv1x1_to4_backward(gpu, dtype, tol, Cin):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(Cin)
+    B, H, W = 2, 9, 13
+    feat = torch.randn(B, H, W, Cin, generator=g).to(dtype)
+    w = torch.randn(4, Cin, generator=g) / 8
+    b = torch.randn(4, generator=g)
+    dout = torch.randn(B, H, W, 4, generator=g)
+    f, ww, bb = feat.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (f @ ww.t() + bb).backward(dout)
+    dw, db = torch.zeros(4, Cin, device=gpu), torch.zeros(4, device=gpu)
+    dfeat = ops.conv1x1_to4_bwd(feat.to(gpu), w.to(gpu), dout.to(gpu), dw, db)
+    assert rel_l2(dfeat.float().cpu(), f.grad) < tol
+    assert rel_l2(dw.cpu(), ww.grad) < 1e-5 and rel_l2(db.cpu(), bb.grad) < 1e-5

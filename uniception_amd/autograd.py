@@ -140,10 +140,10 @@ class LinearFn(Function):
         dt = ctx.dt
         dy = _c(dy)
         need_dx = ctx.needs_input_grad[0]
-        if need_dx:
+        if need_dx and dy.dtype != dt:
             dyT, dyb = _tp(dy, dt, with_copy=True)
         else:
-            dyT, dyb = _tp(dy, dt), None
+            dyT, dyb = _tp(dy, dt), dy
         dW = _wgrad(dyT, _tp(xb, dt)).view(ctx.wshape)
         db = _colsum(dy) if ctx.has_bias else None
         dx = None
@@ -431,3 +431,160 @@ class ConfLossFn(Function):
 
 def conf_loss(pts, conf, gt, alpha: float = 0.2):
     return ConfLossFn.apply(pts, conf, gt.float(), alpha)
+
+
+# =================================================================================================================
+# DPT head (NHWC maps in the head dtype): 3x3 implicit-GEMM convs, 1x1 convs (LinearFn on the pixel matrix),
+# ConvTranspose2d(k=s), bilinear resize, the 4-channel regressor tail, and the dtype hop at the head's entry
+# =================================================================================================================
+class ConvertFn(Function):
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.src = x.dtype
+        x = _c(x)
+        return x if x.dtype == dt else ops.convert(x, dt)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        return (dy if dy.dtype == ctx.src else ops.convert(dy, ctx.src)), None
+
+
+def convert(x, dt):
+    return ConvertFn.apply(x, dt)
+
+
+def _conv3x3_rot_weight(conv, dt):
+    """GEMM weight of the data gradient: [Cin, 9*Cout] with K ordered (ky', kx', o) = W[o, c, 2-ky', 2-kx']."""
+    return engine.prepared(conv, ("c3rot", dt), (conv.weight,),
+                           lambda: conv.weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(conv.in_channels, -1).to(dt).contiguous())
+
+
+class Conv3x3Fn(Function):
+    """y = [residual +] act(conv3x3(relu?(x)) + b) on NHWC maps (dpt_block.py:17-289, dpt.py:116-178,271-277)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, residual2, conv, relu_in, act):
+        x = _c(x)
+        B, H, W, Cin = x.shape
+        s = conv.stride[0]
+        w, b = engine.conv3x3_weights(conv, x.dtype)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        r1 = None if residual is None else _c(residual).reshape(-1, residual.shape[-1])
+        r2 = None if residual2 is None else _c(residual2).reshape(-1, residual2.shape[-1])
+        y = ops.gemm(x, w, b, act=act, residual=r1, residual2=r2, relu_a=relu_in, conv=(B, H, W, Cin, s)).view(B, Ho, Wo, -1)
+        if act not in (None, "none", "relu"):
+            raise UcHipError(f"conv3x3 backward: unsupported fused activation {act}")
+        if act == "relu" and residual is not None:
+            raise UcHipError("conv3x3 backward: fused ReLU together with a residual is not used by the DPT head")
+        ctx.save_for_backward(x, y if act == "relu" else torch.empty(0))
+        ctx.meta = (conv, relu_in, act, bias is not None, residual is not None, residual2 is not None, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        conv, relu_in, act, has_b, has_r1, has_r2, s = ctx.meta
+        B, H, W, Cin = x.shape
+        dt = x.dtype
+        dy = _c(dy)
+        Cout = dy.shape[-1]
+        dz = ops.act_bwd(dy, y, "relu") if act == "relu" else dy
+        dz2 = dz.view(-1, Cout)
+        dWg = _wgrad(_tp(dz2, dt), ops.im2col_t(x, s, relu_in, KPAD))            # [Cout, 9*Cin], K ordered (ky,kx,c)
+        dW = dWg.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        db = _colsum(dz2) if has_b else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            g = dz if s == 1 else ops.dilate_nhwc(dz, H, W, s)
+            dx = ops.gemm(g, _conv3x3_rot_weight(conv, dt), conv=(B, H, W, Cout, 1)).view(B, H, W, Cin)
+            if relu_in:
+                dx = ops.act_bwd(dx, x, "relu")
+        return dx, dW, db, (dy if has_r1 else None), (dy if has_r2 else None), None, None, None
+
+
+def conv3x3(x, conv, relu_in=False, act=None, residual=None, residual2=None):
+    return Conv3x3Fn.apply(x, conv.weight, conv.bias, residual, residual2, conv, relu_in, act)
+
+
+def conv1x1(x, conv):
+    B, H, W, Cin = x.shape
+    y = LinearFn.apply(x.reshape(-1, Cin), conv.weight, conv.bias, conv, x.dtype, x.dtype)
+    return y.view(B, H, W, -1)
+
+
+class ConvTransposeFn(Function):
+    """ConvTranspose2d(kernel = stride, no padding) = GEMM to (u,v,o) columns + pixel scatter (dpt.py:116-140)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ct):
+        x = _c(x)
+        B, H, W, Cin = x.shape
+        k = ct.kernel_size[0]
+        w, b = engine.convt_weights(ct, x.dtype)
+        x2 = x.view(-1, Cin)
+        y = ops.gemm(x2, w, b)
+        ctx.save_for_backward(x2)
+        ctx.meta = (ct, k, (B, H, W, Cin), bias is not None)
+        return ops.convt_scatter(y, B, H, W, k, ct.out_channels)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        ct, k, (B, H, W, Cin), has_b = ctx.meta
+        dt = x2.dtype
+        Cout = ct.out_channels
+        dyg = ops.convt_gather(_c(dy), k)                                        # [B*H*W, k*k*Cout]
+        dWg = _wgrad(_tp(dyg, dt), _tp(x2, dt))                                  # [k*k*Cout, Cin]
+        dW = dWg.view(k, k, Cout, Cin).permute(3, 2, 0, 1)
+        db = _colsum(dyg).view(k * k, Cout).sum(0) if has_b else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wT = _w_t(ct, "ct", (ct.weight,),
+                      lambda: ct.weight.detach().permute(2, 3, 1, 0).reshape(k * k * Cout, Cin).float().contiguous(), dt)
+            dx = ops.gemm(dyg, wT).view(B, H, W, Cin)
+        return dx, dW, db, None
+
+
+def conv_transpose_ks(x, ct):
+    return ConvTransposeFn.apply(x, ct.weight, ct.bias, ct)
+
+
+class BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, crop):
+        x = _c(x)
+        ctx.geom = (x.shape[1], x.shape[2], Ho, Wo)
+        return ops.bilinear_nhwc(x, Ho, Wo, crop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        Hi, Wi, Ho, Wo = ctx.geom
+        return ops.bilinear_nhwc_bwd(_c(dy), Hi, Wi, Ho, Wo), None, None, None
+
+
+def bilinear(x, Ho, Wo, crop=None):
+    return BilinearFn.apply(x, Ho, Wo, crop)
+
+
+class Conv1x1To4Fn(Function):
+    """Regressor tail: features -> 4 decoded channels, fp32 output (dpt.py:271-277 conv2[2])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w4, b4):
+        x = _c(x)
+        ctx.save_for_backward(x, w4)
+        ctx.wshape, ctx.has_b = weight.shape, bias is not None
+        return ops.conv1x1_to4(x, w4, b4)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w4 = ctx.saved_tensors
+        dw = torch.zeros_like(w4)
+        db = torch.zeros(4, dtype=torch.float32, device=x.device)
+        dfeat = ops.conv1x1_to4_bwd(x, w4, _c(dout), dw, db)
+        return dfeat, dw.view(ctx.wshape), (db if ctx.has_b else None), None, None
+
+
+def conv1x1_to4(x, conv, w4, b4):
+    return Conv1x1To4Fn.apply(x, conv.weight, conv.bias, w4, b4)

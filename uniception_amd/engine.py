@@ -165,6 +165,9 @@ def bchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """BCHW-shaped tensor -> contiguous NHWC tensor in `dtype` (free when it already is a channels-last view)."""
     B, C, H, W = feat.shape
     nhwc = feat.permute(0, 2, 3, 1)
+    if _train(feat):   # differentiable hop: the permute is a view for channels-last features, the cast is a Function
+        from . import autograd
+        return autograd.convert(nhwc, dtype)
     if nhwc.is_contiguous():
         return nhwc if nhwc.dtype == dtype else ops.convert(nhwc, dtype)
     if not feat.is_contiguous():
@@ -299,7 +302,21 @@ def act_name(act_module: nn.Module) -> str:
 # ---------------------------------------------------------------------------------------------
 # DPT pieces on NHWC maps
 # ---------------------------------------------------------------------------------------------
+def _train(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def bilinear(x: torch.Tensor, Ho: int, Wo: int, crop=None) -> torch.Tensor:
+    if _train(x):
+        from . import autograd
+        return autograd.bilinear(x, Ho, Wo, crop)
+    return ops.bilinear_nhwc(x, Ho, Wo, crop)
+
+
 def conv1x1(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    if _train(x, conv.weight):
+        from . import autograd
+        return autograd.conv1x1(x, conv)
     B, H, W, Cin = x.shape
     w, b = conv1x1_weights(conv, x.dtype)
     return ops.gemm(x.view(-1, Cin), w, b).view(B, H, W, -1)
@@ -307,6 +324,9 @@ def conv1x1(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
 
 def conv3x3(x: torch.Tensor, conv: nn.Conv2d, relu_in: bool = False, act=None, residual: Optional[torch.Tensor] = None,
             residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if _train(x, conv.weight, residual, residual2):
+        from . import autograd
+        return autograd.conv3x3(x, conv, relu_in, act, residual, residual2)
     B, H, W, Cin = x.shape
     s = conv.stride[0]
     w, b = conv3x3_weights(conv, x.dtype)
@@ -318,6 +338,9 @@ def conv3x3(x: torch.Tensor, conv: nn.Conv2d, relu_in: bool = False, act=None, r
 
 
 def conv_transpose_ks(x: torch.Tensor, ct: nn.ConvTranspose2d) -> torch.Tensor:
+    if _train(x, ct.weight):
+        from . import autograd
+        return autograd.conv_transpose_ks(x, ct)
     B, H, W, Cin = x.shape
     k = ct.kernel_size[0]
     w, b = convt_weights(ct, x.dtype)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from ... import engine, ops
+from ... import autograd, engine, ops
 from ..libs.croco.dpt_block import make_fusion_block, make_nonlinearity, make_scratch, pair
 from .base import PixelTaskOutput, PredictionHeadLayeredInput
 
@@ -98,7 +98,6 @@ class DPTFeature(nn.Module):
         for hook_idx, hook in enumerate(self.hooks):
             assert feats[hook].shape[1] == self.input_feature_dims[hook_idx], (
                 f"Input feature dimension mismatch at hook {hook}. Expected BCHW")
-        engine.require_inference(*feats, self.scratch.layer1_rn.weight)
         dt = engine.head_dtype()
         out = self._nhwc([engine.bchw_to_nhwc(feats[hook], dt) for hook in self.hooks])
         return DPTFeatureInput(features_upsampled_8x=out.permute(0, 3, 1, 2), target_output_shape=dpt_input.target_output_shape)
@@ -131,11 +130,10 @@ class DPTRegressionProcessor(nn.Module):
     def forward(self, dpt_processor_input: DPTFeatureInput):
         x = dpt_processor_input.features_upsampled_8x
         H, W = dpt_processor_input.target_output_shape
-        engine.require_inference(x, self.conv1.weight)
         dt = engine.head_dtype()
         x = engine.bchw_to_nhwc(x, dt)
         x = engine.conv3x3(x, self.conv1)
-        x = ops.bilinear_nhwc(x, H, W)
+        x = engine.bilinear(x, H, W)
         x = engine.conv3x3(x, self.conv2[0], act="relu")
         last = self.conv2[2]
         if last.out_channels == 4 and last.in_channels <= 256 and last.in_channels % 8 == 0:
@@ -143,9 +141,15 @@ class DPTRegressionProcessor(nn.Module):
                                 lambda: (last.weight.detach().reshape(4, -1).float().contiguous(),
                                          last.bias.detach().float().contiguous() if last.bias is not None
                                          else torch.zeros(4, device=last.weight.device)))
-            out = ops.conv1x1_to4(x, w[0], w[1])  # fp32 NHWC [B,H,W,4]
+            if engine._train(x, last.weight):
+                out = autograd.conv1x1_to4(x, last, w[0], w[1])
+            else:
+                out = ops.conv1x1_to4(x, w[0], w[1])  # fp32 NHWC [B,H,W,4]
         else:
             wl, bl = engine.conv1x1_weights(last, dt)
             B, Hh, Ww, Cin = x.shape
-            out = ops.gemm(x.view(-1, Cin), wl, bl, out_dtype=torch.float32).view(B, Hh, Ww, -1)
+            if engine._train(x, last.weight):
+                out = autograd.linear(x.view(-1, Cin), last.weight, last.bias, last, dt, torch.float32).view(B, Hh, Ww, -1)
+            else:
+                out = ops.gemm(x.view(-1, Cin), wl, bl, out_dtype=torch.float32).view(B, Hh, Ww, -1)
         return PixelTaskOutput(decoded_channels=out.permute(0, 3, 1, 2))

@@ -457,3 +457,61 @@ def attention_bwd(q, k, v, o, do, lse, scale: float, out=None):
         o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1), dk.stride(2),
         dv.stride(0), dv.stride(1), dv.stride(2), float(scale), _stream()), "uc_attention_bwd")
     return dq, dk, dv
+
+
+def bilinear_nhwc_bwd(dy: torch.Tensor, Hi: int, Wi: int, Ho: int, Wo: int) -> torch.Tensor:
+    """dy [B,crop_h,crop_w,C] (gradient of bilinear_nhwc's output) -> dx [B,Hi,Wi,C]."""
+    _need_gpu(dy)
+    assert dy.is_contiguous() and dy.dim() == 4
+    B, ch, cw, C = dy.shape
+    dx = torch.empty((B, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().uc_bilinear_nhwc_bwd(dy.data_ptr(), dx.data_ptr(), _dt(dy.dtype), B, Hi, Wi, C, Ho, Wo, ch, cw, _stream()),
+               "uc_bilinear_nhwc_bwd")
+    return dx
+
+
+def convt_gather(dy: torch.Tensor, k: int) -> torch.Tensor:
+    """dy NHWC [B,k*h,k*w,Cout] -> [B*h*w, k*k*Cout]."""
+    _need_gpu(dy)
+    assert dy.is_contiguous() and dy.dim() == 4
+    B, Hk, Wk, Cout = dy.shape
+    h, w = Hk // k, Wk // k
+    out = torch.empty((B * h * w, k * k * Cout), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().uc_convt_gather(dy.data_ptr(), out.data_ptr(), _dt(dy.dtype), B, h, w, k, Cout, _stream()), "uc_convt_gather")
+    return out
+
+
+def im2col_t(x: torch.Tensor, stride: int, relu: bool, pad_to: int = 64) -> torch.Tensor:
+    """x NHWC [B,H,W,Cin] -> [9*Cin, npix_padded] (see uc_im2col_t)."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dim() == 4
+    B, H, W, Cin = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    npix = B * Ho * Wo
+    ld = (npix + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((9 * Cin, ld), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().uc_im2col_t(x.data_ptr(), out.data_ptr(), _dt(x.dtype), B, H, W, Cin, stride, 1 if relu else 0, ld, _stream()),
+               "uc_im2col_t")
+    return out
+
+
+def dilate_nhwc(src: torch.Tensor, H: int, W: int, stride: int) -> torch.Tensor:
+    _need_gpu(src)
+    assert src.is_contiguous() and src.dim() == 4
+    B, h, w, C = src.shape
+    out = torch.empty((B, H, W, C), dtype=src.dtype, device=src.device)
+    _lib.check(_lib.load().uc_dilate_nhwc(src.data_ptr(), out.data_ptr(), _dt(src.dtype), B, h, w, H, W, C, stride, _stream()),
+               "uc_dilate_nhwc")
+    return out
+
+
+def conv1x1_to4_bwd(feat: torch.Tensor, w: torch.Tensor, dout: torch.Tensor, dw: torch.Tensor, db: torch.Tensor) -> torch.Tensor:
+    """feat NHWC [...,Cin], w fp32 [4,Cin], dout fp32 [...,4] -> dfeat (feat's dtype); dw/db accumulated (fp32)."""
+    _need_gpu(feat, w, dout, dw, db)
+    assert feat.is_contiguous() and dout.is_contiguous() and dout.dtype == torch.float32 and w.is_contiguous()
+    Cin = feat.shape[-1]
+    npix = feat.numel() // Cin
+    dfeat = torch.empty_like(feat)
+    _lib.check(_lib.load().uc_conv1x1_to4_bwd(feat.data_ptr(), _dt(feat.dtype), w.data_ptr(), dout.data_ptr(), dfeat.data_ptr(),
+                                              dw.data_ptr(), db.data_ptr(), npix, Cin, _stream()), "uc_conv1x1_to4_bwd")
+    return dfeat
