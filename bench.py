@@ -30,7 +30,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=32, help="image pairs per GPU per step")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
+                    help="fwd: forward inference (BASELINE configs[1], the headline); train: forward + backward + gradient "
+                         "all-reduce + AdamW step (BASELINE configs[2])")
+    ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default 32 fwd, 8 train)")
     ap.add_argument("--img", type=int, default=512)
     ap.add_argument("--head", default="dpt", choices=["dpt", "linear"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -131,12 +134,35 @@ def main():
 
     _lib.load()  # fail loudly if the HIP extension is missing
     torch.manual_seed(0)
-    model = DUSt3R(name="bench", img_size=(args.img, args.img), pred_head_type=args.head).eval().to(dev)
+    if args.pairs is None:
+        args.pairs = 32 if args.mode == "fwd" else 8
+    model = DUSt3R(name="bench", img_size=(args.img, args.img), pred_head_type=args.head).to(dev)
     v1, v2 = make_views(args.pairs, args.img, args.img, rank, dev)
 
-    def step():
-        with torch.no_grad(), engine.precision(args.precision):
-            return model(v1, v2)
+    if args.mode == "train":
+        from uniception_amd import autograd
+        from uniception_amd.training import Trainer
+        model.train()
+        trainer = Trainer(model, lr=1e-5, weight_decay=0.05)
+        trainer.broadcast_parameters(0)
+        g = torch.Generator().manual_seed(2000 + rank)
+        gt1 = torch.randn(args.pairs, args.img, args.img, 3, generator=g).to(dev)
+        gt2 = torch.randn(args.pairs, args.img, args.img, 3, generator=g).to(dev)
+
+        def step():
+            trainer.zero_grad()
+            with engine.precision(args.precision):
+                r1, r2 = model(v1, v2)
+                loss = autograd.conf_loss(r1["pts3d"], r1["conf"], gt1) + autograd.conf_loss(r2["pts3d_in_other_view"], r2["conf"], gt2)
+            loss.backward()
+            trainer.step()
+            return ({"pts3d": loss.detach().reshape(1)},)
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad(), engine.precision(args.precision):
+                return model(v1, v2)
 
     for _ in range(args.warmup):
         step()
@@ -161,18 +187,23 @@ def main():
     pairs_total = world * args.pairs * args.steps
     value = pairs_total / dt
     gflop_pair = GFLOP_ENC_DEC_512 * (args.img / 512) ** 2  # informational (exact only at 512)
+    fwd = args.mode == "fwd"
     line = {
-        "metric": "image-pairs/sec fwd, ViT-L/16 two-view 512x512 (encoder + CroCo decoder + DPT heads + adaptor)",
+        "metric": ("image-pairs/sec fwd, ViT-L/16 two-view 512x512 (encoder + CroCo decoder + DPT heads + adaptor)" if fwd else
+                   "image-pairs/sec fwd+bwd training step, ViT-L/16 two-view 512x512 (forward, backward, gradient all-reduce, AdamW)"),
         "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: ViT-L/16 encoder + 12-block CroCo decoder + {args.head} head, "
-                               f"{args.img}x{args.img} pairs, forward, random-init weights",
+        "config": {"workload": (f"BASELINE configs[{1 if fwd else 2}]: ViT-L/16 encoder + 12-block CroCo decoder + {args.head} head, "
+                                f"{args.img}x{args.img} pairs, " + ("forward" if fwd else "training step with synthetic pointmap targets")
+                                + ", random-init weights"),
                    "pairs_per_gpu": args.pairs, "global_pairs_per_step": world * args.pairs, "img": args.img,
-                   "head": args.head, "parallelism": f"dp{world} (independent pairs per rank, no data-path collective)"},
-        "enc_dec_mfma_frac": round(value / world * gflop_pair / 1e3 / PEAK_BF16_TFLOPS, 4),
+                   "head": args.head,
+                   "parallelism": (f"dp{world} (independent pairs per rank, no data-path collective)" if fwd else
+                                   f"dp{world} (replicated model, bucketed in-place gradient all-reduce over RCCL)")},
+        "enc_dec_mfma_frac": round(value / world * gflop_pair * (1 if fwd else 3) / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and fwd:
         if not args.no_roofline and args.precision == "bf16":
             line["roofline"] = roofline_pass(model, v1, v2, args.precision, min(args.steps, 3))
         if not args.no_cpu_baseline:

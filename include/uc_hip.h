@@ -104,9 +104,10 @@ typedef struct uc_gemm_desc {
     /* training-path extras (bf16 path):
        preact_out: if non-NULL, the value BEFORE the activation (acc + bias) is also stored there, same dtype/ld as C
                    (saved for the activation's backward);
-       split_k   : > 1 splits the K loop over that many workgroup groups whose partial products are accumulated into
-                   C with fp32 atomic adds — C must be fp32 and zero-initialised; no bias/act/residual/rope/vt.
-                   Used by the weight-gradient GEMMs (few output tiles, very long K). */
+       split_k   : > 1 splits the K loop over that many workgroup groups; slice s stores its fp32 partial product to
+                   the slab C + s*M*ldc (C must hold split_k slabs of [M, ldc] fp32; no zero-init needed); no
+                   bias/act/residual/rope/vt.  uc_splitk_reduce sums the slabs.  Used by the weight-gradient GEMMs
+                   (few output tiles, very long K) — plain stores: fp32 atomics run at ~75 G/s and would dominate. */
     void* preact_out;
     int split_k;
     void* C;             /* [M,N] row-major, leading dim ldc (only columns < vt_col0 are written when vt is on) */
@@ -221,6 +222,9 @@ int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const float* b, 
  * Any C; widths 256*{1,2,3,4,6,8} take the register-resident kernel. */
 int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
                      float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + sum_s ws[s*n + i], i < n (n multiple of 4): reduction of uc_gemm's split_k slabs. */
+int uc_splitk_reduce(const float* ws, int split_k, int64_t n, float* out, int accumulate, uc_stream_t stream);
 
 /* Column sums (bias gradients): out[n] += sum_m src[m*ld + n]; out fp32, zero-initialised by the caller. */
 int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, float* out, uc_stream_t stream);

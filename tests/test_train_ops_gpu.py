@@ -150,15 +150,19 @@ def test_adamw_matches_torch(gpu):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,sk", [(768, 768, 6272, 8), (1024, 3072, 4096, 4), (200, 72, 1024, 3)])
 def test_gemm_split_k(gpu, M, N, K, sk):
-    """weight-gradient shape: few output tiles, long K; fp32 atomic accumulation into a zeroed C."""
+    """weight-gradient shape: few output tiles, long K; every K slice stores an fp32 partial slab, then one reduction."""
     from uniception_amd import ops
     g = torch.Generator().manual_seed(M)
     a = torch.randn(M, K, generator=g).bfloat16()
     w = torch.randn(N, K, generator=g).bfloat16()
-    c = torch.zeros(M, N, device=gpu)
-    ops.gemm(a.to(gpu), w.to(gpu), out=c, out_dtype=torch.float32, split_k=sk)
+    ws = ops.gemm(a.to(gpu), w.to(gpu), out_dtype=torch.float32, split_k=sk)
+    assert ws.shape == (sk, M, N)
     ref = a.float() @ w.float().t()
+    c = ops.splitk_reduce(ws)
     assert rel_l2(c.cpu(), ref) < 2e-5
+    base = torch.randn(M, N, generator=g)
+    acc = ops.splitk_reduce(ws, out=base.to(gpu), accumulate=True)
+    assert rel_l2(acc.cpu(), ref + base) < 2e-5
 
 
 def test_gemm_preact_out(gpu):

@@ -43,13 +43,13 @@ def _wgrad(dyT: torch.Tensor, xT: torch.Tensor) -> torch.Tensor:
     """dW [N,K] fp32 = dy^T x with both operands already transposed ([N,Mp], [K,Mp]; Mp = tokens padded to 64)."""
     N, Mp = dyT.shape
     K = xT.shape[0]
-    if dyT.dtype == torch.bfloat16:
+    if dyT.dtype == torch.bfloat16 and (N * K) % 4 == 0:
+        # few output tiles, very long K: split K so that tiles*sk just fills the 256 CUs once (one 256x256-tile workgroup
+        # per CU); the slices store fp32 partial slabs (plain stores) that uc_splitk_reduce sums
         tiles = ((N + 255) // 256) * ((K + 255) // 256)
-        sk = max(1, min(Mp // 256, -(-768 // tiles)))
+        sk = max(1, min(Mp // 512, 256 // tiles))
         if sk > 1:
-            out = torch.zeros((N, K), dtype=torch.float32, device=dyT.device)
-            ops.gemm(dyT, xT, out=out, out_dtype=torch.float32, split_k=sk)
-            return out
+            return ops.splitk_reduce(ops.gemm(dyT, xT, out_dtype=torch.float32, split_k=sk))
     return ops.gemm(dyT, xT, out_dtype=torch.float32)
 
 

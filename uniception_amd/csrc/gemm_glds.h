@@ -24,7 +24,7 @@ struct GldsParams {
     int out_dtype;
     int64_t ldc;
     void* preact;   // optional pre-activation copy (same dtype / ld as C)
-    int split_k;    // >1: K split over blockIdx groups, fp32 atomic accumulation into C
+    int split_k;    // >1: K split over blockIdx groups, slice s writes its fp32 partial product to C + s*M*ldc
     int tiles_m, tiles_n;
     int group_m;  // row panels per L2-sharing tile group (tile traversal order)
     int vec_ok;   // C / residual / bias satisfy the alignment needed by the 4-wide vector epilogue

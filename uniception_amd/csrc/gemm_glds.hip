@@ -74,7 +74,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // Shared epilogue: bias -> activation -> fused RoPE-2D -> residual(s) -> store, or the packed-VT store of V tiles.
 template <int FA>
 __device__ __forceinline__ void glds_epilogue(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
-                                              int64_t wave_n, int lane) {
+                                              int64_t wave_n, int lane, int ksplit) {
     const int frow = lane & 15;
     // =============================== epilogue ===============================
     const int g = lane >> 4;
@@ -146,13 +146,18 @@ __device__ __forceinline__ void glds_epilogue(const GldsParams& p, float4_t (&ac
         const int64_t m = wave_m + 16 * i + frow;
         if (m >= p.M) continue;
         float v[4][4];
-        if (p.split_k > 1) {   // partial product of one K slice: fp32 atomic accumulation, nothing else
+        if (p.split_k > 1) {   // partial product of one K slice -> its own [M, ldc] slab of the workspace, nothing else
+            float* slab = (float*)p.C + (int64_t)ksplit * p.M * p.ldc;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t nb = wave_n + 16 * j + 4 * g;
+                if (p.vec_ok && nb + 3 < p.N) {
+                    *reinterpret_cast<float4_t*>(slab + m * p.ldc + nb) = acc[i][j];
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nb + r < p.N) unsafeAtomicAdd((float*)p.C + m * p.ldc + nb + r, acc[i][j][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < p.N) slab[m * p.ldc + nb + r] = acc[i][j][r];
+                }
             }
             continue;
         }
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     };
     if (mode == 2) main_loop(std::false_type{}); else main_loop(std::true_type{});
 
-    glds_epilogue<FA>(p, acc, mode, wave_m, wave_n, lane);
+    glds_epilogue<FA>(p, acc, mode, wave_m, wave_n, lane, ksplit);
 }
 
 template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE>

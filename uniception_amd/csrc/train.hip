@@ -32,15 +32,17 @@ __device__ __forceinline__ void wave_sum2(float& a, float& b) {
 }
 
 template <typename TD, int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(512) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const typename TD::storage* __restrict__ dy,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int64_t rows, float eps) {
     constexpr int C = NV * 256;
+    __shared__ float red[2 * C];   // block-level dgamma | dbeta (LDS atomics), then ONE global atomic per column per block
     const int lane = threadIdx.x & 63;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave_id = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 8;
+    for (int i = threadIdx.x; i < 2 * C; i += 512) red[i] = 0.f;
     float4_t g[NV], dg[NV], db[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -92,13 +94,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             *reinterpret_cast<float4_t*>(dx + row * C + (i * 64 + lane) * 4) = o;
         }
     }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        unsafeAtomicAdd(dgamma + c + 0, dg[i].x); unsafeAtomicAdd(dgamma + c + 1, dg[i].y);
-        unsafeAtomicAdd(dgamma + c + 2, dg[i].z); unsafeAtomicAdd(dgamma + c + 3, dg[i].w);
-        unsafeAtomicAdd(dbeta + c + 0, db[i].x); unsafeAtomicAdd(dbeta + c + 1, db[i].y);
-        unsafeAtomicAdd(dbeta + c + 2, db[i].z); unsafeAtomicAdd(dbeta + c + 3, db[i].w);
+        atomicAdd(red + c + 0, dg[i].x); atomicAdd(red + c + 1, dg[i].y);
+        atomicAdd(red + c + 2, dg[i].z); atomicAdd(red + c + 3, dg[i].w);
+        atomicAdd(red + C + c + 0, db[i].x); atomicAdd(red + C + c + 1, db[i].y);
+        atomicAdd(red + C + c + 2, db[i].z); atomicAdd(red + C + c + 3, db[i].w);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 512) {
+        unsafeAtomicAdd(dgamma + i, red[i]);
+        unsafeAtomicAdd(dbeta + i, red[C + i]);
     }
 }
 
@@ -153,9 +161,9 @@ extern "C" int uc_layernorm_bwd(const float* x, const float* gamma, const void* 
         UC_CHECK_LAUNCH("uc_layernorm_bwd");
         return UC_OK;
     }
-    const unsigned grid = (unsigned)min((int64_t)512, ceil_div64(rows, 4));
+    const unsigned grid = (unsigned)min((int64_t)256, ceil_div64(rows, 8));
 #define UC_LNB(TD_, NV_)                                                                                                \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TD_, NV_>), dim3(grid), dim3(256), 0, st, x, gamma,                            \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TD_, NV_>), dim3(grid), dim3(512), 0, st, x, gamma,                            \
                        (const typename TD_::storage*)dy, dres, dx, dgamma, dbeta, rows, eps)
 #define UC_LNB_NV(TD_)                      \
     switch (C / 256) {                      \
@@ -187,7 +195,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const typename Tag::storage
     const int64_t r1 = min(M, r0 + rows_per_block);
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (c0 + 3 < N && (ld % 4 == 0)) {
-        for (int64_t r = r0 + rl; r < r1; r += 4) {
+        int64_t r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {   // 4 independent loads in flight
+            const float4_t v0 = tr_load4<Tag>(src + r * ld + c0), v1 = tr_load4<Tag>(src + (r + 4) * ld + c0);
+            const float4_t v2 = tr_load4<Tag>(src + (r + 8) * ld + c0), v3 = tr_load4<Tag>(src + (r + 12) * ld + c0);
+            a[0] += (v0.x + v1.x) + (v2.x + v3.x); a[1] += (v0.y + v1.y) + (v2.y + v3.y);
+            a[2] += (v0.z + v1.z) + (v2.z + v3.z); a[3] += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; r < r1; r += 4) {
             const float4_t v = tr_load4<Tag>(src + r * ld + c0);
             a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
         }
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const typename Tag::storage
 extern "C" int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, float* out, uc_stream_t stream) {
     UC_REQUIRE(src && out && M >= 0 && N > 0 && ld >= N, "uc_colsum: bad argument");
     if (M == 0) return UC_OK;
-    const int64_t rows_per_block = 512;
+    const int64_t rows_per_block = 256;
     dim3 grid((unsigned)ceil_div64(N, 256), (unsigned)min((int64_t)65535, ceil_div64(M, rows_per_block)));
     const int64_t rpb = ceil_div64(M, grid.y);
     hipStream_t st = (hipStream_t)stream;
@@ -220,6 +235,29 @@ extern "C" int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64
     else if (dtype == UC_BF16) hipLaunchKernelGGL((colsum_kernel<BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, M, N, ld, out, rpb);
     else { uc_set_error("uc_colsum: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_colsum");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// split-K reduction: out[i] (+)= sum_s ws[s*n + i]   (the slabs written by uc_gemm with split_k > 1)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int sk, int64_t n4, float* __restrict__ out, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4_t a = accumulate ? reinterpret_cast<const float4_t*>(out)[i] : (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < sk; ++s) {
+            const float4_t v = reinterpret_cast<const float4_t*>(ws)[(int64_t)s * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4_t*>(out)[i] = a;
+    }
+}
+
+extern "C" int uc_splitk_reduce(const float* ws, int split_k, int64_t n, float* out, int accumulate, uc_stream_t stream) {
+    UC_REQUIRE(ws && out && split_k >= 1 && n > 0 && n % 4 == 0, "uc_splitk_reduce: bad argument (n must be a multiple of 4)");
+    const int64_t n4 = n / 4;
+    const unsigned grid = (unsigned)min((int64_t)8192, ceil_div64(n4, 256));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, split_k, n4, out, accumulate);
+    UC_CHECK_LAUNCH("uc_splitk_reduce");
     return UC_OK;
 }
 

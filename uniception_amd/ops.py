@@ -151,11 +151,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         pos, table, rope_cols = rope
         assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * M
         d.rope_cols, d.rope_pos, d.rope_table, d.rope_npos = rope_cols, pos.data_ptr(), table.data_ptr(), table.shape[0]
-    if out is None:
+    if out is None and split_k > 1:
+        out = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
+        d.C, d.out_dtype, d.ldc = out.data_ptr(), _dt(out.dtype), N
+    elif out is None:
         out = torch.empty((M, n_out), dtype=out_dtype or a.dtype, device=a.device)
+    elif split_k > 1:   # workspace of split_k [M,N] fp32 slabs
+        assert out.shape == (split_k, M, N) and out.is_contiguous() and out.dtype == torch.float32
+        d.C, d.out_dtype, d.ldc = out.data_ptr(), _dt(out.dtype), N
     else:
         assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] >= n_out
-    d.C, d.out_dtype, d.ldc = out.data_ptr(), _dt(out.dtype), out.stride(0)
+    if split_k <= 1 or out.dim() == 2:
+        d.C, d.out_dtype, d.ldc = out.data_ptr(), _dt(out.dtype), out.stride(0)
     if preact_out is not None:
         assert preact_out.shape == out.shape and preact_out.stride() == out.stride() and preact_out.dtype == out.dtype
         d.preact_out = preact_out.data_ptr()
@@ -321,6 +328,19 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: f
     _lib.check(_lib.load().uc_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy.dtype), _p(dres), dx.data_ptr(),
                                             dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn, float(eps), _stream()), "uc_layernorm_bwd")
     return dx
+
+
+def splitk_reduce(ws: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """ws [sk, M, N] fp32 slabs (uc_gemm split_k output) -> out [M,N] (= or += the sum over slabs)."""
+    _need_gpu(ws, out)
+    assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.dim() == 3
+    if out is None:
+        assert not accumulate
+        out = torch.empty(ws.shape[1:], dtype=torch.float32, device=ws.device)
+    assert out.is_contiguous() and out.numel() == ws[0].numel() and out.dtype == torch.float32
+    _lib.check(_lib.load().uc_splitk_reduce(ws.data_ptr(), ws.shape[0], out.numel(), out.data_ptr(), 1 if accumulate else 0, _stream()),
+               "uc_splitk_reduce")
+    return out
 
 
 def colsum_(src: torch.Tensor, out: torch.Tensor) -> None:
