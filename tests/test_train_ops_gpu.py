@@ -301,3 +301,49 @@ def test_conv1x1_to4_backward(gpu, dtype, tol, Cin):
     dfeat = ops.conv1x1_to4_bwd(feat.to(gpu), w.to(gpu), dout.to(gpu), dw, db)
     assert rel_l2(dfeat.float().cpu(), f.grad) < tol
     assert rel_l2(dw.cpu(), ww.grad) < 1e-5 and rel_l2(db.cpu(), bb.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------
+# TN contraction (weight gradients without transposes; ds_read_b64_tr_b16 operand loads)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,I,J,sk", [(64, 256, 256, 1), (4096, 768, 768, 5), (1000, 1024, 3072, 2), (777, 72, 200, 3),
+                                      (130, 8, 8, 1), (16384, 1024, 1024, 16)])
+def test_gemm_tn_dense(gpu, T, I, J, sk):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(T + I)
+    a = torch.randn(T, I, generator=g).bfloat16()
+    b = torch.randn(T, J, generator=g).bfloat16()
+    ws = ops.gemm_tn(a.to(gpu), b.to(gpu), split_k=sk)
+    assert ws.shape == (sk, I, J)
+    c = ops.splitk_reduce(ws)
+    ref = a.float().t() @ b.float()
+    assert rel_l2(c.cpu(), ref) < 2e-5
+
+
+def test_gemm_tn_strided_operands(gpu):
+    """operands that are column slices of wider buffers (dq|dk|dv views of a fused qkv gradient)."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(5)
+    T = 500
+    a_full = torch.randn(T, 3 * 128, generator=g).bfloat16()
+    b_full = torch.randn(T, 2 * 192, generator=g).bfloat16()
+    c = ops.splitk_reduce(ops.gemm_tn(a_full.to(gpu)[:, 128:256], b_full.to(gpu)[:, 192:], split_k=2))
+    ref = a_full[:, 128:256].float().t() @ b_full[:, 192:].float()
+    assert rel_l2(c.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("stride,relu,B,H,W,Cin,Cout,sk", [(1, False, 2, 6, 9, 16, 32, 1), (1, True, 1, 16, 16, 64, 256, 2),
+                                                            (2, False, 2, 5, 7, 16, 24, 1), (2, True, 1, 32, 32, 64, 64, 3),
+                                                            (1, False, 1, 64, 64, 128, 128, 4)])
+def test_gemm_tn_conv_weight_gradient(gpu, stride, relu, B, H, W, Cin, Cout, sk):
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g).bfloat16()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g).bfloat16()
+    wref = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    xa = x.float().relu() if relu else x.float()
+    F.conv2d(xa.permute(0, 3, 1, 2), wref, stride=stride, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    ws = ops.gemm_tn(dy.view(-1, Cout).to(gpu), x.to(gpu), split_k=sk, conv=(stride, relu))
+    dW = ops.splitk_reduce(ws).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    assert rel_l2(dW.cpu(), wref.grad) < 2e-5

@@ -39,18 +39,42 @@ def _tp(x2d: torch.Tensor, dt: torch.dtype, with_copy: bool = False):
     return ops.transpose2d(x2d, dt, pad_to=KPAD, with_copy=with_copy)
 
 
-def _wgrad(dyT: torch.Tensor, xT: torch.Tensor) -> torch.Tensor:
-    """dW [N,K] fp32 = dy^T x with both operands already transposed ([N,Mp], [K,Mp]; Mp = tokens padded to 64)."""
-    N, Mp = dyT.shape
-    K = xT.shape[0]
-    if dyT.dtype == torch.bfloat16 and (N * K) % 4 == 0:
-        # few output tiles, very long K: split K so that tiles*sk just fills the 256 CUs once (one 256x256-tile workgroup
-        # per CU); the slices store fp32 partial slabs (plain stores) that uc_splitk_reduce sums
-        tiles = ((N + 255) // 256) * ((K + 255) // 256)
-        sk = max(1, min(Mp // 512, 256 // tiles))
-        if sk > 1:
-            return ops.splitk_reduce(ops.gemm(dyT, xT, out_dtype=torch.float32, split_k=sk))
-    return ops.gemm(dyT, xT, out_dtype=torch.float32)
+def _split_k(I: int, J: int, T: int) -> int:
+    """Few 256x256 output tiles, very long reduction: split it so tiles*sk just fills the 256 CUs once."""
+    tiles = ((I + 255) // 256) * ((J + 255) // 256)
+    return max(1, min(T // 512, 256 // tiles))
+
+
+def _tn_ok(*ts) -> bool:
+    return all(t.dtype == torch.bfloat16 and t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.shape[-1] % 8 == 0
+               and (t.dim() != 2 or t.stride(0) % 8 == 0) for t in ts)
+
+
+def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    """dW [N,K] fp32 = dy^T x for row-major dy [M,N], x [M,K] (any float dtype; operands are taken in dt).
+    bf16: the TN kernel contracts over the slow axis directly (uc_gemm_tn, split-K slabs + uc_splitk_reduce);
+    fp32 verification mode: explicit transposes + the exact fp32 GEMM."""
+    if dt == torch.bfloat16:
+        a = dy2d if dy2d.dtype == dt else ops.convert(_c(dy2d), dt)
+        b = x2d if x2d.dtype == dt else ops.convert(_c(x2d), dt)
+        if _tn_ok(a, b):
+            ws = ops.gemm_tn(a, b, split_k=_split_k(a.shape[1], b.shape[1], a.shape[0]))
+            return ws[0] if ws.shape[0] == 1 else ops.splitk_reduce(ws)
+    return ops.gemm(_tp(_c(dy2d), dt), _tp(_c(x2d), dt), out_dtype=torch.float32)
+
+
+def _wgrad_conv(dz: torch.Tensor, x: torch.Tensor, stride: int, relu_in: bool) -> torch.Tensor:
+    """dW_gemm [Cout, 9*Cin] (K ordered (ky,kx,c)) of a 3x3/pad-1 conv: dz NHWC [B,Ho,Wo,Cout], x NHWC [B,H,W,Cin]."""
+    Cout = dz.shape[-1]
+    dz2 = dz.view(-1, Cout)
+    if x.dtype == torch.bfloat16 and _tn_ok(dz2, x):
+        ws = ops.gemm_tn(dz2, x, split_k=_split_k(Cout, 9 * x.shape[-1], dz2.shape[0]), conv=(stride, relu_in))
+        return ws[0] if ws.shape[0] == 1 else ops.splitk_reduce(ws)
+    return ops.gemm(_tp(dz2, x.dtype), ops.im2col_t(x, stride, relu_in, KPAD), out_dtype=torch.float32)
+
+
+def _as_dt(g: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    return g if g.dtype == dt else ops.convert(g, dt)
 
 
 def _colsum(src2d: torch.Tensor) -> torch.Tensor:
@@ -140,11 +164,8 @@ class LinearFn(Function):
         dt = ctx.dt
         dy = _c(dy)
         need_dx = ctx.needs_input_grad[0]
-        if need_dx and dy.dtype != dt:
-            dyT, dyb = _tp(dy, dt, with_copy=True)
-        else:
-            dyT, dyb = _tp(dy, dt), dy
-        dW = _wgrad(dyT, _tp(xb, dt)).view(ctx.wshape)
+        dyb = _as_dt(dy, dt)
+        dW = _wgrad(dyb, xb, dt).view(ctx.wshape)
         db = _colsum(dy) if ctx.has_bias else None
         dx = None
         if need_dx:
@@ -173,7 +194,7 @@ class PatchEmbedFn(Function):
     def backward(ctx, dtok):
         (cols,) = ctx.saved_tensors
         dtok = _c(dtok)
-        dW = _wgrad(_tp(dtok, ctx.dt), _tp(cols, ctx.dt)).view(ctx.wshape)
+        dW = _wgrad(dtok, cols, ctx.dt).view(ctx.wshape)
         db = _colsum(dtok) if ctx.has_bias else None
         return None, dW, db, None, None, None
 
@@ -225,8 +246,8 @@ class SelfAttnSubLayerFn(Function):
         M, C = x2d.shape
         Dh = C // H
         dxo = _c(dxo)
-        dyT, dyb = _tp(dxo, dt, with_copy=True)
-        dWp = _wgrad(dyT, _tp(o.view(M, C), dt))
+        dyb = _as_dt(dxo, dt)
+        dWp = _wgrad(dyb, o.view(M, C), dt)
         dbp = _colsum(dyb) if has_bp else None
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dt3 = torch.empty_like(t)
@@ -235,7 +256,7 @@ class SelfAttnSubLayerFn(Function):
                           out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]))
         _rope_inverse_(d5[:, :, 0], pos, rope)
         _rope_inverse_(d5[:, :, 1], pos, rope)
-        dWq = _wgrad(_tp(dt3, dt), _tp(h, dt))
+        dWq = _wgrad(dt3, h, dt)
         dbq = _colsum(dt3) if has_bq else None
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
@@ -297,8 +318,8 @@ class CrossAttnSubLayerFn(Function):
         Mq, C = x2d.shape
         Dh = C // H
         dxo = _c(dxo)
-        dyT, dyb = _tp(dxo, dt, with_copy=True)
-        dWp = _wgrad(dyT, _tp(o.view(Mq, C), dt))
+        dyb = _as_dt(dxo, dt)
+        dWp = _wgrad(dyb, o.view(Mq, C), dt)
         dbp = _colsum(dyb) if has_bp else None
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dq = torch.empty_like(q)
@@ -309,13 +330,13 @@ class CrossAttnSubLayerFn(Function):
         _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
         _rope_inverse_(dkv5[:, :, 0], kpos, rope)
         # query side
-        dWq = _wgrad(_tp(dq, dt), _tp(hq, dt))
+        dWq = _wgrad(dq, hq, dt)
         dbq = _colsum(dq) if has_bq else None
         dhq = ops.gemm(dq, lin_weight_t(projq, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dhq, ln.eps, dg, db, dres=dxo)
         # key/value side (the other view's tokens)
-        dWkv = _wgrad(_tp(dkv, dt), _tp(hy, dt))
+        dWkv = _wgrad(dkv, hy, dt)
         dbkv = _colsum(dkv) if (has_bk or has_bv) else None
         dhy = ops.gemm(dkv, kv_weight_t(projk, projv, dt), out_dtype=dt if lny is not None else torch.float32)
         if lny is not None:
@@ -357,12 +378,12 @@ class MlpSubLayerFn(Function):
         x2d, g, h, u, a = ctx.saved_tensors
         ln, fc1, fc2, act, dt, has_b1, has_b2 = ctx.meta
         dxo = _c(dxo)
-        dyT, dyb = _tp(dxo, dt, with_copy=True)
-        dW2 = _wgrad(dyT, _tp(a, dt))
+        dyb = _as_dt(dxo, dt)
+        dW2 = _wgrad(dyb, a, dt)
         db2 = _colsum(dyb) if has_b2 else None
         da = ops.gemm(dyb, lin_weight_t(fc2, dt))
         du = ops.act_bwd(da, u, act) if act != "none" else da
-        dW1 = _wgrad(_tp(du, dt), _tp(h, dt))
+        dW1 = _wgrad(du, h, dt)
         db1 = _colsum(du) if has_b1 else None
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
@@ -491,7 +512,7 @@ class Conv3x3Fn(Function):
         Cout = dy.shape[-1]
         dz = ops.act_bwd(dy, y, "relu") if act == "relu" else dy
         dz2 = dz.view(-1, Cout)
-        dWg = _wgrad(_tp(dz2, dt), ops.im2col_t(x, s, relu_in, KPAD))            # [Cout, 9*Cin], K ordered (ky,kx,c)
+        dWg = _wgrad_conv(dz, x, s, relu_in)                                     # [Cout, 9*Cin], K ordered (ky,kx,c)
         dW = dWg.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         db = _colsum(dz2) if has_b else None
         dx = None
@@ -535,7 +556,7 @@ class ConvTransposeFn(Function):
         dt = x2.dtype
         Cout = ct.out_channels
         dyg = ops.convt_gather(_c(dy), k)                                        # [B*H*W, k*k*Cout]
-        dWg = _wgrad(_tp(dyg, dt), _tp(x2, dt))                                  # [k*k*Cout, Cin]
+        dWg = _wgrad(dyg, x2, dt)                                                # [k*k*Cout, Cin]
         dW = dWg.view(k, k, Cout, Cin).permute(3, 2, 0, 1)
         db = _colsum(dyg).view(k * k, Cout).sum(0) if has_b else None
         dx = None

@@ -1,0 +1,237 @@
+// "TN" bf16 GEMM for gfx950 — the weight-gradient contraction over tokens / pixels, without transposing either operand:
+//
+//   C[I,J] (fp32) = sum_t A[t,i] * B[t,j]        A = dY [T,I] row-major,  B = X [T,J] row-major  (dW = dY^T X)
+//   conv mode:     B[t,j] = act(x[b, oy*s-1+ky, ox*s-1+kx, c]),  t = (b,oy,ox), j = (ky*3+kx)*Cin + c   (implicit im2col)
+//
+// Both operands have the REDUCTION index t on the slow axis, so an MFMA operand (8 consecutive k per lane) is a column
+// walk.  The tiles are staged [64 t][256 i|j] (row = 512 B) by the same lane-linear LDS-DMA as the NT kernel and read
+// with gfx950's transposing LDS load (ds_read_b64_tr_b16): inside a 16-lane group lane q hands in the address of 4
+// consecutive bf16 of row (q>>2) — together a [4 t][16 i] block — and receives column q of it, i.e. 4 consecutive t for
+// its own i.  Two such reads (t, t+4) make one 16x16x32 operand.
+// Bank layout: a wave-instruction is served in two 32-lane halves; a half reads rows {r..r+3} and {r+8..r+11} of one
+// 32-byte column block, so the 32-byte block index is XOR-ed with s(r) = (r&3) | ((r>>3)&1)<<2 — eight distinct
+// 8-bank groups.  As in the NT kernel the permutation is applied to the DMA's per-lane SOURCE address.
+// Split-K over t: slice s stores its partial product to the slab C + s*I*J (plain stores; see uc_splitk_reduce).
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* tn_lds_ptr_t;
+
+struct TnParams {
+    const bf16_t* A;     // [T, I], leading dim lda
+    int64_t lda;
+    const bf16_t* B;     // dense: [T, J] leading dim ldb; conv: NHWC image [cB, cH, cW, cCin]
+    int64_t ldb;
+    int64_t T, I, J;
+    int conv;            // 0 dense, 1 implicit im2col of a 3x3 / pad 1 conv
+    int cB, cH, cW, cCin, cStride, cHo, cWo, relu_b;
+    float* C;            // [split_k][I, J]
+    int split_k;
+    int tiles_i, tiles_j;
+};
+
+__device__ uint4 g_tn_zero[2];   // 16 zero bytes (+ slack): DMA source for rows beyond T and for the conv's zero padding
+
+__device__ __forceinline__ void tn_dma16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
+
+__device__ __forceinline__ int tn_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+__device__ __forceinline__ bf16x4_t tn_relu4(bf16x4_t v) {
+    uint2 u = __builtin_bit_cast(uint2, v);
+    unsigned* q = reinterpret_cast<unsigned*>(&u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned neg = (q[i] >> 15) & 0x00010001u;
+        q[i] &= ~(neg * 0xffffu);
+    }
+    return __builtin_bit_cast(bf16x4_t, u);
+}
+
+#define TN_BM 256
+#define TN_BN 256
+#define TN_STAGE (64 * (TN_BM + TN_BN) * 2)   // 64 KiB: A tile then B tile
+
+template <bool CONV>
+__global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;              // 4 x 4 waves, 64 x 64 outputs each
+
+    const int nwg = p.tiles_i * p.tiles_j;
+    const int ksplit = (int)blockIdx.x / nwg;
+    const int tile = (int)blockIdx.x - ksplit * nwg;
+    const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
+    const int64_t i0 = (int64_t)ti * TN_BM, j0 = (int64_t)tj * TN_BN;
+
+    // ---- DMA plan: 64 instructions per stage, 4 per wave; instruction n covers rows 2n', 2n'+1 (n' = n % 32) of the
+    //      A tile (n < 32, wave-uniform) or the B tile; lane -> row 2n' + (lane>>5), physical 16-byte chunk lane & 31.
+    //      Per lane and instruction only the row and the (clamped) logical column are kept; conv taps are re-derived. ----
+    const int d_rhalf = lane >> 5;
+    int d_col[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 4 + q;
+        const int r = 2 * (n & 31) + d_rhalf;
+        const int pc = lane & 31;
+        const int lc = ((((pc >> 1) ^ tn_swz(r)) << 1) | (pc & 1));      // logical 16-byte chunk held at physical chunk pc
+        const int64_t lim = (n < 32) ? p.I : p.J;
+        int64_t col = ((n < 32) ? i0 : j0) + lc * 8;
+        if (col + 8 > lim) col = lim - 8;                                // duplicate a valid chunk; those outputs are never stored
+        d_col[q] = (int)col;
+    }
+    const unsigned lds_base = (unsigned)(size_t)(tn_lds_ptr_t)smem;
+    auto issue_stage = [&](int stage, int64_t t0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = wave * 4 + q;                                   // wave-uniform
+            const int64_t t = t0 + 2 * (n & 31) + d_rhalf;
+            const void* g = g_tn_zero;
+            if (t < p.T) {
+                if (n < 32) {
+                    g = p.A + t * p.lda + d_col[q];
+                } else if constexpr (!CONV) {
+                    g = p.B + t * p.ldb + d_col[q];
+                } else {
+                    const int tap = d_col[q] / p.cCin;
+                    const int c = d_col[q] - tap * p.cCin;
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const unsigned tt = (unsigned)t;                        // pixel counts fit 32 bits (checked by the launcher)
+                    const unsigned row = tt / (unsigned)p.cWo;
+                    const int ox = (int)(tt - row * (unsigned)p.cWo);
+                    const int b = (int)(row / (unsigned)p.cHo);
+                    const int oy = (int)(row - (unsigned)b * (unsigned)p.cHo);
+                    const int iy = oy * p.cStride - 1 + ky, ix = ox * p.cStride - 1 + kx;
+                    if (iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW)
+                        g = p.B + (((int64_t)b * p.cH + iy) * p.cW + ix) * p.cCin + c;
+                }
+            }
+            tn_dma16(g, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * TN_STAGE + n * 1024)));
+        }
+    };
+
+    // ---- transposing fragment reads: lane (g = lane>>4, q = lane&15); k-step ks, half h:
+    //      row r = 32ks + 8g + 4h + (q>>2), 32-byte block blk (16 columns), piece (q&3)*8 bytes.
+    //      s(r) = (q>>2) | (g&1)<<2 for every (ks,h), so one swizzled offset per fragment + immediates ----
+    const int fg = lane >> 4, fq = lane & 15;
+    const int f_sw = (fq >> 2) | ((fg & 1) << 2);
+    const int f_base = (8 * fg + (fq >> 2)) * 512 + (fq & 3) * 8;
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_off[i] = f_base + (((wr * 4 + i) ^ f_sw) << 5);
+        b_off[i] = f_base + (((wc * 4 + i) ^ f_sw) << 5) + 64 * TN_BM * 2;
+    }
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = (int)((p.T + 63) / 64);
+    const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
+    const int kt0 = ksplit * nk_per;
+    const int nk = max(0, min(nk_per, nk_total - kt0));
+    const int64_t tbase = (int64_t)kt0 * 64;
+
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_v4_t;
+    auto frag = [&](const char* st, int off, int ks, bool relu) -> bf16x8_t {
+        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(tn_lds_ptr_t)(st + off + ks * (32 * 512)));
+        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(tn_lds_ptr_t)(st + off + ks * (32 * 512) + 4 * 512));
+        if (relu) { lo = tn_relu4(lo); hi = tn_relu4(hi); }
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    if (nk > 0) issue_stage(0, tbase);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) issue_stage((kt + 1) & 1, tbase + (int64_t)(kt + 1) * 64);
+        const char* st = smem + (kt & 1) * TN_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag(st, a_off[i], ks, false);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = frag(st, b_off[j], ks, CONV && p.relu_b != 0);
+            // swapped operands: D[row = j][col = i] -> a lane owns 4 consecutive j of one i (16-byte stores)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane (col = lane&15 -> i, rows 4*(lane>>4)+r -> j) ----
+    float* slab = p.C + (int64_t)ksplit * p.I * p.J;
+    const bool vec = (p.J % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t ii = i0 + wr * 64 + 16 * i + fq;
+        if (ii >= p.I) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t jj = j0 + wc * 64 + 16 * j + 4 * fg;
+            if (vec && jj + 3 < p.J) {
+                *reinterpret_cast<float4_t*>(slab + ii * p.J + jj) = acc[i][j];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (jj + r < p.J) slab[ii * p.J + jj + r] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+extern "C" int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t T, int64_t I, int64_t J, int conv_B,
+                          int conv_H, int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, int split_k,
+                          uc_stream_t stream) {
+    UC_REQUIRE(A && B && C, "uc_gemm_tn: null pointer");
+    UC_REQUIRE(T > 0 && I >= 8 && J >= 8 && I % 8 == 0 && J % 8 == 0 && lda % 8 == 0, "uc_gemm_tn: I, J and lda must be multiples of 8");
+    UC_REQUIRE(split_k >= 1 && split_k <= 1024, "uc_gemm_tn: bad split_k");
+    UC_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "uc_gemm_tn: operands must be 16-byte aligned");
+    TnParams p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.T = T; p.I = I; p.J = J;
+    p.conv = conv_B > 0 ? 1 : 0;
+    p.cB = conv_B; p.cH = conv_H; p.cW = conv_W; p.cCin = conv_Cin; p.cStride = conv_stride; p.relu_b = relu_b ? 1 : 0;
+    p.cHo = p.cWo = 0;
+    if (p.conv) {
+        UC_REQUIRE(conv_H > 0 && conv_W > 0 && conv_Cin > 0 && conv_Cin % 8 == 0 && conv_stride > 0, "uc_gemm_tn: bad conv geometry (Cin must be a multiple of 8)");
+        p.cHo = (conv_H - 1) / conv_stride + 1;
+        p.cWo = (conv_W - 1) / conv_stride + 1;
+        UC_REQUIRE(T == (int64_t)conv_B * p.cHo * p.cWo && J == 9 * (int64_t)conv_Cin, "uc_gemm_tn: conv shape mismatch");
+        UC_REQUIRE(T < (int64_t)1 << 31, "uc_gemm_tn: too many pixels");
+    } else {
+        UC_REQUIRE(ldb % 8 == 0 && ldb >= J && !relu_b, "uc_gemm_tn: ldb must be a multiple of 8");
+    }
+    p.C = C; p.split_k = split_k;
+    p.tiles_i = (int)ceil_div64(I, TN_BM);
+    p.tiles_j = (int)ceil_div64(J, TN_BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)p.tiles_i * p.tiles_j * (unsigned)split_k);
+    if (p.conv) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(1024), 2 * TN_STAGE, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(1024), 2 * TN_STAGE, (hipStream_t)stream, p);
+    UC_CHECK_LAUNCH("uc_gemm_tn");
+    return UC_OK;
+}
