@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
                     help="fwd: forward inference (BASELINE configs[1], the headline); train: forward + backward + gradient "
                          "all-reduce + AdamW step (BASELINE configs[2])")
-    ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default 32 fwd, 8 train)")
+    ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default 32 fwd, 16 train)")
     ap.add_argument("--img", type=int, default=512)
     ap.add_argument("--head", default="dpt", choices=["dpt", "linear"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -135,7 +135,7 @@ def main():
     _lib.load()  # fail loudly if the HIP extension is missing
     torch.manual_seed(0)
     if args.pairs is None:
-        args.pairs = 32 if args.mode == "fwd" else 8
+        args.pairs = 32 if args.mode == "fwd" else 16
     model = DUSt3R(name="bench", img_size=(args.img, args.img), pred_head_type=args.head).to(dev)
     v1, v2 = make_views(args.pairs, args.img, args.img, rank, dev)
 

@@ -110,6 +110,11 @@ typedef struct uc_gemm_desc {
                    (few output tiles, very long K) — plain stores: fp32 atomics run at ~75 G/s and would dominate. */
     void* preact_out;
     int split_k;
+    /* dact_u: if non-NULL, the result is multiplied by act'(u[m,n]) with act = dact_act (UC_ACT_GELU_ERF | UC_ACT_RELU) and
+       u laid out like C in the compute dtype — the activation backward of the consumer fused into this data-gradient
+       GEMM (du = (dy W) * act'(u)).  bf16 direct-to-LDS kernels only. */
+    const void* dact_u;
+    int dact_act;
     void* C;             /* [M,N] row-major, leading dim ldc (only columns < vt_col0 are written when vt is on) */
     int out_dtype;       /* UC_F32 | UC_BF16 */
     int64_t ldc;

@@ -347,3 +347,18 @@ def test_gemm_tn_conv_weight_gradient(gpu, stride, relu, B, H, W, Cin, Cout, sk)
     ws = ops.gemm_tn(dy.view(-1, Cout).to(gpu), x.to(gpu), split_k=sk, conv=(stride, relu))
     dW = ops.splitk_reduce(ws).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
     assert rel_l2(dW.cpu(), wref.grad) < 2e-5
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_gemm_fused_activation_backward(gpu, act):
+    """du = (dy W) * act'(u) in the data-gradient GEMM's epilogue == act_bwd(gemm(dy, W), u)."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(17)
+    M, N, K = 777, 512, 256
+    dy = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / 16).bfloat16()
+    u = (torch.randn(M, N, generator=g) * 1.5).bfloat16()
+    fused = ops.gemm(dy.to(gpu), w.to(gpu), dact=(u.to(gpu), act))
+    uu = u.float().requires_grad_(True)
+    (F.gelu(uu) if act == "gelu" else F.relu(uu)).backward(dy.float() @ w.float().t())
+    assert rel_l2(fused.float().cpu(), uu.grad) < 5e-3

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("bias", vp), ("act", i32), ("residual", vp), ("residual2", vp), ("res_dtype", i32), ("ldr", i64),
         ("rope_cols", i64), ("rope_pos", vp), ("rope_table", vp), ("rope_npos", i32),
         ("vt_col0", i64), ("vt_out", vp), ("vt_ntok", i32), ("vt_npad", i32),
-        ("preact_out", vp), ("split_k", i32),
+        ("preact_out", vp), ("split_k", i32), ("dact_u", vp), ("dact_act", i32),
         ("C", vp), ("out_dtype", i32), ("ldc", i64),
     ]
 

@@ -381,8 +381,12 @@ class MlpSubLayerFn(Function):
         dyb = _as_dt(dxo, dt)
         dW2 = _wgrad(dyb, a, dt)
         db2 = _colsum(dyb) if has_b2 else None
-        da = ops.gemm(dyb, lin_weight_t(fc2, dt))
-        du = ops.act_bwd(da, u, act) if act != "none" else da
+        w2t = lin_weight_t(fc2, dt)
+        if act != "none" and dt == torch.bfloat16 and w2t.shape[1] % 64 == 0:
+            du = ops.gemm(dyb, w2t, dact=(u, act))          # act'(u) applied in the data-gradient GEMM's epilogue
+        else:
+            da = ops.gemm(dyb, w2t)
+            du = ops.act_bwd(da, u, act) if act != "none" else da
         dW1 = _wgrad(du, h, dt)
         db1 = _colsum(du) if has_b1 else None
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
@@ -518,9 +522,12 @@ class Conv3x3Fn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             g = dz if s == 1 else ops.dilate_nhwc(dz, H, W, s)
-            dx = ops.gemm(g, _conv3x3_rot_weight(conv, dt), conv=(B, H, W, Cout, 1)).view(B, H, W, Cin)
-            if relu_in:
-                dx = ops.act_bwd(dx, x, "relu")
+            if relu_in and dt == torch.bfloat16 and Cout % 64 == 0:
+                dx = ops.gemm(g, _conv3x3_rot_weight(conv, dt), conv=(B, H, W, Cout, 1), dact=(x.view(-1, Cin), "relu")).view(B, H, W, Cin)
+            else:
+                dx = ops.gemm(g, _conv3x3_rot_weight(conv, dt), conv=(B, H, W, Cout, 1)).view(B, H, W, Cin)
+                if relu_in:
+                    dx = ops.act_bwd(dx, x, "relu")
         return dx, dW, db, (dy if has_r1 else None), (dy if has_r2 else None), None, None, None
 
 

@@ -493,6 +493,12 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         }
         if (d->preact_out) UC_REQUIRE(d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a && d->vt_col0 < 0 && d->rope_cols <= 0,
                                       "uc_gemm: preact_out is implemented on the dense direct-to-LDS kernel only");
+        if (d->dact_u) {
+            UC_REQUIRE(d->dact_act == UC_ACT_GELU_ERF || d->dact_act == UC_ACT_RELU, "uc_gemm: bad dact_act %d", d->dact_act);
+            UC_REQUIRE(d->out_dtype == UC_BF16 && d->split_k <= 1 && d->vt_col0 < 0 && d->rope_cols <= 0 && !d->preact_out &&
+                           ((d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a) || (d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 == 0)),
+                       "uc_gemm: dact_u needs the bf16 direct-to-LDS kernels, bf16 output and a plain epilogue");
+        }
         const bool glds_dense = d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a;
         const bool glds_conv = d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 == 0 &&
                                (int64_t)d->conv_B * d->conv_H * d->conv_W < (int64_t)1 << 30;
@@ -509,6 +515,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                                                (!d->residual2 || (uintptr_t)d->residual2 % 16 == 0));
             g.vec_ok = (c_ok && b_ok && r_ok) ? 1 : 0;
             g.preact = d->preact_out; g.split_k = d->split_k > 1 ? d->split_k : 1;
+            g.dact_u = (const bf16_t*)d->dact_u; g.dact_act = d->dact_act;
             { static int gm = -1; if (gm < 0) { const char* e = getenv("UC_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } g.group_m = gm; }
             { static int dbg = -1; if (dbg < 0) { const char* e = getenv("UC_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
             g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
@@ -535,8 +542,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         else
             hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_CONV3X3>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);
     } else if (d->compute_dtype == UC_F32) {
-        if (d->split_k > 1) {
-            uc_set_error("uc_gemm(f32): split_k is only implemented for the bf16 MFMA path");
+        if (d->split_k > 1 || d->dact_u) {
+            uc_set_error("uc_gemm(f32): split_k / dact_u are only implemented for the bf16 MFMA path");
             return UC_ERR_UNSUPPORTED;
         }
         p.preact = d->preact_out;

@@ -24,6 +24,8 @@ struct GldsParams {
     int out_dtype;
     int64_t ldc;
     void* preact;   // optional pre-activation copy (same dtype / ld as C)
+    const bf16_t* dact_u;   // optional: multiply the result by act'(u), u bf16 [M, ldc]
+    int dact_act;
     int split_k;    // >1: K split over blockIdx groups, slice s writes its fp32 partial product to C + s*M*ldc
     int tiles_m, tiles_n;
     int group_m;  // row panels per L2-sharing tile group (tile traversal order)

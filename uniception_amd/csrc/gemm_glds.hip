@@ -22,7 +22,35 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #include "gemm_glds.h"
 #include <type_traits>
 
-__device__ __forceinline__ float glds_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU of the bf16 MFMA path.  libm's erff is a branchy two-range evaluation (~50 VALU ops per element once both
+// sides of the branch run in a wave); with only 16 K-steps per fc1 tile that epilogue cost as much as the MFMA loop.
+// Abramowitz-Stegun 7.1.26: erf(z) = 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1/(1 + p z), |error| <= 1.5e-7 — at fp32
+// rounding level and three orders below the bf16 output's own rounding.  (The fp32 verification kernel keeps erff.)
+__device__ __forceinline__ float glds_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);            // erf(|x|/sqrt2)
+    const float erf_s = __builtin_copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_s);
+}
+// d/dx of the activation at pre-activation x: GELU' = Phi(x) + x phi(x); ReLU' = [x > 0]
+__device__ __forceinline__ float glds_dact(float x, int act) {
+    if (act == UC_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);      // exp(-x^2/2)
+    const float erf_s = __builtin_copysignf(fmaf(-poly * t, e, 1.0f), x);
+    return fmaf(0.5f, erf_s, 0.5f) + x * e * 0.39894228040143267794f;
+}
 __device__ __forceinline__ float glds_act(float v, int act) {
     if (act == UC_ACT_GELU_ERF) return glds_gelu(v);
     if (act == UC_ACT_RELU) return fmaxf(v, 0.f);
@@ -220,6 +248,20 @@ __device__ __forceinline__ void glds_epilogue(const GldsParams& p, float4_t (&ac
                             v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual2)[idx] : bf16_to_f32(((const bf16_t*)p.residual2)[idx]);
                     }
                 }
+            }
+            if (p.dact_u) {   // fused activation backward: out = v * act'(u)
+                float u4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) {
+                    const uint2 uu = *reinterpret_cast<const uint2*>(p.dact_u + m * p.ldc + nb);
+                    u4[0] = __uint_as_float(uu.x << 16); u4[1] = __uint_as_float(uu.x & 0xffff0000u);
+                    u4[2] = __uint_as_float(uu.y << 16); u4[3] = __uint_as_float(uu.y & 0xffff0000u);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < p.N) u4[r] = bf16_to_f32(p.dact_u[m * p.ldc + nb + r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j][r] *= glds_dact(u4[r], p.dact_act);
             }
             if (full) {
                 if (p.out_dtype == UC_F32) {

@@ -102,7 +102,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rope: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
          vt: Optional[Tuple[int, torch.Tensor, int]] = None,
          conv: Optional[Tuple[int, int, int, int, int]] = None, preact_out: Optional[torch.Tensor] = None,
-         split_k: int = 1) -> torch.Tensor:
+         split_k: int = 1, dact: Optional[Tuple[torch.Tensor, str]] = None) -> torch.Tensor:
     """C[M,N] = epilogue(A . W^T).
 
     a    : dense [M,K] (row stride a.stride(0), unit column stride) or, with conv=(B,H,W,Cin,stride), an NHWC image.
@@ -167,6 +167,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         assert preact_out.shape == out.shape and preact_out.stride() == out.stride() and preact_out.dtype == out.dtype
         d.preact_out = preact_out.data_ptr()
     d.split_k = int(split_k)
+    if dact is not None:   # fused activation backward: out *= act'(u)
+        u, act_name = dact
+        assert u.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and u.shape == out.shape and u.stride() == out.stride()
+        d.dact_u, d.dact_act = u.data_ptr(), ACT[act_name]
     _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
     return out
 
