@@ -189,8 +189,8 @@ def main():
     gflop_pair = GFLOP_ENC_DEC_512 * (args.img / 512) ** 2  # informational (exact only at 512)
     fwd = args.mode == "fwd"
     line = {
-        "metric": ("image-pairs/sec fwd, ViT-L/16 two-view 512x512 (encoder + CroCo decoder + DPT heads + adaptor)" if fwd else
-                   "image-pairs/sec fwd+bwd training step, ViT-L/16 two-view 512x512 (forward, backward, gradient all-reduce, AdamW)"),
+        "metric": (f"image-pairs/sec fwd, ViT-L/16 two-view {args.img}x{args.img} (encoder + CroCo decoder + {args.head} heads + adaptor)" if fwd else
+                   f"image-pairs/sec fwd+bwd training step, ViT-L/16 two-view {args.img}x{args.img} (forward, backward, gradient all-reduce, AdamW)"),
         "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
