@@ -34,7 +34,10 @@ def parse():
                     help="fwd: forward inference (BASELINE configs[1], the headline); train: forward + backward + gradient "
                          "all-reduce + AdamW step (BASELINE configs[2])")
     ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default 32 fwd, 16 train)")
-    ap.add_argument("--img", type=int, default=512)
+    ap.add_argument("--encoder", default="croco", choices=["croco", "dinov2"],
+                    help="croco: the DUSt3R factory model; dinov2: BASELINE configs[3] — DINOv2 ViT-L/14 encoder (frozen in "
+                         "train mode) + the same decoder and heads, default 518x518")
+    ap.add_argument("--img", type=int, default=None)
     ap.add_argument("--head", default="dpt", choices=["dpt", "linear"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,8 +139,18 @@ def main():
     torch.manual_seed(0)
     if args.pairs is None:
         args.pairs = 32 if args.mode == "fwd" else 16
-    model = DUSt3R(name="bench", img_size=(args.img, args.img), pred_head_type=args.head).to(dev)
+    if args.img is None:
+        args.img = 512 if args.encoder == "croco" else 518
+    model = DUSt3R(name="bench", img_size=(args.img, args.img), pred_head_type=args.head)
+    norm_type = "dust3r"
+    if args.encoder == "dinov2":   # the factory hard-codes the CroCo encoder (factory/dust3r.py:115-122): swap it
+        from uniception_amd.models.encoders import encoder_factory
+        model.encoder = encoder_factory("dinov2", name="bench_dinov2", size="large")
+        model.encoder.requires_grad_(False)
+        norm_type = "dinov2"
+    model = model.to(dev)
     v1, v2 = make_views(args.pairs, args.img, args.img, rank, dev)
+    v1["data_norm_type"] = v2["data_norm_type"] = norm_type
 
     if args.mode == "train":
         from uniception_amd import autograd
@@ -188,17 +201,19 @@ def main():
     value = pairs_total / dt
     gflop_pair = GFLOP_ENC_DEC_512 * (args.img / 512) ** 2  # informational (exact only at 512)
     fwd = args.mode == "fwd"
+    enc_name = "ViT-L/16" if args.encoder == "croco" else "DINOv2 ViT-L/14"
     line = {
-        "metric": (f"image-pairs/sec fwd, ViT-L/16 two-view {args.img}x{args.img} (encoder + CroCo decoder + {args.head} heads + adaptor)" if fwd else
-                   f"image-pairs/sec fwd+bwd training step, ViT-L/16 two-view {args.img}x{args.img} (forward, backward, gradient all-reduce, AdamW)"),
+        "metric": (f"image-pairs/sec fwd, {enc_name} two-view {args.img}x{args.img} (encoder + CroCo decoder + {args.head} heads + adaptor)" if fwd else
+                   f"image-pairs/sec fwd+bwd training step, {enc_name} two-view {args.img}x{args.img} (forward, backward, gradient all-reduce, AdamW)"),
         "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": (f"BASELINE configs[{1 if fwd else 2}]: ViT-L/16 encoder + 12-block CroCo decoder + {args.head} head, "
+        "config": {"workload": (f"BASELINE configs[{(1 if fwd else 2) if args.encoder == 'croco' else 3}]: "
+                                f"{'ViT-L/16 CroCo' if args.encoder == 'croco' else 'DINOv2 ViT-L/14'} encoder + 12-block CroCo decoder + {args.head} head, "
                                 f"{args.img}x{args.img} pairs, " + ("forward" if fwd else "training step with synthetic pointmap targets")
                                 + ", random-init weights"),
                    "pairs_per_gpu": args.pairs, "global_pairs_per_step": world * args.pairs, "img": args.img,
-                   "head": args.head,
+                   "head": args.head, "encoder": args.encoder,
                    "parallelism": (f"dp{world} (independent pairs per rank, no data-path collective)" if fwd else
                                    f"dp{world} (replicated model, bucketed in-place gradient all-reduce over RCCL)")},
         "enc_dec_mfma_frac": round(value / world * gflop_pair * (1 if fwd else 3) / 1e3 / PEAK_BF16_TFLOPS, 4),

@@ -215,6 +215,17 @@ int uc_pointmap_adaptor(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp
 int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const float* b, float* out,
                    int64_t npix, int Cin, uc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Token-sequence assembly for cls/register-token ViTs (DINOv2 `prepare_tokens_with_masks`, reached through
+ * encoders/dinov2.py:188): out [B, 1+R+hw, D] = [cls + pos[0] | reg[0..R) | tok[b,i] + pos[1+i]], all fp32.
+ * uc_token_slice copies rows src[b, src_off + i, :] -> dst[b, dst_off + i, :], i < n (splitting cls/registers from
+ * the patch tokens after the final norm, encoders/dinov2.py:191-216).
+ * ---------------------------------------------------------------------------------- */
+int uc_assemble_tokens(const float* tok, const float* cls, const float* reg, const float* pos, float* out, int B, int hw,
+                       int R, int D, uc_stream_t stream);
+int uc_token_slice(const float* src, float* dst, int B, int Ns, int Nd, int src_off, int dst_off, int n, int D,
+                   uc_stream_t stream);
+
 /* ====================================================================================
  * Training path (backward of the same hot path; config 3 of BASELINE.json).
  * The reference has no hand-written backward: it relies on PyTorch autograd over the modules cited above, so each

@@ -276,6 +276,58 @@ def pointmap_adaptor(x: Tensor, conf_vmin: float = 1.0, conf_vmax: float = float
 
 
 # ---------------------------------------------------------------------------------------------
+# DINOv2 ViT-S/B/L-14 encoder (BASELINE config 4).  PARITY UNPINNED: the reference loads this network from torch.hub
+# ("facebookresearch/dinov2", encoders/dinov2.py:91-102) — third-party, not vendored, no pinned revision, not fetchable
+# here — so this is a restatement of the PUBLISHED architecture (prepare_tokens_with_masks / interpolate_pos_encoding /
+# NestedTensorBlock without drop-path / forward_features), anchored only on the reference's call sites
+# (encoders/dinov2.py:140-163 SDPA attention, :188-216 output split).  It checks the HIP module against the same reading
+# of the architecture, nothing more.
+# ---------------------------------------------------------------------------------------------
+def dinov2_pos_embed(sd: SD, prefix: str, h0: int, w0: int, num_registers: int) -> Tensor:
+    pe = sd[prefix + "pos_embed"].float()
+    N = pe.shape[1] - 1
+    M = int(math.sqrt(N))
+    if (h0, w0) == (M, M):
+        return pe
+    grid = pe[:, 1:].reshape(1, M, M, -1).permute(0, 3, 1, 2)
+    if num_registers > 0:      # *_reg hub models: interpolate_antialias=True, interpolate_offset=0.0
+        grid = F.interpolate(grid, size=(h0, w0), mode="bicubic", antialias=True)
+    else:                      # plain hub models: interpolate_offset=0.1 passed as a scale factor
+        grid = F.interpolate(grid, scale_factor=((h0 + 0.1) / M, (w0 + 0.1) / M), mode="bicubic", antialias=False)
+    return torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, h0 * w0, -1)], dim=1)
+
+
+def dinov2_encoder(img: Tensor, sd: SD, prefix: str, *, num_heads: int, num_registers: int = 0, patch_size: int = 14,
+                   norm: bool = True, take: Sequence[int] = ()):
+    """-> (features [B,D,h,w], registers [B,D,1+R]) and, if `take`, the (normed) token streams after those blocks."""
+    B, _, H, W = img.shape
+    h0, w0 = H // patch_size, W // patch_size
+    x = F.conv2d(img, sd[prefix + "patch_embed.proj.weight"], sd[prefix + "patch_embed.proj.bias"], stride=patch_size)
+    x = x.flatten(2).transpose(1, 2)                                            # [B, hw, D]
+    x = torch.cat([sd[prefix + "cls_token"].expand(B, -1, -1), x], dim=1) + dinov2_pos_embed(sd, prefix, h0, w0, num_registers)
+    if num_registers > 0:
+        x = torch.cat([x[:, :1], sd[prefix + "register_tokens"].expand(B, -1, -1), x[:, 1:]], dim=1)
+    depth = 1 + max(int(k[len(prefix) + 7:].split(".")[0]) for k in sd if k.startswith(prefix + "blocks."))
+    Cd = x.shape[-1]
+    taken = []
+    for i in range(depth):
+        bp = f"{prefix}blocks.{i}."
+        h = layer_norm(x, sd, bp + "norm1")
+        N = h.shape[1]
+        qkv = linear(h, sd, bp + "attn.qkv").view(B, N, 3, num_heads, Cd // num_heads).permute(2, 0, 3, 1, 4)
+        a = linear(sdpa(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, N, Cd), sd, bp + "attn.proj")
+        x = x + sd[bp + "ls1.gamma"] * a
+        x = x + sd[bp + "ls2.gamma"] * mlp(layer_norm(x, sd, bp + "norm2"), sd, bp + "mlp")
+        if i in take:
+            taken.append(layer_norm(x, sd, prefix + "norm") if norm else x)
+    xn = layer_norm(x, sd, prefix + "norm") if norm else x
+    R = num_registers
+    feats = xn[:, 1 + R:].permute(0, 2, 1).reshape(B, Cd, h0, w0)
+    regs = xn[:, :1 + R].permute(0, 2, 1)
+    return (feats, regs, taken) if take else (feats, regs)
+
+
+# ---------------------------------------------------------------------------------------------
 # two-view model (factory/dust3r.py:250-332)
 # ---------------------------------------------------------------------------------------------
 def dust3r_forward(sd: SD, img1: Tensor, img2: Tensor, *, head: str, enc_depth: int = 24, enc_heads: int = 16,

@@ -375,3 +375,64 @@ extern "C" int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const
     UC_CHECK_LAUNCH("uc_conv1x1_to4");
     return UC_OK;
 }
+
+// =======================================================================================
+// Token-sequence assembly of cls/register-token ViTs (DINOv2): [cls + pos0 | registers | patches + pos] and the
+// reverse split.  fp32 residual stream, float4 per lane.
+// =======================================================================================
+__global__ void assemble_tokens_kernel(const float* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ reg,
+                                       const float* __restrict__ pos, float* __restrict__ out, int B, int hw, int R, int D4,
+                                       int64_t items) {
+    const int Nt = 1 + R + hw;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(it % D4);
+        const int n = (int)((it / D4) % Nt);
+        const int b = (int)(it / ((int64_t)D4 * Nt));
+        float4_t v;
+        if (n == 0) {
+            const float4_t c = reinterpret_cast<const float4_t*>(cls)[d4], p = reinterpret_cast<const float4_t*>(pos)[d4];
+            v = (float4_t){c.x + p.x, c.y + p.y, c.z + p.z, c.w + p.w};
+        } else if (n <= R) {
+            v = reinterpret_cast<const float4_t*>(reg)[(int64_t)(n - 1) * D4 + d4];
+        } else {
+            const int i = n - 1 - R;
+            const float4_t t = reinterpret_cast<const float4_t*>(tok)[((int64_t)b * hw + i) * D4 + d4];
+            const float4_t p = reinterpret_cast<const float4_t*>(pos)[(int64_t)(1 + i) * D4 + d4];
+            v = (float4_t){t.x + p.x, t.y + p.y, t.z + p.z, t.w + p.w};
+        }
+        reinterpret_cast<float4_t*>(out)[it] = v;
+    }
+}
+
+extern "C" int uc_assemble_tokens(const float* tok, const float* cls, const float* reg, const float* pos, float* out, int B,
+                                  int hw, int R, int D, uc_stream_t stream) {
+    UC_REQUIRE(tok && cls && pos && out && (R == 0 || reg), "uc_assemble_tokens: null pointer");
+    UC_REQUIRE(B > 0 && hw > 0 && R >= 0 && D > 0 && D % 4 == 0, "uc_assemble_tokens: bad shape (D must be a multiple of 4)");
+    const int64_t items = (int64_t)B * (1 + R + hw) * (D / 4);
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(EW_GRID(items)), dim3(256), 0, (hipStream_t)stream, tok, cls, reg, pos, out, B,
+                       hw, R, D / 4, items);
+    UC_CHECK_LAUNCH("uc_assemble_tokens");
+    return UC_OK;
+}
+
+__global__ void token_slice_kernel(const float* __restrict__ src, float* __restrict__ dst, int Ns, int Nd, int src_off, int dst_off,
+                                   int n, int D4, int64_t items) {
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(it % D4);
+        const int i = (int)((it / D4) % n);
+        const int b = (int)(it / ((int64_t)D4 * n));
+        reinterpret_cast<float4_t*>(dst)[((int64_t)b * Nd + dst_off + i) * D4 + d4] =
+            reinterpret_cast<const float4_t*>(src)[((int64_t)b * Ns + src_off + i) * D4 + d4];
+    }
+}
+
+extern "C" int uc_token_slice(const float* src, float* dst, int B, int Ns, int Nd, int src_off, int dst_off, int n, int D,
+                              uc_stream_t stream) {
+    UC_REQUIRE(src && dst && B > 0 && n > 0 && D > 0 && D % 4 == 0, "uc_token_slice: bad argument (D must be a multiple of 4)");
+    UC_REQUIRE(src_off >= 0 && dst_off >= 0 && src_off + n <= Ns && dst_off + n <= Nd, "uc_token_slice: slice out of range");
+    const int64_t items = (int64_t)B * n * (D / 4);
+    hipLaunchKernelGGL(token_slice_kernel, dim3(EW_GRID(items)), dim3(256), 0, (hipStream_t)stream, src, dst, Ns, Nd, src_off, dst_off,
+                       n, D / 4, items);
+    UC_CHECK_LAUNCH("uc_token_slice");
+    return UC_OK;
+}

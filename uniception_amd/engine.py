@@ -149,6 +149,16 @@ def patch_weights(conv: nn.Conv2d, dtype: torch.dtype):
                     lambda: (conv.weight.detach().reshape(conv.out_channels, -1).to(dtype).contiguous(), _f32c(conv.bias)))
 
 
+def layerscale_lin_weights(lin: nn.Linear, gamma: torch.Tensor, dtype: torch.dtype):
+    """LayerScale folded into the preceding linear: gamma * (x W^T + b) = x (gamma[:,None] W)^T + gamma*b — zero kernel work."""
+    def build():
+        g = gamma.detach().float()
+        w = (lin.weight.detach().float() * g[:, None]).to(dtype).contiguous()
+        b = (lin.bias.detach().float() * g).contiguous() if lin.bias is not None else None
+        return w, b
+    return prepared(lin, ("ls", dtype), (lin.weight, lin.bias, gamma), build)
+
+
 def ln_params(ln: nn.LayerNorm):
     return prepared(ln, "ln", (ln.weight, ln.bias), lambda: (_f32c(ln.weight), _f32c(ln.bias)))
 
@@ -207,12 +217,13 @@ def _pos2d(pos: torch.Tensor) -> torch.Tensor:
 # (proj applied) with `residual` added by the proj GEMM epilogue when given.
 # ---------------------------------------------------------------------------------------------
 def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.Linear, num_heads: int, rope, pos,
-                   scale: float, residual: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+                   scale: float, residual: Optional[torch.Tensor], out_dtype: torch.dtype, proj_wb=None) -> torch.Tensor:
+    """proj_wb: optional prepared (W, b) overriding proj's own (e.g. with a LayerScale folded in)."""
     dtype = h2d.dtype
     M, Cd = h2d.shape
     Dh = Cd // num_heads
     wq, bq = lin_weights(qkv, dtype)
-    wp, bp = lin_weights(proj, dtype)
+    wp, bp = proj_wb if proj_wb is not None else lin_weights(proj, dtype)
     native = rope is None or is_native_rope(rope)
     if dtype == torch.bfloat16 and Dh == 64 and native:
         vt = ops.vt_buffer(B, num_heads, N, h2d.device)
@@ -282,9 +293,9 @@ def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk
 
 
 def mlp(h2d: torch.Tensor, fc1: nn.Linear, fc2: nn.Linear, act: str, residual: Optional[torch.Tensor],
-        out_dtype: torch.dtype) -> torch.Tensor:
+        out_dtype: torch.dtype, fc2_wb=None) -> torch.Tensor:
     w1, b1 = lin_weights(fc1, h2d.dtype)
-    w2, b2 = lin_weights(fc2, h2d.dtype)
+    w2, b2 = fc2_wb if fc2_wb is not None else lin_weights(fc2, h2d.dtype)
     g = ops.gemm(h2d, w1, b1, act=act)
     return ops.gemm(g, w2, b2, residual=residual, out_dtype=out_dtype)
 

@@ -2,11 +2,14 @@
 from .base import (EncoderGlobalRepInput, EncoderGlobalRepOutput, EncoderInput, EncoderOutput, UniCeptionEncoderBase,  # noqa: F401
                    UniCeptionViTEncoderBase, ViTEncoderInput, ViTEncoderNonImageInput, ViTEncoderOutput)
 from .croco import CroCoEncoder, CroCoIntermediateFeatureReturner
+from .dinov2 import DINOv2Encoder, DINOv2IntermediateFeatureReturner
 from .image_normalizations import IMAGE_NORMALIZATION_DICT  # noqa: F401
 
 ENCODER_CONFIGS = {
     "croco": {"class": CroCoEncoder, "intermediate_feature_returner_class": CroCoIntermediateFeatureReturner,
               "supported_models": ["CroCov2", "DUSt3R", "MASt3R"]},
+    "dinov2": {"class": DINOv2Encoder, "intermediate_feature_returner_class": DINOv2IntermediateFeatureReturner,
+               "supported_models": ["DINOv2", "DINOv2-Registers", "DINOv2-Depth-Anythingv2"]},
 }
 
 

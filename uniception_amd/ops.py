@@ -315,6 +315,30 @@ def conv1x1_to4(feat: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.T
     return out
 
 
+def assemble_tokens(tok: torch.Tensor, cls: torch.Tensor, reg: Optional[torch.Tensor], pos: torch.Tensor) -> torch.Tensor:
+    """tok fp32 [B,hw,D], cls [D], reg [R,D]|None, pos [1+hw,D] -> [B, 1+R+hw, D] = [cls+pos0 | reg | tok+pos]."""
+    _need_gpu(tok, cls, reg, pos)
+    B, hw, D = tok.shape
+    R = 0 if reg is None else reg.shape[0]
+    for t in (tok, cls, reg, pos):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    assert cls.numel() == D and pos.shape == (1 + hw, D)
+    out = torch.empty((B, 1 + R + hw, D), dtype=torch.float32, device=tok.device)
+    _lib.check(_lib.load().uc_assemble_tokens(tok.data_ptr(), cls.data_ptr(), _p(reg), pos.data_ptr(), out.data_ptr(), B, hw, R, D,
+                                              _stream()), "uc_assemble_tokens")
+    return out
+
+
+def token_slice(src: torch.Tensor, start: int, n: int) -> torch.Tensor:
+    """src fp32 [B,Ns,D] -> contiguous [B,n,D] copy of rows start..start+n."""
+    _need_gpu(src)
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 3
+    B, Ns, D = src.shape
+    dst = torch.empty((B, n, D), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().uc_token_slice(src.data_ptr(), dst.data_ptr(), B, Ns, n, start, 0, n, D, _stream()), "uc_token_slice")
+    return dst
+
+
 # --------------------------------------------------------------------------------------------
 # training path
 # --------------------------------------------------------------------------------------------
