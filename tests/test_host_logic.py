@@ -90,11 +90,12 @@ def test_training_inputs_are_rejected_not_mishandled():
     one go to the HIP autograd path, which needs a device."""
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    from uniception_amd.models.prediction_heads.dpt import DPTRegressionProcessor
-    from uniception_amd.models.prediction_heads.dpt import DPTFeatureInput
-    reg = DPTRegressionProcessor(input_feature_dim=32, output_dim=4)
+    dino = encoder_factory("dinov2", name="d", size="small", keep_first_n_layers=1)   # LayerScale folding: inference only
     with pytest.raises(UcHipError, match="backward"):
-        reg(DPTFeatureInput(features_upsampled_8x=torch.zeros(1, 32, 8, 8), target_output_shape=(16, 16)))
+        dino(ViTEncoderInput(image=torch.zeros(1, 3, 28, 28), data_norm_type="dinov2"))
+    dino.requires_grad_(False)
+    with pytest.raises(UcHipError, match="HIP device only"):
+        dino(ViTEncoderInput(image=torch.zeros(1, 3, 28, 28), data_norm_type="dinov2"))
     enc = encoder_factory("croco", name="e", data_norm_type="dust3r", img_size=(32, 32), enc_embed_dim=64, enc_depth=1, enc_num_heads=1)
     with pytest.raises(UcHipError, match="HIP device only"):
         enc(ViTEncoderInput(image=torch.zeros(1, 3, 32, 32), data_norm_type="dust3r"))

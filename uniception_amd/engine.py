@@ -65,8 +65,8 @@ def head_dtype() -> torch.dtype:
 def require_inference(*tensors) -> None:
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise UcHipError(
-            "uniception_amd: this module has no HIP backward yet (the transformer blocks, patch embedding, linear head, "
-            "adaptor and loss do); run it under torch.no_grad() or freeze it (requires_grad_(False))."
+            "uniception_amd: this module has no HIP backward (the CroCo encoder, the cross-attention decoder, the DPT and "
+            "linear heads, the adaptor and the loss do); run it under torch.no_grad() or freeze it (requires_grad_(False))."
         )
 
 
