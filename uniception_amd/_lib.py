@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuc_hip.so")
+LIB_PATH = os.environ.get("UC_HIP_LIB") or os.path.join(_HERE, "libuc_hip.so")   # UC_HIP_LIB: A/B-test another build
 
 UC_F32, UC_BF16, UC_F16 = 0, 1, 2
 UC_A_DENSE, UC_A_CONV3X3 = 0, 1

@@ -528,6 +528,10 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 const int64_t t256x128 = ceil_div64(d->M, 256) * ceil_div64(d->N, 128);
                 const int64_t sk = d->split_k > 1 ? d->split_k : 1;
                 variant = t256 * sk >= 192 ? 2 : (t256x128 * sk >= 160 ? 1 : 0);
+                // a 256-wide tile whose last column block is at most half full wastes a 128-column slab of MFMA work per row
+                // panel (N = 128: half of every tile): take the 256x128 tile there
+                const int64_t waste256 = ceil_div64(d->N, 256) * 256 - d->N, waste128 = ceil_div64(d->N, 128) * 128 - d->N;
+                if (variant == 2 && waste256 - waste128 >= 128 && t256x128 * sk >= 160) variant = 1;
             }
             uc_launch_gemm_glds(g, variant, st);
             UC_CHECK_LAUNCH("uc_gemm(glds)");

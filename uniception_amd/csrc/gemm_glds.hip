@@ -325,41 +325,43 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     const int64_t wave_n = n0 + wc * 64;
 
     // ---- per-wave epilogue mode (wave-uniform) ----
-    const bool is_vt = p.vt_col0 >= 0 && wave_n >= p.vt_col0;
-    const bool is_rope = !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
+    const bool is_vt = A_MODE == UC_A_DENSE && p.vt_col0 >= 0 && wave_n >= p.vt_col0;        // conv tiles take neither epilogue
+    const bool is_rope = A_MODE == UC_A_DENSE && !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
     const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
 
     // ---- DMA source pointers: instruction I = wave*PER + q covers combined-tile rows [8I, 8I+8) ----
     // dense: src[q] + k0.   conv: A rows are gathered per K-step from the 3x3 window (one tap per 64-channel K-step,
     // because Cin % 64 == 0); positions inside the zero padding read from g_zero_chunk instead.
-    const bf16_t* src[PER];
-    int c_iy0[PER], c_ix0[PER], c_pix[PER], c_c8[PER];
-    bool is_a[PER];
+    // Dense: one 64-bit source pointer per instruction.  Conv: two 32-bit words per instruction — A rows keep the packed
+    // window origin (oy*s | ox*s << 16) and the image's first pixel index, W rows a 32-bit element offset; the lane's
+    // channel chunk is re-derived — so the 16-wave 256x256 tile stays inside its 128-VGPR budget.
+    const bf16_t* src[A_MODE == UC_A_DENSE ? PER : 1];
+    int st0[A_MODE == UC_A_DENSE ? 1 : PER], st1[A_MODE == UC_A_DENSE ? 1 : PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int rr = (wave * PER + q) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((rr >> 1) & 7);   // logical chunk stored at physical chunk (lane&7) of row rr
-        is_a[q] = (wave * PER + q) * 8 < BM_;         // wave-uniform: an instruction is all-A or all-W
-        c_iy0[q] = c_ix0[q] = c_pix[q] = 0;
-        c_c8[q] = c * 8;
         if (rr < BM_) {
             int64_t m = m0 + rr;
             if (m >= p.M) m = p.M - 1;
-            if (A_MODE == UC_A_DENSE) {
+            if constexpr (A_MODE == UC_A_DENSE) {
                 src[q] = p.A + m * p.lda + c * 8;
             } else {
                 const int ox = (int)(m % p.cWo);
                 const int oy = (int)((m / p.cWo) % p.cHo);
                 const int b = (int)(m / ((int64_t)p.cWo * p.cHo));
-                c_iy0[q] = oy * p.cStride - 1;
-                c_ix0[q] = ox * p.cStride - 1;
-                c_pix[q] = b * p.cH * p.cW;
-                src[q] = p.A;
+                st0[q] = (oy * p.cStride) | ((ox * p.cStride) << 16);
+                st1[q] = b * p.cH * p.cW;
             }
         } else {
             int64_t n = n0 + (rr - BM_);
             if (n >= p.N) n = p.N - 1;
-            src[q] = p.W + n * p.K + c * 8;
+            if constexpr (A_MODE == UC_A_DENSE) {
+                src[q] = p.W + n * p.K + c * 8;
+            } else {
+                st0[q] = (int)(n * p.K + c * 8);      // < 2^31 elements (checked by the launcher)
+                st1[q] = 0;
+            }
         }
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;   // LDS byte address of the dynamic region
@@ -373,32 +375,35 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const bf16_t* g;
-            if (A_MODE != UC_A_DENSE && is_a[q]) {
-                const int iy = c_iy0[q] + ky, ix = c_ix0[q] + kx;
-                const bool ok = iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-                g = ok ? p.A + ((int64_t)(c_pix[q] + iy * p.cW + ix) * p.cCin + ch0 + c_c8[q])
-                       : reinterpret_cast<const bf16_t*>(g_zero_chunk) + c_c8[q];
-            } else {
+            if constexpr (A_MODE == UC_A_DENSE) {
                 g = src[q] + k0;
+            } else {
+                const bool is_a = (wave * PER + q) * 8 < BM_;   // wave-uniform: an instruction is all-A or all-W
+                if (is_a) {
+                    const int rr = (wave * PER + q) * 8 + (lane >> 3);
+                    const int c8 = ((lane & 7) ^ ((rr >> 1) & 7)) * 8;
+                    const int iy = (st0[q] & 0xffff) - 1 + ky, ix = (st0[q] >> 16) - 1 + kx;
+                    const bool ok = iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+                    g = ok ? p.A + ((int64_t)(st1[q] + iy * p.cW + ix) * p.cCin + ch0 + c8)
+                           : reinterpret_cast<const bf16_t*>(g_zero_chunk) + c8;
+                } else {
+                    g = p.W + st0[q] + k0;
+                }
             }
             dma16_to_lds(g, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE_BYTES + wave * (PER * 1024) + q * 1024)));
         }
     };
 
     // ---- fragment addressing (identity row maps: conflict-free under the (row>>1)&7 chunk swizzle) ----
+    // Row r of fragment i is wr*WTM + 16 i + frow (A) / BM + wc*64 + 16 j + frow (W): the swizzle key (r>>1)&7 only depends
+    // on frow (all other terms are multiples of 16), and the row offsets are one base + compile-time multiples of 2 KiB —
+    // two base registers and two swizzled chunk offsets (one per 32-wide K half) address all 8..12 fragment reads.
     const int frow = lane & 15;
     const int fk = lane >> 4;
-    int a_off[FA], a_sw[FA], w_off[4], w_sw[4];
-#pragma unroll
-    for (int i = 0; i < FA; ++i) {
-        const int row = wr * WTM + 16 * i + frow;
-        a_off[i] = row * 128; a_sw[i] = (row >> 1) & 7;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = BM_ + wc * 64 + 16 * j + frow;
-        w_off[j] = row * 128; w_sw[j] = (row >> 1) & 7;
-    }
+    const int f_sw = (frow >> 1) & 7;
+    const int a_base = (wr * WTM + frow) * 128;
+    const int w_base = (BM_ + wc * 64 + frow) * 128;
+    const int ch_off[2] = {((0 * 4 + fk) ^ f_sw) << 4, ((1 * 4 + fk) ^ f_sw) << 4};
 
     float4_t acc[FA][4];
 #pragma unroll
@@ -418,13 +423,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
         constexpr bool SWAP = decltype(swap_tag)::value;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = ks * 4 + fk;
             bf16x8_t af[FA], wf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_off[j] + ((chunk ^ w_sw[j]) << 4));
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 2048);
 #pragma unroll
             for (int i = 0; i < FA; ++i) {
-                uint4 raw = *reinterpret_cast<const uint4*>(st + a_off[i] + ((chunk ^ a_sw[i]) << 4));
+                uint4 raw = *reinterpret_cast<const uint4*>(st + a_base + ch_off[ks] + i * 2048);
                 if constexpr (A_MODE != UC_A_DENSE) {
                     if (p.relu_a) raw = glds_relu_bf16x8(raw);   // uniform flag: ReLU of the DPT residual conv unit, applied on load
                 }
@@ -466,7 +470,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
             }
         }
     };
-    if (mode == 2) main_loop(std::false_type{}); else main_loop(std::true_type{});
+    if constexpr (A_MODE == UC_A_DENSE) {
+        if (mode == 2) main_loop(std::false_type{}); else main_loop(std::true_type{});
+    } else {
+        main_loop(std::true_type{});
+    }
 
     glds_epilogue<FA>(p, acc, mode, wave_m, wave_n, lane, ksplit);
 }
@@ -496,10 +504,7 @@ static void launch_variant(const GldsParams& p, hipStream_t st) {
 int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
     switch (variant) {
         case 1: launch_variant<256, 128, 4, 2, 2>(p, st); break;
-        case 2:
-            if (p.a_mode == UC_A_CONV3X3) launch_variant<256, 128, 4, 2, 2>(p, st);   // the 16-wave tile has no registers for the gather
-            else launch_variant_mode<256, 256, 4, 4, 2, UC_A_DENSE>(p, st);
-            break;
+        case 2: launch_variant<256, 256, 4, 4, 2>(p, st); break;
         case 3: launch_variant<256, 128, 4, 2, 3>(p, st); break;
         case 4: if (p.a_mode == UC_A_DENSE) launch_variant_mode<256, 256, 2, 4, 2, UC_A_DENSE>(p, st); else launch_variant<256, 128, 4, 2, 2>(p, st); break;
         default: launch_variant<128, 128, 2, 2, 2>(p, st); break;
