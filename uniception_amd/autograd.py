@@ -15,7 +15,6 @@ sub-layer's backward is one Function calling uc_hip entry points:
 Precision follows the forward: bf16 operands with fp32 accumulation, fp32 residual stream, fp32 weight gradients; in
 fp32 verification mode every kernel is the exact-fp32 variant.
 """
-import math
 from typing import Optional
 
 import torch

@@ -15,7 +15,7 @@ Precision: fp32 ("verification mode", exact-fp32 kernels) unless CUDA autocast i
 import contextlib
 import os
 import weakref
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn

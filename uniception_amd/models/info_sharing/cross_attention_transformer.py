@@ -6,7 +6,7 @@ returns) enter without a copy, BCHW outputs are channels-last views of the token
 """
 from copy import deepcopy
 from functools import partial
-from typing import Callable, List, Optional, Tuple, Type, Union
+from typing import Callable, List, Optional, Type, Union
 
 import torch
 import torch.nn as nn

@@ -3,10 +3,9 @@
 Public modules keep the reference's parameters/state_dict keys.  `forward` accepts BCHW-shaped tensors like the
 reference; the fused head pipeline calls the `_nhwc` methods directly and never leaves channel-last layout.
 """
-import torch
 import torch.nn as nn
 
-from .... import engine, ops
+from .... import engine
 
 
 def pair(t):

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ... import autograd, engine, ops
-from .base import AdaptorInput, RegressionAdaptorOutput, RegressionWithConfidenceAdaptorOutput, UniCeptionAdaptorBase
+from .base import AdaptorInput, RegressionWithConfidenceAdaptorOutput, UniCeptionAdaptorBase
 
 
 def _as_f32_map(x):

@@ -11,7 +11,7 @@ asynchronously IN PLACE — no staging copies.  xGMI rings are per-link bound, s
 collectives for the whole model) rather than the 25 MiB NVSwitch-era default.  `step()` waits for the handles and applies
 uc_adamw with grad_scale = 1/world_size (the mean) on the two contiguous ranges.
 """
-from typing import Iterable, List, Optional
+from typing import List
 
 import torch
 import torch.distributed as dist
