@@ -101,3 +101,35 @@ def test_frozen_encoder_and_no_grad_still_run(gpu):
     k = "info_sharing.multi_view_branches.0.0.mlp.fc1.weight"
     g = dict(model.named_parameters())[k].grad.float().cpu()
     assert rel_l2(g.flatten()[sample_indices(g.numel(), 512)], gold[k + "__samples"]) < 1e-3
+
+
+def test_three_view_decoder_backward_matches_oracle_autograd(gpu):
+    """num_views = 3 (K/V = concatenation of the other views, cross_attention_transformer.py:246-256) with an Identity
+    proj_embed: gradients w.r.t. the input feature maps and the parameters vs autograd over the oracle."""
+    from oracle import dust3r_oracle as O
+    from uniception_amd import engine
+    from uniception_amd.models.info_sharing.base import MultiViewTransformerInput
+    from uniception_amd.models.info_sharing.cross_attention_transformer import MultiViewCrossAttentionTransformer
+    from uniception_amd.models.libs.croco.pos_embed import RoPE2D
+
+    m = MultiViewCrossAttentionTransformer(name="mv3", input_embed_dim=128, num_views=3, depth=2, dim=128, num_heads=2,
+                                           custom_positional_encoding=RoPE2D(freq=100.0)).train()
+    O.fill_state_dict_(m.state_dict())
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    feats = [torch.randn(2, 128, 3, 4, generator=g) for _ in range(3)]
+    wts = [torch.randn(2, 128, 3, 4, generator=g) for _ in range(3)]
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    final, _ = O.cross_attention_transformer(fr, sd, "", depth=2, num_heads=2)
+    sum((o * w).sum() for o, w in zip(final, wts)).backward()
+
+    m = m.to(gpu)
+    fg = [f.to(gpu).requires_grad_(True) for f in feats]
+    with engine.precision("fp32"):
+        out = m(MultiViewTransformerInput(features=fg))
+    sum((o * w.to(gpu)).sum() for o, w in zip(out.features, wts)).backward()
+    for a, b in zip(fg, fr):
+        assert rel_l2(a.grad.cpu(), b.grad) < 1e-3
+    worst = max(rel_l2(p.grad.cpu(), sd[k].grad) for k, p in m.named_parameters())
+    print(f"\n[3-view decoder grads] worst parameter rel-L2 {worst:.2e}")
+    assert worst < 1e-3
