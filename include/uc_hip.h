@@ -290,16 +290,17 @@ int uc_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
              float weight_decay, int step, float grad_scale, uc_stream_t stream);
 
 /* Attention backward (forward: uc_attention_fwd, which must have been called with a non-NULL lse).
- *   inputs : Q,K,V,O,dO as [B,N,H,64] strided views (bf16), LSE fp32 [B,H,Nq] (natural log of the softmax denominator of
- *            the scaled scores), plus the packed transposes (layout of uc_vt_pack) QT, dOT [B,H,64,Nq_pad] and KT [B,H,64,Nk_pad];
- *   outputs: dQ [B,Nq,H,64], dK, dV [B,Nk,H,64] bf16 (strided like the inputs).
- *   delta fp32 [B,H,Nq] is scratch for rowsum(dO*O). */
+ *   inputs : Q,K,V,O,dO as [B,N,H,64] strided views (bf16; dO addressed with O's strides), LSE fp32 [B,H,Nq] (natural log of
+ *            the softmax denominator of the scaled scores);
+ *   outputs: dQ [B,Nq,H,64], dK, dV [B,Nk,H,64] bf16 (own strides, e.g. slices of one fused dqkv buffer).
+ *   delta fp32 [B,H,Nq] is scratch for rowsum(dO*O).  All operands are row-major: the transposed MFMA operands are formed
+ *   inside the kernels with LDS transpose-reads. */
 int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-                     const void* QT, const void* dOT, const void* KT, void* dQ, void* dK, void* dV, float* delta, int B,
-                     int H, int Nq, int Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
-                     int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
-                     int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
-                     int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream);
+                     void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb, int64_t q_sn,
+                     int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                     int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb,
+                     int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
+                     uc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * DPT head backward helpers (forward ops: uc_bilinear_nhwc, uc_convt_scatter, uc_gemm conv mode, uc_conv1x1_to4).

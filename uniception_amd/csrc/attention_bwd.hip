@@ -3,26 +3,33 @@
 //   S = scale Q K^T,  P = exp(S - LSE),  dV = P^T dO,  dP = dO V^T,  D = rowsum(dO * O),
 //   dS = P * (dP - D),  dQ = scale dS K,  dK = scale dS^T Q.
 //
-// Two kernels, no atomics:
-//  * attn_bwd_dq_kernel  — a workgroup owns 128 queries (4 waves x 32) and streams KV tiles.  Swapped products keep a
-//    query in one lane pair: S^T = K Q^T, dP^T = V dO^T (A operands = K / V rows from LDS, B operands = Q^T / dO^T in
-//    registers); dS^T in accumulator layout is the B operand of  dQ^T += K^T dS^T  with K^T read from the packed "KT" tile.
-//  * attn_bwd_dkv_kernel — a workgroup owns 128 keys and streams Q tiles.  Un-swapped products keep a KEY in one lane
-//    pair: S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS, B = K^T / V^T in registers); P and dS in accumulator layout
-//    are the B operands of  dV^T += dO^T P  and  dK^T += Q^T dS  with dO^T / Q^T read from the packed "dOT"/"QT" tiles.
-// The packed-transposed tensors use the VT layout of the forward (uc_hip.h): inside each group of 16 positions the index
-// is permuted so that the accumulator register order IS the MFMA k-slot order.
-// LDS tiles are 64 rows x 128 B with the (row>>1)&7 chunk swizzle (conflict-free ds_read_b128), single-buffered.
+// Two kernels, no atomics, every operand read from ROW-MAJOR tiles:
+//  * attn_bwd_dq_kernel  — a workgroup owns 128 queries (4 waves x 32) and streams 64-key K/V tiles.  Swapped products
+//    keep a query in one lane pair: S^T = K Q^T, dP^T = V dO^T (A operands = K / V rows via ds_read_b128, B operands =
+//    Q^T / dO^T in registers); dS^T in accumulator layout is the B operand of  dQ^T += K^T dS^T.
+//  * attn_bwd_dkv_kernel — a workgroup owns 128 keys and streams 64-query Q/dO tiles.  Un-swapped products keep a KEY in
+//    one lane pair: S = Q K^T, dP = dO V^T; P and dS in accumulator layout are the B operands of  dV^T += dO^T P  and
+//    dK^T += Q^T dS.
+// The transposed A operands (K^T, Q^T, dO^T: 8 consecutive keys/queries of one channel per lane) come out of the SAME
+// row-major LDS tiles through gfx950's transposing LDS read (ds_read_b64_tr_b16): a 16-lane group hands in the addresses of
+// four rows and receives, per lane, one column of that 4x16 block.  The rows need not be adjacent, so they are picked to
+// match the accumulator register order of P / dS ((r&3) + 8*(r>>2) + 4*hi): rows base..base+3 and base+8..base+11 —
+// no packed transposes, no permutation pass.
+// LDS tiles are 64 rows x 128 B with the (row>>1)&7 chunk swizzle (conflict-free ds_read_b128; the transposing reads see
+// 2-way conflicts between rows r and r+2, which the MFMA/VALU work hides), single-buffered, 2-3 workgroups per CU.
 #include "common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* ab_lds_ptr_t;
+typedef __attribute__((address_space(3))) bf16x4_t* ab_lds_v4_t;
 
 struct AttnBwdParams {
-    const bf16_t *Q, *K, *V, *O, *dO, *QT, *dOT, *KT;
+    const bf16_t *Q, *K, *V, *O, *dO;
     const float* LSE;
     float* delta;
     bf16_t *dQ, *dK, *dV;
-    int B, H, Nq, Nk, nq_pad, nk_pad;
+    int B, H, Nq, Nk;
     int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
     int64_t dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh;
     float scale;
@@ -32,21 +39,20 @@ struct AttnBwdParams {
 
 __device__ __forceinline__ int bswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ int key_of_pos16(int pp) {  // inverse of uc_vt_perm inside a 16-group
-    const int hi = pp >> 3, j = pp & 7;
-    return (j & 3) + 8 * (j >> 2) + 4 * hi;
-}
-
-// zero the packed-transposed positions whose source index is >= n_valid (tail tile), chunk = 8 positions starting at p0
-__device__ __forceinline__ uint4 mask_packed_chunk(uint4 v, int p0_in_tile, int tile0, int n_valid) {
-    const int gbase = tile0 + (p0_in_tile & ~15);
-    const int pbase = p0_in_tile & 15;
-    unsigned m[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (gbase + key_of_pos16(pbase + j) >= n_valid) m[j >> 1] &= (j & 1) ? 0x0000ffffu : 0xffff0000u;
-    v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
-    return v;
+// Transposed MFMA A operand out of a row-major [64 rows][64 channels] swizzled tile: for the 32-channel block `cb` the lane
+// (channel = 32 cb + (lane & 31), k half = lane >> 5) receives rows  slab16*16 + 4*(lane>>5) + {0,1,2,3, 8,9,10,11}.
+__device__ __forceinline__ bf16x8_t tr_operand(const char* tile, int slab16, int cb, int lane) {
+    const int jj = lane & 15;
+    const int d0 = cb * 32 + (((lane >> 4) & 1) << 4);            // first channel of this 16-lane group's block
+    const int piece = jj & 3;
+    const int chunk = (d0 >> 3) + (piece >> 1);
+    const int row0 = slab16 * 16 + 4 * (lane >> 5) + (jj >> 2);
+    const int row1 = row0 + 8;
+    const char* a0 = tile + row0 * 128 + ((chunk ^ ((row0 >> 1) & 7)) << 4) + ((piece & 1) << 3);
+    const char* a1 = tile + row1 * 128 + ((chunk ^ ((row1 >> 1) & 7)) << 4) + ((piece & 1) << 3);
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ab_lds_v4_t)(ab_lds_ptr_t)a0);
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ab_lds_v4_t)(ab_lds_ptr_t)a1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // delta[b,h,q] = sum_d dO[q,d] * O[q,d]
@@ -79,7 +85,7 @@ __global__ void attn_delta_kernel(AttnBwdParams p) {
 // dQ
 // =================================================================================================================
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * TB];   // K rows | V rows | KT
+    __shared__ __attribute__((aligned(16))) char smem[2 * TB];   // K rows | V rows
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -91,7 +97,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
 
     const bf16_t* Kb = p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
     const bf16_t* Vb = p.V + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
-    const bf16_t* KTb = p.KT + ((int64_t)b * p.H + h) * 64 * (int64_t)p.nk_pad;
 
     bf16x8_t qf[4], dof[4];
     {
@@ -128,9 +133,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
             if (key >= p.Nk) key = p.Nk - 1;
             *reinterpret_cast<uint4*>(smem + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * p.k_sn + cc * 8);
             *reinterpret_cast<uint4*>(smem + TB + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * p.v_sn + cc * 8);
-            uint4 kt = *reinterpret_cast<const uint4*>(KTb + (int64_t)row * p.nk_pad + k0 + cc * 8);
-            if (k0 + 64 > p.Nk) kt = mask_packed_chunk(kt, cc * 8, k0, p.Nk);
-            *reinterpret_cast<uint4*>(smem + 2 * TB + w_off + i * 32 * 128) = kt;
         }
         __syncthreads();
 
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const bf16x8_t ktf = *reinterpret_cast<const bf16x8_t*>(smem + 2 * TB + r_off[g] + db * (32 * 128));
-                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[g], dq[db], 0, 0, 0);
+                // K^T[d-block db, 16-key slab g]: clamped duplicate rows of a tail tile meet dS = 0
+                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(smem, g, db, lane), dsf[g], dq[db], 0, 0, 0);
             }
     }
     if (q_ok) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
 // dK, dV
 // =================================================================================================================
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TB + 512];   // Q rows | dO rows | QT | dOT | lse2[64] delta[64]
+    __shared__ __attribute__((aligned(16))) char smem[2 * TB + 512];   // Q rows | dO rows | lse2[64] delta[64]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -200,11 +202,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 
     const bf16_t* Qb = p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const bf16_t* dOb = p.dO + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
-    const bf16_t* QTb = p.QT + ((int64_t)b * p.H + h) * 64 * (int64_t)p.nq_pad;
-    const bf16_t* dOTb = p.dOT + ((int64_t)b * p.H + h) * 64 * (int64_t)p.nq_pad;
     const float* lse_b = p.LSE + ((int64_t)b * p.H + h) * p.Nq;
     const float* dl_b = p.delta + ((int64_t)b * p.H + h) * p.Nq;
-    float* s_lse = reinterpret_cast<float*>(smem + 4 * TB);
+    float* s_lse = reinterpret_cast<float*>(smem + 2 * TB);
     float* s_dl = s_lse + 64;
 
     bf16x8_t kf[4], vf[4];   // B operands: lane key = l31, channels 16s + 8hi .. +7
@@ -239,14 +239,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
             if (q >= p.Nq) q = p.Nq - 1;
             *reinterpret_cast<uint4*>(smem + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Qb + (int64_t)q * p.q_sn + cc * 8);
             *reinterpret_cast<uint4*>(smem + TB + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(dOb + (int64_t)q * p.o_sn + cc * 8);
-            uint4 qt = *reinterpret_cast<const uint4*>(QTb + (int64_t)row * p.nq_pad + q0 + cc * 8);
-            uint4 dt = *reinterpret_cast<const uint4*>(dOTb + (int64_t)row * p.nq_pad + q0 + cc * 8);
-            if (q0 + 64 > p.Nq) {
-                qt = mask_packed_chunk(qt, cc * 8, q0, p.Nq);
-                dt = mask_packed_chunk(dt, cc * 8, q0, p.Nq);
-            }
-            *reinterpret_cast<uint4*>(smem + 2 * TB + w_off + i * 32 * 128) = qt;
-            *reinterpret_cast<uint4*>(smem + 3 * TB + w_off + i * 32 * 128) = dt;
         }
         if (tid < 64) {
             const int q = q0 + tid;
@@ -291,10 +283,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int g = qb * 2 + hf;   // 16-query slab inside the tile -> chunks 2g, 2g+1
-                    const bf16x8_t dota = *reinterpret_cast<const bf16x8_t*>(smem + 3 * TB + r_off[g] + db * (32 * 128));
-                    const bf16x8_t qta = *reinterpret_cast<const bf16x8_t*>(smem + 2 * TB + r_off[g] + db * (32 * 128));
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dota, pfr[hf], dv[db], 0, 0, 0);   // dV^T[d, key]
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsfr[hf], dk[db], 0, 0, 0);   // dK^T[d, key]
+                    // queries beyond Nq are clamped duplicates in the tiles; their P / dS columns are exactly 0
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(smem + TB, g, db, lane), pfr[hf], dv[db], 0, 0, 0);   // dV^T[d, key]
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(smem, g, db, lane), dsfr[hf], dk[db], 0, 0, 0);       // dK^T[d, key]
                 }
         }
     }
@@ -318,12 +309,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 }
 
 extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-                                const void* QT, const void* dOT, const void* KT, void* dQ, void* dK, void* dV, float* delta,
-                                int B, int H, int Nq, int Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb,
-                                int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
-                                int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn,
-                                int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream) {
-    UC_REQUIRE(Q && K && V && O && dO && LSE && QT && dOT && KT && dQ && dK && dV && delta, "uc_attention_bwd: null pointer");
+                                void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb,
+                                int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
+                                int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh,
+                                int64_t dk_sb, int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
+                                uc_stream_t stream) {
+    UC_REQUIRE(Q && K && V && O && dO && LSE && dQ && dK && dV && delta, "uc_attention_bwd: null pointer");
     UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B <= 65535 && H <= 65535, "uc_attention_bwd: bad shape");
     UC_REQUIRE(q_sn % 8 == 0 && k_sn % 8 == 0 && v_sn % 8 == 0 && o_sn % 8 == 0 && q_sh % 8 == 0 && k_sh % 8 == 0 && v_sh % 8 == 0 &&
                    o_sh % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0,
@@ -333,9 +324,9 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
                "uc_attention_bwd: output strides must be multiples of 4 elements");
     AttnBwdParams p;
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (const bf16_t*)O; p.dO = (const bf16_t*)dO;
-    p.QT = (const bf16_t*)QT; p.dOT = (const bf16_t*)dOT; p.KT = (const bf16_t*)KT; p.LSE = LSE; p.delta = delta;
+    p.LSE = LSE; p.delta = delta;
     p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
-    p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.nq_pad = (Nq + 63) / 64 * 64; p.nk_pad = (Nk + 63) / 64 * 64;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
     p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh; p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh;
     p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh; p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.dk_sb = dk_sb; p.dk_sn = dk_sn;
     p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh; p.scale = scale;

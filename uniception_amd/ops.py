@@ -518,10 +518,9 @@ def attention_bwd(q, k, v, o, do, lse, scale: float, out=None):
             o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1),
             dk.stride(2), dv.stride(0), dv.stride(1), dv.stride(2), float(scale), _stream()), "uc_attention_bwd_f32")
         return dq, dk, dv
-    qt, dot, kt = vt_pack(q), vt_pack(do), vt_pack(k)
     _lib.check(_lib.load().uc_attention_bwd(
-        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), qt.data_ptr(), dot.data_ptr(),
-        kt.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk,
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+        dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk,
         q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
         o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1), dk.stride(2),
         dv.stride(0), dv.stride(1), dv.stride(2), float(scale), _stream()), "uc_attention_bwd")
