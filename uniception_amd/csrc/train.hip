@@ -227,8 +227,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const typename Tag::storage
 extern "C" int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, float* out, uc_stream_t stream) {
     UC_REQUIRE(src && out && M >= 0 && N > 0 && ld >= N, "uc_colsum: bad argument");
     if (M == 0) return UC_OK;
-    const int64_t rows_per_block = 64;   // enough row slabs to fill 256 CUs even for N = 768 (3 column blocks)
-    dim3 grid((unsigned)ceil_div64(N, 256), (unsigned)min((int64_t)65535, ceil_div64(M, rows_per_block)));
+    // row slabs: enough blocks to fill the chip (~2048 in total), never so many that the per-block column atomics
+    // (fp32 atomics sustain only ~75 G/s) outweigh the streaming: 8.4 M rows x 128 columns with 64-row slabs = 8.4 M atomics
+    const unsigned gx = (unsigned)ceil_div64(N, 256);
+    const int64_t max_slabs = max((int64_t)1, (int64_t)2048 / gx);
+    dim3 grid(gx, (unsigned)min(max_slabs, ceil_div64(M, 64)));
     const int64_t rpb = ceil_div64(M, grid.y);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UC_F32) hipLaunchKernelGGL((colsum_kernel<F32Tag>), grid, dim3(256), 0, st, (const float*)src, M, N, ld, out, rpb);
