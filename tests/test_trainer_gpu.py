@@ -55,3 +55,56 @@ def test_trainer_steps_match_torch_adamw(gpu, mode):
     for n, p in model.named_parameters():
         off, k = tr.flat.offsets[n]
         assert p.data_ptr() == tr.flat.param.data_ptr() + 4 * off and p.grad.data_ptr() == tr.flat.grad.data_ptr() + 4 * off
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# two ranks (gloo transport, both on cuda:0 — RCCL refuses two ranks on one device) running the REAL training step:
+# sharded pairs, hook-launched bucket all-reduce on GPU gradients, uc_adamw — against one process on the full batch
+# ---------------------------------------------------------------------------------------------------------------
+def _ddp_worker(rank, world, port, out_path):
+    import os
+    import torch.distributed as dist
+    from uniception_amd.training import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        model, c = build_case_model("tiny_linear")
+        model = model.to(dev).train()
+        imgs = [t[rank:rank + 1].to(dev) for t in case_images(c)]          # this rank's pair
+        gts = [t[rank:rank + 1].to(dev) for t in grad_targets(c)]
+        tr = Trainer(model, lr=2e-3, weight_decay=0.05, bucket_bytes=1 << 20)   # several buckets
+        tr.broadcast_parameters(0)
+        assert len(tr.buckets.buckets) > 1
+        for _ in range(2):
+            tr.zero_grad()
+            _loss(model, imgs, gts, "fp32").backward()
+            tr.step()
+        if rank == 0:
+            torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_equals_single_process_full_batch(gpu, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    from uniception_amd.training import Trainer
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out_path = str(tmp_path / "rank0.pt")
+    mp.spawn(_ddp_worker, args=(2, port, out_path), nprocs=2, join=True)
+    two_rank = torch.load(out_path)
+
+    model, c = build_case_model("tiny_linear")
+    model = model.to(gpu).train()
+    imgs = [t.to(gpu) for t in case_images(c)]
+    gts = [t.to(gpu) for t in grad_targets(c)]
+    tr = Trainer(model, lr=2e-3, weight_decay=0.05)
+    for _ in range(2):
+        tr.zero_grad()
+        _loss(model, imgs, gts, "fp32").backward()
+        tr.step()
+    worst = max(rel_l2(two_rank[k], v.detach().cpu()) for k, v in model.state_dict().items())
+    print(f"\n[2-rank vs 1-process] worst parameter deviation after 2 steps {worst:.2e}")
+    assert worst < 1e-5
