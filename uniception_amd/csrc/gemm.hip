@@ -483,7 +483,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         static int forced_variant = -2;
         if (forced_variant == -2) {
             const char* e = getenv("UC_GEMM_VARIANT");
-            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..2: glds tile variants
+            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..2: glds tile variants (others: 128x128)
         }
         if (d->split_k > 1) {
             UC_REQUIRE(d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a, "uc_gemm: split_k needs a dense operand with K %% 64 == 0");

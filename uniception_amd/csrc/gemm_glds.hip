@@ -499,14 +499,11 @@ static void launch_variant(const GldsParams& p, hipStream_t st) {
     else launch_variant_mode<BM_, BN_, WM_, WN_, STAGES, UC_A_DENSE>(p, st);
 }
 
-// variant: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2 of 64x64), 2 = 256x256 (4x4 of 64x64),
-//          3 = 256x128 3-stage ring
+// variant: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2 of 64x64), 2 = 256x256 (4x4 of 64x64)
 int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
     switch (variant) {
         case 1: launch_variant<256, 128, 4, 2, 2>(p, st); break;
         case 2: launch_variant<256, 256, 4, 4, 2>(p, st); break;
-        case 3: launch_variant<256, 128, 4, 2, 3>(p, st); break;
-        case 4: if (p.a_mode == UC_A_DENSE) launch_variant_mode<256, 256, 2, 4, 2, UC_A_DENSE>(p, st); else launch_variant<256, 128, 4, 2, 2>(p, st); break;
         default: launch_variant<128, 128, 2, 2, 2>(p, st); break;
     }
     return 0;
