@@ -148,6 +148,17 @@ int uc_attention_fwd(const void* Q, const void* K, const void* V, void* O, int d
                      float* lse /* optional fp32 [B,H,Nq]: log-sum-exp of the scaled scores, saved for the backward */,
                      uc_stream_t stream);
 
+/* FP8 attention forward (BASELINE config 5): same contract as uc_attention_fwd with UC_BF16 operands and D == 64, but both
+ * products run on the K=64 block-scaled e4m3 MFMA (unit scales).  Q, K: bf16 strided views (converted to e4m3 inside the
+ * kernel); VT8: V transposed per head in e4m3, [B,H,64,Npad] bytes, Npad = roundup(Nk,64), keys permuted inside every group
+ * of 64 so that position 32*hh + 16*kb + r holds key 32*kb + (r&3) + 8*(r>>2) + 4*hh, zero padded — produced by
+ * uc_vt_pack_fp8 from a row-major bf16 V.  O: bf16.  Inference only (no LSE). */
+int uc_attention_fwd_fp8(const void* Q, const void* K, const void* VT8, void* O, int B, int H, int Nq, int Nk, int64_t q_sb,
+                         int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t o_sb, int64_t o_sn,
+                         int64_t o_sh, float scale, uc_stream_t stream);
+int uc_vt_pack_fp8(const void* V, void* VT8, int B, int H, int Nk, int D, int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                   uc_stream_t stream);
+
 /* Row-major bf16 V[b*v_sb + n*v_sn + h*v_sh + d] -> packed VT [B,H,D,Npad] (layout above). */
 int uc_vt_pack(const void* V, void* VT, int B, int H, int Nk, int D, int64_t v_sb, int64_t v_sn,
                int64_t v_sh, uc_stream_t stream);

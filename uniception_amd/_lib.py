@@ -44,6 +44,8 @@ SIGNATURES = {
     "uc_layernorm": [vp, i32, vp, vp, vp, i32, i64, i32, f32, vp],
     "uc_gemm": [C.POINTER(GemmDesc), vp],
     "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
+    "uc_attention_fwd_fp8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [f32, vp],
+    "uc_vt_pack_fp8": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
     "uc_vt_pack": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
     "uc_patch_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_nchw_to_nhwc": [vp, i32, vp, i32, i32, i32, i32, i32, vp],

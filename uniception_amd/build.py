@@ -11,7 +11,7 @@ import hashlib
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libuc_hip.so")
-SOURCES = ["error.hip", "rope_norm.hip", "gemm.hip", "gemm_glds.hip", "gemm_tn.hip", "attention.hip", "attention_bwd.hip", "elementwise.hip", "train.hip", "dpt_bwd.hip"]
+SOURCES = ["error.hip", "rope_norm.hip", "gemm.hip", "gemm_glds.hip", "gemm_tn.hip", "attention.hip", "attention_fp8.hip", "attention_bwd.hip", "elementwise.hip", "train.hip", "dpt_bwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 

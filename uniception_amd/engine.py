@@ -49,6 +49,27 @@ def set_head_precision(mode: str) -> None:
     _head_mode = mode
 
 
+_attn_mode: str = os.environ.get("UNICEPTION_AMD_ATTENTION", "bf16")   # "bf16" | "fp8": matrix format of the bf16 path's attention
+
+
+@contextlib.contextmanager
+def attention_precision(name: str):
+    """"fp8": softmax(QK^T)V of the bf16 compute path runs on the e4m3 K=64 MFMA kernel (BASELINE config 5; inference only,
+    head_dim 64, ~5e-2 relative error on the attention output — the format's precision); "bf16": default."""
+    global _attn_mode
+    assert name in ("bf16", "fp8")
+    prev = _attn_mode
+    _attn_mode = name
+    try:
+        yield
+    finally:
+        _attn_mode = prev
+
+
+def _fp8_attention() -> bool:
+    return _attn_mode == "fp8" and not torch.is_grad_enabled()
+
+
 def compute_dtype() -> torch.dtype:
     if _forced_dtype is not None:
         return _forced_dtype
@@ -225,7 +246,11 @@ def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.L
     wq, bq = lin_weights(qkv, dtype)
     wp, bp = proj_wb if proj_wb is not None else lin_weights(proj, dtype)
     native = rope is None or is_native_rope(rope)
-    if dtype == torch.bfloat16 and Dh == 64 and native:
+    if dtype == torch.bfloat16 and Dh == 64 and native and _fp8_attention():
+        ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
+        t5 = ops.gemm(h2d, wq, bq, rope=ep).view(B, N, 3, num_heads, Dh)
+        o = ops.attention_fp8(t5[:, :, 0], t5[:, :, 1], ops.vt_pack_fp8(t5[:, :, 2]), scale)
+    elif dtype == torch.bfloat16 and Dh == 64 and native:
         vt = ops.vt_buffer(B, num_heads, N, h2d.device)
         ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
         qk = ops.gemm(h2d, wq, bq, rope=ep, vt=(2 * Cd, vt, N))
@@ -274,7 +299,13 @@ def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk
     wkv, bkv = kv_weights(projk, projv, dtype)
     wp, bp = lin_weights(proj, dtype)
     native = rope is None or is_native_rope(rope)
-    if dtype == torch.bfloat16 and Dh == 64 and native:
+    if dtype == torch.bfloat16 and Dh == 64 and native and _fp8_attention():
+        epq = _rope_epilogue(rope, _pos2d(qpos), Cd) if rope is not None else None
+        epk = _rope_epilogue(rope, _pos2d(kpos), Cd) if rope is not None else None
+        q = ops.gemm(hq2d, wq, bq, rope=epq).view(B, Nq, num_heads, Dh)
+        kv5 = ops.gemm(hkv2d, wkv, bkv, rope=epk).view(B, Nk, 2, num_heads, Dh)
+        o = ops.attention_fp8(q, kv5[:, :, 0], ops.vt_pack_fp8(kv5[:, :, 1]), scale)
+    elif dtype == torch.bfloat16 and Dh == 64 and native:
         vt = ops.vt_buffer(B, num_heads, Nk, hq2d.device)
         epq = _rope_epilogue(rope, _pos2d(qpos), Cd) if rope is not None else None
         epk = _rope_epilogue(rope, _pos2d(kpos), Cd) if rope is not None else None

@@ -192,6 +192,33 @@ def vt_pack(v: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def vt_pack_fp8(v: torch.Tensor) -> torch.Tensor:
+    """v: [B,N,H,64] bf16 view -> e4m3 V^T [B,H,64,Npad] (uint8) in the k-slot order of the fp8 attention kernel."""
+    _need_gpu(v)
+    B, N, H, D = v.shape
+    assert v.dtype == torch.bfloat16 and v.stride(3) == 1 and D == 64
+    npad = (N + 63) // 64 * 64
+    out = torch.empty((B, H, D, npad), dtype=torch.uint8, device=v.device)
+    _lib.check(_lib.load().uc_vt_pack_fp8(v.data_ptr(), out.data_ptr(), B, H, N, D, v.stride(0), v.stride(1), v.stride(2),
+                                          _stream()), "uc_vt_pack_fp8")
+    return out
+
+
+def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt8: torch.Tensor, scale: float) -> torch.Tensor:
+    """q [B,Nq,H,64], k [B,Nk,H,64] bf16 views; vt8 from vt_pack_fp8.  Returns O [B,Nq,H,64] bf16."""
+    _need_gpu(q, k, vt8)
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    assert q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and D == 64 and q.stride(3) == 1 and k.stride(3) == 1
+    assert vt8.dtype == torch.uint8 and vt8.is_contiguous() and vt8.shape == (B, H, 64, (Nk + 63) // 64 * 64)
+    out = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
+    _lib.check(_lib.load().uc_attention_fwd_fp8(
+        q.data_ptr(), k.data_ptr(), vt8.data_ptr(), out.data_ptr(), B, H, Nq, Nk, q.stride(0), q.stride(1), q.stride(2),
+        k.stride(0), k.stride(1), k.stride(2), out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()),
+        "uc_attention_fwd_fp8")
+    return out
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, v_packed: bool = False,
               out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [B,Nq,H,D], k [B,Nk,H,D] strided views (stride(3)==1); v same, or packed VT [B,H,D,Npad] when v_packed.
