@@ -255,9 +255,12 @@ int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_
  *   conv_B > 0: B is the IMPLICIT im2col of the NHWC image [conv_B,conv_H,conv_W,conv_Cin] of a 3x3 / pad-1 conv with the
  *   given stride: B[t,(ky*3+kx)*Cin+c] = act(x[b,oy*s-1+ky,ox*s-1+kx,c]), t=(b,oy,ox), J = 9*Cin, relu_b = ReLU-on-load.
  *   C holds split_k slabs of [I,J] fp32 (sum them with uc_splitk_reduce).  I, J, lda, ldb multiples of 8.
+ *   colsum_a (optional): split_k slabs of [I] fp32 receiving sum_t A[t,i] — the bias gradient, formed from the A fragments
+ *   already in registers (no extra pass over dY).
  *   (the reference gets these products from autograd's addmm / conv backward.) */
 int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t T, int64_t I, int64_t J, int conv_B, int conv_H,
-               int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, int split_k, uc_stream_t stream);
+               int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, float* colsum_a, int split_k,
+               uc_stream_t stream);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_s ws[s*n + i], i < n (n multiple of 4): reduction of uc_gemm's split_k slabs. */
 int uc_splitk_reduce(const float* ws, int split_k, int64_t n, float* out, int accumulate, uc_stream_t stream);

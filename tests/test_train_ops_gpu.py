@@ -313,11 +313,14 @@ def test_gemm_tn_dense(gpu, T, I, J, sk):
     g = torch.Generator().manual_seed(T + I)
     a = torch.randn(T, I, generator=g).bfloat16()
     b = torch.randn(T, J, generator=g).bfloat16()
-    ws = ops.gemm_tn(a.to(gpu), b.to(gpu), split_k=sk)
-    assert ws.shape == (sk, I, J)
+    ws, cs = ops.gemm_tn(a.to(gpu), b.to(gpu), split_k=sk, colsum=True)
+    assert ws.shape == (sk, I, J) and cs.shape == (sk, I)
     c = ops.splitk_reduce(ws)
     ref = a.float().t() @ b.float()
     assert rel_l2(c.cpu(), ref) < 2e-5
+    # fused bias gradient: column sums of the first operand
+    assert rel_l2(cs.sum(0).cpu(), a.float().sum(0)) < 2e-5
+    assert torch.equal(ops.splitk_reduce(ops.gemm_tn(a.to(gpu), b.to(gpu), split_k=sk)), c)
 
 
 def test_gemm_tn_strided_operands(gpu):
@@ -344,9 +347,10 @@ def test_gemm_tn_conv_weight_gradient(gpu, stride, relu, B, H, W, Cin, Cout, sk)
     wref = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
     xa = x.float().relu() if relu else x.float()
     F.conv2d(xa.permute(0, 3, 1, 2), wref, stride=stride, padding=1).backward(dy.float().permute(0, 3, 1, 2))
-    ws = ops.gemm_tn(dy.view(-1, Cout).to(gpu), x.to(gpu), split_k=sk, conv=(stride, relu))
+    ws, cs = ops.gemm_tn(dy.view(-1, Cout).to(gpu), x.to(gpu), split_k=sk, conv=(stride, relu), colsum=True)
     dW = ops.splitk_reduce(ws).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
     assert rel_l2(dW.cpu(), wref.grad) < 2e-5
+    assert rel_l2(cs.sum(0).cpu(), dy.float().sum((0, 1, 2))) < 2e-5
 
 
 @pytest.mark.parametrize("act", ["gelu", "relu"])

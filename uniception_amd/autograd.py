@@ -8,7 +8,7 @@ sub-layer's backward is one Function calling uc_hip entry points:
         dx = LN_bwd(x, gamma, df/dh) + d(x_out)              (residual add fused into uc_layernorm_bwd)
     linear y = h W^T + b:
         dW = dy^T h   -> uc_transpose2d (both operands, K padded to 64) + split-K uc_gemm with fp32 atomics
-        db = uc_colsum(dy),   dh = uc_gemm(dy, W^T)          (W^T prepared once per weight version)
+        db = column sums of dy formed inside uc_gemm_tn; dh = uc_gemm(dy, W^T)   (W^T prepared once per weight version)
     attention: uc_attention_fwd saves LSE; uc_attention_bwd recomputes P tile by tile (dQ kernel + dK/dV kernel)
     RoPE: gradients of the rotated q/k are rotated back in place with the inverse angle (curope2d.py:24-28)
 
@@ -49,27 +49,40 @@ def _tn_ok(*ts) -> bool:
                and (t.dim() != 2 or t.stride(0) % 8 == 0) for t in ts)
 
 
-def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
-    """dW [N,K] fp32 = dy^T x for row-major dy [M,N], x [M,K] (any float dtype; operands are taken in dt).
-    bf16: the TN kernel contracts over the slow axis directly (uc_gemm_tn, split-K slabs + uc_splitk_reduce);
-    fp32 verification mode: explicit transposes + the exact fp32 GEMM."""
+def _reduce_slabs(ws: torch.Tensor) -> torch.Tensor:
+    return ws[0] if ws.shape[0] == 1 else ops.splitk_reduce(ws)
+
+
+def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype, bias: bool = False):
+    """(dW [N,K] fp32, db [N] fp32 | None) = (dy^T x, column sums of dy) for row-major dy [M,N], x [M,K].
+    bf16: the TN kernel contracts over the slow axis directly (uc_gemm_tn: split-K slabs + uc_splitk_reduce) and forms the
+    bias gradient from the dy fragments it already holds; fp32 verification mode: explicit transposes + the exact fp32
+    GEMM + uc_colsum."""
     if dt == torch.bfloat16:
         a = dy2d if dy2d.dtype == dt else ops.convert(_c(dy2d), dt)
         b = x2d if x2d.dtype == dt else ops.convert(_c(x2d), dt)
         if _tn_ok(a, b):
-            ws = ops.gemm_tn(a, b, split_k=_split_k(a.shape[1], b.shape[1], a.shape[0]))
-            return ws[0] if ws.shape[0] == 1 else ops.splitk_reduce(ws)
-    return ops.gemm(_tp(_c(dy2d), dt), _tp(_c(x2d), dt), out_dtype=torch.float32)
+            sk = _split_k(a.shape[1], b.shape[1], a.shape[0])
+            if bias:
+                ws, cs = ops.gemm_tn(a, b, split_k=sk, colsum=True)
+                return _reduce_slabs(ws), _reduce_slabs(cs.unsqueeze(1)).reshape(-1)
+            return _reduce_slabs(ops.gemm_tn(a, b, split_k=sk)), None
+    dW = ops.gemm(_tp(_c(dy2d), dt), _tp(_c(x2d), dt), out_dtype=torch.float32)
+    return dW, (_colsum(_c(dy2d)) if bias else None)
 
 
-def _wgrad_conv(dz: torch.Tensor, x: torch.Tensor, stride: int, relu_in: bool) -> torch.Tensor:
-    """dW_gemm [Cout, 9*Cin] (K ordered (ky,kx,c)) of a 3x3/pad-1 conv: dz NHWC [B,Ho,Wo,Cout], x NHWC [B,H,W,Cin]."""
+def _wgrad_conv(dz: torch.Tensor, x: torch.Tensor, stride: int, relu_in: bool, bias: bool = False):
+    """(dW_gemm [Cout, 9*Cin] with K ordered (ky,kx,c), db | None) of a 3x3/pad-1 conv: dz NHWC [B,Ho,Wo,Cout], x NHWC."""
     Cout = dz.shape[-1]
     dz2 = dz.view(-1, Cout)
     if x.dtype == torch.bfloat16 and _tn_ok(dz2, x):
-        ws = ops.gemm_tn(dz2, x, split_k=_split_k(Cout, 9 * x.shape[-1], dz2.shape[0]), conv=(stride, relu_in))
-        return ws[0] if ws.shape[0] == 1 else ops.splitk_reduce(ws)
-    return ops.gemm(_tp(dz2, x.dtype), ops.im2col_t(x, stride, relu_in, KPAD), out_dtype=torch.float32)
+        sk = _split_k(Cout, 9 * x.shape[-1], dz2.shape[0])
+        if bias:
+            ws, cs = ops.gemm_tn(dz2, x, split_k=sk, conv=(stride, relu_in), colsum=True)
+            return _reduce_slabs(ws), _reduce_slabs(cs.unsqueeze(1)).reshape(-1)
+        return _reduce_slabs(ops.gemm_tn(dz2, x, split_k=sk, conv=(stride, relu_in))), None
+    dW = ops.gemm(_tp(dz2, x.dtype), ops.im2col_t(x, stride, relu_in, KPAD), out_dtype=torch.float32)
+    return dW, (_colsum(dz2) if bias else None)
 
 
 def _as_dt(g: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
@@ -164,8 +177,8 @@ class LinearFn(Function):
         dy = _c(dy)
         need_dx = ctx.needs_input_grad[0]
         dyb = _as_dt(dy, dt)
-        dW = _wgrad(dyb, xb, dt).view(ctx.wshape)
-        db = _colsum(dy) if ctx.has_bias else None
+        dW, db = _wgrad(dyb, xb, dt, ctx.has_bias)
+        dW = dW.view(ctx.wshape)
         dx = None
         if need_dx:
             wT = _w_t(ctx.owner, "lin2d", (ctx.weight,),
@@ -193,8 +206,8 @@ class PatchEmbedFn(Function):
     def backward(ctx, dtok):
         (cols,) = ctx.saved_tensors
         dtok = _c(dtok)
-        dW = _wgrad(dtok, cols, ctx.dt).view(ctx.wshape)
-        db = _colsum(dtok) if ctx.has_bias else None
+        dW, db = _wgrad(dtok, cols, ctx.dt, ctx.has_bias)
+        dW = dW.view(ctx.wshape)
         return None, dW, db, None, None, None
 
 
@@ -246,8 +259,7 @@ class SelfAttnSubLayerFn(Function):
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dWp = _wgrad(dyb, o.view(M, C), dt)
-        dbp = _colsum(dyb) if has_bp else None
+        dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp)
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dt3 = torch.empty_like(t)
         d5, t5 = dt3.view(B, N, 3, H, Dh), t.view(B, N, 3, H, Dh)
@@ -255,8 +267,7 @@ class SelfAttnSubLayerFn(Function):
                           out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]))
         _rope_inverse_(d5[:, :, 0], pos, rope)
         _rope_inverse_(d5[:, :, 1], pos, rope)
-        dWq = _wgrad(dt3, h, dt)
-        dbq = _colsum(dt3) if has_bq else None
+        dWq, dbq = _wgrad(dt3, h, dt, has_bq)
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)
@@ -318,8 +329,7 @@ class CrossAttnSubLayerFn(Function):
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dWp = _wgrad(dyb, o.view(Mq, C), dt)
-        dbp = _colsum(dyb) if has_bp else None
+        dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp)
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
@@ -329,14 +339,12 @@ class CrossAttnSubLayerFn(Function):
         _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
         _rope_inverse_(dkv5[:, :, 0], kpos, rope)
         # query side
-        dWq = _wgrad(dq, hq, dt)
-        dbq = _colsum(dq) if has_bq else None
+        dWq, dbq = _wgrad(dq, hq, dt, has_bq)
         dhq = ops.gemm(dq, lin_weight_t(projq, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dhq, ln.eps, dg, db, dres=dxo)
         # key/value side (the other view's tokens)
-        dWkv = _wgrad(dkv, hy, dt)
-        dbkv = _colsum(dkv) if (has_bk or has_bv) else None
+        dWkv, dbkv = _wgrad(dkv, hy, dt, has_bk or has_bv)
         dhy = ops.gemm(dkv, kv_weight_t(projk, projv, dt), out_dtype=dt if lny is not None else torch.float32)
         if lny is not None:
             dgy, dby = torch.zeros_like(gy), torch.zeros_like(gy)
@@ -378,16 +386,14 @@ class MlpSubLayerFn(Function):
         ln, fc1, fc2, act, dt, has_b1, has_b2 = ctx.meta
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dW2 = _wgrad(dyb, a, dt)
-        db2 = _colsum(dyb) if has_b2 else None
+        dW2, db2 = _wgrad(dyb, a, dt, has_b2)
         w2t = lin_weight_t(fc2, dt)
         if act != "none" and dt == torch.bfloat16 and w2t.shape[1] % 64 == 0:
             du = ops.gemm(dyb, w2t, dact=(u, act))          # act'(u) applied in the data-gradient GEMM's epilogue
         else:
             da = ops.gemm(dyb, w2t)
             du = ops.act_bwd(da, u, act) if act != "none" else da
-        dW1 = _wgrad(du, h, dt)
-        db1 = _colsum(du) if has_b1 else None
+        dW1, db1 = _wgrad(du, h, dt, has_b1)
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)
@@ -515,9 +521,8 @@ class Conv3x3Fn(Function):
         Cout = dy.shape[-1]
         dz = ops.act_bwd(dy, y, "relu") if act == "relu" else dy
         dz2 = dz.view(-1, Cout)
-        dWg = _wgrad_conv(dz, x, s, relu_in)                                     # [Cout, 9*Cin], K ordered (ky,kx,c)
+        dWg, db = _wgrad_conv(dz, x, s, relu_in, has_b)                          # [Cout, 9*Cin], K ordered (ky,kx,c)
         dW = dWg.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
-        db = _colsum(dz2) if has_b else None
         dx = None
         if ctx.needs_input_grad[0]:
             g = dz if s == 1 else ops.dilate_nhwc(dz, H, W, s)
@@ -562,9 +567,9 @@ class ConvTransposeFn(Function):
         dt = x2.dtype
         Cout = ct.out_channels
         dyg = ops.convt_gather(_c(dy), k)                                        # [B*H*W, k*k*Cout]
-        dWg = _wgrad(dyg, x2, dt)                                                # [k*k*Cout, Cin]
+        dWg, dbg = _wgrad(dyg, x2, dt, has_b)                                    # [k*k*Cout, Cin], [k*k*Cout]
         dW = dWg.view(k, k, Cout, Cin).permute(3, 2, 0, 1)
-        db = _colsum(dyg).view(k * k, Cout).sum(0) if has_b else None
+        db = dbg.view(k * k, Cout).sum(0) if has_b else None
         dx = None
         if ctx.needs_input_grad[0]:
             wT = _w_t(ct, "ct", (ct.weight,),

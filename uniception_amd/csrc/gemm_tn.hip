@@ -16,6 +16,7 @@
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* tn_lds_ptr_t;
 
 struct TnParams {
@@ -27,6 +28,7 @@ struct TnParams {
     int conv;            // 0 dense, 1 implicit im2col of a 3x3 / pad 1 conv
     int cB, cH, cW, cCin, cStride, cHo, cWo, relu_b;
     float* C;            // [split_k][I, J]
+    float* colsum;       // optional [split_k][I]: sum_t A[t,i] (the bias gradient), written by the tj == 0 tiles
     int split_k;
     int tiles_i, tiles_j;
 };
@@ -156,6 +158,12 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
+    // fused bias gradient: the waves of the first column tile that own A rows (wc == 0) also add up their A fragments
+    // (v_dot2 against ones: 4 per fragment) — sum_t A[t,i] costs no extra pass over dY
+    const bool do_colsum = p.colsum != nullptr && tj == 0 && wc == 0;   // wave-uniform
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+
     if (nk > 0) issue_stage(0, tbase);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -168,6 +176,15 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
             bf16x8_t af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = frag(st, a_off[i], ks, false);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    csum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(af[i], af[i], 0, 1), ones2, csum[i], false);
+                    csum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(af[i], af[i], 2, 3), ones2, csum[i], false);
+                    csum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(af[i], af[i], 4, 5), ones2, csum[i], false);
+                    csum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(af[i], af[i], 6, 7), ones2, csum[i], false);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = frag(st, b_off[j], ks, CONV && p.relu_b != 0);
             // swapped operands: D[row = j][col = i] -> a lane owns 4 consecutive j of one i (16-byte stores)
@@ -175,6 +192,17 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (do_colsum) {   // lanes fq, fq+16, fq+32, fq+48 hold the four k-groups of column i: fold them, lane group 0 stores
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = csum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int64_t ii = i0 + wr * 64 + 16 * i + fq;
+            if (fg == 0 && ii < p.I) p.colsum[(int64_t)ksplit * p.I + ii] = v;
         }
     }
 
@@ -200,8 +228,8 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
 }
 
 extern "C" int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t T, int64_t I, int64_t J, int conv_B,
-                          int conv_H, int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, int split_k,
-                          uc_stream_t stream) {
+                          int conv_H, int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, float* colsum_a,
+                          int split_k, uc_stream_t stream) {
     UC_REQUIRE(A && B && C, "uc_gemm_tn: null pointer");
     UC_REQUIRE(T > 0 && I >= 8 && J >= 8 && I % 8 == 0 && J % 8 == 0 && lda % 8 == 0, "uc_gemm_tn: I, J and lda must be multiples of 8");
     UC_REQUIRE(split_k >= 1 && split_k <= 1024, "uc_gemm_tn: bad split_k");
@@ -220,7 +248,7 @@ extern "C" int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
     } else {
         UC_REQUIRE(ldb % 8 == 0 && ldb >= J && !relu_b, "uc_gemm_tn: ldb must be a multiple of 8");
     }
-    p.C = C; p.split_k = split_k;
+    p.C = C; p.colsum = colsum_a; p.split_k = split_k;
     p.tiles_i = (int)ceil_div64(I, TN_BM);
     p.tiles_j = (int)ceil_div64(J, TN_BN);
     static bool attr_set = false;
