@@ -55,6 +55,35 @@ __device__ __forceinline__ bf16x8_t tr_operand(const char* tile, int slab16, int
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Asynchronous global -> LDS copy of one [64 rows][64 bf16] tile in the swizzled image (global_load_lds_dwordx4, 1 KiB per
+// wave-instruction: lane -> row 8 n + (lane >> 3), physical chunk lane & 7 <- logical chunk (lane & 7) ^ ((row >> 1) & 7)).
+// Wave w issues instructions 2w and 2w+1; rows beyond n_rows re-read the last valid row (their scores are masked).
+__device__ __forceinline__ void ab_dma16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
+
+__device__ __forceinline__ void dma_tile(const bf16_t* base, int64_t row_stride, int row0, int n_rows, unsigned lds_tile, int wave,
+                                         int lane) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = wave * 2 + q;
+        const int rr = n * 8 + (lane >> 3);
+        int row = row0 + rr;
+        if (row >= n_rows) row = n_rows - 1;
+        const int c = (lane & 7) ^ ((rr >> 1) & 7);
+        ab_dma16(base + (int64_t)row * row_stride + c * 8, __builtin_amdgcn_readfirstlane(lds_tile + (unsigned)(n * 1024)));
+    }
+}
+
 // delta[b,h,q] = sum_d dO[q,d] * O[q,d]
 __global__ void attn_delta_kernel(AttnBwdParams p) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,7 +114,7 @@ __global__ void attn_delta_kernel(AttnBwdParams p) {
 // dQ
 // =================================================================================================================
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * TB];   // K rows | V rows
+    __shared__ __attribute__((aligned(16))) char smem_all[4 * TB];   // 2 stages x (K rows | V rows), filled by LDS-DMA
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -116,25 +145,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
     dq[0] = (float16_t)(0.f);
     dq[1] = (float16_t)(0.f);
 
-    const int cc = tid & 7, sr = tid >> 3;
     int r_off[4];
 #pragma unroll
     for (int st = 0; st < 4; ++st) r_off[st] = bswz(l31, 2 * st + hi);
-    const int w_off = bswz(sr, cc);
+    const unsigned lds0 = (unsigned)(size_t)(ab_lds_ptr_t)smem_all;
 
     const int nt = (p.Nk + 63) / 64;
+    dma_tile(Kb, p.k_sn, 0, p.Nk, lds0, wave, lane);
+    dma_tile(Vb, p.v_sn, 0, p.Nk, lds0 + TB, wave, lane);
     for (int t = 0; t < nt; ++t) {
         const int k0 = t * 64;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = sr + 32 * i;
-            int key = k0 + row;
-            if (key >= p.Nk) key = p.Nk - 1;
-            *reinterpret_cast<uint4*>(smem + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * p.k_sn + cc * 8);
-            *reinterpret_cast<uint4*>(smem + TB + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * p.v_sn + cc * 8);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // tile t landed for every wave; everyone is done reading the other buffer
+        asm volatile("" ::: "memory");
+        if (t + 1 < nt) {
+            dma_tile(Kb, p.k_sn, k0 + 64, p.Nk, lds0 + ((t + 1) & 1) * 2 * TB, wave, lane);
+            dma_tile(Vb, p.v_sn, k0 + 64, p.Nk, lds0 + ((t + 1) & 1) * 2 * TB + TB, wave, lane);
         }
-        __syncthreads();
+        const char* smem = smem_all + (t & 1) * 2 * TB;
 
         bf16x8_t dsf[4];
 #pragma unroll
@@ -190,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
 // dK, dV
 // =================================================================================================================
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * TB + 512];   // Q rows | dO rows | lse2[64] delta[64]
+    __shared__ __attribute__((aligned(16))) char smem_all[4 * TB + 1024];   // 2 stages x (Q rows | dO rows) + 2 x (lse2[64] delta[64])
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -204,8 +232,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     const bf16_t* dOb = p.dO + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
     const float* lse_b = p.LSE + ((int64_t)b * p.H + h) * p.Nq;
     const float* dl_b = p.delta + ((int64_t)b * p.H + h) * p.Nq;
-    float* s_lse = reinterpret_cast<float*>(smem + 2 * TB);
-    float* s_dl = s_lse + 64;
+    float* s_aux = reinterpret_cast<float*>(smem_all + 4 * TB);   // [stage][lse2 64 | delta 64]
 
     bf16x8_t kf[4], vf[4];   // B operands: lane key = l31, channels 16s + 8hi .. +7
     {
@@ -222,30 +249,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     dk[0] = (float16_t)(0.f); dk[1] = (float16_t)(0.f);
     dv[0] = (float16_t)(0.f); dv[1] = (float16_t)(0.f);
 
-    const int cc = tid & 7, sr = tid >> 3;
     int r_off[4];
 #pragma unroll
     for (int st = 0; st < 4; ++st) r_off[st] = bswz(l31, 2 * st + hi);
-    const int w_off = bswz(sr, cc);
+    const unsigned lds0 = (unsigned)(size_t)(ab_lds_ptr_t)smem_all;
 
     const int nt = (p.Nq + 63) / 64;
-    for (int t = 0; t < nt; ++t) {
-        const int q0 = t * 64;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = sr + 32 * i;
-            int q = q0 + row;
-            if (q >= p.Nq) q = p.Nq - 1;
-            *reinterpret_cast<uint4*>(smem + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(Qb + (int64_t)q * p.q_sn + cc * 8);
-            *reinterpret_cast<uint4*>(smem + TB + w_off + i * 32 * 128) = *reinterpret_cast<const uint4*>(dOb + (int64_t)q * p.o_sn + cc * 8);
-        }
+    auto stage_aux = [&](int stage, int q0) {   // per-query scalars of the tile: plain loads, 64 threads
         if (tid < 64) {
             const int q = q0 + tid;
-            s_lse[tid] = (q < p.Nq) ? lse_b[q] * 1.44269504088896340736f : 0.f;
-            s_dl[tid] = (q < p.Nq) ? dl_b[q] : 0.f;
+            s_aux[stage * 128 + tid] = (q < p.Nq) ? lse_b[q] * 1.44269504088896340736f : 0.f;
+            s_aux[stage * 128 + 64 + tid] = (q < p.Nq) ? dl_b[q] : 0.f;
         }
+    };
+    dma_tile(Qb, p.q_sn, 0, p.Nq, lds0, wave, lane);
+    dma_tile(dOb, p.o_sn, 0, p.Nq, lds0 + TB, wave, lane);
+    stage_aux(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int q0 = t * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        asm volatile("" ::: "memory");
+        if (t + 1 < nt) {
+            dma_tile(Qb, p.q_sn, q0 + 64, p.Nq, lds0 + ((t + 1) & 1) * 2 * TB, wave, lane);
+            dma_tile(dOb, p.o_sn, q0 + 64, p.Nq, lds0 + ((t + 1) & 1) * 2 * TB + TB, wave, lane);
+            stage_aux((t + 1) & 1, q0 + 64);
+        }
+        const char* smem = smem_all + (t & 1) * 2 * TB;
+        const float* s_lse = s_aux + (t & 1) * 128;
+        const float* s_dl = s_lse + 64;
 
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
