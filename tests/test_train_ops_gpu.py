@@ -366,3 +366,15 @@ def test_gemm_fused_activation_backward(gpu, act):
     uu = u.float().requires_grad_(True)
     (F.gelu(uu) if act == "gelu" else F.relu(uu)).backward(dy.float() @ w.float().t())
     assert rel_l2(fused.float().cpu(), uu.grad) < 5e-3
+
+
+@pytest.mark.parametrize("T,I,J,sk", [(4096, 128, 1152, 7), (1000, 64, 256, 2), (300, 128, 72, 1), (2048, 96, 2304, 3)])
+def test_gemm_tn_half_height_tile(gpu, T, I, J, sk):
+    """I <= 128 takes the 128 x 256 tile (8 waves): same results, no half-empty MFMA tiles."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(T + I + J)
+    a = torch.randn(T, I, generator=g).bfloat16()
+    b = torch.randn(T, J, generator=g).bfloat16()
+    ws, cs = ops.gemm_tn(a.to(gpu), b.to(gpu), split_k=sk, colsum=True)
+    assert rel_l2(ops.splitk_reduce(ws).cpu(), a.float().t() @ b.float()) < 2e-5
+    assert rel_l2(cs.sum(0).cpu(), a.float().sum(0)) < 2e-5

@@ -61,49 +61,57 @@ __device__ __forceinline__ bf16x4_t tn_relu4(bf16x4_t v) {
     return __builtin_bit_cast(bf16x4_t, u);
 }
 
-#define TN_BM 256
 #define TN_BN 256
-#define TN_STAGE (64 * (TN_BM + TN_BN) * 2)   // 64 KiB: A tile then B tile
 
-template <bool CONV>
-__global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
+// BM_ x 256 x 64 workgroup tile (BM_ = 256: 4x4 waves, BM_ = 128: 2x4 waves — for I <= 128, e.g. the 128-channel convs of the
+// DPT regressor, where a 256-row tile would be half empty); every wave owns 64 x 64 outputs.
+template <int BM_, bool CONV>
+__global__ __launch_bounds__(BM_ * 4) void gemm_tn_kernel(TnParams p) {
+    constexpr int NW = BM_ / 64 * 4;                 // waves per workgroup
+    constexpr int A_ROW = BM_ * 2;                   // bytes per t-row of the A tile (512 / 256); B rows are 512 B
+    constexpr int A_TILE = 64 * A_ROW;
+    constexpr int STAGE = A_TILE + 64 * TN_BN * 2;   // A tile then B tile
+    constexpr int NI_A = A_TILE / 1024;              // 1-KiB DMA instructions of the A tile (32 / 16)
+    constexpr int PER = (NI_A + 32) / NW;            // per wave (4 / 6)
+    constexpr int RA = 1024 / A_ROW;                 // A rows per DMA instruction (2 / 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;              // 4 x 4 waves, 64 x 64 outputs each
+    const int wr = wave >> 2, wc = wave & 3;              // (BM_/64) x 4 waves, 64 x 64 outputs each
 
     const int nwg = p.tiles_i * p.tiles_j;
     const int ksplit = (int)blockIdx.x / nwg;
     const int tile = (int)blockIdx.x - ksplit * nwg;
     const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
-    const int64_t i0 = (int64_t)ti * TN_BM, j0 = (int64_t)tj * TN_BN;
+    const int64_t i0 = (int64_t)ti * BM_, j0 = (int64_t)tj * TN_BN;
 
-    // ---- DMA plan: 64 instructions per stage, 4 per wave; instruction n covers rows 2n', 2n'+1 (n' = n % 32) of the
-    //      A tile (n < 32, wave-uniform) or the B tile; lane -> row 2n' + (lane>>5), physical 16-byte chunk lane & 31.
-    //      Per lane and instruction only the row and the (clamped) logical column are kept; conv taps are re-derived. ----
-    const int d_rhalf = lane >> 5;
-    int d_col[4];
+    // ---- DMA plan: NI_A + 32 one-KiB instructions per stage, PER per wave.  Instruction n < NI_A covers RA rows of the A
+    //      tile (lane -> row n*RA + lane / (64/RA), physical 16-byte chunk lane % (64/RA)); the others 2 rows of the B tile.
+    //      Per lane and instruction only the (clamped) logical column is kept; rows and conv taps are re-derived. ----
+    const int d_ra = (int)((unsigned)lane / (64u / RA)), d_rb = (int)((unsigned)lane >> 5);   // lane's row inside an A / B instruction
+#define TN_DROW(n_) ((n_) < NI_A ? (n_) * RA + d_ra : 2 * ((n_) - NI_A) + d_rb)
+    int d_col[PER];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int n = wave * 4 + q;
-        const int r = 2 * (n & 31) + d_rhalf;
-        const int pc = lane & 31;
+    for (int q = 0; q < PER; ++q) {
+        const int n = wave * PER + q;
+        const int r = TN_DROW(n);
+        const int pc = n < NI_A ? (int)((unsigned)lane % (64u / RA)) : (lane & 31);
         const int lc = ((((pc >> 1) ^ tn_swz(r)) << 1) | (pc & 1));      // logical 16-byte chunk held at physical chunk pc
-        const int64_t lim = (n < 32) ? p.I : p.J;
-        int64_t col = ((n < 32) ? i0 : j0) + lc * 8;
+        const int64_t lim = (n < NI_A) ? p.I : p.J;
+        int64_t col = ((n < NI_A) ? i0 : j0) + lc * 8;
         if (col + 8 > lim) col = lim - 8;                                // duplicate a valid chunk; those outputs are never stored
         d_col[q] = (int)col;
     }
     const unsigned lds_base = (unsigned)(size_t)(tn_lds_ptr_t)smem;
     auto issue_stage = [&](int stage, int64_t t0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = wave * 4 + q;                                   // wave-uniform
-            const int64_t t = t0 + 2 * (n & 31) + d_rhalf;
+        for (int q = 0; q < PER; ++q) {
+            const int n = wave * PER + q;                                 // wave-uniform
+            const int64_t t = t0 + __builtin_amdgcn_readfirstlane(n < NI_A ? n * RA : 2 * (n - NI_A)) + (n < NI_A ? d_ra : d_rb);
             const void* g = g_tn_zero;
             if (t < p.T) {
-                if (n < 32) {
+                if (n < NI_A) {
                     g = p.A + t * p.lda + d_col[q];
                 } else if constexpr (!CONV) {
                     g = p.B + t * p.ldb + d_col[q];
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
                         g = p.B + (((int64_t)b * p.cH + iy) * p.cW + ix) * p.cCin + c;
                 }
             }
-            tn_dma16(g, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * TN_STAGE + n * 1024)));
+            tn_dma16(g, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE + n * 1024)));
         }
     };
 
@@ -130,12 +138,12 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
     //      s(r) = (q>>2) | (g&1)<<2 for every (ks,h), so one swizzled offset per fragment + immediates ----
     const int fg = lane >> 4, fq = lane & 15;
     const int f_sw = (fq >> 2) | ((fg & 1) << 2);
-    const int f_base = (8 * fg + (fq >> 2)) * 512 + (fq & 3) * 8;
+    const int f_row = 8 * fg + (fq >> 2);
     int a_off[4], b_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a_off[i] = f_base + (((wr * 4 + i) ^ f_sw) << 5);
-        b_off[i] = f_base + (((wc * 4 + i) ^ f_sw) << 5) + 64 * TN_BM * 2;
+        a_off[i] = f_row * A_ROW + (fq & 3) * 8 + (((wr * 4 + i) ^ f_sw) << 5);
+        b_off[i] = f_row * 512 + (fq & 3) * 8 + (((wc * 4 + i) ^ f_sw) << 5) + A_TILE;
     }
 
     float4_t acc[4][4];
@@ -151,12 +159,13 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
     const int64_t tbase = (int64_t)kt0 * 64;
 
     typedef __attribute__((address_space(3))) bf16x4_t* lds_v4_t;
-    auto frag = [&](const char* st, int off, int ks, bool relu) -> bf16x8_t {
-        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(tn_lds_ptr_t)(st + off + ks * (32 * 512)));
-        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(tn_lds_ptr_t)(st + off + ks * (32 * 512) + 4 * 512));
-        if (relu) { lo = tn_relu4(lo); hi = tn_relu4(hi); }
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
+#define TN_FRAG(dst_, st_, off_, ks_, ROWB_, relu_)                                                                                 \
+    do {                                                                                                                            \
+        bf16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(tn_lds_ptr_t)((st_) + (off_) + (ks_) * (32 * (ROWB_))));                 \
+        bf16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(tn_lds_ptr_t)((st_) + (off_) + (ks_) * (32 * (ROWB_)) + 4 * (ROWB_)));   \
+        if (relu_) { lo_ = tn_relu4(lo_); hi_ = tn_relu4(hi_); }                                                                     \
+        (dst_) = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                                                          \
+    } while (0)
 
     // fused bias gradient: the waves of the first column tile that own A rows (wc == 0) also add up their A fragments
     // (v_dot2 against ones: 4 per fragment) — sum_t A[t,i] costs no extra pass over dY
@@ -170,12 +179,12 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt + 1 < nk) issue_stage((kt + 1) & 1, tbase + (int64_t)(kt + 1) * 64);
-        const char* st = smem + (kt & 1) * TN_STAGE;
+        const char* st = smem + (kt & 1) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8_t af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag(st, a_off[i], ks, false);
+            for (int i = 0; i < 4; ++i) TN_FRAG(af[i], st, a_off[i], ks, A_ROW, false);
             if (do_colsum) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(TnParams p) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = frag(st, b_off[j], ks, CONV && p.relu_b != 0);
+            for (int j = 0; j < 4; ++j) TN_FRAG(bf[j], st, b_off[j], ks, 512, CONV && p.relu_b != 0);
             // swapped operands: D[row = j][col = i] -> a lane owns 4 consecutive j of one i (16-byte stores)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -249,17 +258,27 @@ extern "C" int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
         UC_REQUIRE(ldb % 8 == 0 && ldb >= J && !relu_b, "uc_gemm_tn: ldb must be a multiple of 8");
     }
     p.C = C; p.colsum = colsum_a; p.split_k = split_k;
-    p.tiles_i = (int)ceil_div64(I, TN_BM);
+    const bool narrow = I <= 128;                   // half-height tile for the 128-row products (no half-empty MFMA tiles)
+    p.tiles_i = (int)ceil_div64(I, narrow ? 128 : 256);
     p.tiles_j = (int)ceil_div64(J, TN_BN);
+    constexpr int SM256 = 2 * (64 * 256 * 2 + 64 * TN_BN * 2), SM128 = 2 * (64 * 128 * 2 + 64 * TN_BN * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SM256);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SM256);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SM128);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SM128);
         attr_set = true;
     }
     const dim3 grid((unsigned)p.tiles_i * p.tiles_j * (unsigned)split_k);
-    if (p.conv) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(1024), 2 * TN_STAGE, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(1024), 2 * TN_STAGE, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    if (narrow) {
+        if (p.conv) hipLaunchKernelGGL((gemm_tn_kernel<128, true>), grid, dim3(512), SM128, st, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<128, false>), grid, dim3(512), SM128, st, p);
+    } else {
+        if (p.conv) hipLaunchKernelGGL((gemm_tn_kernel<256, true>), grid, dim3(1024), SM256, st, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<256, false>), grid, dim3(1024), SM256, st, p);
+    }
     UC_CHECK_LAUNCH("uc_gemm_tn");
     return UC_OK;
 }
