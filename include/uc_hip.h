@@ -262,8 +262,11 @@ int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t T
                int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, float* colsum_a, int split_k,
                uc_stream_t stream);
 
-/* out[i] = (accumulate ? out[i] : 0) + sum_s ws[s*n + i], i < n (n multiple of 4): reduction of uc_gemm's split_k slabs. */
-int uc_splitk_reduce(const float* ws, int split_k, int64_t n, float* out, int accumulate, uc_stream_t stream);
+/* out[i] = (accumulate ? out[i] : 0) + sum_s ws[s*slab_stride + i], i < n (n, slab_stride multiples of 4): reduction of the
+ * split_k slabs of uc_gemm / uc_gemm_tn (a row range of every slab when slab_stride > n); with accumulate it adds the result
+ * straight into a gradient buffer. */
+int uc_splitk_reduce(const float* ws, int split_k, int64_t n, int64_t slab_stride, float* out, int accumulate,
+                     uc_stream_t stream);
 
 /* Column sums (bias gradients): out[n] += sum_m src[m*ld + n]; out fp32, zero-initialised by the caller. */
 int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, float* out, uc_stream_t stream);

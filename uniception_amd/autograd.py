@@ -53,8 +53,30 @@ def _reduce_slabs(ws: torch.Tensor) -> torch.Tensor:
     return ws[0] if ws.shape[0] == 1 else ops.splitk_reduce(ws)
 
 
-def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype, bias: bool = False):
+# Gradient sink (switched on by training.Trainer): weight gradients that come out of the TN kernel as split-K slabs are
+# reduced STRAIGHT INTO the parameter's existing .grad (a view of the flat gradient buffer) — the reduction kernel does
+# autograd's accumulation and the Function returns None for that input.  The parameter's AccumulateGrad node still runs
+# once all of its contributions are in (with an undefined gradient) and fires its post-accumulate hooks, so the bucket
+# bookkeeping of the trainer needs no extra signal; should a PyTorch build skip the hook for undefined gradients, the
+# trainer's finish() reduces the buckets that never completed.
+_grad_sink = False
+
+
+def set_grad_sink(enabled) -> None:
+    global _grad_sink
+    _grad_sink = bool(enabled)
+
+
+def _sinkable(param, rows: int, cols: int) -> bool:
+    g = param.grad
+    return (_grad_sink and g is not None and g.dtype == torch.float32 and g.is_contiguous()
+            and g.numel() == rows * cols and param.requires_grad)
+
+
+def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype, bias: bool = False, sink=None):
     """(dW [N,K] fp32, db [N] fp32 | None) = (dy^T x, column sums of dy) for row-major dy [M,N], x [M,K].
+    sink: optional list of (parameter, row0, row1) covering the rows of dW; when every target has a gradient buffer the
+    slabs are reduced into those buffers and dW is returned as None (see _grad_sink).
     bf16: the TN kernel contracts over the slow axis directly (uc_gemm_tn: split-K slabs + uc_splitk_reduce) and forms the
     bias gradient from the dy fragments it already holds; fp32 verification mode: explicit transposes + the exact fp32
     GEMM + uc_colsum."""
@@ -63,10 +85,17 @@ def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype, bias: bool = 
         b = x2d if x2d.dtype == dt else ops.convert(_c(x2d), dt)
         if _tn_ok(a, b):
             sk = _split_k(a.shape[1], b.shape[1], a.shape[0])
+            K = b.shape[1]
             if bias:
                 ws, cs = ops.gemm_tn(a, b, split_k=sk, colsum=True)
-                return _reduce_slabs(ws), _reduce_slabs(cs.unsqueeze(1)).reshape(-1)
-            return _reduce_slabs(ops.gemm_tn(a, b, split_k=sk)), None
+                db = _reduce_slabs(cs.unsqueeze(1)).reshape(-1)
+            else:
+                ws, db = ops.gemm_tn(a, b, split_k=sk), None
+            if sink is not None and all(_sinkable(p, r1 - r0, K) for p, r0, r1 in sink):
+                for p, r0, r1 in sink:
+                    ops.splitk_reduce(ws[:, r0:r1], out=p.grad.view(r1 - r0, K), accumulate=True)
+                return None, db
+            return _reduce_slabs(ws), db
     dW = ops.gemm(_tp(_c(dy2d), dt), _tp(_c(x2d), dt), out_dtype=torch.float32)
     return dW, (_colsum(_c(dy2d)) if bias else None)
 
@@ -177,8 +206,8 @@ class LinearFn(Function):
         dy = _c(dy)
         need_dx = ctx.needs_input_grad[0]
         dyb = _as_dt(dy, dt)
-        dW, db = _wgrad(dyb, xb, dt, ctx.has_bias)
-        dW = dW.view(ctx.wshape)
+        dW, db = _wgrad(dyb, xb, dt, ctx.has_bias, sink=[(ctx.weight, 0, ctx.wshape[0])])
+        dW = None if dW is None else dW.view(ctx.wshape)
         dx = None
         if need_dx:
             wT = _w_t(ctx.owner, "lin2d", (ctx.weight,),
@@ -199,15 +228,15 @@ class PatchEmbedFn(Function):
         cols = ops.patch_gather(img, P, dt)
         w, b = engine.patch_weights(owner, dt)
         ctx.save_for_backward(cols)
-        ctx.dt, ctx.wshape, ctx.has_bias = dt, weight.shape, bias is not None
+        ctx.dt, ctx.wshape, ctx.has_bias, ctx.weight = dt, weight.shape, bias is not None, weight
         return ops.gemm(cols, w, b, out_dtype=torch.float32)
 
     @staticmethod
     def backward(ctx, dtok):
         (cols,) = ctx.saved_tensors
         dtok = _c(dtok)
-        dW, db = _wgrad(dtok, cols, ctx.dt, ctx.has_bias)
-        dW = dW.view(ctx.wshape)
+        dW, db = _wgrad(dtok, cols, ctx.dt, ctx.has_bias, sink=[(ctx.weight, 0, ctx.wshape[0])])
+        dW = None if dW is None else dW.view(ctx.wshape)
         return None, dW, db, None, None, None
 
 
@@ -259,7 +288,7 @@ class SelfAttnSubLayerFn(Function):
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp)
+        dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp, sink=[(proj.weight, 0, C)])
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dt3 = torch.empty_like(t)
         d5, t5 = dt3.view(B, N, 3, H, Dh), t.view(B, N, 3, H, Dh)
@@ -267,7 +296,7 @@ class SelfAttnSubLayerFn(Function):
                           out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]))
         _rope_inverse_(d5[:, :, 0], pos, rope)
         _rope_inverse_(d5[:, :, 1], pos, rope)
-        dWq, dbq = _wgrad(dt3, h, dt, has_bq)
+        dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * C)])
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)
@@ -329,7 +358,7 @@ class CrossAttnSubLayerFn(Function):
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp)
+        dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp, sink=[(proj.weight, 0, C)])
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
@@ -339,12 +368,12 @@ class CrossAttnSubLayerFn(Function):
         _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
         _rope_inverse_(dkv5[:, :, 0], kpos, rope)
         # query side
-        dWq, dbq = _wgrad(dq, hq, dt, has_bq)
+        dWq, dbq = _wgrad(dq, hq, dt, has_bq, sink=[(projq.weight, 0, C)])
         dhq = ops.gemm(dq, lin_weight_t(projq, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dhq, ln.eps, dg, db, dres=dxo)
         # key/value side (the other view's tokens)
-        dWkv, dbkv = _wgrad(dkv, hy, dt, has_bk or has_bv)
+        dWkv, dbkv = _wgrad(dkv, hy, dt, has_bk or has_bv, sink=[(projk.weight, 0, C), (projv.weight, C, 2 * C)])
         dhy = ops.gemm(dkv, kv_weight_t(projk, projv, dt), out_dtype=dt if lny is not None else torch.float32)
         if lny is not None:
             dgy, dby = torch.zeros_like(gy), torch.zeros_like(gy)
@@ -352,7 +381,8 @@ class CrossAttnSubLayerFn(Function):
         else:
             dgy = dby = None
             dy = dhy
-        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWkv[:C], dbkv[:C] if has_bk else None, dWkv[C:],
+        dWk, dWv = (None, None) if dWkv is None else (dWkv[:C], dWkv[C:])
+        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbkv[:C] if has_bk else None, dWv,
                 dbkv[C:] if has_bv else None, dWp, dbp) + (None,) * 15
 
 
@@ -386,14 +416,14 @@ class MlpSubLayerFn(Function):
         ln, fc1, fc2, act, dt, has_b1, has_b2 = ctx.meta
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dW2, db2 = _wgrad(dyb, a, dt, has_b2)
+        dW2, db2 = _wgrad(dyb, a, dt, has_b2, sink=[(fc2.weight, 0, fc2.weight.shape[0])])
         w2t = lin_weight_t(fc2, dt)
         if act != "none" and dt == torch.bfloat16 and w2t.shape[1] % 64 == 0:
             du = ops.gemm(dyb, w2t, dact=(u, act))          # act'(u) applied in the data-gradient GEMM's epilogue
         else:
             da = ops.gemm(dyb, w2t)
             du = ops.act_bwd(da, u, act) if act != "none" else da
-        dW1, db1 = _wgrad(du, h, dt, has_b1)
+        dW1, db1 = _wgrad(du, h, dt, has_b1, sink=[(fc1.weight, 0, fc1.weight.shape[0])])
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)

@@ -242,24 +242,26 @@ extern "C" int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// split-K reduction: out[i] (+)= sum_s ws[s*n + i]   (the slabs written by uc_gemm with split_k > 1)
+// split-K reduction: out[i] (+)= sum_s ws[s*slab_stride + i]   (the slabs written by uc_gemm / uc_gemm_tn)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int sk, int64_t n4, float* __restrict__ out, int accumulate) {
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int sk, int64_t n4, int64_t stride4, float* __restrict__ out, int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4_t a = accumulate ? reinterpret_cast<const float4_t*>(out)[i] : (float4_t){0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < sk; ++s) {
-            const float4_t v = reinterpret_cast<const float4_t*>(ws)[(int64_t)s * n4 + i];
+            const float4_t v = reinterpret_cast<const float4_t*>(ws)[(int64_t)s * stride4 + i];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         reinterpret_cast<float4_t*>(out)[i] = a;
     }
 }
 
-extern "C" int uc_splitk_reduce(const float* ws, int split_k, int64_t n, float* out, int accumulate, uc_stream_t stream) {
-    UC_REQUIRE(ws && out && split_k >= 1 && n > 0 && n % 4 == 0, "uc_splitk_reduce: bad argument (n must be a multiple of 4)");
+extern "C" int uc_splitk_reduce(const float* ws, int split_k, int64_t n, int64_t slab_stride, float* out, int accumulate,
+                                uc_stream_t stream) {
+    UC_REQUIRE(ws && out && split_k >= 1 && n > 0 && n % 4 == 0 && slab_stride >= n && slab_stride % 4 == 0,
+               "uc_splitk_reduce: bad argument (n and slab_stride must be multiples of 4)");
     const int64_t n4 = n / 4;
     const unsigned grid = (unsigned)min((int64_t)8192, ceil_div64(n4, 256));
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, split_k, n4, out, accumulate);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, split_k, n4, slab_stride / 4, out, accumulate);
     UC_CHECK_LAUNCH("uc_splitk_reduce");
     return UC_OK;
 }

@@ -410,15 +410,17 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, split_k: int = 1, conv: Optional[T
 
 
 def splitk_reduce(ws: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """ws [sk, M, N] fp32 slabs (uc_gemm split_k output) -> out [M,N] (= or += the sum over slabs)."""
+    """ws [sk, M, N] fp32 slabs (uc_gemm split_k / uc_gemm_tn output, or a row range ws_full[:, r0:r1] of them) ->
+    out [M,N] (= or += the sum over slabs)."""
     _need_gpu(ws, out)
-    assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.dim() == 3
+    assert ws.dtype == torch.float32 and ws.dim() == 3 and ws.stride(2) == 1 and ws.stride(1) == ws.shape[2]
     if out is None:
         assert not accumulate
         out = torch.empty(ws.shape[1:], dtype=torch.float32, device=ws.device)
-    assert out.is_contiguous() and out.numel() == ws[0].numel() and out.dtype == torch.float32
-    _lib.check(_lib.load().uc_splitk_reduce(ws.data_ptr(), ws.shape[0], out.numel(), out.data_ptr(), 1 if accumulate else 0, _stream()),
-               "uc_splitk_reduce")
+    assert out.is_contiguous() and out.numel() == ws.shape[1] * ws.shape[2] and out.dtype == torch.float32
+    stride = ws.stride(0) if ws.shape[0] > 1 else out.numel()
+    _lib.check(_lib.load().uc_splitk_reduce(ws.data_ptr(), ws.shape[0], out.numel(), stride, out.data_ptr(), 1 if accumulate else 0,
+                                            _stream()), "uc_splitk_reduce")
     return out
 
 

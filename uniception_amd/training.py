@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import engine, ops
+from . import autograd, engine, ops
 
 
 def _no_decay(name: str, p: torch.Tensor) -> bool:
@@ -100,17 +100,44 @@ class GradientBuckets:
         for n in names:
             self._bucket_of[n] = b
 
+    def _ready(self, name) -> None:
+        if name in self._done:          # a gradient is complete once per step, whoever reports it
+            return
+        self._done.add(name)
+        b = self._bucket_of[name]
+        self._left[b] -= 1
+        if self._left[b] == 0:
+            lo, hi = self.buckets[b]
+            self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
     def _make_hook(self, name):
         def hook(_p):
-            b = self._bucket_of[name]
-            self._left[b] -= 1
-            if self._left[b] == 0:
-                lo, hi = self.buckets[b]
-                self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._ready(name)
         return hook
 
     def start_step(self) -> None:
         self._left = list(self._pending)
+        self._done = set()
+        self.handles = []
+
+    def _ready(self, name) -> None:
+        if name in self._done:          # a gradient is complete once per step, whoever reports it
+            return
+        self._done.add(name)
+        b = self._bucket_of[name]
+        self._left[b] -= 1
+        if self._left[b] == 0:
+            lo, hi = self.buckets[b]
+            self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _make_hook(self, name):
+        def hook(_p):
+            self._ready(name)
+        return hook
+
+    def start_step(self) -> None:
+        self._left = list(self._pending)
+        self._done = set()
         self.handles = []
 
     def finish(self) -> None:
@@ -140,6 +167,7 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.flat.param)
         self.steps = 0
         self.buckets.start_step()
+        autograd.set_grad_sink(True)   # TN weight gradients are reduced straight into flat.grad
 
     @property
     def world_size(self) -> int:
