@@ -255,12 +255,13 @@ int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_
  *   conv_B > 0: B is the IMPLICIT im2col of the NHWC image [conv_B,conv_H,conv_W,conv_Cin] of a 3x3 / pad-1 conv with the
  *   given stride: B[t,(ky*3+kx)*Cin+c] = act(x[b,oy*s-1+ky,ox*s-1+kx,c]), t=(b,oy,ox), J = 9*Cin, relu_b = ReLU-on-load.
  *   C holds split_k slabs of [I,J] fp32 (sum them with uc_splitk_reduce).  I, J, lda, ldb multiples of 8.
- *   colsum_a (optional): split_k slabs of [I] fp32 receiving sum_t A[t,i] — the bias gradient, formed from the A fragments
- *   already in registers (no extra pass over dY).
+ *   colsum_a (optional): sum_t A[t,i] — the bias gradient, formed from the A fragments already in registers (no extra pass
+ *   over dY): split_k slabs of [I] fp32, or with colsum_atomic != 0 ONE [I] buffer every K slice adds to atomically (+=),
+ *   e.g. the bias's gradient buffer itself.
  *   (the reference gets these products from autograd's addmm / conv backward.) */
 int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t T, int64_t I, int64_t J, int conv_B, int conv_H,
-               int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, float* colsum_a, int split_k,
-               uc_stream_t stream);
+               int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, float* colsum_a, int colsum_atomic,
+               int split_k, uc_stream_t stream);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_s ws[s*slab_stride + i], i < n (n, slab_stride multiples of 4): reduction of the
  * split_k slabs of uc_gemm / uc_gemm_tn (a row range of every slab when slab_stride > n); with accumulate it adds the result

@@ -73,7 +73,23 @@ def _sinkable(param, rows: int, cols: int) -> bool:
             and g.numel() == rows * cols and param.requires_grad)
 
 
-def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype, bias: bool = False, sink=None):
+def _bias_target(bias_sink, N: int):
+    """One contiguous fp32 [N] view covering the gradient buffers of the bias parameter(s) of a linear (two adjacent ones
+    for the fused K|V projection), or None when they cannot take direct accumulation."""
+    if not _grad_sink or not bias_sink or any(p is None or not _sinkable(p, p.numel(), 1) for p in bias_sink):
+        return None
+    g0 = bias_sink[0].grad
+    total, ptr = 0, g0.data_ptr()
+    for p in bias_sink:
+        if p.grad.data_ptr() != ptr + 4 * total:
+            return None          # not adjacent in the flat gradient buffer
+        total += p.numel()
+    if total != N:
+        return None
+    return g0.reshape(-1) if len(bias_sink) == 1 else torch.as_strided(g0, (N,), (1,))
+
+
+def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype, bias: bool = False, sink=None, bias_sink=None):
     """(dW [N,K] fp32, db [N] fp32 | None) = (dy^T x, column sums of dy) for row-major dy [M,N], x [M,K].
     sink: optional list of (parameter, row0, row1) covering the rows of dW; when every target has a gradient buffer the
     slabs are reduced into those buffers and dW is returned as None (see _grad_sink).
@@ -86,7 +102,10 @@ def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype, bias: bool = 
         if _tn_ok(a, b):
             sk = _split_k(a.shape[1], b.shape[1], a.shape[0])
             K = b.shape[1]
-            if bias:
+            bt = _bias_target(bias_sink, a.shape[1]) if bias else None
+            if bt is not None:      # bias gradient added atomically into the bias's own gradient buffer: db is returned None
+                ws, db = ops.gemm_tn(a, b, split_k=sk, colsum_into=bt), None
+            elif bias:
                 ws, cs = ops.gemm_tn(a, b, split_k=sk, colsum=True)
                 db = _reduce_slabs(cs.unsqueeze(1)).reshape(-1)
             else:
@@ -288,7 +307,7 @@ class SelfAttnSubLayerFn(Function):
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp, sink=[(proj.weight, 0, C)])
+        dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dt3 = torch.empty_like(t)
         d5, t5 = dt3.view(B, N, 3, H, Dh), t.view(B, N, 3, H, Dh)
@@ -296,7 +315,7 @@ class SelfAttnSubLayerFn(Function):
                           out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]))
         _rope_inverse_(d5[:, :, 0], pos, rope)
         _rope_inverse_(d5[:, :, 1], pos, rope)
-        dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * C)])
+        dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * C)], bias_sink=[qkv.bias])
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)
@@ -358,7 +377,7 @@ class CrossAttnSubLayerFn(Function):
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp, sink=[(proj.weight, 0, C)])
+        dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
@@ -368,12 +387,13 @@ class CrossAttnSubLayerFn(Function):
         _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
         _rope_inverse_(dkv5[:, :, 0], kpos, rope)
         # query side
-        dWq, dbq = _wgrad(dq, hq, dt, has_bq, sink=[(projq.weight, 0, C)])
+        dWq, dbq = _wgrad(dq, hq, dt, has_bq, sink=[(projq.weight, 0, C)], bias_sink=[projq.bias])
         dhq = ops.gemm(dq, lin_weight_t(projq, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dhq, ln.eps, dg, db, dres=dxo)
         # key/value side (the other view's tokens)
-        dWkv, dbkv = _wgrad(dkv, hy, dt, has_bk or has_bv, sink=[(projk.weight, 0, C), (projv.weight, C, 2 * C)])
+        dWkv, dbkv = _wgrad(dkv, hy, dt, has_bk or has_bv, sink=[(projk.weight, 0, C), (projv.weight, C, 2 * C)],
+                            bias_sink=[projk.bias, projv.bias] if (has_bk and has_bv) else None)
         dhy = ops.gemm(dkv, kv_weight_t(projk, projv, dt), out_dtype=dt if lny is not None else torch.float32)
         if lny is not None:
             dgy, dby = torch.zeros_like(gy), torch.zeros_like(gy)
@@ -382,8 +402,9 @@ class CrossAttnSubLayerFn(Function):
             dgy = dby = None
             dy = dhy
         dWk, dWv = (None, None) if dWkv is None else (dWkv[:C], dWkv[C:])
-        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbkv[:C] if has_bk else None, dWv,
-                dbkv[C:] if has_bv else None, dWp, dbp) + (None,) * 15
+        dbk = dbkv[:C] if (has_bk and dbkv is not None) else None
+        dbv = dbkv[C:] if (has_bv and dbkv is not None) else None
+        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbk, dWv, dbv, dWp, dbp) + (None,) * 15
 
 
 def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt):
@@ -416,14 +437,14 @@ class MlpSubLayerFn(Function):
         ln, fc1, fc2, act, dt, has_b1, has_b2 = ctx.meta
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dW2, db2 = _wgrad(dyb, a, dt, has_b2, sink=[(fc2.weight, 0, fc2.weight.shape[0])])
+        dW2, db2 = _wgrad(dyb, a, dt, has_b2, sink=[(fc2.weight, 0, fc2.weight.shape[0])], bias_sink=[fc2.bias])
         w2t = lin_weight_t(fc2, dt)
         if act != "none" and dt == torch.bfloat16 and w2t.shape[1] % 64 == 0:
             du = ops.gemm(dyb, w2t, dact=(u, act))          # act'(u) applied in the data-gradient GEMM's epilogue
         else:
             da = ops.gemm(dyb, w2t)
             du = ops.act_bwd(da, u, act) if act != "none" else da
-        dW1, db1 = _wgrad(du, h, dt, has_b1, sink=[(fc1.weight, 0, fc1.weight.shape[0])])
+        dW1, db1 = _wgrad(du, h, dt, has_b1, sink=[(fc1.weight, 0, fc1.weight.shape[0])], bias_sink=[fc1.bias])
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)

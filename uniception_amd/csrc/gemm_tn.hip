@@ -28,7 +28,8 @@ struct TnParams {
     int conv;            // 0 dense, 1 implicit im2col of a 3x3 / pad 1 conv
     int cB, cH, cW, cCin, cStride, cHo, cWo, relu_b;
     float* C;            // [split_k][I, J]
-    float* colsum;       // optional [split_k][I]: sum_t A[t,i] (the bias gradient), written by the tj == 0 tiles
+    float* colsum;       // optional: sum_t A[t,i] (the bias gradient) from the tj == 0 tiles: [split_k][I] slabs, or
+    int colsum_atomic;   //           with colsum_atomic one [I] buffer that every K slice adds to atomically (+=)
     int split_k;
     int tiles_i, tiles_j;
 };
@@ -211,7 +212,10 @@ __global__ __launch_bounds__(BM_ * 4) void gemm_tn_kernel(TnParams p) {
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             const int64_t ii = i0 + wr * 64 + 16 * i + fq;
-            if (fg == 0 && ii < p.I) p.colsum[(int64_t)ksplit * p.I + ii] = v;
+            if (fg == 0 && ii < p.I) {
+                if (p.colsum_atomic) unsafeAtomicAdd(p.colsum + ii, v);      // split_k adds per column: negligible contention
+                else p.colsum[(int64_t)ksplit * p.I + ii] = v;
+            }
         }
     }
 
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(BM_ * 4) void gemm_tn_kernel(TnParams p) {
 
 extern "C" int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t T, int64_t I, int64_t J, int conv_B,
                           int conv_H, int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, float* colsum_a,
-                          int split_k, uc_stream_t stream) {
+                          int colsum_atomic, int split_k, uc_stream_t stream) {
     UC_REQUIRE(A && B && C, "uc_gemm_tn: null pointer");
     UC_REQUIRE(T > 0 && I >= 8 && J >= 8 && I % 8 == 0 && J % 8 == 0 && lda % 8 == 0, "uc_gemm_tn: I, J and lda must be multiples of 8");
     UC_REQUIRE(split_k >= 1 && split_k <= 1024, "uc_gemm_tn: bad split_k");
@@ -257,7 +261,7 @@ extern "C" int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
     } else {
         UC_REQUIRE(ldb % 8 == 0 && ldb >= J && !relu_b, "uc_gemm_tn: ldb must be a multiple of 8");
     }
-    p.C = C; p.colsum = colsum_a; p.split_k = split_k;
+    p.C = C; p.colsum = colsum_a; p.colsum_atomic = colsum_atomic ? 1 : 0; p.split_k = split_k;
     const bool narrow = I <= 128;                   // half-height tile for the 128-row products (no half-empty MFMA tiles)
     p.tiles_i = (int)ceil_div64(I, narrow ? 128 : 256);
     p.tiles_j = (int)ceil_div64(J, TN_BN);

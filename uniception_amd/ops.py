@@ -386,11 +386,12 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: f
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, split_k: int = 1, conv: Optional[Tuple[int, bool]] = None,
-            colsum: bool = False):
+            colsum: bool = False, colsum_into: Optional[torch.Tensor] = None):
     """Weight-gradient contraction over the slow axis: returns fp32 slabs [split_k, I, J] of  sum_t a[t,i] * b[t,j].
     a: [T,I] bf16 (unit column stride).  b: [T,J] bf16, or with conv=(stride, relu) the NHWC input [B,H,W,Cin] of a
     3x3/pad-1 conv whose im2col ([T, 9*Cin], T = output pixels) is formed implicitly.
-    colsum=True: also returns slabs [split_k, I] of sum_t a[t,i] (the bias gradient)."""
+    colsum=True: also returns slabs [split_k, I] of sum_t a[t,i] (the bias gradient).
+    colsum_into: fp32 [I] buffer that receives += sum_t a[t,i] atomically instead (e.g. the bias's gradient buffer)."""
     _need_gpu(a, b)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1
     T, I = a.shape
@@ -403,9 +404,13 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, split_k: int = 1, conv: Optional[T
         Bc, Hc, Wc, Cin = b.shape
         J, ldb, cg = 9 * Cin, 0, (Bc, Hc, Wc, Cin, stride)
     out = torch.empty((split_k, I, J), dtype=torch.float32, device=a.device)
-    cs = torch.empty((split_k, I), dtype=torch.float32, device=a.device) if colsum else None
+    if colsum_into is not None:
+        assert colsum_into.dtype == torch.float32 and colsum_into.is_contiguous() and colsum_into.numel() == I and not colsum
+        cs, atomic = colsum_into, 1
+    else:
+        cs, atomic = (torch.empty((split_k, I), dtype=torch.float32, device=a.device) if colsum else None), 0
     _lib.check(_lib.load().uc_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), ldb, T, I, J, *cg, 1 if relu else 0, out.data_ptr(),
-                                      _p(cs), split_k, _stream()), "uc_gemm_tn")
+                                      _p(cs), atomic, split_k, _stream()), "uc_gemm_tn")
     return (out, cs) if colsum else out
 
 
