@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--attention", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: e4m3 K=64 MFMA attention kernel (BASELINE configs[4]; forward only)")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph (latency mode, small --pairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-max-s", type=float, default=30.0)
@@ -175,9 +176,16 @@ def main():
     else:
         model.eval()
 
-        def step():
-            with torch.no_grad(), engine.precision(args.precision), engine.attention_precision(args.attention):
-                return model(v1, v2)
+        if args.graph:
+            from uniception_amd.graphs import GraphedTwoView
+            graphed = GraphedTwoView(model, v1, v2, precision=args.precision, attention=args.attention)
+
+            def step():
+                return graphed(v1, v2)
+        else:
+            def step():
+                with torch.no_grad(), engine.precision(args.precision), engine.attention_precision(args.attention):
+                    return model(v1, v2)
 
     for _ in range(args.warmup):
         step()
@@ -215,7 +223,7 @@ def main():
                                 f"{args.img}x{args.img} pairs, " + ("forward" if fwd else "training step with synthetic pointmap targets")
                                 + ", random-init weights"),
                    "pairs_per_gpu": args.pairs, "global_pairs_per_step": world * args.pairs, "img": args.img,
-                   "head": args.head, "encoder": args.encoder, "attention": args.attention,
+                   "head": args.head, "encoder": args.encoder, "attention": args.attention, "hipgraph": bool(args.graph),
                    "parallelism": (f"dp{world} (independent pairs per rank, no data-path collective)" if fwd else
                                    f"dp{world} (replicated model, bucketed in-place gradient all-reduce over RCCL)")},
         "enc_dec_mfma_frac": round(value / world * gflop_pair * (1 if fwd else 3) / 1e3 / PEAK_BF16_TFLOPS, 4),

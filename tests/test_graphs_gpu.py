@@ -1,0 +1,36 @@
+"""hipGraph replay of the two-view forward equals the eager forward and follows new inputs."""
+import pytest
+import torch
+
+from tests.helpers import build_case_model, case_images
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graphed_forward_matches_eager(gpu):
+    from uniception_amd import engine
+    from uniception_amd.graphs import GraphedTwoView
+    from uniception_amd.models.factory import DUSt3R
+    from oracle import dust3r_oracle as O
+    torch.manual_seed(0)
+    model = DUSt3R(name="g", img_size=(64, 96), pred_head_type="linear")
+    O.fill_state_dict_(model.state_dict())
+    model = model.to(gpu).eval()
+    g = torch.Generator().manual_seed(1)
+
+    def views(seed):
+        gg = torch.Generator().manual_seed(seed)
+        a, b = torch.randn(2, 3, 64, 96, generator=gg).to(gpu), torch.randn(2, 3, 64, 96, generator=gg).to(gpu)
+        return ({"img": a, "instance": ["a0", "a1"], "data_norm_type": "dust3r"}, {"img": b, "instance": ["b0", "b1"], "data_norm_type": "dust3r"})
+
+    v1, v2 = views(1)
+    graphed = GraphedTwoView(model, v1, v2, precision="bf16")
+    for seed in (1, 2, 3):
+        v1, v2 = views(seed)
+        with torch.no_grad(), engine.precision("bf16"):
+            e1, e2 = model(v1, v2)
+        r1, r2 = graphed(v1, v2)
+        torch.cuda.synchronize()
+        assert torch.equal(r1["pts3d"], e1["pts3d"]) and torch.equal(r2["conf"], e2["conf"])
+    with pytest.raises(ValueError):
+        graphed({"img": torch.zeros(1, 3, 64, 96, device=gpu)}, v2)
