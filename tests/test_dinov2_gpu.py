@@ -57,3 +57,84 @@ def test_bf16_and_intermediate_returner(gpu):
                 assert o.features.shape == (1, 384, 4, 5) and o.registers.shape == (1, 384, 1)
                 assert rel_l2(o.features.cpu(), t[:, 1:].permute(0, 2, 1).reshape(1, 384, 4, 5)) < tol
                 assert rel_l2(o.registers.cpu(), t[:, :1].permute(0, 2, 1)) < tol
+
+
+def _config4_model(gpu):
+    """BASELINE config 4 in miniature: DINOv2 (small, 2 blocks, patch 14) -> 2-view decoder with intermediate taps -> DPT heads
+    -> adaptor, composed from the modules exactly as the factory composes the CroCo variant."""
+    from uniception_amd.models.encoders import encoder_factory
+    from uniception_amd.models.info_sharing.cross_attention_transformer import MultiViewCrossAttentionTransformerIFR
+    from uniception_amd.models.libs.croco.pos_embed import RoPE2D
+    from uniception_amd.models.prediction_heads.adaptors import PointMapWithConfidenceAdaptor
+    from uniception_amd.models.prediction_heads.dpt import DPTFeature, DPTRegressionProcessor
+    import torch.nn as nn
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = encoder_factory("dinov2", name="d", size="small", keep_first_n_layers=2)
+            self.info_sharing = MultiViewCrossAttentionTransformerIFR(
+                name="dec", input_embed_dim=384, num_views=2, depth=3, dim=192, num_heads=3, custom_positional_encoding=RoPE2D(freq=100.0),
+                indices=[0, 1], norm_intermediate=False)
+            for v in (1, 2):
+                setattr(self, f"dpt_feature_head{v}", DPTFeature(patch_size=14, hooks=[0, 1, 2, 3], input_feature_dims=[384, 192, 192, 192],
+                                                                 layer_dims=[16, 32, 64, 128], feature_dim=32))
+                setattr(self, f"dpt_regressor_head{v}", DPTRegressionProcessor(input_feature_dim=32, output_dim=4))
+            self.adaptor = PointMapWithConfidenceAdaptor(name="pointmap", pointmap_mode="exp", pointmap_vmin=-float("inf"),
+                                                         pointmap_vmax=float("inf"), confidence_type="exp", confidence_vmin=1,
+                                                         confidence_vmax=float("inf"))
+    m = M().eval()
+    from tests.golden.cases import GAINS as G2
+    O.fill_state_dict_(m.state_dict(), gains=dict(GAINS, **G2))
+    return m
+
+
+def _config4_forward(m, img1, img2):
+    from uniception_amd.models.encoders.base import ViTEncoderInput
+    from uniception_amd.models.info_sharing.base import MultiViewTransformerInput
+    from uniception_amd.models.prediction_heads.base import AdaptorInput, PredictionHeadLayeredInput
+    H, W = img1.shape[-2:]
+    feats = m.encoder(ViTEncoderInput(image=torch.cat([img1, img2], 0), data_norm_type="dinov2")).features
+    f1, f2 = feats.chunk(2, dim=0)
+    final, inter = m.info_sharing(MultiViewTransformerInput(features=[f1, f2]))
+    outs = []
+    for v in range(2):
+        lay = [(f1, f2)[v], inter[0].features[v], inter[1].features[v], final.features[v]]
+        up8 = getattr(m, f"dpt_feature_head{v + 1}")(PredictionHeadLayeredInput(list_features=lay, target_output_shape=(H, W)))
+        dec = getattr(m, f"dpt_regressor_head{v + 1}")(up8).decoded_channels
+        a = m.adaptor(AdaptorInput(adaptor_feature=dec, output_shape_hw=(H, W)))
+        outs.append((a.value.permute(0, 2, 3, 1).contiguous(), a.confidence.permute(0, 2, 3, 1).contiguous()))
+    return outs
+
+
+def test_config4_pipeline_matches_oracle_composition_and_trains_with_frozen_encoder(gpu):
+    from uniception_amd import autograd, engine
+    m = _config4_model(gpu)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    img1, img2 = torch.randn(1, 3, 70, 98, generator=g), torch.randn(1, 3, 70, 98, generator=g)
+    with torch.no_grad():
+        enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+        feats, _ = O.dinov2_encoder(torch.cat([img1, img2], 0), enc_sd, "model.", num_heads=6)
+        final, taken = O.cross_attention_transformer([feats[:1], feats[1:]], sd, "info_sharing.", depth=3, num_heads=3, indices=(0, 1),
+                                                     norm_intermediate=False)
+        ref = []
+        for v in range(2):
+            up8 = O.dpt_feature([feats[v:v + 1], taken[0][v], taken[1][v], final[v]], sd, f"dpt_feature_head{v + 1}.")
+            pts, conf = O.pointmap_adaptor(O.dpt_regressor(up8, (70, 98), sd, f"dpt_regressor_head{v + 1}."))
+            ref.append((pts.permute(0, 2, 3, 1), conf.permute(0, 2, 3, 1)))
+        m = m.to(gpu)
+        with engine.precision("fp32"):
+            out = _config4_forward(m, img1.to(gpu), img2.to(gpu))
+    for (p, c), (pr, cr) in zip(out, ref):
+        assert rel_l2(p.cpu(), pr) < 1e-3 and rel_l2(c.cpu(), cr) < 1e-3
+    # fine-tuning set-up: frozen DINOv2 encoder (inference kernels), decoder + heads trained
+    m.train()
+    m.encoder.requires_grad_(False)
+    with engine.precision("bf16"):
+        (p1, c1), (p2, c2) = _config4_forward(m, img1.to(gpu), img2.to(gpu))
+        loss = autograd.conf_loss(p1, c1, torch.zeros_like(p1)) + autograd.conf_loss(p2, c2, torch.zeros_like(p2))
+    loss.backward()
+    assert all(p.grad is None for p in m.encoder.parameters())
+    gnorm = sum(float(p.grad.norm()) for p in m.info_sharing.parameters())
+    assert gnorm > 0 and torch.isfinite(torch.tensor(gnorm))
