@@ -362,11 +362,12 @@ def test_pointmap_adaptor(gpu):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv1x1_to4(gpu, dtype):
+@pytest.mark.parametrize("Cin", [128, 16, 256, 8, 72])   # 8 * 2^k: lane-cooperative kernel; 72: one-thread-per-pixel fallback
+def test_conv1x1_to4(gpu, dtype, Cin):
     from uniception_amd import ops
-    g = torch.Generator().manual_seed(16)
-    f = torch.randn(2, 5, 7, 128, generator=g).to(dtype)
-    w = torch.randn(4, 128, generator=g) / 11
+    g = torch.Generator().manual_seed(16 + Cin)
+    f = torch.randn(2, 37, 29, Cin, generator=g).to(dtype)
+    w = torch.randn(4, Cin, generator=g) / 11
     b = torch.randn(4, generator=g)
     ref = f.float() @ w.t() + b
     out = ops.conv1x1_to4(f.to(gpu), w.to(gpu), b.to(gpu))

@@ -362,11 +362,69 @@ __global__ __launch_bounds__(256) void conv1x1_to4_kernel(const typename Tag::st
     }
 }
 
+// Coalesced form for Cin = 8 * 2^k (<= 256): C8 = Cin/8 consecutive lanes share a pixel, each loads ONE 16-byte chunk (so a
+// wave reads 1 KiB of consecutive memory per load instead of 64 scattered 16-byte pieces), keeps its 4x8 weights in
+// registers and the 4 partial sums are folded across the C8 lanes with xor-shuffles.
+template <typename Tag, int C8>
+__global__ __launch_bounds__(256) void conv1x1_to4_coop_kernel(const typename Tag::storage* __restrict__ feat,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int64_t npix) {
+    constexpr int Cin = C8 * 8;
+    constexpr int PPB = 256 / C8;                  // pixels per block-iteration
+    const int chunk = threadIdx.x % C8, pl = threadIdx.x / C8;
+    float wr[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[o][e] = w[o * Cin + chunk * 8 + e];
+    const float4_t b4 = *reinterpret_cast<const float4_t*>(bias);
+    for (int64_t pix = (int64_t)blockIdx.x * PPB + pl; pix < npix; pix += (int64_t)gridDim.x * PPB) {
+        const V8 x = load8<Tag>(feat + pix * Cin + chunk * 8);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[0] = fmaf(x.v[e], wr[0][e], a[0]);
+            a[1] = fmaf(x.v[e], wr[1][e], a[1]);
+            a[2] = fmaf(x.v[e], wr[2][e], a[2]);
+            a[3] = fmaf(x.v[e], wr[3][e], a[3]);
+        }
+#pragma unroll
+        for (int off = C8 / 2; off > 0; off >>= 1) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) a[o] += __shfl_xor(a[o], off, 64);
+        }
+        if (chunk == 0)
+            *reinterpret_cast<float4_t*>(out + pix * 4) = (float4_t){a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
+    }
+}
+
+template <typename Tag>
+static bool launch_conv1x1_to4_coop(const void* feat, const float* w, const float* b, float* out, int64_t npix, int Cin, hipStream_t st) {
+    const int C8 = Cin / 8;
+#define UC_C1X1(C8_)                                                                                                         \
+    case C8_: {                                                                                                              \
+        const unsigned grid = (unsigned)min((int64_t)65536, ceil_div64(npix, 256 / C8_));                                    \
+        hipLaunchKernelGGL((conv1x1_to4_coop_kernel<Tag, C8_>), dim3(grid), dim3(256), 0, st,                                \
+                           (const typename Tag::storage*)feat, w, b, out, npix);                                             \
+        return true;                                                                                                         \
+    }
+    switch (C8) {
+        UC_C1X1(1) UC_C1X1(2) UC_C1X1(4) UC_C1X1(8) UC_C1X1(16) UC_C1X1(32)
+        default: return false;
+    }
+#undef UC_C1X1
+}
+
 extern "C" int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const float* b, float* out, int64_t npix,
                               int Cin, uc_stream_t stream) {
     UC_REQUIRE(feat && w && b && out && npix > 0, "uc_conv1x1_to4: bad argument");
     UC_REQUIRE(Cin > 0 && Cin <= 256 && Cin % 8 == 0, "uc_conv1x1_to4: Cin must be a multiple of 8 and <= 256 (got %d)", Cin);
     hipStream_t st = (hipStream_t)stream;
+    if (((uintptr_t)b % 16 == 0) && ((dtype == UC_F32 && launch_conv1x1_to4_coop<F32Tag>(feat, w, b, out, npix, Cin, st)) ||
+                                      (dtype == UC_BF16 && launch_conv1x1_to4_coop<BF16Tag>(feat, w, b, out, npix, Cin, st)))) {
+        UC_CHECK_LAUNCH("uc_conv1x1_to4");
+        return UC_OK;
+    }
     if (dtype == UC_F32)
         hipLaunchKernelGGL((conv1x1_to4_kernel<F32Tag>), dim3(EW_GRID(npix)), dim3(256), 0, st, (const float*)feat, w, b, out, npix, Cin);
     else if (dtype == UC_BF16)
