@@ -130,3 +130,41 @@ def test_two_rank_bf16_gradient_sink_equals_autograd_accumulation(gpu, tmp_path)
     worst = max(rel_l2(with_sink[k], without[k]) for k in without)
     print(f"\n[2-rank bf16 all-reduced gradients] sink vs autograd accumulation {worst:.2e} (run-to-run noise {noise:.2e})")
     assert worst < max(1e-5, 4 * noise)
+
+
+def test_checkpoint_resume_continues_identically(gpu, tmp_path):
+    """train 2 steps, checkpoint (model + trainer state), train 2 more; a fresh process state restored from the checkpoint
+    must reproduce the last 2 steps (fp32 kernels: bit-for-bit up to the atomics' summation order)."""
+    from uniception_amd.training import Trainer
+    model, c = build_case_model("tiny_linear")
+    model = model.to(gpu).train()
+    imgs = [t.to(gpu) for t in case_images(c)]
+    gts = [t.to(gpu) for t in grad_targets(c)]
+    tr = Trainer(model, lr=2e-3, weight_decay=0.05)
+
+    def steps(trainer, mdl, n):
+        for _ in range(n):
+            trainer.zero_grad()
+            _loss(mdl, imgs, gts, "fp32").backward()
+            trainer.step()
+
+    steps(tr, model, 2)
+    ckpt = {"model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "trainer": tr.state_dict()}
+    torch.save(ckpt, tmp_path / "ckpt.pt")
+    steps(tr, model, 2)
+
+    model2, _ = build_case_model("tiny_linear")
+    model2 = model2.to(gpu).train()
+    tr2 = Trainer(model2, lr=1.0)                      # hyper-parameters come back from the checkpoint
+    ck = torch.load(tmp_path / "ckpt.pt")
+    model2.load_state_dict(ck["model"])
+    tr2.parameters_changed()
+    tr2.load_state_dict(ck["trainer"])
+    assert tr2.steps == 2 and tr2.lr == 2e-3
+    steps(tr2, model2, 2)
+    worst = max(rel_l2(v.detach().cpu(), model.state_dict()[k].detach().cpu()) for k, v in model2.state_dict().items())
+    print(f"\n[resume] worst parameter deviation after resuming {worst:.2e}")
+    assert worst < 1e-5
+    for n, p in model2.named_parameters():   # still views of the flat buffer after load_state_dict
+        off, k = tr2.flat.offsets[n]
+        assert p.data_ptr() == tr2.flat.param.data_ptr() + 4 * off

@@ -195,3 +195,27 @@ class Trainer:
             ops.adamw_(self.flat.param[nd:], self.flat.grad[nd:], self.exp_avg[nd:], self.exp_avg_sq[nd:], self.lr, b1, b2,
                        self.eps, 0.0, self.steps, grad_scale=gs)
         engine.bump_weight_epoch()   # the kernel wrote through raw pointers: invalidate the prepared-weight cache
+
+    # ---- checkpoint / resume -------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """Optimizer state for checkpointing (the parameters themselves are in model.state_dict(), whose tensors are views of
+        the flat buffer).  Layout-independent: moments are stored per parameter name."""
+        out = {"steps": self.steps, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+               "exp_avg": {}, "exp_avg_sq": {}}
+        for n, (off, k) in self.flat.offsets.items():
+            out["exp_avg"][n] = self.exp_avg[off:off + k].detach().cpu().clone()
+            out["exp_avg_sq"][n] = self.exp_avg_sq[off:off + k].detach().cpu().clone()
+        return out
+
+    def load_state_dict(self, state: dict) -> None:
+        self.steps = int(state["steps"])
+        self.lr, self.betas, self.eps, self.weight_decay = state["lr"], tuple(state["betas"]), state["eps"], state["weight_decay"]
+        for n, (off, k) in self.flat.offsets.items():
+            self.exp_avg[off:off + k].copy_(state["exp_avg"][n].reshape(-1))
+            self.exp_avg_sq[off:off + k].copy_(state["exp_avg_sq"][n].reshape(-1))
+
+    def parameters_changed(self) -> None:
+        """Call after writing parameters from outside (model.load_state_dict on the flattened model copies INTO the flat
+        buffer): invalidates the prepared bf16 / transposed weight copies."""
+        engine.bump_weight_epoch()
+
