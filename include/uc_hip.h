@@ -246,9 +246,11 @@ int uc_token_slice(const float* src, float* dst, int B, int Ns, int Nd, int src_
 /* LayerNorm backward (forward: uc_layernorm).  x fp32 [rows,C], dy [rows,C] (dy_dtype f32|bf16), gamma fp32 [C].
  *   dx[r,:]  = rstd*(a - mean(a) - xhat*mean(a*xhat)) (+ dres[r,:] if dres != NULL),  a = dy*gamma, xhat = (x-mean)*rstd
  *   dgamma[c] += sum_r dy*xhat, dbeta[c] += sum_r dy     (fp32 atomic accumulation: zero them first)
+ *   dx_bf16 (optional): a bf16 copy of dx written in the same pass — dx is the gradient of the residual stream, which the
+ *   previous sub-layer's backward GEMMs consume in bf16.
  * Any C; widths 256*{1,2,3,4,6,8} take the register-resident kernel. */
 int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
-                     float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream);
+                     void* dx_bf16, float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream);
 
 /* "TN" contraction over tokens / pixels for weight gradients, no operand transposes (bf16 in, fp32 out):
  *     C[s][i,j] = sum_{t in K-slice s} A[t,i] * B[t,j]        A = dY [T,I] (lda),  B = X [T,J] (ldb),  dW = dY^T X

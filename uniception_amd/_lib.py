@@ -58,7 +58,7 @@ SIGNATURES = {
     "uc_conv1x1_to4": [vp, i32, vp, vp, vp, i64, i32, vp],
     "uc_assemble_tokens": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "uc_token_slice": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
-    "uc_layernorm_bwd": [vp, vp, vp, i32, vp, vp, vp, vp, i64, i32, f32, vp],
+    "uc_layernorm_bwd": [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "uc_gemm_tn": [vp, i64, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp],
     "uc_splitk_reduce": [vp, i32, i64, i64, vp, i32, vp],
     "uc_colsum": [vp, i32, i64, i64, i64, vp, vp],

@@ -15,6 +15,7 @@ sub-layer's backward is one Function calling uc_hip entry points:
 Precision follows the forward: bf16 operands with fp32 accumulation, fp32 residual stream, fp32 weight gradients; in
 fp32 verification mode every kernel is the exact-fp32 variant.
 """
+import weakref
 from typing import Optional
 
 import torch
@@ -133,8 +134,30 @@ def _wgrad_conv(dz: torch.Tensor, x: torch.Tensor, stride: int, relu_in: bool, b
     return dW, (_colsum(dz2) if bias else None)
 
 
+# bf16 twins of residual-stream gradients: uc_layernorm_bwd writes a bf16 copy of the dx it produces; the sub-layer that
+# receives exactly that tensor as its d(x_out) (autograd hands it over untouched when x_out had a single consumer) takes
+# the twin instead of running a conversion pass.  Keyed by storage address, validated by OBJECT IDENTITY through a weak
+# reference (a recycled address can never alias a stale entry), a handful of entries at most.
+_twins = {}
+
+
+def _ln_bwd_residual(x2d, g, dh, eps, dg, db, dres, dt):
+    if dt != torch.bfloat16:
+        return ops.layernorm_bwd(x2d, g, dh, eps, dg, db, dres=dres)
+    dx, twin = ops.layernorm_bwd(x2d, g, dh, eps, dg, db, dres=dres, bf16_twin=True)
+    if len(_twins) > 8:
+        _twins.clear()
+    _twins[dx.data_ptr()] = (weakref.ref(dx), dx._version, twin)
+    return dx
+
+
 def _as_dt(g: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
-    return g if g.dtype == dt else ops.convert(g, dt)
+    if g.dtype == dt:
+        return g
+    hit = _twins.pop(g.data_ptr(), None)
+    if hit is not None and dt == torch.bfloat16 and hit[0]() is g and hit[1] == g._version:
+        return hit[2]
+    return ops.convert(g, dt)
 
 
 def _colsum(src2d: torch.Tensor) -> torch.Tensor:
@@ -318,7 +341,7 @@ class SelfAttnSubLayerFn(Function):
         dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * C)], bias_sink=[qkv.bias])
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
-        dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)
+        dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
         return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10
 
 
@@ -390,7 +413,7 @@ class CrossAttnSubLayerFn(Function):
         dWq, dbq = _wgrad(dq, hq, dt, has_bq, sink=[(projq.weight, 0, C)], bias_sink=[projq.bias])
         dhq = ops.gemm(dq, lin_weight_t(projq, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
-        dx = ops.layernorm_bwd(x2d, g, dhq, ln.eps, dg, db, dres=dxo)
+        dx = _ln_bwd_residual(x2d, g, dhq, ln.eps, dg, db, dxo, dt)
         # key/value side (the other view's tokens)
         dWkv, dbkv = _wgrad(dkv, hy, dt, has_bk or has_bv, sink=[(projk.weight, 0, C), (projv.weight, C, 2 * C)],
                             bias_sink=[projk.bias, projv.bias] if (has_bk and has_bv) else None)
@@ -447,7 +470,7 @@ class MlpSubLayerFn(Function):
         dW1, db1 = _wgrad(du, h, dt, has_b1, sink=[(fc1.weight, 0, fc1.weight.shape[0])], bias_sink=[fc1.bias])
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
-        dx = ops.layernorm_bwd(x2d, g, dh, ln.eps, dg, db, dres=dxo)
+        dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
         return (dx, dg, db, dW1, db1, dW2, db2) + (None,) * 5
 
 

@@ -35,8 +35,8 @@ template <typename TD, int NV>
 __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const typename TD::storage* __restrict__ dy,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int64_t rows, float eps) {
+                                                            bf16_t* __restrict__ dx_b, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int64_t rows, float eps) {
     constexpr int C = NV * 256;
     __shared__ float red[2 * C];   // block-level dgamma | dbeta (LDS atomics), then ONE global atomic per column per block
     const int lane = threadIdx.x & 63;
@@ -92,6 +92,12 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const float* __restr
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             *reinterpret_cast<float4_t*>(dx + row * C + (i * 64 + lane) * 4) = o;
+            if (dx_b) {   // bf16 twin of dx: the operand the previous sub-layer's backward GEMMs will want
+                uint2 pk;
+                pk.x = pack_bf16x2(o.x, o.y);
+                pk.y = pack_bf16x2(o.z, o.w);
+                *reinterpret_cast<uint2*>(dx_b + row * C + (i * 64 + lane) * 4) = pk;
+            }
         }
     }
     __syncthreads();
@@ -115,8 +121,8 @@ template <typename TD>
 __global__ __launch_bounds__(256) void layernorm_bwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                     const typename TD::storage* __restrict__ dy,
                                                                     const float* __restrict__ dres, float* __restrict__ dx,
-                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                    int64_t rows, int C, float eps) {
+                                                                    bf16_t* __restrict__ dx_b, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -141,13 +147,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_generic_kernel(const float*
         float o = rstd * (d * gamma[c] - s1 - xh * s2);
         if (dres) o += dres[row * C + c];
         dx[row * C + c] = o;
+        if (dx_b) dx_b[row * C + c] = f32_to_bf16(o);
         unsafeAtomicAdd(dgamma + c, d * xh);
         unsafeAtomicAdd(dbeta + c, d);
     }
 }
 
 extern "C" int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
-                                float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream) {
+                                void* dx_bf16, float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream) {
+    bf16_t* dx_b = (bf16_t*)dx_bf16;
     UC_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "uc_layernorm_bwd: null pointer");
     UC_REQUIRE(rows >= 0 && C > 0, "uc_layernorm_bwd: bad shape");
     UC_REQUIRE(dy_dtype == UC_F32 || dy_dtype == UC_BF16, "uc_layernorm_bwd: bad dy dtype %d", dy_dtype);
@@ -156,15 +164,15 @@ extern "C" int uc_layernorm_bwd(const float* x, const float* gamma, const void* 
     const int nv = C / 256;
     if (C % 256 != 0 || !(nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8)) {
         const unsigned g = (unsigned)ceil_div64(rows, 4);
-        if (dy_dtype == UC_F32) hipLaunchKernelGGL((layernorm_bwd_generic_kernel<F32Tag>), dim3(g), dim3(256), 0, st, x, gamma, (const float*)dy, dres, dx, dgamma, dbeta, rows, C, eps);
-        else hipLaunchKernelGGL((layernorm_bwd_generic_kernel<BF16Tag>), dim3(g), dim3(256), 0, st, x, gamma, (const bf16_t*)dy, dres, dx, dgamma, dbeta, rows, C, eps);
+        if (dy_dtype == UC_F32) hipLaunchKernelGGL((layernorm_bwd_generic_kernel<F32Tag>), dim3(g), dim3(256), 0, st, x, gamma, (const float*)dy, dres, dx, dx_b, dgamma, dbeta, rows, C, eps);
+        else hipLaunchKernelGGL((layernorm_bwd_generic_kernel<BF16Tag>), dim3(g), dim3(256), 0, st, x, gamma, (const bf16_t*)dy, dres, dx, dx_b, dgamma, dbeta, rows, C, eps);
         UC_CHECK_LAUNCH("uc_layernorm_bwd");
         return UC_OK;
     }
     const unsigned grid = (unsigned)min((int64_t)256, ceil_div64(rows, 8));
 #define UC_LNB(TD_, NV_)                                                                                                \
     hipLaunchKernelGGL((layernorm_bwd_kernel<TD_, NV_>), dim3(grid), dim3(512), 0, st, x, gamma,                            \
-                       (const typename TD_::storage*)dy, dres, dx, dgamma, dbeta, rows, eps)
+                       (const typename TD_::storage*)dy, dres, dx, dx_b, dgamma, dbeta, rows, eps)
 #define UC_LNB_NV(TD_)                      \
     switch (C / 256) {                      \
         case 1: UC_LNB(TD_, 1); break;      \
