@@ -7,7 +7,8 @@ sub-layer's backward is one Function calling uc_hip entry points:
     pre-LN sub-layer  x_out = x + f(LN(x)):   backward gets d(x_out) and returns
         dx = LN_bwd(x, gamma, df/dh) + d(x_out)              (residual add fused into uc_layernorm_bwd)
     linear y = h W^T + b:
-        dW = dy^T h   -> uc_transpose2d (both operands, K padded to 64) + split-K uc_gemm with fp32 atomics
+        dW = dy^T h   -> uc_gemm_tn (both operands row-major, transposing LDS reads, split-K slabs + uc_splitk_reduce —
+                         straight into the flat gradient buffer under the Trainer); fp32 mode: uc_transpose2d + fp32 uc_gemm
         db = column sums of dy formed inside uc_gemm_tn; dh = uc_gemm(dy, W^T)   (W^T prepared once per weight version)
     attention: uc_attention_fwd saves LSE; uc_attention_bwd recomputes P tile by tile (dQ kernel + dK/dV kernel)
     RoPE: gradients of the rotated q/k are rotated back in place with the inverse angle (curope2d.py:24-28)
