@@ -34,7 +34,10 @@ enum uc_status {
 
 /* Text of the last error on the calling thread ("" if none). */
 const char* uc_last_error(void);
-/* ABI version; bumped when a signature changes. */
+/* ABI version; bumped when a signature or the uc_gemm_desc layout changes.
+ *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
+ *      fp8 attention, DINOv2 token ops. */
+#define UC_ABI_VERSION 2
 int uc_abi_version(void);
 
 /* ------------------------------------------------------------------------------------

@@ -81,6 +81,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 2   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+
+
 def load():
     """Load libuc_hip.so (once). Raises UcHipError if it has not been built."""
     global _lib
@@ -98,6 +101,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = i32
         fn.argtypes = args
+    if lib.uc_abi_version() != ABI_VERSION:
+        raise UcHipError(f"{LIB_PATH} has ABI version {lib.uc_abi_version()}, this binding expects {ABI_VERSION}: rebuild it "
+                         "with `python -m uniception_amd.build`")
     _lib = lib
     return lib
 

@@ -11,4 +11,4 @@ void uc_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* uc_last_error(void) { return g_uc_err; }
-extern "C" int uc_abi_version(void) { return 1; }
+extern "C" int uc_abi_version(void) { return UC_ABI_VERSION; }
