@@ -20,6 +20,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 #include "gemm_glds.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // erf-GELU of the bf16 MFMA path.  libm's erff is a branchy two-range evaluation (~50 VALU ops per element once both
@@ -502,9 +503,25 @@ static void launch_variant(const GldsParams& p, hipStream_t st) {
 // variant: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2 of 64x64), 2 = 256x256 (4x4 of 64x64)
 int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
     switch (variant) {
-        case 1: launch_variant<256, 128, 4, 2, 2>(p, st); break;
+        case 1: {
+            static int deep1 = -1;
+            if (deep1 < 0) { const char* e = getenv("UC_GEMM_SMALL_STAGES"); deep1 = e ? atoi(e) : 3; }
+            const int64_t wgs = ceil_div64(p.M, 256) * ceil_div64(p.N, 128) * (p.split_k > 1 ? p.split_k : 1);
+            if (deep1 == 3 && wgs <= 256) launch_variant<256, 128, 4, 2, 3>(p, st);   // latency regime, see below
+            else launch_variant<256, 128, 4, 2, 2>(p, st);
+            break;
+        }
         case 2: launch_variant<256, 256, 4, 4, 2>(p, st); break;
-        default: launch_variant<128, 128, 2, 2, 2>(p, st); break;
+        default: {
+            // latency regime (fewer workgroups than CUs: every K-step waits for its own DMA): a 3-stage ring keeps two
+            // stages in flight per workgroup
+            static int deep = -1;
+            if (deep < 0) { const char* e = getenv("UC_GEMM_SMALL_STAGES"); deep = e ? atoi(e) : 3; }
+            const int64_t wgs = ceil_div64(p.M, 128) * ceil_div64(p.N, 128) * (p.split_k > 1 ? p.split_k : 1);
+            if (deep == 3 && wgs <= 512) launch_variant<128, 128, 2, 2, 3>(p, st);
+            else launch_variant<128, 128, 2, 2, 2>(p, st);
+            break;
+        }
     }
     return 0;
 }

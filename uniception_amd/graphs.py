@@ -6,7 +6,7 @@ capture) and replays it with the inputs copied into static buffers.  Shapes, pre
 time; call `recapture()` after changing weights (the prepared bf16 weight copies are graph inputs by address, and a rebuilt
 cache would leave the graph reading freed memory).
 
-Measured (MI355X, ViT-L + DPT, 512x512): the replay takes the same 16.6 / 18.7 / 25.6 ms for 1 / 2 / 4 pairs as the eager
+Measured (MI355X, ViT-L + DPT, 512x512): the replay takes the same time for 1 / 2 / 4 pairs (15.2 / 17.6 / 24.3 ms) as the eager
 path — the asynchronous launch path already keeps ahead of the GPU, whose small-batch time is set by tile-count-starved GEMMs
 (M = 2048 tokens gives 128 tiles for 256 CUs).  The graph therefore buys CPU headroom (one replay call instead of ~640
 launches per forward), not latency.
