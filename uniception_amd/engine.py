@@ -388,3 +388,43 @@ def conv_transpose_ks(x: torch.Tensor, ct: nn.ConvTranspose2d) -> torch.Tensor:
     w, b = convt_weights(ct, x.dtype)
     y = ops.gemm(x.view(-1, Cin), w, b)
     return ops.convt_scatter(y, B, H, W, k, ct.out_channels)
+
+
+# ---------------------------------------------------------------------------------------------
+# two-stream execution of independent branches (latency regime)
+# ---------------------------------------------------------------------------------------------
+_side_streams = {}
+# Two-stream execution pays while a branch's launches leave CUs idle: -25 % time at 1 pair, -12 % at 8, -5 % at 16 pairs; at
+# 64 pairs it is +1-3 % but every kernel then overlaps a foreign one, which inflates per-kernel durations (the dense GEMM's
+# average 464 -> 607 us) and blurs the roofline accounting of the headline run — so it is limited to <= 16 pairs x 1024 tokens.
+BRANCH_TOKENS_MAX = int(os.environ.get("UNICEPTION_AMD_BRANCH_TOKENS_MAX", "16384"))
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=()):
+    """Runs two independent sub-graphs; when they are small (`rows` tokens/pixels each <= BRANCH_TOKENS_MAX: their kernels
+    launch fewer workgroups than the chip has CUs) and no gradient is recorded, the second one goes to a side HIP stream so
+    both halves of the chip work.  `inputs1` are the tensors fn1 reads that were produced on the current stream (they are
+    recorded on the side stream for the caching allocator); outputs of fn1 are recorded on the current stream."""
+    if torch.is_grad_enabled() or rows > BRANCH_TOKENS_MAX or not inputs1 or not inputs1[0].is_cuda:
+        return fn0(), fn1()
+    main = torch.cuda.current_stream()
+    side = side_stream(inputs1[0].device)
+    side.wait_stream(main)
+    for t in inputs1:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        out1 = fn1()
+    out0 = fn0()
+    main.wait_stream(side)
+    for t in (out1 if isinstance(out1, (tuple, list)) else (out1,)):
+        if torch.is_tensor(t):
+            t.record_stream(main)
+    return out0, out1
+

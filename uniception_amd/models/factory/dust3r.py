@@ -8,6 +8,7 @@ from typing import List, Tuple
 import torch
 import torch.nn as nn
 
+from ... import engine
 from ..encoders.base import ViTEncoderInput
 from ..encoders.croco import CroCoEncoder
 from ..info_sharing.base import MultiViewTransformerInput
@@ -154,11 +155,15 @@ class DUSt3R(nn.Module):
                                  final.features[v].float()] for v in range(2)}
 
         with torch.autocast("cuda", enabled=False):
-            ho1 = self._downstream_head(1, outs, shape1)
-            ho2 = self._downstream_head(2, outs, shape2)
-            fo1 = self.adaptor(AdaptorInput(adaptor_feature=ho1.decoded_channels, output_shape_hw=shape1))
-            fo2 = self.adaptor(AdaptorInput(adaptor_feature=ho2.decoded_channels, output_shape_hw=shape2))
-            res1 = {"pts3d": fo1.value.permute(0, 2, 3, 1).contiguous(), "conf": fo1.confidence.permute(0, 2, 3, 1).contiguous()}
-            res2 = {"pts3d_in_other_view": fo2.value.permute(0, 2, 3, 1).contiguous(),
-                    "conf": fo2.confidence.permute(0, 2, 3, 1).contiguous()}
+            def head(num, shape):
+                ho = self._downstream_head(num, outs, shape)
+                fo = self.adaptor(AdaptorInput(adaptor_feature=ho.decoded_channels, output_shape_hw=shape))
+                return fo.value.permute(0, 2, 3, 1).contiguous(), fo.confidence.permute(0, 2, 3, 1).contiguous()
+
+            # the two heads are independent: on two streams when the batch is too small to fill the chip
+            feats2 = outs["2"] if isinstance(outs["2"], list) else [outs["2"]]
+            n_tok = feats2[-1].shape[0] * feats2[-1].shape[2] * feats2[-1].shape[3]
+            (p1, c1), (p2, c2) = engine.run_branches(lambda: head(1, shape1), lambda: head(2, shape2), n_tok, inputs1=tuple(feats2))
+            res1 = {"pts3d": p1, "conf": c1}
+            res2 = {"pts3d_in_other_view": p2, "conf": c2}
         return res1, res2

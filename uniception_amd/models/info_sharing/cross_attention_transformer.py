@@ -129,6 +129,15 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
             pos = [None] * V
         taken = []
         for d in range(self.depth):
+            if V == 2:   # the two branches of a depth level are independent (Jacobi update): two streams when they are small
+                b0, b1 = self.multi_view_branches[0][d], self.multi_view_branches[1][d]
+                x0, x1 = xs
+                xs = list(engine.run_branches(
+                    lambda: b0.forward_tokens(x0, x1, B, N, N, pos[0], pos[1], dt),
+                    lambda: b1.forward_tokens(x1, x0, B, N, N, pos[1], pos[0], dt), B * N, inputs1=(x0, x1)))
+                if d in take_indices:
+                    taken.append([engine.layernorm(x, self.norm, torch.float32) if norm_intermediate else x for x in xs])
+                continue
             new = []
             for v in range(V):
                 others = [u for u in range(V) if u != v]
