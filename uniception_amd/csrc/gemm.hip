@@ -513,7 +513,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const bool b_ok = !d->bias || ((uintptr_t)d->bias % 16 == 0);
             const bool r_ok = !d->residual || (((uintptr_t)d->residual % 16 == 0) && (d->ldr % 4 == 0) &&
                                                (!d->residual2 || (uintptr_t)d->residual2 % 16 == 0));
-            g.vec_ok = (c_ok && b_ok && r_ok) ? 1 : 0;
+            const bool x_ok = (!d->preact_out || (uintptr_t)d->preact_out % 16 == 0) && (!d->dact_u || (uintptr_t)d->dact_u % 8 == 0);
+            g.vec_ok = (c_ok && b_ok && r_ok && x_ok) ? 1 : 0;
             g.preact = d->preact_out; g.split_k = d->split_k > 1 ? d->split_k : 1;
             g.dact_u = (const bf16_t*)d->dact_u; g.dact_act = d->dact_act;
             { static int gm = -1; if (gm < 0) { const char* e = getenv("UC_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } g.group_m = gm; }
@@ -533,8 +534,53 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 const int64_t waste256 = ceil_div64(d->N, 256) * 256 - d->N, waste128 = ceil_div64(d->N, 128) * 128 - d->N;
                 if (variant == 2 && waste256 - waste128 >= 128 && t256x128 * sk >= 160) variant = 1;
             }
+            static int trace_on = -1;
+            if (trace_on < 0) { const char* e = getenv("UC_GEMM_TRACE"); trace_on = e ? atoi(e) : 0; }
+            g.trace = nullptr;
+            static unsigned long long* trace_buf = nullptr;
+            const size_t trace_cap = 1 << 16;
+            if (trace_on) {
+                if (!trace_buf) (void)hipMalloc((void**)&trace_buf, trace_cap * 6 * sizeof(unsigned long long));
+                g.trace = trace_buf;
+            }
             uc_launch_gemm_glds(g, variant, st);
             UC_CHECK_LAUNCH("uc_gemm(glds)");
+            if (trace_on) {   // diagnostics only: per-CU timeline statistics of this launch to stderr
+                (void)hipStreamSynchronize(st);
+                const int bm = variant >= 1 ? 256 : 128, bn = variant == 2 ? 256 : 128;
+                size_t nwg = (size_t)ceil_div64(d->M, bm) * ceil_div64(d->N, bn) * (size_t)g.split_k;
+                if (nwg > trace_cap) nwg = trace_cap;
+                unsigned long long* h = (unsigned long long*)malloc(nwg * 6 * sizeof(unsigned long long));
+                (void)hipMemcpy(h, trace_buf, nwg * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                double pro = 0, loop = 0, epi = 0; unsigned long long tmin = ~0ull, tmax = 0;
+                for (size_t i = 0; i < nwg; ++i) {
+                    pro += (double)(h[i*6+1] - h[i*6+0]); loop += (double)(h[i*6+2] - h[i*6+1]); epi += (double)(h[i*6+3] - h[i*6+2]);
+                    if (h[i*6+0] < tmin) tmin = h[i*6+0];
+                    if (h[i*6+3] > tmax) tmax = h[i*6+3];
+                }
+                // per-CU gaps: sort WGs by (xcc, hw id cu/se bits) then start time
+                struct Rec { unsigned long long key, s, e; };
+                Rec* r = (Rec*)malloc(nwg * sizeof(Rec));
+                for (size_t i = 0; i < nwg; ++i) {
+                    const unsigned hw = (unsigned)h[i*6+4];
+                    const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+                    r[i].key = ((h[i*6+5] & 0xf) << 12) | (se << 8) | (sh << 4) | cu; r[i].s = h[i*6+0]; r[i].e = h[i*6+3];
+                }
+                qsort(r, nwg, sizeof(Rec), [](const void* a, const void* b) -> int {
+                    const Rec* x = (const Rec*)a; const Rec* y = (const Rec*)b;
+                    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+                    return x->s < y->s ? -1 : (x->s > y->s ? 1 : 0); });
+                double gap = 0; size_t ngap = 0, ncu = 0; double overlap = 0;
+                for (size_t i = 0; i < nwg; ++i) {
+                    if (i == 0 || r[i].key != r[i-1].key) { ++ncu; continue; }
+                    const double gp = (double)r[i].s - (double)r[i-1].e;
+                    if (gp >= 0) { gap += gp; ++ngap; } else overlap += 1;
+                }
+                fprintf(stderr, "[uc_gemm trace] M=%lld N=%lld K=%lld variant=%d wgs=%zu cus=%zu span=%.1f us | per WG: prologue %.2f us, loop %.2f us, epilogue %.2f us | same-CU gap %.2f us (n=%zu, overlapping pairs %.0f)\n",
+                        (long long)d->M, (long long)d->N, (long long)d->K, variant, nwg, ncu, (tmax - tmin) * 0.01,
+                        pro / nwg * 0.01, loop / nwg * 0.01, epi / nwg * 0.01, ngap ? gap / ngap * 0.01 : 0.0, ngap, overlap);
+                free(h); free(r);
+            }
             return UC_OK;
         }
         p.tiles_m = (int)ceil_div64(d->M, BM);

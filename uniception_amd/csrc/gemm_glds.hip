@@ -97,19 +97,20 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_byte
         : "memory");
 }
 
+// chunk swizzle key of LDS row r: 128-B rows (r>>1)&7, 64-B rows 3*((r>>2)&1) — both make the ds_read_b128 fragment
+// loads (lane = row, lane>>4 = k chunk) conflict-free within the hardware's 16-lane service groups
+template <int BK_>
+__device__ __forceinline__ int glds_swz(int r) { return BK_ == 64 ? ((r >> 1) & 7) : (((r >> 2) & 1) * 3); }
+
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-// Shared epilogue: bias -> activation -> fused RoPE-2D -> residual(s) -> store, or the packed-VT store of V tiles.
+// Epilogue of V tiles that are written in the packed VT layout (un-swapped orientation).
 template <int FA>
-__device__ __forceinline__ void glds_epilogue(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
-                                              int64_t wave_n, int lane, int ksplit) {
+__device__ __forceinline__ void glds_epilogue_vt(const GldsParams& p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane) {
     const int frow = lane & 15;
-    // =============================== epilogue ===============================
     const int g = lane >> 4;
-    if (wave_n >= p.N) return;
-
-    if (mode == 2) {
+    {
         // acc[i][j][r]: token row m = wave_m + 16i + 4g + r, channel column wave_n + 16j + frow
         const int head = (int)((wave_n - p.vt_col0) >> 6);
         const int nheads = (int)((p.N - p.vt_col0) >> 6);
@@ -150,155 +151,215 @@ __device__ __forceinline__ void glds_epilogue(const GldsParams& p, float4_t (&ac
                 }
             }
         }
-        return;
     }
+}
 
-    // swapped modes: acc[i][j][r]: row m = wave_m + 16i + frow; 4 consecutive columns wave_n + 16j + 4g + r
-    float b4[4][4];
+// Epilogue of the swapped orientation (bias -> activation -> fused RoPE-2D -> residual(s) -> dact -> store).
+//
+// In the accumulator layout one store instruction touches 16 rows x 32-64 B, and the vector memory path retires about
+// one row segment per 4 cycles per CU whatever its width: a 256x256 tile's store tail took 7 us (bf16 or fp32 output,
+// tools/probes/store_tail.hip) against 1-2 us when every instruction covers whole 128-B lines.  So each wave bounces its
+// 16x64 fragment rows through a private, XOR-swizzled 4-KiB LDS block (the stage buffers are free after the K-loop)
+// and does all global traffic — pre-activation copy, residual reads, dact reads, the store — with a lane owning 4
+// consecutive columns and 16 lanes covering one row (4 rows x 256 B of fp32 or 4 x 128 B of bf16 per instruction).
+// Bias/activation move to that layout too; RoPE (partner channels live in one lane of the accumulator layout) is
+// applied before the bounce.
+//
+// Run-time option tests must not sit inside per-element code: a `p.act` test per value compiled into a scalar compare
+// and branch per ELEMENT (the epilogue then cost as much as six K-steps, half of it instruction fetch: the kernel was
+// 40 k lines of ISA).  The two shapes that carry the forward are specialised at compile time —
+//   KIND 0: bf16 output, no residual (qkv, fc1, kv projections, every convolution), ACT a template parameter;
+//   KIND 1: fp32 output added to one or two fp32 residual streams (proj, fc2);
+// everything else (split-K slabs, pre-activation copies, dact, bf16 residuals, partial column blocks, unaligned
+// operands) takes a rolled generic drain whose option tests are per 4-column group.
+template <int ACT>
+__device__ __forceinline__ float glds_act_c(float v) {
+    if constexpr (ACT == UC_ACT_GELU_ERF) return glds_gelu(v);
+    else if constexpr (ACT == UC_ACT_RELU) return fmaxf(v, 0.f);
+    else return v;
+}
+
+// LDS bounce block of one wave: 16 rows x 256 B, 16-B chunk c of row r stored at chunk c ^ r (conflict-free for the
+// accumulator-layout ds_write_b128 and the row-contiguous ds_read_b128 alike)
+__device__ __forceinline__ void glds_bounce_write(char* buf, int frow, int g, int j, float4_t v) {
+    *reinterpret_cast<float4_t*>(buf + frow * 256 + (((4 * j + g) ^ frow) << 4)) = v;
+}
+__device__ __forceinline__ float4_t glds_bounce_read(const char* buf, int R, int cchunk) {
+    return *reinterpret_cast<const float4_t*>(buf + R * 256 + ((cchunk ^ R) << 4));
+}
+
+// accumulator rows of fragment row-block i (+ bias and RoPE for mode 1) -> bounce block
+template <int FA>
+__device__ __forceinline__ void glds_stage_rows(const GldsParams& p, float4_t (&acc)[FA][4], int i, int mode, int64_t wave_m,
+                                                int64_t wave_n, int frow, int g, char* buf) {
+    if (mode == 1) {
+        const int64_t m = min(wave_m + 16 * i + frow, p.M - 1);
+        int py = (int)p.rope_pos[m * 2 + 0];
+        int px = (int)p.rope_pos[m * 2 + 1];
+        py = min(max(py, 0), p.rope_npos - 1);
+        px = min(max(px, 0), p.rope_npos - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t nb = wave_n + 16 * j + 4 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b4[j][r] = 0.f;
-        if (p.bias) {
-            if (p.vec_ok && nb + 3 < p.N) {
-                const float4_t bb = *reinterpret_cast<const float4_t*>(p.bias + nb);
-                b4[j][0] = bb.x; b4[j][1] = bb.y; b4[j][2] = bb.z; b4[j][3] = bb.w;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b4[j][r] = (nb + r < p.N) ? p.bias[nb + r] : 0.f;
+        for (int h = 0; h < 2; ++h) {      // fragment pair (2h, 2h+1) = channels d, d+16 of the y (h = 0) / x (h = 1) half
+            const float4_t* tb = reinterpret_cast<const float4_t*>(p.rope_table + (h ? px : py) * 16 + 4 * g);
+            const float4_t c0 = tb[0], c1 = tb[1];                               // (cos,sin) x 4
+            const float cs[4] = {c0.x, c0.z, c1.x, c1.z}, sn[4] = {c0.y, c0.w, c1.y, c1.w};
+            float4_t bu = (float4_t){0.f, 0.f, 0.f, 0.f}, bw = bu;
+            if (p.bias) {                  // rope tiles are whole 64-column heads inside N (launcher-checked), bias 16-B aligned or scalar
+                const float* bp = p.bias + wave_n + 32 * h + 4 * g;
+                bu = (float4_t){bp[0], bp[1], bp[2], bp[3]};
+                bw = (float4_t){bp[16], bp[17], bp[18], bp[19]};
             }
+            float4_t ou, ow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u = acc[i][2 * h][r] + bu[r], w = acc[i][2 * h + 1][r] + bw[r];   // no activation with RoPE (launcher-checked)
+                ou[r] = u * cs[r] - w * sn[r];
+                ow[r] = w * cs[r] + u * sn[r];
+            }
+            glds_bounce_write(buf, frow, g, 2 * h, ou);
+            glds_bounce_write(buf, frow, g, 2 * h + 1, ow);
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds_bounce_write(buf, frow, g, j, acc[i][j]);
+    }
+}
+
+template <int FA, int ACT, int KIND>
+__device__ __forceinline__ void glds_epilogue_fast(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                                   int64_t wave_n, int lane, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    const int crow = lane >> 4, cchunk = lane & 15;          // drain layout: row 4*pass + crow, columns 4*cchunk..+3
+    const int64_t nb = wave_n + 4 * cchunk;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if (mode != 1 && p.bias) bias4 = *reinterpret_cast<const float4_t*>(p.bias + nb);
+    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;      // row 16i + 4ps + crow exists iff 16i + 4ps < rows_left
+    constexpr int ESZ = KIND == 0 ? 2 : 4;
+    char* cp = (char*)p.C + ((wave_m + crow) * p.ldc + nb) * ESZ;
+    const int64_t cstep = 4 * p.ldc * ESZ;
+    const char* rp = nullptr; const char* rp2 = nullptr; int64_t rstep = 0;
+    if constexpr (KIND == 1) {
+        rp = (const char*)p.residual + ((wave_m + crow) * p.ldr + nb) * 4;
+        rp2 = p.residual2 ? (const char*)p.residual2 + ((wave_m + crow) * p.ldr + nb) * 4 : nullptr;
+        rstep = 4 * p.ldr * 4;
     }
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
-        const int64_t m = wave_m + 16 * i + frow;
-        if (m >= p.M) continue;
-        float v[4][4];
-        if (p.split_k > 1) {   // partial product of one K slice -> its own [M, ldc] slab of the workspace, nothing else
-            float* slab = (float*)p.C + (int64_t)ksplit * p.M * p.ldc;
+        char* buf = wbuf + (i & 1) * 4096;
+        glds_stage_rows<FA>(p, acc, i, mode, wave_m, wave_n, frow, g, buf);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t nb = wave_n + 16 * j + 4 * g;
-                if (p.vec_ok && nb + 3 < p.N) {
-                    *reinterpret_cast<float4_t*>(slab + m * p.ldc + nb) = acc[i][j];
+        for (int ps = 0; ps < 4; ++ps) {
+            float4_t v = glds_bounce_read(buf, 4 * ps + crow, cchunk);
+            if (16 * i + 4 * ps < rows_left) {
+                if (mode != 1) {
+                    v += bias4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = glds_act_c<ACT>(v[r]);
+                }
+                if constexpr (KIND == 0) {
+                    *reinterpret_cast<uint2*>(cp) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (nb + r < p.N) slab[m * p.ldc + nb + r] = acc[i][j][r];
+                    v += *reinterpret_cast<const float4_t*>(rp);
+                    if (rp2) v += *reinterpret_cast<const float4_t*>(rp2);
+                    *reinterpret_cast<float4_t*>(cp) = v;
                 }
             }
-            continue;
-        }
-        if (p.preact) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t nb = wave_n + 16 * j + 4 * g;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (nb + r >= p.N) continue;
-                    const float u = acc[i][j][r] + b4[j][r];
-                    if (p.out_dtype == UC_F32) ((float*)p.preact)[m * p.ldc + nb + r] = u;
-                    else ((bf16_t*)p.preact)[m * p.ldc + nb + r] = f32_to_bf16(u);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[j][r] = glds_act(acc[i][j][r] + b4[j][r], p.act);
-        if (mode == 1) {
-            int py = (int)p.rope_pos[m * 2 + 0];
-            int px = (int)p.rope_pos[m * 2 + 1];
-            py = min(max(py, 0), p.rope_npos - 1);
-            px = min(max(px, 0), p.rope_npos - 1);
-            const float4_t* ty = reinterpret_cast<const float4_t*>(p.rope_table + py * 16 + 4 * g);
-            const float4_t* tx = reinterpret_cast<const float4_t*>(p.rope_table + px * 16 + 4 * g);
-            const float4_t cy0 = ty[0], cy1 = ty[1], cx0 = tx[0], cx1 = tx[1];  // (cos,sin) x 4
-            const float cyc[4] = {cy0.x, cy0.z, cy1.x, cy1.z}, cys[4] = {cy0.y, cy0.w, cy1.y, cy1.w};
-            const float cxc[4] = {cx0.x, cx0.z, cx1.x, cx1.z}, cxs[4] = {cx0.y, cx0.w, cx1.y, cx1.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float u0 = v[0][r], w0 = v[1][r], u1 = v[2][r], w1 = v[3][r];
-                v[0][r] = u0 * cyc[r] - w0 * cys[r];
-                v[1][r] = w0 * cyc[r] + u0 * cys[r];
-                v[2][r] = u1 * cxc[r] - w1 * cxs[r];
-                v[3][r] = w1 * cxc[r] + u1 * cxs[r];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t nb = wave_n + 16 * j + 4 * g;
-            if (nb >= p.N) continue;
-            const bool full = p.vec_ok && nb + 3 < p.N;
-            if (p.residual) {
-                if (full && p.res_dtype == UC_F32) {
-                    const float4_t r4 = *reinterpret_cast<const float4_t*>((const float*)p.residual + m * p.ldr + nb);
-                    v[j][0] += r4.x; v[j][1] += r4.y; v[j][2] += r4.z; v[j][3] += r4.w;
-                    if (p.residual2) {
-                        const float4_t s4 = *reinterpret_cast<const float4_t*>((const float*)p.residual2 + m * p.ldr + nb);
-                        v[j][0] += s4.x; v[j][1] += s4.y; v[j][2] += s4.z; v[j][3] += s4.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (nb + r >= p.N) continue;
-                        const int64_t idx = m * p.ldr + nb + r;
-                        v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual)[idx] : bf16_to_f32(((const bf16_t*)p.residual)[idx]);
-                        if (p.residual2)
-                            v[j][r] += p.res_dtype == UC_F32 ? ((const float*)p.residual2)[idx] : bf16_to_f32(((const bf16_t*)p.residual2)[idx]);
-                    }
-                }
-            }
-            if (p.dact_u) {   // fused activation backward: out = v * act'(u)
-                float u4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (full) {
-                    const uint2 uu = *reinterpret_cast<const uint2*>(p.dact_u + m * p.ldc + nb);
-                    u4[0] = __uint_as_float(uu.x << 16); u4[1] = __uint_as_float(uu.x & 0xffff0000u);
-                    u4[2] = __uint_as_float(uu.y << 16); u4[3] = __uint_as_float(uu.y & 0xffff0000u);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (nb + r < p.N) u4[r] = bf16_to_f32(p.dact_u[m * p.ldc + nb + r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[j][r] *= glds_dact(u4[r], p.dact_act);
-            }
-            if (full) {
-                if (p.out_dtype == UC_F32) {
-                    *reinterpret_cast<float4_t*>((float*)p.C + m * p.ldc + nb) = (float4_t){v[j][0], v[j][1], v[j][2], v[j][3]};
-                } else {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(v[j][0], v[j][1]);
-                    pk.y = pack_bf16x2(v[j][2], v[j][3]);
-                    *reinterpret_cast<uint2*>((bf16_t*)p.C + m * p.ldc + nb) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (nb + r >= p.N) continue;
-                    if (p.out_dtype == UC_F32) ((float*)p.C)[m * p.ldc + nb + r] = v[j][r];
-                    else ((bf16_t*)p.C)[m * p.ldc + nb + r] = f32_to_bf16(v[j][r]);
-                }
-            }
+            cp += cstep;
+            if constexpr (KIND == 1) { rp += rstep; if (rp2) rp2 += rstep; }
         }
     }
 }
 
-// BM_ x BN_ workgroup tile, WAVES_M x WAVES_N wavefronts; a wave owns (16*FA) x 64 outputs, FA = BM_/WAVES_M/16.
-template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES, int A_MODE>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(GldsParams p) {
+// 4 values of row m, columns nb..nb+3 of a [*, ld] matrix of dtype dt: vector access when `full`, else per element inside N
+__device__ __forceinline__ float4_t glds_load4(const void* base, int dt, int64_t idx, bool full, int64_t nb, int64_t N) {
+    float4_t v = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if (full) {
+        if (dt == UC_F32) v = *reinterpret_cast<const float4_t*>((const float*)base + idx);
+        else {
+            const uint2 q = *reinterpret_cast<const uint2*>((const bf16_t*)base + idx);
+            v = (float4_t){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+        }
+    } else {
+        for (int r = 0; r < 4; ++r)
+            if (nb + r < N) v[r] = dt == UC_F32 ? ((const float*)base)[idx + r] : bf16_to_f32(((const bf16_t*)base)[idx + r]);
+    }
+    return v;
+}
+__device__ __forceinline__ void glds_store4(void* base, int dt, int64_t idx, bool full, int64_t nb, int64_t N, float4_t v) {
+    if (full) {
+        if (dt == UC_F32) *reinterpret_cast<float4_t*>((float*)base + idx) = v;
+        else *reinterpret_cast<uint2*>((bf16_t*)base + idx) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    } else {
+        for (int r = 0; r < 4; ++r) {
+            if (nb + r >= N) continue;
+            if (dt == UC_F32) ((float*)base)[idx + r] = v[r]; else ((bf16_t*)base)[idx + r] = f32_to_bf16(v[r]);
+        }
+    }
+}
+
+template <int FA>
+__device__ __forceinline__ void glds_epilogue_generic(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                                      int64_t wave_n, int lane, int ksplit, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    const int crow = lane >> 4, cchunk = lane & 15;
+    const int64_t nb = wave_n + 4 * cchunk;
+    const bool full = p.vec_ok && nb + 3 < p.N;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if (mode != 1 && p.bias && p.split_k <= 1) bias4 = glds_load4(p.bias, UC_F32, nb, full, nb, p.N);
+    float* slab = (float*)p.C + (int64_t)ksplit * p.M * p.ldc;
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        char* buf = wbuf + (i & 1) * 4096;
+        glds_stage_rows<FA>(p, acc, i, mode, wave_m, wave_n, frow, g, buf);
+#pragma unroll 1
+        for (int ps = 0; ps < 4; ++ps) {
+            const int R = 4 * ps + crow;
+            float4_t v = glds_bounce_read(buf, R, cchunk);
+            const int64_t m = wave_m + 16 * i + R;
+            if (m >= p.M || nb >= p.N) continue;
+            const int64_t ci = m * p.ldc + nb;
+            if (p.split_k > 1) { glds_store4(slab, UC_F32, ci, full, nb, p.N, v); continue; }
+            if (mode != 1) {
+                v += bias4;
+                if (p.preact) glds_store4(p.preact, p.out_dtype, ci, full, nb, p.N, v);
+                if (p.act == UC_ACT_GELU_ERF) { for (int r = 0; r < 4; ++r) v[r] = glds_gelu(v[r]); }
+                else if (p.act == UC_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+            }
+            if (p.residual) {
+                v += glds_load4(p.residual, p.res_dtype, m * p.ldr + nb, full, nb, p.N);
+                if (p.residual2) v += glds_load4(p.residual2, p.res_dtype, m * p.ldr + nb, full, nb, p.N);
+            }
+            if (p.dact_u) {   // fused activation backward: out = v * act'(u)
+                const float4_t u = glds_load4(p.dact_u, UC_BF16, ci, full, nb, p.N);
+                if (p.dact_act == UC_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f; }
+                else { for (int r = 0; r < 4; ++r) v[r] *= glds_dact(u[r], UC_ACT_GELU_ERF); }
+            }
+            glds_store4(p.C, p.out_dtype, ci, full, nb, p.N, v);
+        }
+    }
+}
+
+// BK_ = 64 (128-B LDS rows) or 32 (64-B rows: half the LDS per stage, so two 8-wave workgroups share a CU and one's
+// prologue/epilogue runs under the other's K-loop); WGS_PER_CU is the co-residency the register budget is sized for.
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES_N / 4) void gemm_bf16_glds_kernel(GldsParams p) {
     static_assert(BN_ / WAVES_N == 64, "a wave owns 64 output columns (one 64-wide head)");
     constexpr int WTM = BM_ / WAVES_M;
     constexpr int FA = WTM / 16;          // A-row fragments per wave (4 or 8)
     static_assert(WTM % 16 == 0 && (FA == 4 || FA == 8), "wave tile rows");
     constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int STAGE_BYTES = (BM_ + BN_) * 128;
-    constexpr int NI = (BM_ + BN_) / 8;   // 1-KiB DMA instructions per stage
+    static_assert(BK_ == 64 || BK_ == 32, "K-step");
+    constexpr int ROWB = BK_ * 2;         // bytes per LDS row
+    constexpr int CPR = ROWB / 16;        // 16-byte chunks per row (8 or 4)
+    constexpr int RPI = 1024 / ROWB;      // rows per 1-KiB DMA instruction (8 or 16)
+    constexpr int STAGE_BYTES = (BM_ + BN_) * ROWB;
+    constexpr int NI = (BM_ + BN_) / RPI; // 1-KiB DMA instructions per stage
     constexpr int PER = NI / NW;          // per wave
     static_assert(NI % NW == 0, "DMA instructions must split evenly over the waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (p.trace) tr0 = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -340,8 +401,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     int st0[A_MODE == UC_A_DENSE ? 1 : PER], st1[A_MODE == UC_A_DENSE ? 1 : PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const int rr = (wave * PER + q) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((rr >> 1) & 7);   // logical chunk stored at physical chunk (lane&7) of row rr
+        const int rr = (wave * PER + q) * RPI + lane / CPR;
+        const int c = (lane % CPR) ^ glds_swz<BK_>(rr);   // logical chunk stored at physical chunk (lane % CPR) of row rr
         if (rr < BM_) {
             int64_t m = m0 + rr;
             if (m >= p.M) m = p.M - 1;
@@ -379,10 +440,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
             if constexpr (A_MODE == UC_A_DENSE) {
                 g = src[q] + k0;
             } else {
-                const bool is_a = (wave * PER + q) * 8 < BM_;   // wave-uniform: an instruction is all-A or all-W
+                const bool is_a = (wave * PER + q) * RPI < BM_;   // wave-uniform: an instruction is all-A or all-W
                 if (is_a) {
-                    const int rr = (wave * PER + q) * 8 + (lane >> 3);
-                    const int c8 = ((lane & 7) ^ ((rr >> 1) & 7)) * 8;
+                    const int rr = (wave * PER + q) * RPI + lane / CPR;
+                    const int c8 = ((lane % CPR) ^ glds_swz<BK_>(rr)) * 8;
                     const int iy = (st0[q] & 0xffff) - 1 + ky, ix = (st0[q] >> 16) - 1 + kx;
                     const bool ok = iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
                     g = ok ? p.A + ((int64_t)(st1[q] + iy * p.cW + ix) * p.cCin + ch0 + c8)
@@ -401,10 +462,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
     // two base registers and two swizzled chunk offsets (one per 32-wide K half) address all 8..12 fragment reads.
     const int frow = lane & 15;
     const int fk = lane >> 4;
-    const int f_sw = (frow >> 1) & 7;
-    const int a_base = (wr * WTM + frow) * 128;
-    const int w_base = (BM_ + wc * 64 + frow) * 128;
-    const int ch_off[2] = {((0 * 4 + fk) ^ f_sw) << 4, ((1 * 4 + fk) ^ f_sw) << 4};
+    const int f_sw = glds_swz<BK_>(frow);
+    const int a_base = (wr * WTM + frow) * ROWB;
+    const int w_base = (BM_ + wc * 64 + frow) * ROWB;
+    const int ch_off[2] = {((0 * 4 + fk) ^ f_sw) << 4, ((1 * 4 + fk) ^ f_sw) << 4};   // [1] unused when BK_ == 32
 
     float4_t acc[FA][4];
 #pragma unroll
@@ -413,23 +474,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     // K range of this workgroup (whole K unless split_k > 1)
-    const int nk_total = (int)(p.K / 64);
+    const int nk_total = (int)(p.K / BK_);
     const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
     const int kt0 = ksplit * nk_per;
-    const int nk = max(0, min(nk_per, nk_total - kt0));
-    const int64_t kbase = (int64_t)kt0 * 64;
+    int nk = max(0, min(nk_per, nk_total - kt0));
+    if (p.dbg & 8) nk = min(nk, 1);                      // diagnostics: one K-step only (launch + prologue + epilogue cost)
+    const int64_t kbase = (int64_t)kt0 * BK_;
     // SWAP: first MFMA operand = W rows -> C^T fragments (lane owns 4 consecutive columns of one row);
     // !SWAP (VT tiles): first operand = A rows (lane owns 4 consecutive tokens of one channel).
     auto compute_stage = [&](const char* st, auto swap_tag) {
         constexpr bool SWAP = decltype(swap_tag)::value;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK_ / 32; ++ks) {
             bf16x8_t af[FA], wf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 2048);
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 16 * ROWB);
 #pragma unroll
             for (int i = 0; i < FA; ++i) {
-                uint4 raw = *reinterpret_cast<const uint4*>(st + a_base + ch_off[ks] + i * 2048);
+                uint4 raw = *reinterpret_cast<const uint4*>(st + a_base + ch_off[ks] + i * 16 * ROWB);
                 if constexpr (A_MODE != UC_A_DENSE) {
                     if (p.relu_a) raw = glds_relu_bf16x8(raw);   // uniform flag: ReLU of the DPT residual conv unit, applied on load
                 }
@@ -451,21 +513,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
             for (int kt = 0; kt < nk; ++kt) {
                 wait_vmcnt<0>();                 // this wave's pieces of stage kt have landed
                 __builtin_amdgcn_s_barrier();    // ... and everyone else's; every wave is done reading stage kt-1
+                if (p.trace && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
                 asm volatile("" ::: "memory");
-                if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * 64);
+                if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
                 compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag);
             }
         } else {
             // 3-stage ring, DMA two K-steps ahead: the loads of step kt+1 stay in flight across the barrier of step kt.
             if (nk > 0) issue_stage(0, kbase);
-            if (nk > 1) issue_stage(1, kbase + 64);
+            if (nk > 1) issue_stage(1, kbase + BK_);
             int cur = 0;
             for (int kt = 0; kt < nk; ++kt) {
                 if (kt + 1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
+                if (p.trace && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
                 asm volatile("" ::: "memory");
                 int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
-                if (kt + 2 < nk) issue_stage(nxt, kbase + (int64_t)(kt + 2) * 64);
+                if (kt + 2 < nk) issue_stage(nxt, kbase + (int64_t)(kt + 2) * BK_);
                 compute_stage(smem + cur * STAGE_BYTES, swap_tag);
                 cur = (cur == 2) ? 0 : cur + 1;
             }
@@ -477,15 +541,57 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_glds_kernel(G
         main_loop(std::true_type{});
     }
 
-    glds_epilogue<FA>(p, acc, mode, wave_m, wave_n, lane, ksplit);
+    if (p.dbg & 4) {                                     // diagnostics: no epilogue (keeps the accumulators live)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s == 12345.678f) reinterpret_cast<float*>(p.C)[0] = s;
+        return;
+    }
+    // every wave is done with the last stage: the ring becomes the epilogue's bounce space (8 KiB per wave)
+    static_assert(STAGES * STAGE_BYTES >= NW * 8192, "bounce space");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (p.trace) tr2 = __builtin_amdgcn_s_memrealtime();
+    if (wave_n < p.N) {
+        // a fresh definition of the lane id: keeps the compiler from hoisting the epilogue's per-lane address math above
+        // the K-loop, where it spilled loop-carried registers of the 128-VGPR kernels
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        char* wbuf = smem + wave * 8192;
+        const bool plain = p.vec_ok && wave_n + 64 <= p.N && p.split_k <= 1 && !p.preact && !p.dact_u && !(p.dbg & 16);
+        if (mode == 2) glds_epilogue_vt<FA>(p, acc, wave_m, wave_n, lane);
+        else if (plain && p.out_dtype == UC_BF16 && !p.residual) {
+            if (p.act == UC_ACT_GELU_ERF) glds_epilogue_fast<FA, UC_ACT_GELU_ERF, 0>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            else if (p.act == UC_ACT_RELU) glds_epilogue_fast<FA, UC_ACT_RELU, 0>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_fast<FA, UC_ACT_NONE, 0>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+        } else if (plain && p.out_dtype == UC_F32 && p.residual && p.res_dtype == UC_F32 && p.act == UC_ACT_NONE)
+            glds_epilogue_fast<FA, UC_ACT_NONE, 1>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+        else
+            glds_epilogue_generic<FA>(p, acc, mode, wave_m, wave_n, lane, ksplit, wbuf);
+    }
+    if (p.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* t = p.trace + (size_t)blockIdx.x * 6;
+            t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime(); t[4] = hw; t[5] = xcc;
+        }
+    }
 }
 
-template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE>
+template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1>
 static void launch_variant_mode(GldsParams p, hipStream_t st) {
     p.tiles_m = (int)ceil_div64(p.M, BM_);
     p.tiles_n = (int)ceil_div64(p.N, BN_);
-    auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES, A_MODE>;
-    constexpr int smem = STAGES * (BM_ + BN_) * 128;
+    auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES, A_MODE, BK_, WGS_PER_CU>;
+    constexpr int smem = STAGES * (BM_ + BN_) * BK_ * 2;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -512,6 +618,10 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
             break;
         }
         case 2: launch_variant<256, 256, 4, 4, 2>(p, st); break;
+        case 3:   // two co-resident workgroups per CU (dense operands only)
+            if (p.a_mode == UC_A_CONV3X3) launch_variant<256, 128, 4, 2, 2>(p, st);
+            else launch_variant_mode<256, 128, 4, 2, 3, UC_A_DENSE, 32, 2>(p, st);
+            break;
         default: {
             // latency regime (fewer workgroups than CUs: every K-step waits for its own DMA): a 3-stage ring keeps two
             // stages in flight per workgroup
