@@ -19,6 +19,7 @@
 #include "common.h"
 #include "gemm_glds.h"
 #include <stdlib.h>
+#include <algorithm>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
@@ -500,8 +501,12 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                        "uc_gemm: dact_u needs the bf16 direct-to-LDS kernels, bf16 output and a plain epilogue");
         }
         const bool glds_dense = d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a;
+        // the conv DMA addresses a tile's input window (the images its 256 output rows touch) with 32-bit byte offsets
+        const int64_t conv_window_bytes = d->a_mode == UC_A_CONV3X3
+            ? (256 / std::max<int64_t>(1, (int64_t)d->conv_Ho * d->conv_Wo) + 2) * (int64_t)d->conv_H * d->conv_W * d->conv_Cin * 2 : 0;
         const bool glds_conv = d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 == 0 &&
-                               (int64_t)d->conv_B * d->conv_H * d->conv_W < (int64_t)1 << 30;
+                               (int64_t)d->conv_B * d->conv_H * d->conv_W < (int64_t)1 << 30 && conv_window_bytes < (int64_t)1 << 31 &&
+                               (int64_t)256 * d->K * 2 < (int64_t)1 << 31;
         if ((glds_dense || glds_conv) && forced_variant != -1) {
             GldsParams g;
             g.A = (const bf16_t*)d->A; g.lda = d->lda; g.W = (const bf16_t*)d->W; g.M = d->M; g.N = d->N; g.K = d->K;
@@ -533,6 +538,11 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 // panel (N = 128: half of every tile): take the 256x128 tile there
                 const int64_t waste256 = ceil_div64(d->N, 256) * 256 - d->N, waste128 = ceil_div64(d->N, 128) * 128 - d->N;
                 if (variant == 2 && waste256 - waste128 >= 128 && t256x128 * sk >= 160) variant = 1;
+                // 256x128 tiles with enough workgroups for two per CU: the 32-deep K-step form (72 KiB of LDS, two co-resident
+                // 8-wave workgroups) keeps 16 waves on a CU where the 64-deep form (96 KiB) leaves 8
+                static int co = -1;
+                if (co < 0) { const char* e = getenv("UC_GEMM_CORESIDENT"); co = e ? atoi(e) : 1; }
+                if (variant == 1 && t256x128 * sk >= 512 && co) variant = 3;
             }
             static int trace_on = -1;
             if (trace_on < 0) { const char* e = getenv("UC_GEMM_TRACE"); trace_on = e ? atoi(e) : 0; }

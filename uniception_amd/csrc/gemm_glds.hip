@@ -65,9 +65,6 @@ __device__ __forceinline__ int glds_xcd_remap(int bid, int nwg) {
     return base + k;
 }
 
-// 128 zero bytes: DMA source for im2col positions that fall into the convolution's zero padding
-__device__ uint4 g_zero_chunk[8];
-
 __device__ __forceinline__ uint4 glds_relu_bf16x8(uint4 v) {
     unsigned* q = reinterpret_cast<unsigned*>(&v);
 #pragma unroll
@@ -101,6 +98,22 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_byte
 // loads (lane = row, lane>>4 = k chunk) conflict-free within the hardware's 16-lane service groups
 template <int BK_>
 __device__ __forceinline__ int glds_swz(int r) { return BK_ == 64 ? ((r >> 1) & 7) : (((r >> 2) & 1) * 3); }
+
+// Buffer-addressed form: source = descriptor base + voff + soff (bytes); a lane whose offset is outside the descriptor's
+// range gets zeros written to its 16 LDS bytes.  s_nop 4 covers SGPR (descriptor / soffset / M0) write -> VMEM read.
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16_buf_to_lds(unsigned voff, uint4_t srd, unsigned soff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff)
+        : "memory");
+}
 
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
@@ -391,68 +404,77 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     const bool is_rope = A_MODE == UC_A_DENSE && !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
     const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
 
-    // ---- DMA source pointers: instruction I = wave*PER + q covers combined-tile rows [8I, 8I+8) ----
-    // dense: src[q] + k0.   conv: A rows are gathered per K-step from the 3x3 window (one tap per 64-channel K-step,
-    // because Cin % 64 == 0); positions inside the zero padding read from g_zero_chunk instead.
-    // Dense: one 64-bit source pointer per instruction.  Conv: two 32-bit words per instruction — A rows keep the packed
-    // window origin (oy*s | ox*s << 16) and the image's first pixel index, W rows a 32-bit element offset; the lane's
-    // channel chunk is re-derived — so the 16-wave 256x256 tile stays inside its 128-VGPR budget.
+    // ---- DMA sources: instruction I = wave*PER + q covers combined-tile rows [RPI*I, RPI*(I+1)) ----
+    // Dense: one 64-bit source pointer per instruction, advanced by k0.
+    // Conv: buffer-addressed DMA.  Two wave-uniform descriptors (the input window of this tile, shifted back by one image
+    // row + one pixel so that tap (ky,kx) is a non-negative uniform soffset, and the tile's weight rows); per instruction a
+    // 32-bit byte offset of the lane's row and a 9-bit mask of the taps that fall inside the image.  A tap in the zero
+    // padding sets the lane's offset to 0xffffffff: out of the descriptor's range, and the hardware writes zeros to LDS
+    // (tools/probes/buffer_lds.hip) — no 64-bit per-lane address math, no padding source, half the address registers.
     const bf16_t* src[A_MODE == UC_A_DENSE ? PER : 1];
-    int st0[A_MODE == UC_A_DENSE ? 1 : PER], st1[A_MODE == UC_A_DENSE ? 1 : PER];
+    unsigned st0[A_MODE == UC_A_DENSE ? 1 : PER], st1[A_MODE == UC_A_DENSE ? 1 : PER];
+    uint4_t srd_a = (uint4_t){0u, 0u, 0u, 0u}, srd_w = srd_a;
+    if constexpr (A_MODE != UC_A_DENSE) {
+        const int64_t hw_out = (int64_t)p.cWo * p.cHo;
+        const int b0 = (int)(min(m0, p.M - 1) / hw_out);
+        const unsigned long long pa = (unsigned long long)(p.A + ((int64_t)b0 * p.cH * p.cW - (p.cW + 1)) * p.cCin);
+        const unsigned long long pw = (unsigned long long)(p.W + min(n0, p.N - 1) * p.K);
+        srd_a = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
+        srd_w = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pw), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pw >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int rr = (wave * PER + q) * RPI + lane / CPR;
-        const int c = (lane % CPR) ^ glds_swz<BK_>(rr);   // logical chunk stored at physical chunk (lane % CPR) of row rr
-        if (rr < BM_) {
-            int64_t m = m0 + rr;
-            if (m >= p.M) m = p.M - 1;
-            if constexpr (A_MODE == UC_A_DENSE) {
-                src[q] = p.A + m * p.lda + c * 8;
+        for (int q = 0; q < PER; ++q) {
+            const int rr = (wave * PER + q) * RPI + lane / CPR;
+            const int c = (lane % CPR) ^ glds_swz<BK_>(rr);
+            if (rr < BM_) {
+                const unsigned m = (unsigned)min(m0 + rr, p.M - 1);          // < 2^30 output pixels (launcher-checked)
+                const unsigned mrow = m / (unsigned)p.cWo;
+                const int ox = (int)(m - mrow * (unsigned)p.cWo) * p.cStride;
+                const unsigned b = mrow / (unsigned)p.cHo;
+                const int oy = (int)(mrow - b * (unsigned)p.cHo) * p.cStride;
+                st0[q] = (unsigned)((((int64_t)((int)b - b0) * p.cH + oy) * p.cW + ox) * p.cCin + c * 8) * 2u;
+                unsigned colmask = 0, mask = 0;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) colmask |= ((unsigned)(ox - 1 + kx) < (unsigned)p.cW ? 1u : 0u) << kx;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) mask |= ((unsigned)(oy - 1 + ky) < (unsigned)p.cH ? colmask : 0u) << (3 * ky);
+                st1[q] = mask;
             } else {
-                const int ox = (int)(m % p.cWo);
-                const int oy = (int)((m / p.cWo) % p.cHo);
-                const int b = (int)(m / ((int64_t)p.cWo * p.cHo));
-                st0[q] = (oy * p.cStride) | ((ox * p.cStride) << 16);
-                st1[q] = b * p.cH * p.cW;
+                const int64_t n = min(n0 + (rr - BM_), p.N - 1);
+                st0[q] = (unsigned)((n - min(n0, p.N - 1)) * p.K + c * 8) * 2u;
+                st1[q] = 0x1ffu;
             }
-        } else {
-            int64_t n = n0 + (rr - BM_);
-            if (n >= p.N) n = p.N - 1;
-            if constexpr (A_MODE == UC_A_DENSE) {
-                src[q] = p.W + n * p.K + c * 8;
-            } else {
-                st0[q] = (int)(n * p.K + c * 8);      // < 2^31 elements (checked by the launcher)
-                st1[q] = 0;
-            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int rr = (wave * PER + q) * RPI + lane / CPR;
+            const int c = (lane % CPR) ^ glds_swz<BK_>(rr);   // logical chunk stored at physical chunk (lane % CPR) of row rr
+            if (rr < BM_) src[q] = p.A + min(m0 + rr, p.M - 1) * p.lda + c * 8;
+            else src[q] = p.W + min(n0 + (rr - BM_), p.N - 1) * p.K + c * 8;
         }
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;   // LDS byte address of the dynamic region
     auto issue_stage = [&](int stage, int64_t k0) {
-        int ky = 0, kx = 0, ch0 = 0;
-        if (A_MODE != UC_A_DENSE) {
-            const int tap = (int)(k0 / p.cCin);
-            ch0 = (int)(k0 % p.cCin);
-            ky = tap / 3; kx = tap - 3 * ky;
+        int tap = 0;
+        unsigned soff_a = 0, soff_w = 0;
+        if constexpr (A_MODE != UC_A_DENSE) {
+            tap = (int)(k0 / p.cCin);
+            const int ch0 = (int)(k0 % p.cCin);
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            soff_a = (unsigned)(((ky * p.cW + kx) * p.cCin + ch0) * 2);
+            soff_w = (unsigned)(k0 * 2);
         }
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            const bf16_t* g;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE_BYTES + wave * (PER * 1024) + q * 1024));
             if constexpr (A_MODE == UC_A_DENSE) {
-                g = src[q] + k0;
+                dma16_to_lds(src[q] + k0, dst);
             } else {
                 const bool is_a = (wave * PER + q) * RPI < BM_;   // wave-uniform: an instruction is all-A or all-W
-                if (is_a) {
-                    const int rr = (wave * PER + q) * RPI + lane / CPR;
-                    const int c8 = ((lane % CPR) ^ glds_swz<BK_>(rr)) * 8;
-                    const int iy = (st0[q] & 0xffff) - 1 + ky, ix = (st0[q] >> 16) - 1 + kx;
-                    const bool ok = iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-                    g = ok ? p.A + ((int64_t)(st1[q] + iy * p.cW + ix) * p.cCin + ch0 + c8)
-                           : reinterpret_cast<const bf16_t*>(g_zero_chunk) + c8;
-                } else {
-                    g = p.W + st0[q] + k0;
-                }
+                const unsigned vo = ((st1[q] >> tap) & 1u) ? st0[q] : 0xffffffffu;
+                if (is_a) dma16_buf_to_lds(vo, srd_a, soff_a, dst);
+                else dma16_buf_to_lds(vo, srd_w, soff_w, dst);
             }
-            dma16_to_lds(g, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE_BYTES + wave * (PER * 1024) + q * 1024)));
         }
     };
 
@@ -486,9 +508,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
         constexpr bool SWAP = decltype(swap_tag)::value;
 #pragma unroll
         for (int ks = 0; ks < BK_ / 32; ++ks) {
-            bf16x8_t af[FA], wf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 16 * ROWB);
+            bf16x8_t af[FA];
 #pragma unroll
             for (int i = 0; i < FA; ++i) {
                 uint4 raw = *reinterpret_cast<const uint4*>(st + a_base + ch_off[ks] + i * 16 * ROWB);
@@ -497,13 +517,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
                 }
                 af[i] = __builtin_bit_cast(bf16x8_t, raw);
             }
+            if constexpr (A_MODE == UC_A_DENSE) {
+                bf16x8_t wf[4];
 #pragma unroll
-            for (int i = 0; i < FA; ++i)
+                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 16 * ROWB);
+#pragma unroll
+                for (int i = 0; i < FA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                    }
+            } else {
+                // conv tiles carry more loop state (offsets, tap masks, two descriptors): W fragments are read one at a time
+                // (20 instead of 32 fragment registers) so that nothing spills inside the K-loop
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                    const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 16 * ROWB);
+#pragma unroll
+                    for (int i = 0; i < FA; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], acc[i][j], 0, 0, 0);
                 }
+            }
         }
     };
     auto main_loop = [&](auto swap_tag) {
@@ -619,7 +653,7 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
         }
         case 2: launch_variant<256, 256, 4, 4, 2>(p, st); break;
         case 3:   // two co-resident workgroups per CU (dense operands only)
-            if (p.a_mode == UC_A_CONV3X3) launch_variant<256, 128, 4, 2, 2>(p, st);
+            if (p.a_mode == UC_A_CONV3X3) launch_variant_mode<256, 128, 4, 2, 3, UC_A_CONV3X3, 32, 2>(p, st);
             else launch_variant_mode<256, 128, 4, 2, 3, UC_A_DENSE, 32, 2>(p, st);
             break;
         default: {
