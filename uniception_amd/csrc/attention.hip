@@ -14,6 +14,7 @@
 //
 // attn_f32_kernel — verification mode: one thread per query row, fp32 FMA chains, expf.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
@@ -228,6 +229,175 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// attn_bf16_dma_kernel — the same algorithm for Nk % 64 == 0 (every shape of the 512/1024-pixel forward) with the K and
+// VT tiles staged by buffer-addressed LDS-DMA instead of global -> VGPR -> LDS.  The register-staged kernel needs 184
+// registers (152 VGPR + the score accumulators pushed into 32 AGPRs: 2 waves per SIMD, 64 v_accvgpr moves per key tile);
+// without the 16 staging registers, the tail masks and the per-tile address math this one fits the 128-register budget
+// of 4 waves per SIMD.  Descriptors: K rows / VT rows of this (batch, head); the per-lane byte offsets are loop
+// invariant, the tile advance is a wave-uniform soffset.
+// ---------------------------------------------------------------------------------------
+typedef unsigned att_uint4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void att_dma16(unsigned voff, att_uint4_t srd, unsigned soff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff)
+        : "memory");
+}
+__device__ __forceinline__ att_uint4_t att_make_srd(const void* base) {
+    const unsigned long long pa = (unsigned long long)base;
+    return (att_uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa),
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
+}
+
+__global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE_BYTES];  // 2 stages x (K tile + VT tile)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const bf16_t* Qb = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const bf16_t* Kb = (const bf16_t*)p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const bf16_t* VTb = (const bf16_t*)p.V + ((int64_t)b * p.H + h) * 64 * (int64_t)p.npad;
+
+    bf16x8_t qf[4];
+    {
+        int q = q0 + l31;
+        if (q >= p.Nq) q = p.Nq - 1;  // clamp; rows beyond Nq are never stored
+        const bf16_t* qp = Qb + (int64_t)q * p.q_sn + hi * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+    }
+
+    // ---- DMA assignment: a tile is 8 instructions of 8 rows x 128 B; wave w issues instructions 2w, 2w+1 of both tiles ----
+    const att_uint4_t srd_k = att_make_srd(Kb), srd_v = att_make_srd(VTb);
+    unsigned voff_k[2], voff_v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (wave * 2 + i) * 8 + (lane >> 3);
+        const int cch = (lane & 7) ^ ((rr >> 1) & 7);         // logical chunk stored at physical chunk lane&7 of row rr
+        voff_k[i] = (unsigned)(((int64_t)rr * p.k_sn + cch * 8) * 2);
+        voff_v[i] = (unsigned)(((int64_t)rr * p.npad + cch * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    const unsigned kstep = (unsigned)(KV_TILE * p.k_sn * 2);   // bytes between key tiles of K
+    auto issue_tile = [&](int t, int buf) {
+        const unsigned dst = lds0 + (unsigned)(buf * 2 * ATT_TILE_BYTES + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            att_dma16(voff_k[i], srd_k, (unsigned)t * kstep, __builtin_amdgcn_readfirstlane(dst + i * 1024));
+            att_dma16(voff_v[i], srd_v, (unsigned)t * (KV_TILE * 2), __builtin_amdgcn_readfirstlane(dst + ATT_TILE_BYTES + i * 1024));
+        }
+    };
+    int r_off[4];   // fragment read offsets: row l31 (+32 via immediate), chunk 2*st+hi, st = 0..3 (K and VT tiles alike)
+#pragma unroll
+    for (int st = 0; st < 4; ++st) r_off[st] = att_swz(l31, 2 * st + hi);
+
+    float16_t o[2];
+    o[0] = (float16_t)(0.f);
+    o[1] = (float16_t)(0.f);
+    float m_run = -1e30f;
+    float l_run = 0.f;
+    const float c = p.scale * 1.44269504088896340736f;  // scale * log2(e)
+
+    const int nt = p.Nk / KV_TILE;
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
+        const char* sk = smem + buf * 2 * ATT_TILE_BYTES;
+        const char* sv = sk + ATT_TILE_BYTES;
+
+        float16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            s[kb] = (float16_t)(0.f);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + r_off[st] + kb * (32 * 128));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kb], 0, 0, 0);
+            }
+        }
+        float mt = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const bool grow = (mt - m_run) * c > 8.0f;     // deferred rescale, see attn_bf16_kernel
+        if (__any(grow)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float mc = m_run * c;
+        float psum = 0.f;
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    e[j] = __builtin_amdgcn_exp2f(fmaf(s[kb][hf * 8 + j], c, -mc));
+                    psum += e[j];
+                }
+                union { bf16x8_t v; unsigned u[4]; } pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk.u[j] = pack_bf16x2(e[2 * j], e[2 * j + 1]);
+                pf[kb * 2 + hf] = pk.v;
+            }
+        }
+        l_run += psum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sv + r_off[g] + db * (32 * 128));
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o[db], 0, 0, 0);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 have landed
+        __syncthreads();                                      // ... everyone's; and every wave is done reading tile t
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (p.lse && q < p.Nq && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + q] = m_run * p.scale + logf(l_tot);
+    if (q < p.Nq) {
+        bf16_t* op = (bf16_t*)p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = db * 32 + 8 * g4 + 4 * hi;
+                uint2 pk;
+                pk.x = pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv);
+                pk.y = pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + d) = pk;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // row-major V -> VT packing (for callers that did not get VT from the GEMM epilogue)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__ V, bf16_t* __restrict__ VT, int H,
@@ -353,7 +523,12 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         UC_REQUIRE(o_sb % 4 == 0 && o_sn % 4 == 0 && o_sh % 4 == 0, "uc_attention_fwd(bf16): O strides must be multiples of 4");
         UC_REQUIRE(((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)O % 8 == 0),
                    "uc_attention_fwd(bf16): pointer alignment");
-        hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
+        static int use_dma = -1;
+        if (use_dma < 0) { const char* e = getenv("UC_ATTN_DMA"); use_dma = e ? atoi(e) : 1; }
+        // DMA-staged kernel: whole 64-key tiles, 32-bit byte offsets inside one (batch, head)'s K rows / VT rows
+        const bool dma_ok = use_dma && Nk % KV_TILE == 0 && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
+        if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
     } else if (dtype == UC_F32) {
         UC_REQUIRE(v_layout == UC_V_ROWMAJOR, "uc_attention_fwd(f32): V must be row-major");
         UC_REQUIRE(D <= 64, "uc_attention_fwd(f32): head_dim must be <= 64 (got %d)", D);
