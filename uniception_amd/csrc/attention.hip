@@ -262,24 +262,29 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid.  Workgroup w runs on XCD w % 8 (round-robin dispatch): the nq query tiles that share one (batch, head)'s
+    // K/VT rows are given ids that differ by multiples of 8, so that they meet in ONE XCD's L2 instead of pulling the
+    // same K/VT through all eight.
+    const int nq = (p.Nq + 127) / 128;
+    const int nbh = p.B * p.H;
+    int qt, bh;
+    {
+        const int w = blockIdx.x;
+        const int per_group = 8 * nq;
+        const int grp = w / per_group, within = w - grp * per_group;
+        if ((grp + 1) * 8 <= nbh) { bh = grp * 8 + (within & 7); qt = within >> 3; }
+        else { const int rem = w - (nbh / 8) * 8 * nq; bh = (nbh / 8) * 8 + rem / nq; qt = rem % nq; }   // last, partial group: plain order
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * 128 + wave * 32;
 
     const bf16_t* Qb = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const bf16_t* Kb = (const bf16_t*)p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
     const bf16_t* VTb = (const bf16_t*)p.V + ((int64_t)b * p.H + h) * 64 * (int64_t)p.npad;
 
-    bf16x8_t qf[4];
-    {
-        int q = q0 + l31;
-        if (q >= p.Nq) q = p.Nq - 1;  // clamp; rows beyond Nq are never stored
-        const bf16_t* qp = Qb + (int64_t)q * p.q_sn + hi * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
-    }
-
     // ---- DMA assignment: a tile is 8 instructions of 8 rows x 128 B; wave w issues instructions 2w, 2w+1 of both tiles ----
     const att_uint4_t srd_k = att_make_srd(Kb), srd_v = att_make_srd(VTb);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
     unsigned voff_k[2], voff_v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -288,7 +293,6 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
         voff_k[i] = (unsigned)(((int64_t)rr * p.k_sn + cch * 8) * 2);
         voff_v[i] = (unsigned)(((int64_t)rr * p.npad + cch * 8) * 2);
     }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
     const unsigned kstep = (unsigned)(KV_TILE * p.k_sn * 2);   // bytes between key tiles of K
     auto issue_tile = [&](int t, int buf) {
         const unsigned dst = lds0 + (unsigned)(buf * 2 * ATT_TILE_BYTES + wave * 2048);
@@ -298,9 +302,35 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
             att_dma16(voff_v[i], srd_v, (unsigned)t * (KV_TILE * 2), __builtin_amdgcn_readfirstlane(dst + ATT_TILE_BYTES + i * 1024));
         }
     };
+
+    // ---- Q: the wave's 32 query rows (128 B each) arrive by DMA too — 4 instructions of 8 whole rows instead of 4 loads
+    //      that touch 32 rows x 32 B each (the vector memory path pays per row segment) — into the second stage buffer,
+    //      which the K/VT ring only needs from tile 1 on.  Rows beyond Nq fall outside the descriptor: zeros. ----
+    {
+        const unsigned long long qa = (unsigned long long)(Qb + (int64_t)q0 * p.q_sn);
+        const int64_t q_rows = min((int64_t)32, (int64_t)p.Nq - q0);
+        att_uint4_t srd_q = att_make_srd((const void*)qa);
+        srd_q.z = (unsigned)__builtin_amdgcn_readfirstlane((int)(q_rows > 0 ? ((q_rows - 1) * p.q_sn + 64) * 2 : 0));
+        const unsigned dstq = lds0 + (unsigned)(2 * ATT_TILE_BYTES + wave * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = i * 8 + (lane >> 3);
+            const int cch = (lane & 7) ^ ((rr >> 1) & 7);
+            att_dma16((unsigned)(((int64_t)rr * p.q_sn + cch * 8) * 2), srd_q, 0u, __builtin_amdgcn_readfirstlane(dstq + i * 1024));
+        }
+    }
     int r_off[4];   // fragment read offsets: row l31 (+32 via immediate), chunk 2*st+hi, st = 0..3 (K and VT tiles alike)
 #pragma unroll
     for (int st = 0; st < 4; ++st) r_off[st] = att_swz(l31, 2 * st + hi);
+
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // Q^T fragments (B operand): lane (q = l31, hi) holds Q[q][16s + 8hi .. +7], s = 0..3
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(smem + 2 * ATT_TILE_BYTES + wave * 4096 + r_off[s]);
+    __syncthreads();     // every wave holds its Q fragments before tile 1 overwrites the buffer
 
     float16_t o[2];
     o[0] = (float16_t)(0.f);
@@ -310,10 +340,6 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
     const float c = p.scale * 1.44269504088896340736f;  // scale * log2(e)
 
     const int nt = p.Nk / KV_TILE;
-    issue_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
@@ -378,22 +404,29 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
         __syncthreads();                                      // ... everyone's; and every wave is done reading tile t
     }
 
+    // ---- normalise; bounce the wave's 32 x 64 outputs through its private 4 KiB of the (now free) ring so that every
+    //      store instruction writes 8 whole 128-B rows instead of 32 rows x 16 B ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = __builtin_amdgcn_rcpf(l_tot);
     const int q = q0 + l31;
     if (p.lse && q < p.Nq && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + q] = m_run * p.scale + logf(l_tot);
-    if (q < p.Nq) {
-        bf16_t* op = (bf16_t*)p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh;
+    char* ob = smem + wave * 4096;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = db * 32 + 8 * g4 + 4 * hi;
-                uint2 pk;
-                pk.x = pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv);
-                pk.y = pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv);
-                *reinterpret_cast<uint2*>(op + d) = pk;
-            }
+        for (int g4 = 0; g4 < 4; ++g4) {
+            uint2 pk;       // channels 32db + 8g4 + 4hi .. +3 of query l31 = half of 16-B chunk 4db + g4
+            pk.x = pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv);
+            pk.y = pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv);
+            *reinterpret_cast<uint2*>(ob + l31 * 128 + (((4 * db + g4) ^ (l31 & 7)) << 4) + hi * 8) = pk;
+        }
+    bf16_t* obase = (bf16_t*)p.O + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int R = 8 * ps + (lane >> 3);
+        const int chunk = (lane & 7) ^ (R & 7);
+        const uint4 v = *reinterpret_cast<const uint4*>(ob + R * 128 + ((lane & 7) << 4));
+        if (q0 + R < p.Nq) *reinterpret_cast<uint4*>(obase + (int64_t)(q0 + R) * p.o_sn + chunk * 8) = v;
     }
 }
 
@@ -526,8 +559,8 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         static int use_dma = -1;
         if (use_dma < 0) { const char* e = getenv("UC_ATTN_DMA"); use_dma = e ? atoi(e) : 1; }
         // DMA-staged kernel: whole 64-key tiles, 32-bit byte offsets inside one (batch, head)'s K rows / VT rows
-        const bool dma_ok = use_dma && Nk % KV_TILE == 0 && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
-        if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
+        const bool dma_ok = use_dma && (int64_t)((Nq + 127) / 128) * H * B < ((int64_t)1 << 31) && Nk % KV_TILE == 0 && (uintptr_t)O % 16 == 0 && o_sb % 8 == 0 && o_sn % 8 == 0 && o_sh % 8 == 0 && (int64_t)32 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
+        if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
     } else if (dtype == UC_F32) {
         UC_REQUIRE(v_layout == UC_V_ROWMAJOR, "uc_attention_fwd(f32): V must be row-major");
