@@ -242,36 +242,51 @@ template <int FA, int ACT, int KIND>
 __device__ __forceinline__ void glds_epilogue_fast(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
                                                    int64_t wave_n, int lane, char* wbuf) {
     const int frow = lane & 15, g = lane >> 4;
-    const int crow = lane >> 4, cchunk = lane & 15;          // drain layout: row 4*pass + crow, columns 4*cchunk..+3
-    const int64_t nb = wave_n + 4 * cchunk;
-    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f};
-    if (mode != 1 && p.bias) bias4 = *reinterpret_cast<const float4_t*>(p.bias + nb);
-    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;      // row 16i + 4ps + crow exists iff 16i + 4ps < rows_left
+    // drain layout.  KIND 0 (bf16 out): a lane owns 8 consecutive columns, 8 lanes cover a row, an instruction stores 8
+    // rows x 128 B as dwordx4.  KIND 1 (fp32): 4 columns per lane, 16 lanes per row, 4 rows x 256 B per instruction.
+    constexpr int LPR = KIND == 0 ? 8 : 16;              // lanes per row
+    constexpr int RPP = 64 / LPR;                        // rows per pass
+    constexpr int NPS = 16 / RPP;                        // passes per 16-row block
+    const int crow = lane / LPR, cc = lane % LPR;
+    const int64_t nb = wave_n + (KIND == 0 ? 8 : 4) * cc;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f}, bias4b = bias4;
+    if (mode != 1 && p.bias) {
+        bias4 = *reinterpret_cast<const float4_t*>(p.bias + nb);
+        if constexpr (KIND == 0) bias4b = *reinterpret_cast<const float4_t*>(p.bias + nb + 4);
+    }
+    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;      // row 16i + RPP*ps + crow exists iff 16i + RPP*ps < rows_left
     constexpr int ESZ = KIND == 0 ? 2 : 4;
     char* cp = (char*)p.C + ((wave_m + crow) * p.ldc + nb) * ESZ;
-    const int64_t cstep = 4 * p.ldc * ESZ;
+    const int64_t cstep = RPP * p.ldc * ESZ;
     const char* rp = nullptr; const char* rp2 = nullptr; int64_t rstep = 0;
     if constexpr (KIND == 1) {
         rp = (const char*)p.residual + ((wave_m + crow) * p.ldr + nb) * 4;
         rp2 = p.residual2 ? (const char*)p.residual2 + ((wave_m + crow) * p.ldr + nb) * 4 : nullptr;
-        rstep = 4 * p.ldr * 4;
+        rstep = RPP * p.ldr * 4;
     }
+    // the next row block is staged before the current one is drained: its LDS writes overlap this block's global traffic
+    glds_stage_rows<FA>(p, acc, 0, mode, wave_m, wave_n, frow, g, wbuf);
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
-        char* buf = wbuf + (i & 1) * 4096;
-        glds_stage_rows<FA>(p, acc, i, mode, wave_m, wave_n, frow, g, buf);
+        const char* buf = wbuf + (i & 1) * 4096;
+        if (i + 1 < FA) glds_stage_rows<FA>(p, acc, i + 1, mode, wave_m, wave_n, frow, g, wbuf + ((i + 1) & 1) * 4096);
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            float4_t v = glds_bounce_read(buf, 4 * ps + crow, cchunk);
-            if (16 * i + 4 * ps < rows_left) {
-                if (mode != 1) {
-                    v += bias4;
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int R = RPP * ps + crow;
+            if constexpr (KIND == 0) {
+                float4_t v = glds_bounce_read(buf, R, 2 * cc), w = glds_bounce_read(buf, R, 2 * cc + 1);
+                if (16 * i + RPP * ps < rows_left) {
+                    if (mode != 1) {
+                        v += bias4; w += bias4b;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = glds_act_c<ACT>(v[r]);
+                        for (int r = 0; r < 4; ++r) { v[r] = glds_act_c<ACT>(v[r]); w[r] = glds_act_c<ACT>(w[r]); }
+                    }
+                    *reinterpret_cast<uint4*>(cp) = (uint4){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w), pack_bf16x2(w.x, w.y), pack_bf16x2(w.z, w.w)};
                 }
-                if constexpr (KIND == 0) {
-                    *reinterpret_cast<uint2*>(cp) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-                } else {
+            } else {
+                float4_t v = glds_bounce_read(buf, R, cc);
+                if (16 * i + RPP * ps < rows_left) {
+                    if (mode != 1) v += bias4;
                     v += *reinterpret_cast<const float4_t*>(rp);
                     if (rp2) v += *reinterpret_cast<const float4_t*>(rp2);
                     *reinterpret_cast<float4_t*>(cp) = v;
@@ -504,7 +519,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     const int64_t kbase = (int64_t)kt0 * BK_;
     // SWAP: first MFMA operand = W rows -> C^T fragments (lane owns 4 consecutive columns of one row);
     // !SWAP (VT tiles): first operand = A rows (lane owns 4 consecutive tokens of one channel).
-    auto compute_stage = [&](const char* st, auto swap_tag) {
+    auto compute_stage = [&](const char* st, auto swap_tag, auto&& mid) {
         constexpr bool SWAP = decltype(swap_tag)::value;
 #pragma unroll
         for (int ks = 0; ks < BK_ / 32; ++ks) {
@@ -538,6 +553,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
                     for (int i = 0; i < FA; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], acc[i][j], 0, 0, 0);
                 }
             }
+            if (ks == 0) mid();
         }
     };
     auto main_loop = [&](auto swap_tag) {
@@ -546,11 +562,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             if (nk > 0) issue_stage(0, kbase);
             for (int kt = 0; kt < nk; ++kt) {
                 wait_vmcnt<0>();                 // this wave's pieces of stage kt have landed
-                __builtin_amdgcn_s_barrier();    // ... and everyone else's; every wave is done reading stage kt-1
+                if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();    // ... and everyone else's; every wave is done reading stage kt-1
                 if (p.trace && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
                 asm volatile("" ::: "memory");
-                if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
-                compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag);
+                // where the next stage's DMA is issued (same-box A/B): dense pieces cost one 64-bit add each and go first
+                // (behind the first MFMA group they lost 0-5 %, split between the wave halves of a SIMD 2-8 %); conv pieces
+                // carry the tap test, s_nop 4 and a descriptor select and go behind the wave's first 16 queued MFMAs (+5 % on
+                // the 256-channel convs)
+                if constexpr (A_MODE == UC_A_DENSE) {
+                    if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
+                    compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag, [] {});
+                } else {
+                    compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag, [&] {
+                        if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
+                    });
+                }
             }
         } else {
             // 3-stage ring, DMA two K-steps ahead: the loads of step kt+1 stay in flight across the barrier of step kt.
@@ -564,7 +590,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
                 asm volatile("" ::: "memory");
                 int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
                 if (kt + 2 < nk) issue_stage(nxt, kbase + (int64_t)(kt + 2) * BK_);
-                compute_stage(smem + cur * STAGE_BYTES, swap_tag);
+                compute_stage(smem + cur * STAGE_BYTES, swap_tag, [] {});
                 cur = (cur == 2) ? 0 : cur + 1;
             }
         }
