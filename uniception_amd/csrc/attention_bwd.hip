@@ -113,13 +113,24 @@ __global__ void attn_delta_kernel(AttnBwdParams p) {
 // =================================================================================================================
 // dQ
 // =================================================================================================================
+// 1-D grid -> (tile, batch*head): workgroup w runs on XCD w % 8 (round-robin dispatch), so the nt tiles that share one
+// (batch, head)'s operands get ids that differ by multiples of 8 and meet in ONE XCD's L2 (see attn_bf16_dma_kernel)
+__device__ __forceinline__ void ab_xcd_order(int w, int nt, int nbh, int& tile, int& bh) {
+    const int per_group = 8 * nt;
+    const int grp = w / per_group, within = w - grp * per_group;
+    if ((grp + 1) * 8 <= nbh) { bh = grp * 8 + (within & 7); tile = within >> 3; }
+    else { const int rem = w - (nbh / 8) * 8 * nt; bh = (nbh / 8) * 8 + rem / nt; tile = rem % nt; }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem_all[4 * TB];   // 2 stages x (K rows | V rows), filled by LDS-DMA
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int tile_, bh_;
+    ab_xcd_order((int)blockIdx.x, (p.Nq + 127) / 128, p.B * p.H, tile_, bh_);
+    const int b = bh_ / p.H, h = bh_ - b * p.H;
+    const int q0 = tile_ * 128 + wave * 32;
     int q = q0 + l31;
     const bool q_ok = q < p.Nq;
     if (!q_ok) q = p.Nq - 1;
@@ -222,8 +233,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int key0 = blockIdx.x * 128 + wave * 32;
+    int tile_, bh_;
+    ab_xcd_order((int)blockIdx.x, (p.Nk + 127) / 128, p.B * p.H, tile_, bh_);
+    const int b = bh_ / p.H, h = bh_ - b * p.H;
+    const int key0 = tile_ * 128 + wave * 32;
     int key = key0 + l31;
     const bool key_ok = key < p.Nk;
     if (!key_ok) key = p.Nk - 1;
@@ -365,8 +378,8 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * H * Nq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((Nk + 127) / 128) * H * B)), dim3(256), 0, st, p);
     UC_CHECK_LAUNCH("uc_attention_bwd");
     return UC_OK;
 }

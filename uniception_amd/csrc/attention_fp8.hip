@@ -56,8 +56,18 @@ __global__ __launch_bounds__(256) void attn_fp8_kernel(AttnF8Params p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid; query tiles of one (batch, head) get ids that differ by multiples of 8 = one XCD's L2 (see attn_bf16_dma_kernel)
+    const int nq = (p.Nq + 127) / 128, nbh = p.B * p.H;
+    int qt, bh;
+    {
+        const int w = blockIdx.x;
+        const int per_group = 8 * nq;
+        const int grp = w / per_group, within = w - grp * per_group;
+        if ((grp + 1) * 8 <= nbh) { bh = grp * 8 + (within & 7); qt = within >> 3; }
+        else { const int rem = w - (nbh / 8) * 8 * nq; bh = (nbh / 8) * 8 + rem / nq; qt = rem % nq; }
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * 128 + wave * 32;
 
     const bf16_t* Qb = p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const bf16_t* Kb = p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
@@ -217,7 +227,7 @@ extern "C" int uc_attention_fwd_fp8(const void* Q, const void* K, const void* VT
     p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.npad = (Nk + 63) / 64 * 64;
     p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
     p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh; p.scale = scale;
-    hipLaunchKernelGGL(attn_fp8_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_fp8_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, (hipStream_t)stream, p);
     UC_CHECK_LAUNCH("uc_attention_fwd_fp8");
     return UC_OK;
 }
