@@ -36,8 +36,8 @@ enum uc_status {
 const char* uc_last_error(void);
 /* ABI version; bumped when a signature or the uc_gemm_desc layout changes.
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
- *      fp8 attention, DINOv2 token ops. */
-#define UC_ABI_VERSION 2
+ *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added. */
+#define UC_ABI_VERSION 3
 int uc_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
@@ -161,6 +161,11 @@ int uc_attention_fwd_fp8(const void* Q, const void* K, const void* VT8, void* O,
                          int64_t o_sh, float scale, uc_stream_t stream);
 int uc_vt_pack_fp8(const void* V, void* VT8, int B, int H, int Nk, int D, int64_t v_sb, int64_t v_sn, int64_t v_sh,
                    uc_stream_t stream);
+/* The same attention with K pre-packed too (Nk % 64 == 0): K8 = e4m3 rows [B,H,Nk,64] from uc_k_pack_fp8 (one conversion
+ * per key instead of one per key AND query tile); both tiles are staged by LDS-DMA.  Q: bf16 strided view. */
+int uc_attention_fwd_fp8_k8(const void* Q, const void* K8, const void* VT8, void* O, int B, int H, int Nq, int Nk, int64_t q_sb,
+                            int64_t q_sn, int64_t q_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale, uc_stream_t stream);
+int uc_k_pack_fp8(const void* K, void* K8, int B, int H, int Nk, int64_t k_sb, int64_t k_sn, int64_t k_sh, uc_stream_t stream);
 
 /* Row-major bf16 V[b*v_sb + n*v_sn + h*v_sh + d] -> packed VT [B,H,D,Npad] (layout above). */
 int uc_vt_pack(const void* V, void* VT, int B, int H, int Nk, int D, int64_t v_sb, int64_t v_sn,

@@ -24,7 +24,7 @@ for (B, H, N) in [(64, 16, 1024), (32, 12, 1024), (16, 16, 4096), (8, 12, 4096),
     vt, vt8 = ops.vt_pack(v), ops.vt_pack_fp8(v)
     fl = 4.0 * B * H * N * N * 64
     t16 = timeit(lambda: ops.attention(q, k, vt, 0.125, v_packed=True))
-    t8 = timeit(lambda: ops.attention_fp8(q, k, vt8, 0.125))
+    t8 = timeit(lambda: ops.attention_fp8(q, k, vt8, 0.125))   # includes the K pre-pack when N % 64 == 0
     tp = timeit(lambda: ops.vt_pack_fp8(v))
     print(f"B={B} H={H} N={N}: bf16 {t16*1e6:8.1f} us {fl/t16/1e12:7.1f} TF/s | fp8 {t8*1e6:8.1f} us {fl/t8/1e12:7.1f} TF/s | "
           f"fp8 V pack {tp*1e6:6.1f} us", flush=True)

@@ -46,6 +46,8 @@ SIGNATURES = {
     "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
     "uc_attention_fwd_fp8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [f32, vp],
     "uc_vt_pack_fp8": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
+    "uc_attention_fwd_fp8_k8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 6 + [f32, vp],
+    "uc_k_pack_fp8": [vp, vp, i32, i32, i32, i64, i64, i64, vp],
     "uc_vt_pack": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
     "uc_patch_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_nchw_to_nhwc": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
@@ -81,7 +83,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 2   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 3   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

@@ -204,14 +204,36 @@ def vt_pack_fp8(v: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt8: torch.Tensor, scale: float) -> torch.Tensor:
-    """q [B,Nq,H,64], k [B,Nk,H,64] bf16 views; vt8 from vt_pack_fp8.  Returns O [B,Nq,H,64] bf16."""
+def k_pack_fp8(k: torch.Tensor) -> torch.Tensor:
+    """k: [B,N,H,64] bf16 view -> e4m3 rows [B,H,Npad,64] (uint8), zero padded: the K operand of the DMA-staged fp8 kernel."""
+    _need_gpu(k)
+    B, N, H, D = k.shape
+    assert k.dtype == torch.bfloat16 and k.stride(3) == 1 and D == 64
+    npad = (N + 63) // 64 * 64
+    out = torch.empty((B, H, npad, D), dtype=torch.uint8, device=k.device)
+    _lib.check(_lib.load().uc_k_pack_fp8(k.data_ptr(), out.data_ptr(), B, H, N, k.stride(0), k.stride(1), k.stride(2), _stream()),
+               "uc_k_pack_fp8")
+    return out
+
+
+def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt8: torch.Tensor, scale: float, prepack_k: Optional[bool] = None) -> torch.Tensor:
+    """q [B,Nq,H,64], k [B,Nk,H,64] bf16 views; vt8 from vt_pack_fp8.  Returns O [B,Nq,H,64] bf16.
+    prepack_k (default: whenever Nk % 64 == 0): convert K once (k_pack_fp8) and run the LDS-DMA kernel
+    (uc_attention_fwd_fp8_k8); otherwise the kernel converts K tiles while staging them (uc_attention_fwd_fp8)."""
     _need_gpu(q, k, vt8)
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     assert q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and D == 64 and q.stride(3) == 1 and k.stride(3) == 1
     assert vt8.dtype == torch.uint8 and vt8.is_contiguous() and vt8.shape == (B, H, 64, (Nk + 63) // 64 * 64)
     out = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
+    if prepack_k is None:
+        prepack_k = Nk % 64 == 0
+    if prepack_k:
+        k8 = k_pack_fp8(k)
+        _lib.check(_lib.load().uc_attention_fwd_fp8_k8(
+            q.data_ptr(), k8.data_ptr(), vt8.data_ptr(), out.data_ptr(), B, H, Nq, Nk, q.stride(0), q.stride(1), q.stride(2),
+            out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()), "uc_attention_fwd_fp8_k8")
+        return out
     _lib.check(_lib.load().uc_attention_fwd_fp8(
         q.data_ptr(), k.data_ptr(), vt8.data_ptr(), out.data_ptr(), B, H, Nq, Nk, q.stride(0), q.stride(1), q.stride(2),
         k.stride(0), k.stride(1), k.stride(2), out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()),
