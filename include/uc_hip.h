@@ -139,7 +139,10 @@ int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);
  *         VT[((b*H + h)*D + d) * Npad + 16*(n/16) + uc_vt_perm(n%16)],  Npad = roundup(Nk,64)
  *         uc_vt_perm(w) = ((w>>2)&1)*8 + (w&3) + 4*(w>>3)
  *       (required by the UC_BF16 MFMA path; produced by uc_gemm's vt epilogue or uc_vt_pack;
- *        v_sb/v_sn/v_sh are ignored).
+ *        v_sb/v_sn/v_sh are ignored).  Positions that hold no key (n >= Nk: the tail of the last 16-key group, where
+ *        they are interleaved with its keys, and the groups up to Npad) must hold finite values — the kernel multiplies
+ *        them by probability 0.  uc_vt_pack writes zeros there; a caller that lets uc_gemm fill VT clears
+ *        positions 16*(Nk/16) .. Npad of every row first.
  * UC_BF16 requires D == 64; UC_F32 supports D <= 64.
  * ---------------------------------------------------------------------------------- */
 enum uc_v_layout { UC_V_ROWMAJOR = 0, UC_V_PACKED_T = 1 };

@@ -229,10 +229,11 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// attn_bf16_dma_kernel — the same algorithm for Nk % 64 == 0 (every shape of the 512/1024-pixel forward) with the K and
+// attn_bf16_dma_kernel — the same algorithm (the VT pad positions of a ragged last tile must hold zeros: uc_vt_pack and
+// ops.vt_buffer guarantee it) with the K and
 // VT tiles staged by buffer-addressed LDS-DMA instead of global -> VGPR -> LDS.  The register-staged kernel needs 184
 // registers (152 VGPR + the score accumulators pushed into 32 AGPRs: 2 waves per SIMD, 64 v_accvgpr moves per key tile);
-// without the 16 staging registers, the tail masks and the per-tile address math this one fits the 128-register budget
+// without the 16 staging registers, the per-chunk tail masks of V and the per-tile address math this one fits the 128-register budget
 // of 4 waves per SIMD.  Descriptors: K rows / VT rows of this (batch, head); the per-lane byte offsets are loop
 // invariant, the tile advance is a wave-uniform soffset.
 // ---------------------------------------------------------------------------------------
@@ -283,7 +284,9 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
     const bf16_t* VTb = (const bf16_t*)p.V + ((int64_t)b * p.H + h) * 64 * (int64_t)p.npad;
 
     // ---- DMA assignment: a tile is 8 instructions of 8 rows x 128 B; wave w issues instructions 2w, 2w+1 of both tiles ----
-    const att_uint4_t srd_k = att_make_srd(Kb), srd_v = att_make_srd(VTb);
+    att_uint4_t srd_k = att_make_srd(Kb);
+    srd_k.z = (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)p.Nk - 1) * p.k_sn + 64) * 2));   // key rows >= Nk read as zeros
+    const att_uint4_t srd_v = att_make_srd(VTb);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
     unsigned voff_k[2], voff_v[2];
 #pragma unroll
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
     float l_run = 0.f;
     const float c = p.scale * 1.44269504088896340736f;  // scale * log2(e)
 
-    const int nt = p.Nk / KV_TILE;
+    const int nt = (p.Nk + KV_TILE - 1) / KV_TILE;
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
@@ -355,6 +358,14 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + r_off[st] + kb * (32 * 128));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kb], 0, 0, 0);
             }
+        }
+        if (t == nt - 1 && (p.Nk & (KV_TILE - 1))) {    // ragged last tile: keys >= Nk (zero K rows, zero VT pads) leave the softmax
+            const int k0 = t * KV_TILE;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Nk) s[kb][r] = -1e30f;
         }
         float mt = s[0][0];
 #pragma unroll
@@ -559,7 +570,7 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         static int use_dma = -1;
         if (use_dma < 0) { const char* e = getenv("UC_ATTN_DMA"); use_dma = e ? atoi(e) : 1; }
         // DMA-staged kernel: whole 64-key tiles, 32-bit byte offsets inside one (batch, head)'s K rows / VT rows
-        const bool dma_ok = use_dma && (int64_t)((Nq + 127) / 128) * H * B < ((int64_t)1 << 31) && Nk % KV_TILE == 0 && (uintptr_t)O % 16 == 0 && o_sb % 8 == 0 && o_sn % 8 == 0 && o_sh % 8 == 0 && (int64_t)32 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
+        const bool dma_ok = use_dma && (int64_t)((Nq + 127) / 128) * H * B < ((int64_t)1 << 31) && (uintptr_t)O % 16 == 0 && o_sb % 8 == 0 && o_sn % 8 == 0 && o_sh % 8 == 0 && (int64_t)32 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
         if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
     } else if (dtype == UC_F32) {

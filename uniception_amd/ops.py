@@ -177,7 +177,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 
 def vt_buffer(B: int, H: int, ntok: int, device) -> torch.Tensor:
     npad = (ntok + 63) // 64 * 64
-    return torch.empty((B, H, 64, npad), dtype=torch.bfloat16, device=device)
+    vt = torch.empty((B, H, 64, npad), dtype=torch.bfloat16, device=device)
+    if npad != ntok:
+        # pad key positions must be finite (the attention kernel multiplies them by P = 0).  Keys are permuted inside every
+        # group of 16 positions, so the pads of a ragged group are interleaved with its keys: clear the whole last group(s)
+        vt[..., (ntok // 16) * 16:].zero_()
+    return vt
 
 
 def vt_pack(v: torch.Tensor) -> torch.Tensor:
