@@ -19,7 +19,7 @@ def timeit(fn, iters=10):
 
 
 for (B, H, W, Cin, Cout, relu) in [(32, 128, 128, 256, 256, True), (32, 64, 64, 256, 256, True), (32, 32, 32, 256, 256, False),
-                                   (32, 256, 256, 256, 128, False), (32, 512, 512, 128, 128, False)]:
+                                   (32, 256, 256, 256, 128, False), (32, 512, 512, 128, 128, False), (32, 128, 128, 96, 256, False)]:
     x = (torch.randn(B, H, W, Cin, device=dev) * 0.5).bfloat16()
     w = (torch.randn(Cout, 9 * Cin, device=dev) / (3 * Cin ** 0.5)).bfloat16()
     b = torch.randn(Cout, device=dev)

@@ -497,14 +497,15 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         if (d->dact_u) {
             UC_REQUIRE(d->dact_act == UC_ACT_GELU_ERF || d->dact_act == UC_ACT_RELU, "uc_gemm: bad dact_act %d", d->dact_act);
             UC_REQUIRE(d->out_dtype == UC_BF16 && d->split_k <= 1 && d->vt_col0 < 0 && d->rope_cols <= 0 && !d->preact_out &&
-                           ((d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a) || (d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 == 0)),
+                           ((d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a) || (d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 32 == 0)),
                        "uc_gemm: dact_u needs the bf16 direct-to-LDS kernels, bf16 output and a plain epilogue");
         }
         const bool glds_dense = d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a;
         // the conv DMA addresses a tile's input window (the images its 256 output rows touch) with 32-bit byte offsets
         const int64_t conv_window_bytes = d->a_mode == UC_A_CONV3X3
             ? (256 / std::max<int64_t>(1, (int64_t)d->conv_Ho * d->conv_Wo) + 2) * (int64_t)d->conv_H * d->conv_W * d->conv_Cin * 2 : 0;
-        const bool glds_conv = d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 == 0 &&
+        // Cin % 64 == 0: any tile; Cin % 32 == 0 (the DPT's 96-channel reassemble stage): the 32-deep K-step tile only
+        const bool glds_conv = d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 32 == 0 &&
                                (int64_t)d->conv_B * d->conv_H * d->conv_W < (int64_t)1 << 30 && conv_window_bytes < (int64_t)1 << 31 &&
                                (int64_t)256 * d->K * 2 < (int64_t)1 << 31;
         if ((glds_dense || glds_conv) && forced_variant != -1) {
@@ -527,7 +528,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
             g.cStride = d->conv_stride; g.cHo = d->conv_Ho; g.cWo = d->conv_Wo;
             int variant = forced_variant;
-            if (variant < 0) {
+            if (d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 != 0) variant = 3;
+            else if (variant < 0) {
                 // tile choice: the 256x256 tile (16 waves) has the best steady state (least LDS fill per flop) but needs
                 // enough tiles to cover the 256 CUs; smaller problems fall back to 256x128 / 128x128 tiles.
                 const int64_t t256 = ceil_div64(d->M, 256) * ceil_div64(d->N, 256);
