@@ -181,8 +181,10 @@ __device__ __forceinline__ void glds_epilogue_vt(const GldsParams& p, float4_t (
 // Run-time option tests must not sit inside per-element code: a `p.act` test per value compiled into a scalar compare
 // and branch per ELEMENT (the epilogue then cost as much as six K-steps, half of it instruction fetch: the kernel was
 // 40 k lines of ISA).  The two shapes that carry the forward are specialised at compile time —
-//   KIND 0: bf16 output, no residual (qkv, fc1, kv projections, every convolution), ACT a template parameter;
-//   KIND 1: fp32 output added to one or two fp32 residual streams (proj, fc2);
+//   glds_epilogue_bf16: bf16 output, no residual (qkv, fc1, kv projections, every convolution), ACT a template parameter,
+//                       bf16 bounce;
+//   glds_epilogue_fast<.., KIND 1>: fp32 output added to one or two fp32 residual streams (proj, fc2), fp32 bounce
+//                       (its KIND 0 form is the fp32-bounce variant of the bf16 store, kept for A/B runs);
 // everything else (split-K slabs, pre-activation copies, dact, bf16 residuals, partial column blocks, unaligned
 // operands) takes a rolled generic drain whose option tests are per 4-column group.
 template <int ACT>
@@ -294,6 +296,80 @@ __device__ __forceinline__ void glds_epilogue_fast(const GldsParams& p, float4_t
             }
             cp += cstep;
             if constexpr (KIND == 1) { rp += rstep; if (rp2) rp2 += rstep; }
+        }
+    }
+}
+
+// bf16 output without residual (qkv, fc1, kv / q projections, every convolution): bias, activation / RoPE and the bf16
+// rounding happen in the accumulator layout, and the bounce carries bf16 — half the LDS bytes of the fp32 bounce
+// (ds_write_b64 + one ds_read_b128 per 16-byte store instead of ds_write_b128 + two reads).  Block of one wave: 16 rows x
+// 128 B; 16-byte chunk c of row r sits at chunk c ^ (r & 7), its two 8-byte halves swapped when r & 8 (rows r and r + 8
+// would otherwise hit the same banks in one ds_write_b64 lane group).
+template <int FA, int ACT>
+__device__ __forceinline__ void glds_epilogue_bf16(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                                   int64_t wave_n, int lane, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    float4_t b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b4[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        if (mode != 1 && p.bias) b4[j] = *reinterpret_cast<const float4_t*>(p.bias + wave_n + 16 * j + 4 * g);
+    }
+    const int wr_off = frow * 128 + (((g & 1) ^ (frow >> 3)) << 3);       // + ((2j + (g>>1)) ^ (frow & 7)) << 4
+    auto stage = [&](int i, char* buf) {
+        if (mode == 1) {
+            const int64_t m = min(wave_m + 16 * i + frow, p.M - 1);
+            int py = (int)p.rope_pos[m * 2 + 0];
+            int px = (int)p.rope_pos[m * 2 + 1];
+            py = min(max(py, 0), p.rope_npos - 1);
+            px = min(max(px, 0), p.rope_npos - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4_t* tb = reinterpret_cast<const float4_t*>(p.rope_table + (h ? px : py) * 16 + 4 * g);
+                const float4_t c0 = tb[0], c1 = tb[1];
+                const float cs[4] = {c0.x, c0.z, c1.x, c1.z}, sn[4] = {c0.y, c0.w, c1.y, c1.w};
+                float4_t bu = (float4_t){0.f, 0.f, 0.f, 0.f}, bw = bu;
+                if (p.bias) {
+                    const float* bp = p.bias + wave_n + 32 * h + 4 * g;
+                    bu = (float4_t){bp[0], bp[1], bp[2], bp[3]};
+                    bw = (float4_t){bp[16], bp[17], bp[18], bp[19]};
+                }
+                float ou[4], ow[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = acc[i][2 * h][r] + bu[r], w = acc[i][2 * h + 1][r] + bw[r];
+                    ou[r] = u * cs[r] - w * sn[r];
+                    ow[r] = w * cs[r] + u * sn[r];
+                }
+                *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ou[0], ou[1]), pack_bf16x2(ou[2], ou[3])};
+                *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + 2 + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ow[0], ow[1]), pack_bf16x2(ow[2], ow[3])};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4_t v = acc[i][j] + b4[j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = glds_act_c<ACT>(v[r]);
+                *reinterpret_cast<uint2*>(buf + wr_off + (((2 * j + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            }
+        }
+    };
+    const int crow = lane >> 3, pch = lane & 7;              // drain: row 8*ps + crow, physical chunk pch
+    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;
+    char* cp = (char*)p.C + ((wave_m + crow) * p.ldc + wave_n) * 2;
+    const int64_t cstep = 8 * p.ldc * 2;
+    stage(0, wbuf);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const char* buf = wbuf + (i & 1) * 2048;
+        if (i + 1 < FA) stage(i + 1, wbuf + ((i + 1) & 1) * 2048);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int R = 8 * ps + crow;
+            uint4 v = *reinterpret_cast<const uint4*>(buf + R * 128 + (pch << 4));
+            if (ps) v = (uint4){v.z, v.w, v.x, v.y};         // rows 8..15 store their halves swapped
+            if (16 * i + 8 * ps < rows_left) *reinterpret_cast<uint4*>(cp + ((pch ^ (R & 7)) << 4)) = v;
+            cp += cstep;
         }
     }
 }
@@ -624,9 +700,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
         const bool plain = p.vec_ok && wave_n + 64 <= p.N && p.split_k <= 1 && !p.preact && !p.dact_u && !(p.dbg & 16);
         if (mode == 2) glds_epilogue_vt<FA>(p, acc, wave_m, wave_n, lane);
         else if (plain && p.out_dtype == UC_BF16 && !p.residual) {
-            if (p.act == UC_ACT_GELU_ERF) glds_epilogue_fast<FA, UC_ACT_GELU_ERF, 0>(p, acc, mode, wave_m, wave_n, lane, wbuf);
-            else if (p.act == UC_ACT_RELU) glds_epilogue_fast<FA, UC_ACT_RELU, 0>(p, acc, mode, wave_m, wave_n, lane, wbuf);
-            else glds_epilogue_fast<FA, UC_ACT_NONE, 0>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            if (p.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            else if (p.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_bf16<FA, UC_ACT_NONE>(p, acc, mode, wave_m, wave_n, lane, wbuf);
         } else if (plain && p.out_dtype == UC_F32 && p.residual && p.res_dtype == UC_F32 && p.act == UC_ACT_NONE)
             glds_epilogue_fast<FA, UC_ACT_NONE, 1>(p, acc, mode, wave_m, wave_n, lane, wbuf);
         else
