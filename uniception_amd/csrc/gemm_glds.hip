@@ -120,9 +120,39 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // Epilogue of V tiles that are written in the packed VT layout (un-swapped orientation).
 template <int FA>
-__device__ __forceinline__ void glds_epilogue_vt(const GldsParams& p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane) {
+__device__ __forceinline__ void glds_epilogue_vt(const GldsParams& p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane,
+                                                 char* wbuf) {
     const int frow = lane & 15;
     const int g = lane >> 4;
+    if (FA == 4 && (p.vt_ntok & 63) == 0 && wave_m + 64 <= p.M && ((uintptr_t)p.vt_out & 15) == 0 && !(p.dbg & 16)) {
+        // The wave's 64 tokens are one aligned 64-position group of one image: 64 channel rows x 128 contiguous bytes of VT.
+        // Bounce [channel d][position] through the wave's LDS block (chunk c of row d at chunk c ^ (d & 7), 8-byte halves
+        // swapped when d & 8) and store whole rows: 8 x dwordx4 instead of 16 x dwordx2 that touch 16 rows x 32 B each.
+        const int head = (int)((wave_n - p.vt_col0) >> 6);
+        const int nheads = (int)((p.N - p.vt_col0) >> 6);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = 16 * j + frow;
+            const float bc = p.bias ? p.bias[wave_n + d] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint2 pk = (uint2){pack_bf16x2(acc[i][j][0] + bc, acc[i][j][1] + bc), pack_bf16x2(acc[i][j][2] + bc, acc[i][j][3] + bc)};
+                *reinterpret_cast<uint2*>(wbuf + d * 128 + (((2 * i + (g & 1)) ^ (d & 7)) << 4) + (((g >> 1) ^ ((d >> 3) & 1)) << 3)) = pk;
+            }
+        }
+        const int b = (int)(wave_m / p.vt_ntok);
+        const int tok0 = (int)(wave_m - (int64_t)b * p.vt_ntok);
+        bf16_t* base = p.vt_out + ((int64_t)b * nheads + head) * 64 * (int64_t)p.vt_npad + tok0;
+        const int crow = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int d = 8 * ps + crow;
+            uint4 v = *reinterpret_cast<const uint4*>(wbuf + d * 128 + (pch << 4));
+            if (ps & 1) v = (uint4){v.z, v.w, v.x, v.y};
+            *reinterpret_cast<uint4*>(base + (int64_t)d * p.vt_npad + ((pch ^ (d & 7)) << 3)) = v;
+        }
+        return;
+    }
     {
         // acc[i][j][r]: token row m = wave_m + 16i + 4g + r, channel column wave_n + 16j + frow
         const int head = (int)((wave_n - p.vt_col0) >> 6);
@@ -698,7 +728,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
         asm volatile("" : "+v"(lane));
         char* wbuf = smem + wave * 8192;
         const bool plain = p.vec_ok && wave_n + 64 <= p.N && p.split_k <= 1 && !p.preact && !p.dact_u && !(p.dbg & 16);
-        if (mode == 2) glds_epilogue_vt<FA>(p, acc, wave_m, wave_n, lane);
+        if (mode == 2) glds_epilogue_vt<FA>(p, acc, wave_m, wave_n, lane, wbuf);
         else if (plain && p.out_dtype == UC_BF16 && !p.residual) {
             if (p.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF>(p, acc, mode, wave_m, wave_n, lane, wbuf);
             else if (p.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU>(p, acc, mode, wave_m, wave_n, lane, wbuf);
