@@ -122,7 +122,7 @@ __device__ __forceinline__ void ab_xcd_order(int w, int nt, int nbh, int& tile, 
     else { const int rem = w - (nbh / 8) * 8 * nt; bh = (nbh / 8) * 8 + rem / nt; tile = rem % nt; }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem_all[4 * TB];   // 2 stages x (K rows | V rows), filled by LDS-DMA
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
             dma_tile(Vb, p.v_sn, k0 + 64, p.Nk, lds0 + ((t + 1) & 1) * 2 * TB + TB, wave, lane);
         }
         const char* smem = smem_all + (t & 1) * 2 * TB;
+        const bool tail = k0 + 64 > p.Nk;
 
         bf16x8_t dsf[4];
 #pragma unroll
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int r = hf * 8 + j;
-                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float pv = (key < p.Nk) ? __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2)) : 0.f;
+                    float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
+                    if (tail && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Nk) pv = 0.f;   // ragged last tile only (uniform test first)
                     e[j] = pv * (dp[r] - dlt);
                 }
                 union { bf16x8_t v; unsigned u[4]; } pk;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
 // =================================================================================================================
 // dK, dV
 // =================================================================================================================
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem_all[4 * TB + 1024];   // 2 stages x (Q rows | dO rows) + 2 x (lse2[64] delta[64])
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     auto stage_aux = [&](int stage, int q0) {   // per-query scalars of the tile: plain loads, 64 threads
         if (tid < 64) {
             const int q = q0 + tid;
-            s_aux[stage * 128 + tid] = (q < p.Nq) ? lse_b[q] * 1.44269504088896340736f : 0.f;
+            s_aux[stage * 128 + tid] = (q < p.Nq) ? lse_b[q] * 1.44269504088896340736f : 1e30f;   // absent query: P = exp2(-1e30) = 0
             s_aux[stage * 128 + 64 + tid] = (q < p.Nq) ? dl_b[q] : 0.f;
         }
     };
@@ -307,12 +308,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
             for (int hf = 0; hf < 2; ++hf) {
                 float pe[8], de[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int r = hf * 8 + j;
-                    const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;   // query index inside the tile
-                    const float pv = (q0 + ql < p.Nq) ? __builtin_amdgcn_exp2f(fmaf(s[r], c, -s_lse[ql])) : 0.f;
-                    pe[j] = pv;
-                    de[j] = pv * (dp[r] - s_dl[ql]);
+                for (int k = 0; k < 2; ++k) {
+                    // queries qb*32 + 8*(2hf+k) + 4hi + (0..3): four consecutive per-query scalars = one 16-byte LDS read each
+                    const float4_t l4 = *reinterpret_cast<const float4_t*>(s_lse + qb * 32 + 8 * (2 * hf + k) + 4 * hi);
+                    const float4_t d4 = *reinterpret_cast<const float4_t*>(s_dl + qb * 32 + 8 * (2 * hf + k) + 4 * hi);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int r = hf * 8 + 4 * k + jj;
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[jj]));
+                        pe[4 * k + jj] = pv;
+                        de[4 * k + jj] = pv * (dp[r] - d4[jj]);
+                    }
                 }
                 union { bf16x8_t v; unsigned u[4]; } a, d2;
 #pragma unroll
