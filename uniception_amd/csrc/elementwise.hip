@@ -191,31 +191,29 @@ extern "C" int uc_convert(const void* src, int sd, void* dst, int dd, int64_t n,
 // =======================================================================================
 template <typename Tag>
 __global__ void bilinear_kernel(const typename Tag::storage* __restrict__ src, typename Tag::storage* __restrict__ dst,
-                                int B, int Hi, int Wi, int C, int Ho, int Wo, int ch, int cw, float sy, float sx,
-                                int64_t items) {
-    const int C8 = C / 8;
-    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = it;
-        const int c8 = (int)(r % C8); r /= C8;
-        const int ox = (int)(r % cw); r /= cw;
-        const int oy = (int)(r % ch);
-        const int b = (int)(r / ch);
-        const float fy = sy * (float)oy, fx = sx * (float)ox;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const typename Tag::storage* base = src + (int64_t)b * Hi * Wi * C + c8 * 8;
-        const V8 p00 = load8<Tag>(base + ((int64_t)y0 * Wi + x0) * C);
-        const V8 p01 = load8<Tag>(base + ((int64_t)y0 * Wi + x1) * C);
-        const V8 p10 = load8<Tag>(base + ((int64_t)y1 * Wi + x0) * C);
-        const V8 p11 = load8<Tag>(base + ((int64_t)y1 * Wi + x1) * C);
-        V8 o;
+                                int B, int Hi, int Wi, int C, int Ho, int Wo, int ch, int cw, float sy, float sx) {
+    // grid (x: 256-thread pieces of one output row's cw * C/8 items, y: output row, z: image): no 64-bit index division
+    // per item (four of them cost more than the interpolation itself and held the kernel at half the HBM rate)
+    const unsigned C8 = (unsigned)C / 8u;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (unsigned)cw * C8) return;
+    const unsigned ox = t / C8, c8 = t - ox * C8;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const typename Tag::storage* base = src + (int64_t)b * Hi * Wi * C + c8 * 8;
+    const V8 p00 = load8<Tag>(base + ((int64_t)y0 * Wi + x0) * C);
+    const V8 p01 = load8<Tag>(base + ((int64_t)y0 * Wi + x1) * C);
+    const V8 p10 = load8<Tag>(base + ((int64_t)y1 * Wi + x0) * C);
+    const V8 p11 = load8<Tag>(base + ((int64_t)y1 * Wi + x1) * C);
+    V8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            o.v[e] = hy * (hx * p00.v[e] + lx * p01.v[e]) + ly * (hx * p10.v[e] + lx * p11.v[e]);
-        store8<Tag>(dst + it * 8, o);
-    }
+    for (int e = 0; e < 8; ++e)
+        o.v[e] = hy * (hx * p00.v[e] + lx * p01.v[e]) + ly * (hx * p10.v[e] + lx * p11.v[e]);
+    store8<Tag>(dst + (((int64_t)b * ch + oy) * cw) * C + (int64_t)t * 8, o);
 }
 
 extern "C" int uc_bilinear_nhwc(const void* src, void* dst, int dtype, int B, int Hi, int Wi, int C, int Ho, int Wo,
@@ -225,12 +223,13 @@ extern "C" int uc_bilinear_nhwc(const void* src, void* dst, int dtype, int B, in
     UC_REQUIRE(crop_h > 0 && crop_h <= Ho && crop_w > 0 && crop_w <= Wo, "uc_bilinear_nhwc: bad crop");
     const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
     const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
-    const int64_t items = (int64_t)B * crop_h * crop_w * (C / 8);
+    UC_REQUIRE(crop_h <= 65535 && B <= 65535 && (int64_t)crop_w * (C / 8) < ((int64_t)1 << 31), "uc_bilinear_nhwc: shape exceeds the launch grid");
+    const dim3 grid((unsigned)(((int64_t)crop_w * (C / 8) + 255) / 256), (unsigned)crop_h, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UC_F32)
-        hipLaunchKernelGGL((bilinear_kernel<F32Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const float*)src, (float*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx, items);
+        hipLaunchKernelGGL((bilinear_kernel<F32Tag>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx);
     else if (dtype == UC_BF16)
-        hipLaunchKernelGGL((bilinear_kernel<BF16Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx, items);
+        hipLaunchKernelGGL((bilinear_kernel<BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx);
     else { uc_set_error("uc_bilinear_nhwc: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_bilinear_nhwc");
     return UC_OK;
