@@ -270,7 +270,7 @@ __device__ __forceinline__ void glds_stage_rows(const GldsParams& p, float4_t (&
     }
 }
 
-template <int FA, int ACT, int KIND>
+template <int FA, int ACT, int KIND, bool NT = false>
 __device__ __forceinline__ void glds_epilogue_fast(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
                                                    int64_t wave_n, int lane, char* wbuf) {
     const int frow = lane & 15, g = lane >> 4;
@@ -319,9 +319,18 @@ __device__ __forceinline__ void glds_epilogue_fast(const GldsParams& p, float4_t
                 float4_t v = glds_bounce_read(buf, R, cc);
                 if (16 * i + RPP * ps < rows_left) {
                     if (mode != 1) v += bias4;
-                    v += *reinterpret_cast<const float4_t*>(rp);
-                    if (rp2) v += *reinterpret_cast<const float4_t*>(rp2);
-                    *reinterpret_cast<float4_t*>(cp) = v;
+                    // NT (outputs of more than 128 MB, half the Infinity Cache): the residual stream is read once and written once per
+                    // sub-layer — streaming it keeps the A / W panels of the K-loop in the L2s (+1.2 % on the forward); smaller
+                    // outputs (the decoder's) stay cacheable, their consumer (LayerNorm) finds them on chip
+                    if constexpr (NT) {
+                        v += __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(rp));
+                        if (rp2) v += __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(rp2));
+                        __builtin_nontemporal_store(v, reinterpret_cast<float4_t*>(cp));
+                    } else {
+                        v += *reinterpret_cast<const float4_t*>(rp);
+                        if (rp2) v += *reinterpret_cast<const float4_t*>(rp2);
+                        *reinterpret_cast<float4_t*>(cp) = v;
+                    }
                 }
             }
             cp += cstep;
@@ -335,7 +344,7 @@ __device__ __forceinline__ void glds_epilogue_fast(const GldsParams& p, float4_t
 // (ds_write_b64 + one ds_read_b128 per 16-byte store instead of ds_write_b128 + two reads).  Block of one wave: 16 rows x
 // 128 B; 16-byte chunk c of row r sits at chunk c ^ (r & 7), its two 8-byte halves swapped when r & 8 (rows r and r + 8
 // would otherwise hit the same banks in one ds_write_b64 lane group).
-template <int FA, int ACT>
+template <int FA, int ACT, bool NT = false>
 __device__ __forceinline__ void glds_epilogue_bf16(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
                                                    int64_t wave_n, int lane, char* wbuf) {
     const int frow = lane & 15, g = lane >> 4;
@@ -398,7 +407,14 @@ __device__ __forceinline__ void glds_epilogue_bf16(const GldsParams& p, float4_t
             const int R = 8 * ps + crow;
             uint4 v = *reinterpret_cast<const uint4*>(buf + R * 128 + (pch << 4));
             if (ps) v = (uint4){v.z, v.w, v.x, v.y};         // rows 8..15 store their halves swapped
-            if (16 * i + 8 * ps < rows_left) *reinterpret_cast<uint4*>(cp + ((pch ^ (R & 7)) << 4)) = v;
+            if (16 * i + 8 * ps < rows_left) {
+                if constexpr (NT) {
+                    const uint4_t vv = (uint4_t){v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<uint4_t*>(cp + ((pch ^ (R & 7)) << 4)));
+                } else {
+                    *reinterpret_cast<uint4*>(cp + ((pch ^ (R & 7)) << 4)) = v;
+                }
+            }
             cp += cstep;
         }
     }
@@ -730,11 +746,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
         const bool plain = p.vec_ok && wave_n + 64 <= p.N && p.split_k <= 1 && !p.preact && !p.dact_u && !(p.dbg & 16);
         if (mode == 2) glds_epilogue_vt<FA>(p, acc, wave_m, wave_n, lane, wbuf);
         else if (plain && p.out_dtype == UC_BF16 && !p.residual) {
-            if (p.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF>(p, acc, mode, wave_m, wave_n, lane, wbuf);
-            else if (p.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU>(p, acc, mode, wave_m, wave_n, lane, wbuf);
-            else glds_epilogue_bf16<FA, UC_ACT_NONE>(p, acc, mode, wave_m, wave_n, lane, wbuf);
-        } else if (plain && p.out_dtype == UC_F32 && p.residual && p.res_dtype == UC_F32 && p.act == UC_ACT_NONE)
-            glds_epilogue_fast<FA, UC_ACT_NONE, 1>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            if (p.nt_out) {
+                if (p.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+                else if (p.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_bf16<FA, UC_ACT_NONE, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            } else {
+                if (p.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+                else if (p.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_bf16<FA, UC_ACT_NONE>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            }
+        } else if (plain && p.out_dtype == UC_F32 && p.residual && p.res_dtype == UC_F32 && p.act == UC_ACT_NONE) {
+            if (p.nt_out) glds_epilogue_fast<FA, UC_ACT_NONE, 1, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_fast<FA, UC_ACT_NONE, 1>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+        }
         else
             glds_epilogue_generic<FA>(p, acc, mode, wave_m, wave_n, lane, ksplit, wbuf);
     }

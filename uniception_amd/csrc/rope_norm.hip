@@ -3,6 +3,8 @@
 // the layout allows, trig hoisted out of the per-head loop (the reference recomputes nothing per
 // head either: kernels.cu:47-50 computes cos/sin once per (token, channel) and loops over heads).
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------
 // RoPE-2D in place.  Reference arithmetic (curope/kernels.cu:36-81, curope.cpp:21-46):
@@ -156,7 +158,7 @@ __device__ __forceinline__ void ln_store4<BF16Tag>(bf16_t* p, float4_t v) {
 
 // Exact-width variant: C == NV*256, no per-chunk predicates, so all NV 16-byte loads of a row are issued back to back
 // (the predicated generic kernel below serialises them behind exec-mask branches: 2.8 TB/s vs 7+ TB/s cache-hot).
-template <typename TI, typename TO, int NV>
+template <typename TI, typename TO, int NV, bool NT = false>
 __global__ __launch_bounds__(256) void layernorm_exact_kernel(const typename TI::storage* __restrict__ x,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
@@ -168,7 +170,12 @@ __global__ __launch_bounds__(256) void layernorm_exact_kernel(const typename TI:
     const typename TI::storage* xr = x + row * C;
     float4_t v[NV], g[NV], bb[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = ln_load4<TI>(xr + (i * 64 + lane) * 4);
+    for (int i = 0; i < NV; ++i) {
+        // NT: an fp32 residual stream larger than half the Infinity Cache is read once here and once by the next residual
+        // epilogue, two GEMMs later — streaming it leaves the caches to the GEMM operands
+        if constexpr (NT && std::is_same<TI, F32Tag>::value) v[i] = __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(xr + (i * 64 + lane) * 4));
+        else v[i] = ln_load4<TI>(xr + (i * 64 + lane) * 4);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         g[i] = *reinterpret_cast<const float4_t*>(gamma + (i * 64 + lane) * 4);
@@ -280,9 +287,16 @@ static void launch_ln(const void* x, const float* g, const float* b, void* y, in
                      ((uintptr_t)y % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)b % 16 == 0) &&
                      (((int64_t)C * sizeof(SI)) % (4 * sizeof(SI)) == 0);
     const bool exact = vec && (C % 256 == 0);
-#define UC_LN_EXACT(NV_)                                                                                             \
-    hipLaunchKernelGGL((layernorm_exact_kernel<TI, TO, NV_>), dim3(grid), dim3(256), 0, st, (const SI*)x, g, b, (SO*)y, \
-                       rows, eps)
+    static int nt_env = -2;
+    if (nt_env == -2) { const char* e = getenv("UC_LN_NT"); nt_env = e ? atoi(e) : -1; }
+    const bool nt = nt_env >= 0 ? nt_env != 0 : (rows * (int64_t)C * (int64_t)sizeof(SI) > ((int64_t)128 << 20));
+#define UC_LN_EXACT(NV_)                                                                                                          \
+    do {                                                                                                                          \
+        if (nt) hipLaunchKernelGGL((layernorm_exact_kernel<TI, TO, NV_, true>), dim3(grid), dim3(256), 0, st, (const SI*)x, g, b,  \
+                                   (SO*)y, rows, eps);                                                                            \
+        else hipLaunchKernelGGL((layernorm_exact_kernel<TI, TO, NV_, false>), dim3(grid), dim3(256), 0, st, (const SI*)x, g, b,    \
+                                (SO*)y, rows, eps);                                                                               \
+    } while (0)
     if (exact && C == 256) UC_LN_EXACT(1);
     else if (exact && C == 512) UC_LN_EXACT(2);
     else if (exact && C == 768) UC_LN_EXACT(3);
