@@ -746,7 +746,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
         const bool plain = p.vec_ok && wave_n + 64 <= p.N && p.split_k <= 1 && !p.preact && !p.dact_u && !(p.dbg & 16);
         if (mode == 2) glds_epilogue_vt<FA>(p, acc, wave_m, wave_n, lane, wbuf);
         else if (plain && p.out_dtype == UC_BF16 && !p.residual) {
-            if (p.nt_out) {
+            if (p.nt_out & (mode == 1 ? 4 : 2)) {
                 if (p.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
                 else if (p.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
                 else glds_epilogue_bf16<FA, UC_ACT_NONE, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
                 else glds_epilogue_bf16<FA, UC_ACT_NONE>(p, acc, mode, wave_m, wave_n, lane, wbuf);
             }
         } else if (plain && p.out_dtype == UC_F32 && p.residual && p.res_dtype == UC_F32 && p.act == UC_ACT_NONE) {
-            if (p.nt_out) glds_epilogue_fast<FA, UC_ACT_NONE, 1, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            if (p.nt_out & 1) glds_epilogue_fast<FA, UC_ACT_NONE, 1, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
             else glds_epilogue_fast<FA, UC_ACT_NONE, 1>(p, acc, mode, wave_m, wave_n, lane, wbuf);
         }
         else
