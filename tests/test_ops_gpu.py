@@ -372,3 +372,22 @@ def test_conv1x1_to4(gpu, dtype, Cin):
     ref = f.float() @ w.t() + b
     out = ops.conv1x1_to4(f.to(gpu), w.to(gpu), b.to(gpu))
     assert rel_l2(out.cpu(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 4, 4), (2, 3, 9, 18), (1, 2, 196, 196), (2, 2, 65, 65), (2, 12, 4, 8), (1, 2, 130, 1370)])
+def test_attention_ragged_keys_next_to_poisoned_memory(gpu, B, H, Nq, Nk):
+    """Ragged key counts on the LDS-DMA kernel: K is a strided view inside a buffer whose other slots are NaN, so a key row
+    read past Nk (instead of the descriptor's zero fill) or an unmasked pad position would surface as NaN / a wrong softmax."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(17 * Nq + Nk)
+    buf = torch.full((B, Nk, 3, H, 64), float("nan")).bfloat16()
+    buf[:, :, 1] = torch.randn(B, Nk, H, 64, generator=g).bfloat16()
+    buf = buf.to(gpu)
+    k = buf[:, :, 1]
+    q = torch.randn(B, Nq, H, 64, generator=g).bfloat16().to(gpu)
+    v = torch.randn(B, Nk, H, 64, generator=g).bfloat16().to(gpu)
+    o = ops.attention(q, k, ops.vt_pack(v), 0.125, v_packed=True)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * 0.125
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v.float())
+    assert torch.isfinite(o).all()
+    assert rel_l2(o.float().cpu(), ref.cpu()) < 4e-3
