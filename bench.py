@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
                     help="fwd: forward inference (BASELINE configs[1], the headline); train: forward + backward + gradient "
                          "all-reduce + AdamW step (BASELINE configs[2])")
-    ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default 64 fwd, 16 train)")
+    ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default 64 fwd, 32 train)")
     ap.add_argument("--encoder", default="croco", choices=["croco", "dinov2"],
                     help="croco: the DUSt3R factory model; dinov2: BASELINE configs[3] — DINOv2 ViT-L/14 encoder (frozen in "
                          "train mode) + the same decoder and heads, default 518x518")
@@ -148,7 +148,7 @@ def main():
     _lib.load()  # fail loudly if the HIP extension is missing
     torch.manual_seed(0)
     if args.pairs is None:
-        args.pairs = 64 if args.mode == "fwd" else 16
+        args.pairs = 64 if args.mode == "fwd" else 32
     if args.img is None:
         args.img = 512 if args.encoder == "croco" else 518
     model = DUSt3R(name="bench", img_size=(args.img, args.img), pred_head_type=args.head)
