@@ -91,3 +91,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// ---- exact division of n < 2^31 by a run-time constant d >= 1 without the ~28-instruction software divide -------------
+// magic m = ceil(2^(31 + ceil(log2 d)) / d) fits 32 bits and floor(n / d) = (n * m) >> (31 + ceil(log2 d)) for every
+// n < 2^31 (m*d - 2^p < d <= 2^(p-31)).  d == 1 is encoded as m == 0.  Host side fills the pair once per launch.
+struct uc_fastdiv { unsigned m, s; };
+static inline uc_fastdiv uc_make_fastdiv(unsigned d) {
+    uc_fastdiv f; f.m = 0; f.s = 0;
+    if (d <= 1) return f;
+    int l = 0;
+    while ((1u << l) < d) ++l;
+    const int p = 31 + l;
+    f.m = (unsigned)((((unsigned __int128)1 << p) + d - 1) / d);
+    f.s = (unsigned)(p - 32);
+    return f;
+}
+__device__ __forceinline__ unsigned uc_div(unsigned n, uc_fastdiv f) { return f.m ? (__umulhi(n, f.m) >> f.s) : n; }

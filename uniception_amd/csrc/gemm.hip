@@ -527,6 +527,10 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             { static int dbg = -1; if (dbg < 0) { const char* e = getenv("UC_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
             g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
             g.cStride = d->conv_stride; g.cHo = d->conv_Ho; g.cWo = d->conv_Wo;
+            if (d->a_mode == UC_A_CONV3X3) {
+                g.dWo = uc_make_fastdiv((unsigned)d->conv_Wo); g.dHo = uc_make_fastdiv((unsigned)d->conv_Ho);
+                g.dHWo = uc_make_fastdiv((unsigned)d->conv_Ho * (unsigned)d->conv_Wo); g.dCin = uc_make_fastdiv((unsigned)d->conv_Cin);
+            }
             int variant = forced_variant;
             if (d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 != 0) variant = 3;
             else if (variant < 0) {

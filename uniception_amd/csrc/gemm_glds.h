@@ -36,6 +36,7 @@ struct GldsParams {
     unsigned long long* trace;   // diagnostics (UC_GEMM_TRACE): per-workgroup {start, loop start, loop end, end} 100-MHz ticks + HW id
     int a_mode, relu_a;
     int cH, cW, cCin, cStride, cHo, cWo;
+    uc_fastdiv dWo, dHo, dHWo, dCin;   // exact fast division by cWo, cHo, cHo*cWo, cCin (conv index math)
 };
 
 // variant: 0 = 128x128 tile (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)

@@ -552,8 +552,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     unsigned st0[A_MODE == UC_A_DENSE ? 1 : PER], st1[A_MODE == UC_A_DENSE ? 1 : PER];
     uint4_t srd_a = (uint4_t){0u, 0u, 0u, 0u}, srd_w = srd_a;
     if constexpr (A_MODE != UC_A_DENSE) {
-        const int64_t hw_out = (int64_t)p.cWo * p.cHo;
-        const int b0 = (int)(min(m0, p.M - 1) / hw_out);
+        const int b0 = (int)uc_div((unsigned)min(m0, p.M - 1), p.dHWo);     // < 2^30 output pixels (launcher-checked)
         const unsigned long long pa = (unsigned long long)(p.A + ((int64_t)b0 * p.cH * p.cW - (p.cW + 1)) * p.cCin);
         const unsigned long long pw = (unsigned long long)(p.W + min(n0, p.N - 1) * p.K);
         srd_a = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
@@ -564,9 +563,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             const int c = (lane % CPR) ^ glds_swz<BK_>(rr);
             if (rr < BM_) {
                 const unsigned m = (unsigned)min(m0 + rr, p.M - 1);          // < 2^30 output pixels (launcher-checked)
-                const unsigned mrow = m / (unsigned)p.cWo;
+                const unsigned mrow = uc_div(m, p.dWo);
                 const int ox = (int)(m - mrow * (unsigned)p.cWo) * p.cStride;
-                const unsigned b = mrow / (unsigned)p.cHo;
+                const unsigned b = uc_div(mrow, p.dHo);
                 const int oy = (int)(mrow - b * (unsigned)p.cHo) * p.cStride;
                 st0[q] = (unsigned)((((int64_t)((int)b - b0) * p.cH + oy) * p.cW + ox) * p.cCin + c * 8) * 2u;
                 unsigned colmask = 0, mask = 0;
@@ -595,8 +594,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
         int tap = 0;
         unsigned soff_a = 0, soff_w = 0;
         if constexpr (A_MODE != UC_A_DENSE) {
-            tap = (int)(k0 / p.cCin);
-            const int ch0 = (int)(k0 % p.cCin);
+            tap = (int)uc_div((unsigned)k0, p.dCin);
+            const int ch0 = (int)k0 - tap * p.cCin;
             const int ky = tap / 3, kx = tap - 3 * ky;
             soff_a = (unsigned)(((ky * p.cW + kx) * p.cCin + ch0) * 2);
             soff_w = (unsigned)(k0 * 2);

@@ -27,6 +27,7 @@ struct TnParams {
     int64_t T, I, J;
     int conv;            // 0 dense, 1 implicit im2col of a 3x3 / pad 1 conv
     int cB, cH, cW, cCin, cStride, cHo, cWo, relu_b;
+    uc_fastdiv dWo, dHo, dCin;   // exact fast division by cWo, cHo, cCin
     float* C;            // [split_k][I, J]
     float* colsum;       // optional: sum_t A[t,i] (the bias gradient) from the tj == 0 tiles: [split_k][I] slabs, or
     int colsum_atomic;   //           with colsum_atomic one [I] buffer that every K slice adds to atomically (+=)
@@ -117,13 +118,13 @@ __global__ __launch_bounds__(BM_ * 4) void gemm_tn_kernel(TnParams p) {
                 } else if constexpr (!CONV) {
                     g = p.B + t * p.ldb + d_col[q];
                 } else {
-                    const int tap = d_col[q] / p.cCin;
+                    const int tap = (int)uc_div((unsigned)d_col[q], p.dCin);
                     const int c = d_col[q] - tap * p.cCin;
-                    const int ky = tap / 3, kx = tap - 3 * ky;
-                    const unsigned tt = (unsigned)t;                        // pixel counts fit 32 bits (checked by the launcher)
-                    const unsigned row = tt / (unsigned)p.cWo;
+                    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;     // tap / 3 for tap in 0..8
+                    const unsigned tt = (unsigned)t;                        // pixel counts fit 31 bits (checked by the launcher)
+                    const unsigned row = uc_div(tt, p.dWo);
                     const int ox = (int)(tt - row * (unsigned)p.cWo);
-                    const int b = (int)(row / (unsigned)p.cHo);
+                    const int b = (int)uc_div(row, p.dHo);
                     const int oy = (int)(row - (unsigned)b * (unsigned)p.cHo);
                     const int iy = oy * p.cStride - 1 + ky, ix = ox * p.cStride - 1 + kx;
                     if (iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW)
@@ -258,6 +259,7 @@ extern "C" int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
         p.cWo = (conv_W - 1) / conv_stride + 1;
         UC_REQUIRE(T == (int64_t)conv_B * p.cHo * p.cWo && J == 9 * (int64_t)conv_Cin, "uc_gemm_tn: conv shape mismatch");
         UC_REQUIRE(T < (int64_t)1 << 31, "uc_gemm_tn: too many pixels");
+        p.dWo = uc_make_fastdiv((unsigned)p.cWo); p.dHo = uc_make_fastdiv((unsigned)p.cHo); p.dCin = uc_make_fastdiv((unsigned)conv_Cin);
     } else {
         UC_REQUIRE(ldb % 8 == 0 && ldb >= J && !relu_b, "uc_gemm_tn: ldb must be a multiple of 8");
     }
