@@ -29,6 +29,7 @@ struct GldsParams {
     int split_k;    // >1: K split over blockIdx groups, slice s writes its fp32 partial product to C + s*M*ldc
     int tiles_m, tiles_n;
     int group_m;  // row panels per L2-sharing tile group (tile traversal order)
+    uc_fastdiv dNwg, dPerGroup, dGm, dGmLast;   // exact fast division by tiles_m*tiles_n, group_m*tiles_n, group_m, tiles_m % group_m
     int vec_ok;   // C / residual / bias satisfy the alignment needed by the 4-wide vector epilogue
     // implicit-GEMM 3x3 convolution over an NHWC image (a_mode == UC_A_CONV3X3): K = 9*Cin, Cin % 64 == 0
     int dbg;      // diagnostics only (UC_GEMM_DBG): 1 skip the in-loop DMA, 2 skip the in-loop barrier, 4 no epilogue, 8 one K-step, 16 generic epilogue only

@@ -21,6 +21,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 #include "gemm_glds.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 // erf-GELU of the bf16 MFMA path.  libm's erff is a branchy two-range evaluation (~50 VALU ops per element once both
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int ksplit = (int)blockIdx.x / nwg;                 // split-K slice (0 when split_k == 1)
+    const int ksplit = p.split_k > 1 ? (int)uc_div(blockIdx.x, p.dNwg) : 0;   // split-K slice
     const int t = glds_xcd_remap((int)blockIdx.x - ksplit * nwg, nwg);
     // Tile order inside an XCD's run: groups of GM row panels swept column by column, so the ~32 tiles an XCD runs
     // concurrently form a GM x (32/GM) block that shares GM A-panels and 32/GM W-panels in its L2 (a plain row-major
@@ -525,11 +526,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     {
         const int GM = p.group_m;
         const int per_group = GM * p.tiles_n;
-        const int grp = t / per_group, within = t - grp * per_group;
+        const int grp = (int)uc_div((unsigned)t, p.dPerGroup), within = t - grp * per_group;
         const int first_m = grp * GM;
-        const int gsz = min(GM, p.tiles_m - first_m);
-        tm = first_m + within % gsz;
-        tn = within / gsz;
+        const bool last = p.tiles_m - first_m < GM;                        // the ragged last group has tiles_m % GM row panels
+        const int gsz = last ? p.tiles_m - first_m : GM;
+        tn = (int)uc_div((unsigned)within, last ? p.dGmLast : p.dGm);
+        tm = first_m + within - tn * gsz;
     }
     const int64_t m0 = (int64_t)tm * BM_;
     const int64_t n0 = (int64_t)tn * BN_;
@@ -779,6 +781,10 @@ template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE, int BK_ = 
 static void launch_variant_mode(GldsParams p, hipStream_t st) {
     p.tiles_m = (int)ceil_div64(p.M, BM_);
     p.tiles_n = (int)ceil_div64(p.N, BN_);
+    p.dNwg = uc_make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
+    p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
+    p.dGm = uc_make_fastdiv((unsigned)p.group_m);
+    p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
     auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES, A_MODE, BK_, WGS_PER_CU>;
     constexpr int smem = STAGES * (BM_ + BN_) * BK_ * 2;
     static bool attr_set = false;
