@@ -28,6 +28,7 @@ struct AttnParams {
     int npad;     // VT row length
     float scale;
     float* lse;   // optional [B,H,Nq]: log-sum-exp of the scaled scores (saved for the backward)
+    uc_fastdiv dGroup, dNq, dH;   // exact fast division by 8*nq, nq, H (workgroup -> (query tile, batch, head) in the DMA kernel)
 };
 
 #define KV_TILE 64
@@ -272,11 +273,14 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
     {
         const int w = blockIdx.x;
         const int per_group = 8 * nq;
-        const int grp = w / per_group, within = w - grp * per_group;
+        const int grp = (int)uc_div((unsigned)w, p.dGroup), within = w - grp * per_group;
         if ((grp + 1) * 8 <= nbh) { bh = grp * 8 + (within & 7); qt = within >> 3; }
-        else { const int rem = w - (nbh / 8) * 8 * nq; bh = (nbh / 8) * 8 + rem / nq; qt = rem % nq; }   // last, partial group: plain order
+        else {   // last, partial group: plain order
+            const int rem = w - (nbh >> 3) * 8 * nq, rb = (int)uc_div((unsigned)rem, p.dNq);
+            bh = (nbh >> 3) * 8 + rb; qt = rem - rb * nq;
+        }
     }
-    const int b = bh / p.H, h = bh - b * p.H;
+    const int b = (int)uc_div((unsigned)bh, p.dH), h = bh - b * p.H;
     const int q0 = qt * 128 + wave * 32;
 
     const bf16_t* Qb = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
@@ -567,6 +571,7 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         UC_REQUIRE(o_sb % 4 == 0 && o_sn % 4 == 0 && o_sh % 4 == 0, "uc_attention_fwd(bf16): O strides must be multiples of 4");
         UC_REQUIRE(((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)O % 8 == 0),
                    "uc_attention_fwd(bf16): pointer alignment");
+        p.dGroup = uc_make_fastdiv((unsigned)(8 * ((Nq + 127) / 128))); p.dNq = uc_make_fastdiv((unsigned)((Nq + 127) / 128)); p.dH = uc_make_fastdiv((unsigned)H);
         static int use_dma = -1;
         if (use_dma < 0) { const char* e = getenv("UC_ATTN_DMA"); use_dma = e ? atoi(e) : 1; }
         // DMA-staged kernel: whole 64-key tiles, 32-bit byte offsets inside one (batch, head)'s K rows / VT rows
