@@ -470,13 +470,51 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__
     }
 }
 
+// D == 64, 16-byte accesses on both sides: 8-channel chunks in, 8-position chunks out (the generic kernel above moves single
+// bf16 values and divides per element)
+__global__ __launch_bounds__(256) void vt_pack64_kernel(const bf16_t* __restrict__ V, bf16_t* __restrict__ VT, int H, int Nk,
+                                                        int npad, int64_t v_sb, int64_t v_sn, int64_t v_sh) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][64 + 8];   // [key][d], 144-byte rows
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+    const bf16_t* vb = V + (int64_t)b * v_sb + (int64_t)h * v_sh;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = threadIdx.x + it * 256;          // 512 chunks: key = idx >> 3, 8 channels from (idx & 7) * 8
+        const int key = idx >> 3, c8 = idx & 7;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (k0 + key < Nk) v = *reinterpret_cast<const uint4*>(vb + (int64_t)(k0 + key) * v_sn + c8 * 8);
+        *reinterpret_cast<uint4*>(&tile[key][c8 * 8]) = v;
+    }
+    __syncthreads();
+    bf16_t* out = VT + ((int64_t)b * H + h) * 64 * (int64_t)npad + k0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = threadIdx.x + it * 256;          // 512 chunks: channel d = idx >> 3, positions (idx & 7) * 8 .. +7
+        const int d = idx >> 3, p8 = (idx & 7) * 8;
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = p8 + j;
+            e[j] = tile[(pos & ~15) + vt_key_of_pos(pos & 15)][d];
+        }
+        uint4 o;
+        o.x = (unsigned)e[0] | ((unsigned)e[1] << 16); o.y = (unsigned)e[2] | ((unsigned)e[3] << 16);
+        o.z = (unsigned)e[4] | ((unsigned)e[5] << 16); o.w = (unsigned)e[6] | ((unsigned)e[7] << 16);
+        *reinterpret_cast<uint4*>(out + (int64_t)d * npad + p8) = o;
+    }
+}
+
 extern "C" int uc_vt_pack(const void* V, void* VT, int B, int H, int Nk, int D, int64_t v_sb, int64_t v_sn,
                           int64_t v_sh, uc_stream_t stream) {
     UC_REQUIRE(V && VT, "uc_vt_pack: null pointer");
     UC_REQUIRE(B > 0 && H > 0 && Nk > 0 && D > 0 && D <= 256, "uc_vt_pack: bad shape");
     const int npad = (Nk + 63) / 64 * 64;
-    hipLaunchKernelGGL(vt_pack_kernel, dim3(npad / 64, H, B), dim3(256), (size_t)64 * (D + 2) * 2, (hipStream_t)stream,
-                       (const bf16_t*)V, (bf16_t*)VT, H, Nk, D, npad, v_sb, v_sn, v_sh);
+    if (D == 64 && v_sb % 8 == 0 && v_sn % 8 == 0 && v_sh % 8 == 0 && (uintptr_t)V % 16 == 0 && (uintptr_t)VT % 16 == 0)
+        hipLaunchKernelGGL(vt_pack64_kernel, dim3(npad / 64, H, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)V, (bf16_t*)VT, H, Nk,
+                           npad, v_sb, v_sn, v_sh);
+    else
+        hipLaunchKernelGGL(vt_pack_kernel, dim3(npad / 64, H, B), dim3(256), (size_t)64 * (D + 2) * 2, (hipStream_t)stream,
+                           (const bf16_t*)V, (bf16_t*)VT, H, Nk, D, npad, v_sb, v_sn, v_sh);
     UC_CHECK_LAUNCH("uc_vt_pack");
     return UC_OK;
 }
