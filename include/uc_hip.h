@@ -37,7 +37,7 @@ const char* uc_last_error(void);
 /* ABI version; bumped when a signature or the uc_gemm_desc layout changes.
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
  *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added. */
-#define UC_ABI_VERSION 3
+#define UC_ABI_VERSION 4
 int uc_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
@@ -98,6 +98,8 @@ typedef struct uc_gemm_desc {
     const int64_t* rope_pos;   /* [M,2] int64 */
     const float* rope_table;   /* [npos][16][2] fp32 */
     int rope_npos;
+    float rope_base, rope_f0;  /* the frequencies behind rope_table (angle = pos * F0 * base^(-i/16), kernels.cu:36-81): the bf16
+                                  store epilogue rotates with hardware sin/cos of that angle instead of table loads */
     /* "VT" epilogue (bf16 path): output columns [vt_col0, N) are V channels (head-major, head_dim 64);
        instead of C they are written transposed+permuted to vt_out [B,H,64,vt_npad] (see uc_attention_fwd).
        Rows are tokens, vt_ntok per batch element (M = B*vt_ntok).  vt_col0 < 0 disables. */

@@ -188,6 +188,45 @@ def test_gemm_bf16_rope_and_vt_epilogue(gpu):
         assert torch.equal(packed.cpu()[:, :, :, posn], v_ref.bfloat16().permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5"])
+def test_gemm_bf16_tile_variants(gpu, variant, monkeypatch):
+    """Every tile variant of the direct-to-LDS kernel (UC_GEMM_VARIANT is read per call) against the fp32 product, through
+    each specialised epilogue: bf16 store (+GELU), fp32 residual add, RoPE + VT, the generic drain (ragged N, bf16 residual)."""
+    from uniception_amd import ops
+    monkeypatch.setenv("UC_GEMM_VARIANT", variant)
+    g = torch.Generator().manual_seed(50 + int(variant))
+    for (M, N, K) in [(512, 384, 256), (300, 200, 128), (1024, 768, 64)]:
+        a = torch.randn(M, K, generator=g).bfloat16()
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+        bias = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g)
+        ref = a.float() @ w.float().t()
+        ad, wd, bd = a.to(gpu), w.to(gpu), bias.to(gpu)
+        assert rel_l2(ops.gemm(ad, wd, out_dtype=torch.float32).cpu(), ref) < 2e-5
+        assert rel_l2(ops.gemm(ad, wd, bd, act="gelu").cpu().float(), F.gelu(ref + bias)) < 4e-3
+        assert rel_l2(ops.gemm(ad, wd, bd).cpu().float(), ref + bias) < 4e-3
+        assert rel_l2(ops.gemm(ad, wd, bd, residual=res.to(gpu), out_dtype=torch.float32).cpu(), ref + bias + res) < 2e-5
+        rb = res.bfloat16().to(gpu)
+        assert rel_l2(ops.gemm(ad, wd, bd, residual=rb, out_dtype=torch.bfloat16).cpu().float(), ref + bias + res.bfloat16().float()) < 6e-3
+    B, h, w_, H = 3, 8, 16, 3          # 128 tokens per image: the whole-row VT store path
+    N, Cd = h * w_, H * 64
+    x = torch.randn(B * N, 128, generator=g).bfloat16()
+    wq = (torch.randn(3 * Cd, 128, generator=g) / math.sqrt(128)).bfloat16()
+    bias = torch.randn(3 * Cd, generator=g)
+    pos = grid_pos(B, h, w_)
+    table = ops.rope_table(gpu, max(h, w_), 100.0)
+    vt = ops.vt_buffer(B, H, N, gpu)
+    qk = ops.gemm(x.to(gpu), wq.to(gpu), bias.to(gpu), rope=(pos.to(gpu).view(-1, 2), table, 2 * Cd), vt=(2 * Cd, vt, N))
+    full = (x.float() @ wq.float().t() + bias).view(B, N, 3, H, 64)
+    got = qk.cpu().float().view(B, N, 2, H, 64)
+    assert rel_l2(got[:, :, 0], rope_ref(full[:, :, 0], pos, 100.0, 1.0)) < 4e-3
+    assert rel_l2(got[:, :, 1], rope_ref(full[:, :, 1], pos, 100.0, 1.0)) < 4e-3
+    n = torch.arange(N)
+    wv = n % 16
+    posn = (n // 16) * 16 + ((wv >> 2) & 1) * 8 + (wv & 3) + 4 * (wv >> 3)
+    assert rel_l2(vt.cpu().float()[:, :, :, posn].permute(0, 3, 1, 2), full[:, :, 2]) < 4e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("geom", [(2, 9, 11, 16, 24, 1), (1, 37, 37, 32, 40, 2), (2, 8, 8, 96, 256, 1), (1, 6, 5, 8, 8, 2),
                                   (1, 9, 11, 64, 72, 1), (2, 10, 7, 128, 40, 2), (3, 19, 23, 64, 300, 1)])

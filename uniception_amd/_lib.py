@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
         ("conv_B", i32), ("conv_H", i32), ("conv_W", i32), ("conv_Cin", i32), ("conv_stride", i32),
         ("conv_Ho", i32), ("conv_Wo", i32),
         ("bias", vp), ("act", i32), ("residual", vp), ("residual2", vp), ("res_dtype", i32), ("ldr", i64),
-        ("rope_cols", i64), ("rope_pos", vp), ("rope_table", vp), ("rope_npos", i32),
+        ("rope_cols", i64), ("rope_pos", vp), ("rope_table", vp), ("rope_npos", i32), ("rope_base", f32), ("rope_f0", f32),
         ("vt_col0", i64), ("vt_out", vp), ("vt_ntok", i32), ("vt_npad", i32),
         ("preact_out", vp), ("split_k", i32), ("dact_u", vp), ("dact_act", i32),
         ("C", vp), ("out_dtype", i32), ("ldc", i64),
@@ -83,7 +83,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 3   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 4   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

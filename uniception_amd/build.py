@@ -1,31 +1,56 @@
 """Build libuc_hip.so (the C-ABI kernel library) for gfx950 with hipcc, in-tree.
 
 Usage:  python -m uniception_amd.build [--force]
-The .so is written next to this file so that it travels with a snapshot of the repository.
+The .so is written next to this file so that it travels with a snapshot of the repository.  Every source is compiled to
+its own object (in parallel, re-done only when that source or a header changed) and the objects are linked once.
 """
+import hashlib
 import os
 import subprocess
 import sys
-import hashlib
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libuc_hip.so")
-SOURCES = ["error.hip", "rope_norm.hip", "gemm.hip", "gemm_glds.hip", "gemm_tn.hip", "attention.hip", "attention_fp8.hip", "attention_bwd.hip", "elementwise.hip", "train.hip", "dpt_bwd.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wno-unused-result"]
+SOURCES = ["error.hip", "rope_norm.hip", "gemm.hip", "gemm_glds.hip", "gemm_tn.hip", "attention.hip", "attention_fp8.hip",
+           "attention_bwd.hip", "elementwise.hip", "train.hip", "dpt_bwd.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def _read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def _headers_digest():
+    h = hashlib.sha256()
+    for n in sorted(os.listdir(CSRC)):
+        if n.endswith(".h"):
+            h.update(n.encode())
+            h.update(_read(os.path.join(CSRC, n)))
+    h.update(_read(os.path.join(HERE, "..", "include", "uc_hip.h")))
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
 
 
 def _fingerprint():
-    h = hashlib.sha256()
-    names = sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "uc_hip.h")]
-    for n in names:
-        p = os.path.join(CSRC, n)
-        if os.path.isfile(p):
-            with open(p, "rb") as f:
-                h.update(n.encode())
-                h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    """Digest of everything the library is built from (sources, headers, flags): identifies a build of the kernels."""
+    h = hashlib.sha256(_headers_digest().encode())
+    for n in SOURCES:
+        h.update(n.encode())
+        h.update(_read(os.path.join(CSRC, n)))
     return h.hexdigest()
+
+
+def loaded_fingerprint():
+    """Fingerprint recorded next to libuc_hip.so when it was linked (None when the stamp is missing)."""
+    try:
+        with open(LIB + ".stamp") as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def hipcc_path():
@@ -35,6 +60,23 @@ def hipcc_path():
     return "hipcc"
 
 
+def _compile_one(src, hdr, force, verbose):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    stamp = obj + ".stamp"
+    fp = hashlib.sha256(hdr.encode() + _read(os.path.join(CSRC, src))).hexdigest()
+    if not force and os.path.exists(obj) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == fp:
+                return obj, False
+    cmd = [hipcc_path()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print("[uniception_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(fp)
+    return obj, True
+
+
 def build(force=False, verbose=True):
     stamp = LIB + ".stamp"
     fp = _fingerprint()
@@ -42,7 +84,11 @@ def build(force=False, verbose=True):
         with open(stamp) as f:
             if f.read().strip() == fp:
                 return LIB
-    cmd = [hipcc_path()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = _headers_digest()
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = [o for o, _ in ex.map(lambda s: _compile_one(s, hdr, force, verbose), SOURCES)]
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", LIB]
     if verbose:
         print("[uniception_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

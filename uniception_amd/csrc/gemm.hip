@@ -469,6 +469,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         if (d->rope_cols > 0) {
             UC_REQUIRE(d->rope_cols % 64 == 0 && d->rope_cols <= d->N, "uc_gemm: rope_cols must be a multiple of the 64-wide head and <= N");
             UC_REQUIRE(d->rope_pos && d->rope_table && d->rope_npos > 0, "uc_gemm: rope needs positions and table");
+            UC_REQUIRE(d->rope_base > 0.f && d->rope_f0 != 0.f, "uc_gemm: rope needs the base and F0 the table was built with");
             UC_REQUIRE(d->act == UC_ACT_NONE, "uc_gemm: rope epilogue cannot be combined with an activation");
         }
         if (d->vt_col0 >= 0) {
@@ -481,10 +482,12 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             UC_REQUIRE((uintptr_t)d->vt_out % 8 == 0, "uc_gemm: vt_out must be 8-byte aligned");
         }
         // dense operands with K % 64 == 0 take the direct-to-LDS kernel (gemm_glds.hip)
-        static int forced_variant = -2;
-        if (forced_variant == -2) {
+        // re-read on every call (a linear scan of environ, far below the launch cost) so that tests and micro-benchmarks can
+        // switch tile variants inside one process
+        int forced_variant;
+        {
             const char* e = getenv("UC_GEMM_VARIANT");
-            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..2: glds tile variants (others: 128x128)
+            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..5: glds tile variants
         }
         if (d->split_k > 1) {
             UC_REQUIRE(d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a, "uc_gemm: split_k needs a dense operand with K %% 64 == 0");
@@ -513,7 +516,11 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             g.A = (const bf16_t*)d->A; g.lda = d->lda; g.W = (const bf16_t*)d->W; g.M = d->M; g.N = d->N; g.K = d->K;
             g.bias = d->bias; g.act = d->act; g.residual = d->residual; g.residual2 = d->residual2; g.res_dtype = d->res_dtype;
             g.ldr = d->ldr; g.rope_cols = d->rope_cols; g.rope_pos = d->rope_pos; g.rope_table = (const float2*)d->rope_table;
-            g.rope_npos = d->rope_npos; g.vt_col0 = d->vt_col0; g.vt_out = (bf16_t*)d->vt_out; g.vt_ntok = d->vt_ntok;
+            g.rope_npos = d->rope_npos;
+            for (int i = 0; i < 16; ++i)
+                g.rope_turns[i] = d->rope_cols > 0 ? (float)((double)d->rope_f0 * pow((double)d->rope_base, -(double)i / 16.0) / 6.283185307179586476925) : 0.f;
+            g.rope_ratio = d->rope_cols > 0 ? (float)pow((double)d->rope_base, -1.0 / 16.0) : 1.f;
+            g.vt_col0 = d->vt_col0; g.vt_out = (bf16_t*)d->vt_out; g.vt_ntok = d->vt_ntok;
             g.vt_npad = d->vt_npad; g.C = d->C; g.out_dtype = d->out_dtype; g.ldc = d->ldc; g.tiles_m = g.tiles_n = 0;
             const bool c_ok = ((uintptr_t)d->C % 16 == 0) && (d->ldc % 8 == 0);
             const bool b_ok = !d->bias || ((uintptr_t)d->bias % 16 == 0);
@@ -553,6 +560,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             { static int nt = -2; if (nt == -2) { const char* e = getenv("UC_GEMM_NT"); nt = e ? atoi(e) : -1; }
               const int64_t out_bytes = d->M * d->N * (d->out_dtype == UC_F32 ? 4 : 2);
               g.nt_out = out_bytes > ((int64_t)128 << 20) ? (nt >= 0 ? nt : 7) : 0; }   // bit 0: fp32 residual stream, 1: bf16 outputs, 2: bf16 RoPE (q, k) tiles
+            { const char* e = getenv("UC_GEMM_STAGGER"); g.stagger = e ? atoi(e) : 0; }
             static int trace_on = -1;
             if (trace_on < 0) { const char* e = getenv("UC_GEMM_TRACE"); trace_on = e ? atoi(e) : 0; }
             g.trace = nullptr;
@@ -566,7 +574,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             UC_CHECK_LAUNCH("uc_gemm(glds)");
             if (trace_on) {   // diagnostics only: per-CU timeline statistics of this launch to stderr
                 (void)hipStreamSynchronize(st);
-                const int bm = variant >= 1 ? 256 : 128, bn = variant == 2 ? 256 : 128;
+                const int bm = variant >= 1 ? 256 : 128, bn = (variant == 2 || variant == 5) ? 256 : 128;
                 size_t nwg = (size_t)ceil_div64(d->M, bm) * ceil_div64(d->N, bn) * (size_t)g.split_k;
                 if (nwg > trace_cap) nwg = trace_cap;
                 unsigned long long* h = (unsigned long long*)malloc(nwg * 6 * sizeof(unsigned long long));

@@ -17,6 +17,8 @@ struct GldsParams {
     const int64_t* rope_pos;
     const float2* rope_table;
     int rope_npos;
+    float rope_ratio;       // base^(-1/16): frequency ratio of neighbouring channels
+    float rope_turns[16];   // rotation per unit position of channel i of a quarter, in turns: F0 * base^(-i/16) / (2 pi)
     int64_t vt_col0;
     bf16_t* vt_out;
     int vt_ntok, vt_npad;
@@ -33,6 +35,7 @@ struct GldsParams {
     int vec_ok;   // C / residual / bias satisfy the alignment needed by the 4-wide vector epilogue
     // implicit-GEMM 3x3 convolution over an NHWC image (a_mode == UC_A_CONV3X3): K = 9*Cin, Cin % 64 == 0
     int dbg;      // diagnostics only (UC_GEMM_DBG): 1 skip the in-loop DMA, 2 skip the in-loop barrier, 4 no epilogue, 8 one K-step, 16 generic epilogue only
+    int stagger;  // experiment: 100-MHz ticks of start delay per phase group for the first round of workgroups (0 = off)
     int nt_out;   // output (+ residual) streams of more than half the 256 MB Infinity Cache: non-temporal epilogue loads / stores
     unsigned long long* trace;   // diagnostics (UC_GEMM_TRACE): per-workgroup {start, loop start, loop end, end} 100-MHz ticks + HW id
     int a_mode, relu_a;

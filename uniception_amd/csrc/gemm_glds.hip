@@ -340,6 +340,67 @@ __device__ __forceinline__ void glds_epilogue_fast(const GldsParams& p, float4_t
     }
 }
 
+// fp32 output added to an fp32 residual stream (proj, fc2; optionally a second addend).  The output may alias the residual
+// (in-place accumulate), so the compiler keeps every residual load behind the previous store: as written in the generic
+// drain that is one load -> add -> store chain per 4-row pass, 16 HBM round trips per wave, 21 us per 256x256 tile — as
+// long as the K-loop of a K = 1024 GEMM.  Here the residual of row block i + 1 is in flight (4 x 16 B per lane) while block
+// i drains; each element is still read before it is written, which is all the in-place form needs.
+template <int FA, bool NT>
+__device__ __forceinline__ void glds_epilogue_resid(const GldsParams& p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                                    int64_t wave_n, int lane, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    const int crow = lane >> 4, cc = lane & 15;          // drain: 4 columns per lane, 16 lanes per row, 4 rows x 256 B per instruction
+    const int64_t nb = wave_n + 4 * cc;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if (mode != 1 && p.bias) bias4 = *reinterpret_cast<const float4_t*>(p.bias + nb);
+    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;      // row 16i + 4ps + crow exists iff 16i + 4ps < rows_left
+    char* cp = (char*)p.C + ((wave_m + crow) * p.ldc + nb) * 4;
+    const int64_t cstep = 4 * p.ldc * 4;
+    const char* rp = (const char*)p.residual + ((wave_m + crow) * p.ldr + nb) * 4;
+    const char* rp2 = p.residual2 ? (const char*)p.residual2 + ((wave_m + crow) * p.ldr + nb) * 4 : nullptr;
+    const int64_t rstep = 4 * p.ldr * 4;
+    float4_t res[2][4];
+    auto load_res = [&](int i, float4_t (&r)[4]) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            r[ps] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (16 * i + 4 * ps < rows_left) {
+                const float4_t* q = reinterpret_cast<const float4_t*>(rp + (4 * i + ps) * rstep);
+                if constexpr (NT) r[ps] = __builtin_nontemporal_load(q); else r[ps] = *q;
+                if (rp2) {
+                    const float4_t* q2 = reinterpret_cast<const float4_t*>(rp2 + (4 * i + ps) * rstep);
+                    if constexpr (NT) r[ps] += __builtin_nontemporal_load(q2); else r[ps] += *q2;
+                }
+            }
+        }
+    };
+    // staging a row block retires its 16 accumulator registers; the loads that follow take them over
+    glds_stage_rows<FA>(p, acc, 0, mode, wave_m, wave_n, frow, g, wbuf);
+    load_res(0, res[0]);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const char* buf = wbuf + (i & 1) * 4096;
+        if (i + 1 < FA) {
+            glds_stage_rows<FA>(p, acc, i + 1, mode, wave_m, wave_n, frow, g, wbuf + ((i + 1) & 1) * 4096);
+            load_res(i + 1, res[(i + 1) & 1]);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            float4_t v = glds_bounce_read(buf, 4 * ps + crow, cc);
+            if (16 * i + 4 * ps < rows_left) {
+                if (mode != 1) v += bias4;
+                v += res[i & 1][ps];
+                // NT (outputs of more than 128 MB, half the Infinity Cache): the residual stream is read once and written once per
+                // sub-layer — streaming it keeps the A / W panels of the K-loop in the L2s (+1.2 % on the forward); smaller
+                // outputs (the decoder's) stay cacheable, their consumer (LayerNorm) finds them on chip
+                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<float4_t*>(cp));
+                else *reinterpret_cast<float4_t*>(cp) = v;
+            }
+            cp += cstep;
+        }
+    }
+}
+
 // bf16 output without residual (qkv, fc1, kv / q projections, every convolution): bias, activation / RoPE and the bf16
 // rounding happen in the accumulator layout, and the bounce carries bf16 — half the LDS bytes of the fp32 bounce
 // (ds_write_b64 + one ds_read_b128 per 16-byte store instead of ds_write_b128 + two reads).  Block of one wave: 16 rows x
@@ -353,33 +414,39 @@ __device__ __forceinline__ void glds_epilogue_bf16(const GldsParams& p, float4_t
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         b4[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        if (mode != 1 && p.bias) b4[j] = *reinterpret_cast<const float4_t*>(p.bias + wave_n + 16 * j + 4 * g);
+        if (p.bias) b4[j] = *reinterpret_cast<const float4_t*>(p.bias + wave_n + 16 * j + 4 * g);
+    }
+    // RoPE tiles: no loads inside the per-row-block code.  The table form (positions -> table address -> cos/sin, per row
+    // block) was four dependent load chains per wave and cost 7 us per tile; here the positions of all row blocks are read up
+    // front and the rotation angles go through the hardware sin/cos (argument in turns, v_fract first): 16 transcendentals
+    // per row block per lane.  Channel 4g + r of a quarter has frequency F0 * base^(-(4g + r) / 16) (kernels.cu:36-81).
+    unsigned pyx[FA];            // (y | x << 16) of row 16 i + frow: positions below 65536 (launcher-checked table size)
+    float turn0 = 0.f;           // turns per unit position of channel 4g; channel 4g + r: turn0 * rope_ratio^r
+    if (mode == 1) {
+        turn0 = p.rope_turns[4 * g];
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int64_t m = min(wave_m + 16 * i + frow, p.M - 1);
+            const longlong2 yx = *reinterpret_cast<const longlong2*>(p.rope_pos + m * 2);
+            pyx[i] = ((unsigned)min(max((int)yx.x, 0), 65535)) | ((unsigned)min(max((int)yx.y, 0), 65535) << 16);
+        }
     }
     const int wr_off = frow * 128 + (((g & 1) ^ (frow >> 3)) << 3);       // + ((2j + (g>>1)) ^ (frow & 7)) << 4
     auto stage = [&](int i, char* buf) {
         if (mode == 1) {
-            const int64_t m = min(wave_m + 16 * i + frow, p.M - 1);
-            int py = (int)p.rope_pos[m * 2 + 0];
-            int px = (int)p.rope_pos[m * 2 + 1];
-            py = min(max(py, 0), p.rope_npos - 1);
-            px = min(max(px, 0), p.rope_npos - 1);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4_t* tb = reinterpret_cast<const float4_t*>(p.rope_table + (h ? px : py) * 16 + 4 * g);
-                const float4_t c0 = tb[0], c1 = tb[1];
-                const float cs[4] = {c0.x, c0.z, c1.x, c1.z}, sn[4] = {c0.y, c0.w, c1.y, c1.w};
-                float4_t bu = (float4_t){0.f, 0.f, 0.f, 0.f}, bw = bu;
-                if (p.bias) {
-                    const float* bp = p.bias + wave_n + 32 * h + 4 * g;
-                    bu = (float4_t){bp[0], bp[1], bp[2], bp[3]};
-                    bw = (float4_t){bp[16], bp[17], bp[18], bp[19]};
-                }
+            for (int h = 0; h < 2; ++h) {      // fragment pair (2h, 2h+1) = channels d, d+16 of the y (h = 0) / x (h = 1) half
+                const float pa = (float)(h ? (pyx[i] >> 16) : (pyx[i] & 0xffffu));
                 float ou[4], ow[4];
+                float turn = turn0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float u = acc[i][2 * h][r] + bu[r], w = acc[i][2 * h + 1][r] + bw[r];
-                    ou[r] = u * cs[r] - w * sn[r];
-                    ow[r] = w * cs[r] + u * sn[r];
+                    const float tfrac = __builtin_amdgcn_fractf(pa * turn);
+                    turn *= p.rope_ratio;
+                    const float cs = __builtin_amdgcn_cosf(tfrac), sn = __builtin_amdgcn_sinf(tfrac);
+                    const float u = acc[i][2 * h][r] + b4[2 * h][r], w = acc[i][2 * h + 1][r] + b4[2 * h + 1][r];   // no activation with RoPE (launcher-checked)
+                    ou[r] = u * cs - w * sn;
+                    ow[r] = w * cs + u * sn;
                 }
                 *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ou[0], ou[1]), pack_bf16x2(ou[2], ou[3])};
                 *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + 2 + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ow[0], ow[1]), pack_bf16x2(ow[2], ow[3])};
@@ -515,6 +582,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    if (p.stagger > 0 && blockIdx.x < 256u * WGS_PER_CU) {
+        // De-phase the CUs: every tile of a launch costs the same, so without this all 256 CUs reach their epilogues together
+        // and the store / residual traffic arrives at HBM as one burst while the matrix pipes idle.  The first round of
+        // workgroups (one per CU) starts in 8 phase groups; the offsets persist down each CU's chain of tiles.
+        const unsigned phase = (blockIdx.x >> 3) & 7u;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)phase * (unsigned)p.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int ksplit = p.split_k > 1 ? (int)uc_div(blockIdx.x, p.dNwg) : 0;   // split-K slice
@@ -757,8 +833,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
                 else glds_epilogue_bf16<FA, UC_ACT_NONE>(p, acc, mode, wave_m, wave_n, lane, wbuf);
             }
         } else if (plain && p.out_dtype == UC_F32 && p.residual && p.res_dtype == UC_F32 && p.act == UC_ACT_NONE) {
-            if (p.nt_out & 1) glds_epilogue_fast<FA, UC_ACT_NONE, 1, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
-            else glds_epilogue_fast<FA, UC_ACT_NONE, 1>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            if (p.nt_out & 1) glds_epilogue_resid<FA, true>(p, acc, mode, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_resid<FA, false>(p, acc, mode, wave_m, wave_n, lane, wbuf);
         }
         else
             glds_epilogue_generic<FA>(p, acc, mode, wave_m, wave_n, lane, ksplit, wbuf);
@@ -816,6 +892,14 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
         case 3:   // two co-resident workgroups per CU (dense operands only)
             if (p.a_mode == UC_A_CONV3X3) launch_variant_mode<256, 128, 4, 2, 3, UC_A_CONV3X3, 32, 2>(p, st);
             else launch_variant_mode<256, 128, 4, 2, 3, UC_A_DENSE, 32, 2>(p, st);
+            break;
+        case 4:   // 256x128x32, FOUR waves of 128x64, two co-resident workgroups per CU: one's prologue / epilogue runs under the other's K-loop
+            if (p.a_mode == UC_A_CONV3X3) launch_variant_mode<256, 128, 4, 2, 3, UC_A_CONV3X3, 32, 2>(p, st);
+            else launch_variant_mode<256, 128, 2, 2, 3, UC_A_DENSE, 32, 2>(p, st);
+            break;
+        case 5:   // 256x256x64 with eight waves of 128x64
+            if (p.a_mode == UC_A_CONV3X3) launch_variant<256, 256, 4, 4, 2>(p, st);
+            else launch_variant_mode<256, 256, 2, 4, 2, UC_A_DENSE, 64, 1>(p, st);
             break;
         default: {
             // latency regime (fewer workgroups than CUs: every K-step waits for its own DMA): a 3-stage ring keeps two

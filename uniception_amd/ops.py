@@ -79,6 +79,7 @@ def rope_table(device, npos: int, base: float, F0: float = 1.0) -> torch.Tensor:
     if t is None:
         t = torch.empty(npos, 16, 2, dtype=torch.float32, device=device)
         _lib.check(_lib.load().uc_rope_table(t.data_ptr(), npos, 16, float(base), float(F0), _stream()), "uc_rope_table")
+        t.uc_rope_base, t.uc_rope_f0 = float(base), float(F0)   # travel with the table into uc_gemm's descriptor
         _rope_tables[key] = t
     return t
 
@@ -151,6 +152,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         pos, table, rope_cols = rope
         assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * M
         d.rope_cols, d.rope_pos, d.rope_table, d.rope_npos = rope_cols, pos.data_ptr(), table.data_ptr(), table.shape[0]
+        d.rope_base, d.rope_f0 = table.uc_rope_base, table.uc_rope_f0
     if out is None and split_k > 1:
         out = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
         d.C, d.out_dtype, d.ldc = out.data_ptr(), _dt(out.dtype), N
