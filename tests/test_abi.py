@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     # the ctypes signature table covers the same set
     assert sorted(list(_lib.SIGNATURES.keys()) + ["uc_last_error"]) == declared_symbols()
     loaded = _lib.load()
-    assert loaded.uc_abi_version() == 3
+    assert loaded.uc_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define UC_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
     assert loaded.uc_last_error() is not None
 
 
