@@ -123,9 +123,29 @@ typedef struct uc_gemm_desc {
     void* C;             /* [M,N] row-major, leading dim ldc (only columns < vt_col0 are written when vt is on) */
     int out_dtype;       /* UC_F32 | UC_BF16 */
     int64_t ldc;
+    /* LayerNorm fused into the GEMMs around it (bf16 direct-to-LDS path, N % 64 == 0) — the "fused LayerNorm + QKV / fc1" of
+       the pre-LN sub-layers (libs/croco/blocks.py:158-161, utils/transformer_blocks.py:643-646):
+       producer (the GEMM that writes the fp32 residual stream: proj, fc2, patch / input embedding; out_dtype UC_F32):
+         twin_out : if non-NULL, the stored rows are also written as bf16 to twin_out [M, ldt] — the A operand of the consumer;
+         stats_out: if non-NULL, [M][N/64][2] fp32: per row and 64-column block (sum, sum of squared deviations from the block
+                    mean) of the stored values; uc_ln_stats_finalize merges the blocks into (mean, rstd) per row;
+       consumer (qkv, q / kv projections, fc1; out_dtype UC_BF16, no residual):
+         A = the bf16 twin (RAW rows x), W = W * gamma[k] (bf16), bias = b + W beta,
+         ln_stats : [M][2] fp32 (mean, rstd) of the rows of x, ln_colsum: [N] fp32 = sum_k W'[n,k] of the bf16 W';
+         the epilogue forms rstd[m] * (acc[m,n] - mean[m] * ln_colsum[n]) + bias[n] == LayerNorm(x)[m,:] . W[n,:] + b[n]
+         before the activation / RoPE / VT steps.  NULL disables. */
+    void* twin_out;
+    int64_t ldt;
+    float* stats_out;
+    const float* ln_stats;
+    const float* ln_colsum;
 } uc_gemm_desc;
 
 int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);
+
+/* Merge the per-block row statistics a producer GEMM wrote (stats_out: [rows][nblk][2] = (sum, squared deviations from the
+ * block mean) over 64-column blocks, C = 64 * nblk columns) into LayerNorm statistics: out[row] = (mean, 1/sqrt(var_biased + eps)). */
+int uc_ln_stats_finalize(const float* partial, int64_t rows, int nblk, float eps, float* out, uc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Scaled-dot-product attention, no mask, no dropout:  O = softmax(Q K^T * scale) V

@@ -1,0 +1,73 @@
+"""CPU: checkpoint converter.  Real DUSt3R checkpoints are unreachable here, so the maps are exercised on
+synthetic original-format checkpoints: a filled factory model is written with the ORIGINAL key names (the inverse map),
+converted back and loaded strictly into a fresh model; the converted per-module checkpoints load strictly into the modules.
+The GPU half (equal forward outputs through the HIP path) is tests/test_convert_checkpoint_gpu.py."""
+import pytest
+import torch
+
+from oracle import dust3r_oracle as O
+from tests.golden.cases import GAINS
+from uniception_amd.models.factory import DUSt3R
+from uniception_amd.tools import convert_checkpoint as cc
+
+
+def _small(head):
+    m = DUSt3R(name="c", img_size=(32, 48), pred_head_type=head).eval()
+    m.encoder.enc_blocks = m.encoder.enc_blocks[:2]
+    for br in m.info_sharing.multi_view_branches:
+        del br[2:]
+    m.info_sharing.depth = 2
+    return m
+
+
+@pytest.mark.parametrize("head", ["dpt", "linear"])
+def test_round_trip_strict_load(head):
+    src = _small(head)
+    O.fill_state_dict_(src.state_dict(), gains=GAINS)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    orig = cc.uniception_to_original(sd)
+    # the synthetic checkpoint carries the ORIGINAL names only, plus entries a real one has and the path does not use
+    assert all(k.startswith(("patch_embed.", "enc_blocks.", "enc_norm.", "decoder_embed.", "dec_blocks.", "dec_blocks2.", "dec_norm.",
+                             "downstream_head1.", "downstream_head2.")) for k in orig)
+    assert cc.detect_head_type(orig) == head
+    orig["mask_token"] = torch.zeros(1, 1, 768)
+    if head == "dpt":
+        assert "downstream_head1.dpt.act_postprocess.0.0.weight" in orig and "downstream_head2.dpt.head.4.bias" in orig
+        assert "downstream_head1.dpt.scratch.layer1_rn.weight" in orig
+        orig["downstream_head1.dpt.scratch.refinenet4.resConfUnit1.conv1.weight"] = torch.zeros(256, 256, 3, 3)
+        orig["downstream_head1.head_local_features.0.weight"] = torch.zeros(4, 4)       # MASt3R extra
+    else:
+        assert orig["downstream_head1.proj.weight"].shape == (4 * 16 * 16, 768)          # nn.Linear layout in the original
+    conv, dropped = cc.original_to_uniception(orig)
+    assert "mask_token" in dropped and (head != "dpt" or len(dropped) == 3)
+    dst = _small(head)
+    res = dst.load_state_dict(conv, strict=True)          # every key incl. the aliases
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # per-module checkpoints load into the modules
+    mods = cc.split_modules(conv)
+    assert dst.encoder.load_state_dict(mods["encoder"]["model"], strict=True) and mods["encoder"]["data_norm_type"] == "dust3r"
+    dst.info_sharing.load_state_dict(mods["info_sharing"]["model"], strict=True)
+    if head == "dpt":
+        dst.dpt_feature_head1.load_state_dict(mods["dpt_feature_head1"]["model"], strict=True)
+        dst.dpt_regressor_head2.load_state_dict(mods["dpt_regressor_head2"]["model"], strict=True)
+    else:
+        dst.head1.load_state_dict(mods["linear_feature_head1"]["model"], strict=True)
+
+
+def test_croco_checkpoint_duplicates_the_single_decoder():
+    src = _small("linear")
+    O.fill_state_dict_(src.state_dict(), gains=GAINS)
+    orig = cc.uniception_to_original(src.state_dict(), two_decoders=False)
+    assert not any(k.startswith("dec_blocks2.") for k in orig)
+    conv, _ = cc.original_to_uniception(orig)
+    for k, v in conv.items():
+        if k.startswith("info_sharing.multi_view_branches.1."):
+            assert torch.equal(v, conv[k.replace("branches.1.", "branches.0.")])
+    assert any(k.startswith("info_sharing.multi_view_branches.1.") for k in conv)
+
+
+def test_unknown_keys_are_errors():
+    with pytest.raises(KeyError):
+        cc.original_to_uniception({"something_else.weight": torch.zeros(1)})

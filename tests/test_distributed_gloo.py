@@ -75,30 +75,71 @@ def _grad_worker(rank, world, port, bucket_bytes):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         model = _toy_model()
-        flat = FlatParameters(model)
-        buckets = GradientBuckets(flat, bucket_bytes=bucket_bytes)
-        assert buckets.buckets[-1][0] == 0 and buckets.buckets[0][1] == flat.numel      # the buckets tile the flat buffer
-        assert all(a[0] == b[1] for a, b in zip(buckets.buckets[:-1], buckets.buckets[1:]))
+        flat = FlatParameters(model, bucket_bytes)
+        buckets = GradientBuckets(flat)
+        assert buckets.buckets[0][0] == 0 and buckets.buckets[-1][1] == flat.numel      # the buckets tile the flat buffer
+        assert all(a[1] == b[0] for a, b in zip(buckets.buckets[:-1], buckets.buckets[1:]))
         g = torch.Generator().manual_seed(100)
         data = torch.randn(world, 5, 6, generator=g)
+
+        def reference(scale_fn, skip_last_on_rank=None):
+            """sum over ranks of the single-process gradients"""
+            ref_model = _toy_model()
+            tot = {n: torch.zeros_like(p) for n, p in ref_model.named_parameters()}
+            for r in range(world):
+                ref_model.zero_grad()
+                _toy_loss(ref_model, scale_fn(r), skip_last=(skip_last_on_rank == r)).backward()
+                for n, p in ref_model.named_parameters():
+                    if p.grad is not None:
+                        tot[n] += p.grad
+            return tot
+
+        def check(tot):
+            for n, p in model.named_parameters():
+                assert p.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offsets[n][0]   # still a view of the flat buffer
+                assert torch.allclose(p.grad, tot[n], rtol=1e-5, atol=1e-6), n
+
         for step in range(2):   # twice: the per-step bookkeeping must reset
             flat.zero_grad()
             buckets.start_step()
-            model(data[rank] * (step + 1)).square().mean().backward()
+            _toy_loss(model, data[rank] * (step + 1)).backward()
             buckets.finish()
-            # reference: the sum over ranks of the single-process gradients
-            ref_model = _toy_model()
-            tot = [torch.zeros_like(p) for p in ref_model.parameters()]
-            for r in range(world):
-                ref_model.zero_grad()
-                ref_model(data[r] * (step + 1)).square().mean().backward()
-                for t, p in zip(tot, ref_model.parameters()):
-                    t += p.grad
-            for (n, p), t in zip(model.named_parameters(), tot):
-                assert p.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offsets[n][0]   # still a view of the flat buffer
-                assert torch.allclose(p.grad, t, rtol=1e-5, atol=1e-6), n
+            check(reference(lambda r: data[r] * (step + 1)))
+        # a rank whose loss does not reach the last layer leaves buckets incomplete there: finish() issues the rest in bucket
+        # order, so both ranks still run the same sequence of collectives
+        flat.zero_grad()
+        buckets.start_step()
+        _toy_loss(model, data[rank], skip_last=(rank == 1)).backward()
+        buckets.finish()
+        check(reference(lambda r: data[r], skip_last_on_rank=1))
+        # gradient accumulation: micro-batches under `accumulating` only add locally, the last backward exchanges the sum
+        flat.zero_grad()
+        buckets.start_step()
+        buckets.accumulating = True
+        _toy_loss(model, data[rank]).backward()
+        buckets.accumulating = False
+        _toy_loss(model, data[rank] * 3).backward()
+        buckets.finish()
+        t1, t3 = reference(lambda r: data[r]), reference(lambda r: data[r] * 3)
+        check({n: t1[n] + t3[n] for n in t1})
+        # a second backward outside of it is an error, not a silent divergence
+        flat.zero_grad()
+        buckets.start_step()
+        _toy_loss(model, data[rank]).backward()
+        try:
+            _toy_loss(model, data[rank]).backward()
+            raised = False
+        except RuntimeError as e:
+            raised = "no_sync" in str(e)
+        assert raised
+        buckets.finish()
     finally:
         dist.destroy_process_group()
+
+
+def _toy_loss(model, x, skip_last=False):
+    h = model[:-1](x)
+    return h.square().mean() if skip_last else model[-1](h).square().mean()
 
 
 def test_two_rank_bucketed_gradient_allreduce():
@@ -107,17 +148,27 @@ def test_two_rank_bucketed_gradient_allreduce():
 
 
 def test_flat_parameters_keep_module_semantics():
-    from uniception_amd.training import FlatParameters
+    from uniception_amd.training import SLOT_ALIGN, FlatParameters
     model = _toy_model()
     x = torch.randn(4, 6)
     y0 = model(x)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-    flat = FlatParameters(model)
+    flat = FlatParameters(model, bucket_bytes=512)
     assert torch.equal(model(x), y0) and all(torch.equal(v, sd0[k]) for k, v in model.state_dict().items())
-    # decayed tensors (matrices) first, then biases / norm parameters
-    names = [n for n, _ in flat.order]
-    first_nd = next(i for i, n in enumerate(names) if n.endswith("bias") or dict(model.named_parameters())[n].dim() <= 1)
-    assert all(dict(model.named_parameters())[n].dim() > 1 for n in names[:first_nd])
-    assert flat.n_decay == sum(p.numel() for p in model.parameters() if p.dim() > 1)
+    params = dict(model.named_parameters())
+    assert len(flat.buckets) > 1
+    # buckets follow the backward: the LAST registered parameters sit in bucket 0; inside a bucket the decayed tensors
+    # (matrices) come first, then biases / norm parameters; every slot is 64-byte aligned and slots do not overlap
+    assert "5.weight" in flat.buckets[0]["names"] and "0.weight" in flat.buckets[-1]["names"]
+    end = 0
+    for b in flat.buckets:
+        assert b["lo"] == end
+        for n in b["names"]:
+            off, k = flat.offsets[n]
+            assert off % SLOT_ALIGN == 0 and off >= end and k == params[n].numel()
+            assert (off < b["split"]) == (params[n].dim() > 1)
+            end = off + k
+        end = b["hi"]
+    assert end == flat.numel
     flat.param.mul_(2.0)   # parameters are views of the flat buffer
     assert torch.equal(model[0].weight, sd0["0.weight"] * 2)

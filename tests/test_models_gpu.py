@@ -7,11 +7,12 @@ import pytest
 import torch
 
 from tests.golden.cases import CASES
-from tests.helpers import build_case_model, case_images, compare_to_golden, load_golden
+from tests.helpers import HEAD_OUTPUTS, build_case_model, case_images, compare_to_golden, load_golden
 
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
+FP32_MAX_ABS = 1e-2   # the reference's own gate asks for both (examples/models/dust3r/dust3r.py:230)
 # bf16: encoder/decoder features ~1e-2; decoded channels pass through exp/expm1, which amplifies absolute error
 BF16_TOL = {"default": 4e-2}
 
@@ -44,16 +45,20 @@ def run_case(name, gpu, mode):
 def test_fp32_parity_1e3(gpu, name):
     tensors, c = run_case(name, gpu, "fp32")
     report = {}
-    worst = compare_to_golden(load_golden(name), tensors, c, tol=FP32_TOL, report=report)
-    print(f"\n[fp32] {name}: worst {worst[0]} {worst[1]:.2e}")
+    abs_report = {}
+    worst = compare_to_golden(load_golden(name), tensors, c, tol=FP32_TOL, report=report, max_abs_tol=FP32_MAX_ABS, abs_report=abs_report)
+    print(f"\n[fp32] {name}: worst {worst[0]} {worst[1]:.2e}; head outputs max-abs " +
+          ", ".join(f"{k}={abs_report[k]:.1e}" for k in HEAD_OUTPUTS if k in abs_report))
 
 
 @pytest.mark.parametrize("name", list(CASES.keys()))
 def test_bf16_parity(gpu, name):
     tensors, c = run_case(name, gpu, "bf16")
     report = {}
-    worst = compare_to_golden(load_golden(name), tensors, c, tol=BF16_TOL["default"], report=report)
-    print(f"\n[bf16] {name}: worst {worst[0]} {worst[1]:.2e}; " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(report.items())))
+    abs_report = {}
+    worst = compare_to_golden(load_golden(name), tensors, c, tol=BF16_TOL["default"], report=report, abs_report=abs_report)
+    print(f"\n[bf16] {name}: worst {worst[0]} {worst[1]:.2e}; " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(report.items())) +
+          "; head outputs max-abs " + ", ".join(f"{k}={abs_report[k]:.1e}" for k in HEAD_OUTPUTS if k in abs_report))
 
 
 def test_autocast_selects_bf16_and_heads_follow_reference_policy(gpu):

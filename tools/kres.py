@@ -4,7 +4,7 @@ import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "uniception_amd", "csrc", sys.argv[1])
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c", src, "-o",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", *os.environ.get("KRES_FLAGS", "").split(), "-c", src, "-o",
                       "/tmp/_kres.o", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd="/tmp").stderr
 cur = None; rows = []
 for line in out.splitlines():

@@ -43,3 +43,29 @@ if os.environ.get("UC_GEMM_TRACE"):
 else:
     for name, fn in cases:
         print(f"{name:28s} {timeit(fn):8.1f} us", flush=True)
+
+# ---- folded LayerNorm: producer (emit) and consumer (ln=) costs
+import torch.nn.functional as F
+xx = ops.gemm(h, wp, bp, residual=x, out_dtype=torch.float32, emit_ln=True)
+side = xx.uc_ln
+st = side.stats(1e-6)
+cs = wqkv.float().sum(1).contiguous()
+w1 = rnd(4 * C, C, scale=1 / 32); b1 = torch.randn(4 * C, device=dev) * 0.1; cs1 = w1.float().sum(1).contiguous()
+gam = torch.ones(C, device=dev); bet = torch.zeros(C, device=dev)
+fold_cases = [
+    ("proj +res32 emit twin+stats", lambda: ops.gemm(h, wp, bp, residual=x, out=out32, emit_ln=True)),
+    ("ln finalize", lambda: ops.LnSide(side.twin, side.partial).stats(1e-6)),
+    ("layernorm kernel f32->bf16", lambda: ops.layernorm(x, gam, bet, 1e-6, torch.bfloat16)),
+    ("qkv rope+vt ln-fold", lambda: ops.gemm(side.twin, wqkv, bqkv, rope=(pos, table, 2 * C), vt=(2 * C, vt, N), ln=(st, cs))),
+    ("qkv rope+vt", lambda: ops.gemm(h, wqkv, bqkv, rope=(pos, table, 2 * C), vt=(2 * C, vt, N))),
+    ("fc1 gelu ln-fold", lambda: ops.gemm(side.twin, w1, b1, act="gelu", ln=(st, cs1))),
+    ("fc1 gelu", lambda: ops.gemm(h, w1, b1, act="gelu")),
+]
+if os.environ.get("UC_GEMM_TRACE"):
+    for name, fn in fold_cases:
+        print(name, flush=True); sys.stderr.flush()
+        fn(); torch.cuda.synchronize()
+else:
+    for rep in range(2):
+        for name, fn in fold_cases:
+            print(f"{name:28s} {timeit(fn):8.1f} us", flush=True)

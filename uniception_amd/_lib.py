@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("vt_col0", i64), ("vt_out", vp), ("vt_ntok", i32), ("vt_npad", i32),
         ("preact_out", vp), ("split_k", i32), ("dact_u", vp), ("dact_act", i32),
         ("C", vp), ("out_dtype", i32), ("ldc", i64),
+        ("twin_out", vp), ("ldt", i64), ("stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
     ]
 
 
@@ -43,6 +44,7 @@ SIGNATURES = {
     "uc_rope_table": [vp, i32, i32, f32, f32, vp],
     "uc_layernorm": [vp, i32, vp, vp, vp, i32, i64, i32, f32, vp],
     "uc_gemm": [C.POINTER(GemmDesc), vp],
+    "uc_ln_stats_finalize": [vp, i64, i32, f32, vp, vp],
     "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
     "uc_attention_fwd_fp8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [f32, vp],
     "uc_vt_pack_fp8": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],

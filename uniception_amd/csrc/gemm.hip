@@ -487,7 +487,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         int forced_variant;
         {
             const char* e = getenv("UC_GEMM_VARIANT");
-            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..5: glds tile variants
+            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..3: glds tile variants
         }
         if (d->split_k > 1) {
             UC_REQUIRE(d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a, "uc_gemm: split_k needs a dense operand with K %% 64 == 0");
@@ -504,6 +504,24 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                        "uc_gemm: dact_u needs the bf16 direct-to-LDS kernels, bf16 output and a plain epilogue");
         }
         const bool glds_dense = d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a;
+        if (d->ln_stats || d->ln_colsum) {
+            UC_REQUIRE(d->ln_stats && d->ln_colsum, "uc_gemm: the folded LayerNorm needs both ln_stats and ln_colsum");
+            UC_REQUIRE(glds_dense && d->out_dtype == UC_BF16 && !d->residual && !d->preact_out && !d->dact_u && d->split_k <= 1 &&
+                           d->N % 64 == 0 && (d->act == UC_ACT_NONE || d->act == UC_ACT_GELU_ERF),
+                       "uc_gemm: ln_stats needs the dense direct-to-LDS kernel (K %% 64 == 0), bf16 output, N %% 64 == 0 and a plain epilogue");
+            UC_REQUIRE((uintptr_t)d->ln_stats % 8 == 0 && (uintptr_t)d->ln_colsum % 16 == 0 && (uintptr_t)d->C % 16 == 0 && d->ldc % 8 == 0 &&
+                           (!d->bias || (uintptr_t)d->bias % 16 == 0), "uc_gemm: ln_stats / ln_colsum / C / bias alignment");
+        }
+        if (d->twin_out || d->stats_out) {
+            UC_REQUIRE(glds_dense && d->out_dtype == UC_F32 && (!d->residual || d->res_dtype == UC_F32) && d->act == UC_ACT_NONE &&
+                           !d->preact_out && !d->dact_u && d->split_k <= 1 && d->vt_col0 < 0 && d->N % 64 == 0,
+                       "uc_gemm: twin_out / stats_out need the dense direct-to-LDS kernel, fp32 output (+ fp32 residual), N %% 64 == 0");
+            UC_REQUIRE((uintptr_t)d->C % 16 == 0 && d->ldc % 8 == 0 && (!d->bias || (uintptr_t)d->bias % 16 == 0) &&
+                           (!d->residual || ((uintptr_t)d->residual % 16 == 0 && d->ldr % 4 == 0 && (!d->residual2 || (uintptr_t)d->residual2 % 16 == 0))),
+                       "uc_gemm: twin_out / stats_out need 16-byte aligned C / bias / residual");
+            if (d->twin_out) UC_REQUIRE((uintptr_t)d->twin_out % 8 == 0 && d->ldt % 4 == 0 && d->ldt >= d->N, "uc_gemm: twin_out alignment / ldt");
+            if (d->stats_out) UC_REQUIRE((uintptr_t)d->stats_out % 8 == 0, "uc_gemm: stats_out alignment");
+        }
         // the conv DMA addresses a tile's input window (the images its 256 output rows touch) with 32-bit byte offsets
         const int64_t conv_window_bytes = d->a_mode == UC_A_CONV3X3
             ? (256 / std::max<int64_t>(1, (int64_t)d->conv_Ho * d->conv_Wo) + 2) * (int64_t)d->conv_H * d->conv_W * d->conv_Cin * 2 : 0;
@@ -517,9 +535,9 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             g.bias = d->bias; g.act = d->act; g.residual = d->residual; g.residual2 = d->residual2; g.res_dtype = d->res_dtype;
             g.ldr = d->ldr; g.rope_cols = d->rope_cols; g.rope_pos = d->rope_pos; g.rope_table = (const float2*)d->rope_table;
             g.rope_npos = d->rope_npos;
-            for (int i = 0; i < 16; ++i)
-                g.rope_turns[i] = d->rope_cols > 0 ? (float)((double)d->rope_f0 * pow((double)d->rope_base, -(double)i / 16.0) / 6.283185307179586476925) : 0.f;
+            g.rope_turn0 = d->rope_cols > 0 ? (float)((double)d->rope_f0 / 6.283185307179586476925) : 0.f;
             g.rope_ratio = d->rope_cols > 0 ? (float)pow((double)d->rope_base, -1.0 / 16.0) : 1.f;
+            g.rope_l2ratio = d->rope_cols > 0 ? (float)(-log2((double)d->rope_base) / 16.0) : 0.f;
             g.vt_col0 = d->vt_col0; g.vt_out = (bf16_t*)d->vt_out; g.vt_ntok = d->vt_ntok;
             g.vt_npad = d->vt_npad; g.C = d->C; g.out_dtype = d->out_dtype; g.ldc = d->ldc; g.tiles_m = g.tiles_n = 0;
             const bool c_ok = ((uintptr_t)d->C % 16 == 0) && (d->ldc % 8 == 0);
@@ -529,6 +547,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const bool x_ok = (!d->preact_out || (uintptr_t)d->preact_out % 16 == 0) && (!d->dact_u || (uintptr_t)d->dact_u % 8 == 0);
             g.vec_ok = (c_ok && b_ok && r_ok && x_ok) ? 1 : 0;
             g.preact = d->preact_out; g.split_k = d->split_k > 1 ? d->split_k : 1;
+            g.ln_stats = (const float2*)d->ln_stats; g.ln_colsum = d->ln_colsum;
+            g.twin = (bf16_t*)d->twin_out; g.ldt = d->ldt; g.stats_out = (float2*)d->stats_out;
             g.dact_u = (const bf16_t*)d->dact_u; g.dact_act = d->dact_act;
             { static int gm = -1; if (gm < 0) { const char* e = getenv("UC_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } g.group_m = gm; }
             { static int dbg = -1; if (dbg < 0) { const char* e = getenv("UC_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
@@ -574,7 +594,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             UC_CHECK_LAUNCH("uc_gemm(glds)");
             if (trace_on) {   // diagnostics only: per-CU timeline statistics of this launch to stderr
                 (void)hipStreamSynchronize(st);
-                const int bm = variant >= 1 ? 256 : 128, bn = (variant == 2 || variant == 5) ? 256 : 128;
+                const int bm = variant >= 1 ? 256 : 128, bn = variant == 2 ? 256 : 128;
                 size_t nwg = (size_t)ceil_div64(d->M, bm) * ceil_div64(d->N, bn) * (size_t)g.split_k;
                 if (nwg > trace_cap) nwg = trace_cap;
                 unsigned long long* h = (unsigned long long*)malloc(nwg * 6 * sizeof(unsigned long long));
@@ -610,6 +630,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             }
             return UC_OK;
         }
+        UC_REQUIRE(!d->ln_stats && !d->twin_out && !d->stats_out, "uc_gemm: the LayerNorm fusion options need the direct-to-LDS kernel (forced off?)");
         p.tiles_m = (int)ceil_div64(d->M, BM);
         p.tiles_n = (int)ceil_div64(d->N, BN);
         const unsigned grid = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
@@ -619,6 +640,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         else
             hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_CONV3X3>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);
     } else if (d->compute_dtype == UC_F32) {
+        UC_REQUIRE(!d->ln_stats && !d->twin_out && !d->stats_out, "uc_gemm(f32): the LayerNorm fusion options are bf16-path only");
         if (d->split_k > 1 || d->dact_u) {
             uc_set_error("uc_gemm(f32): split_k / dact_u are only implemented for the bf16 MFMA path");
             return UC_ERR_UNSUPPORTED;

@@ -17,14 +17,23 @@ struct GldsParams {
     const int64_t* rope_pos;
     const float2* rope_table;
     int rope_npos;
-    float rope_ratio;       // base^(-1/16): frequency ratio of neighbouring channels
-    float rope_turns[16];   // rotation per unit position of channel i of a quarter, in turns: F0 * base^(-i/16) / (2 pi)
+    float rope_ratio;       // base^(-1/16): frequency ratio of neighbouring channels of a quarter
+    float rope_turn0;       // rotation per unit position of channel 0, in turns: F0 / (2 pi); channel i: rope_turn0 * rope_ratio^i
+    float rope_l2ratio;     // log2(rope_ratio)
     int64_t vt_col0;
     bf16_t* vt_out;
     int vt_ntok, vt_npad;
     void* C;
     int out_dtype;
     int64_t ldc;
+    // LayerNorm folded into this GEMM (consumer side): A holds raw rows x, W has gamma folded in; the bf16-store epilogues
+    // compute rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]
+    const float2* ln_stats;   // [M] (mean, rstd)
+    const float* ln_colsum;   // [N] sum_k W'[n,k]
+    // producer side (fp32-output epilogue): bf16 twin of the stored rows and per-row statistics of every 64-column block
+    bf16_t* twin;             // [M, ldt] bf16 copy of C, or NULL
+    int64_t ldt;
+    float2* stats_out;        // [M][N/64] (sum, sum of squared deviations from the block mean), or NULL
     void* preact;   // optional pre-activation copy (same dtype / ld as C)
     const bf16_t* dact_u;   // optional: multiply the result by act'(u), u bf16 [M, ldc]
     int dact_act;

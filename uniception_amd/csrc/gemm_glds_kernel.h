@@ -1,0 +1,1039 @@
+#pragma once
+// Dense bf16 GEMM for gfx950 with direct global->LDS staging (global_load_lds_dwordx4, 1 KiB per wave-instruction).
+//
+//   C[M,N] = epilogue(A[M,K] . W[N,K]^T),  K % 64 == 0, A/W bf16 row-major.
+//
+// Tile geometry: BM x BN x 64 per workgroup, every wavefront owns a 64x64 sub-tile (4x4 MFMA 16x16x32 fragments).
+// LDS image of a stage: (BM + BN) rows x 128 B.  The DMA writes lane-linear (wave base + lane*16), so the
+// XOR swizzle that makes the ds_read_b128 fragment loads conflict-free (chunk ^= (row>>1)&7) is applied to the
+// per-lane SOURCE address; the fragment reads apply the same involution.  Two stages; the loads of K-step t+1
+// are issued before the MFMAs of step t and drained by the barrier that ends the step.
+//
+// Operand orientation: for ordinary tiles the MFMA computes C^T fragments (first operand = W rows), so a lane owns
+// 4 CONSECUTIVE output columns of one row: bias/residual/stores are 8/16-byte vector accesses and, with the W-row
+// permutation 16*(a>>2)+4j+(a&3), a lane's 16 values are 16 consecutive columns.  Tiles that take the RoPE epilogue
+// keep the identity column map (partner channel d+16 = next fragment, same lane/register); V tiles that are written
+// in the packed VT layout use the un-swapped orientation (a lane owns 4 consecutive TOKENS of one channel).
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+#include "gemm_glds.h"
+#include <stdlib.h>
+
+// How the epilogues see the kernel parameters: through the kernarg segment (scalar loads at the point of use), see the
+// kernel's epilogue section.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((opencl_constant)) GldsParams& glds_pe_t;
+#else
+typedef const GldsParams& glds_pe_t;
+#endif
+#include <algorithm>
+#include <type_traits>
+
+// erf-GELU of the bf16 MFMA path.  libm's erff is a branchy two-range evaluation (~50 VALU ops per element once both
+// sides of the branch run in a wave); with only 16 K-steps per fc1 tile that epilogue cost as much as the MFMA loop.
+// Abramowitz-Stegun 7.1.26: erf(z) = 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1/(1 + p z), |error| <= 1.5e-7 — at fp32
+// rounding level and three orders below the bf16 output's own rounding.  (The fp32 verification kernel keeps erff.)
+__device__ __forceinline__ float glds_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);            // erf(|x|/sqrt2)
+    const float erf_s = __builtin_copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_s);
+}
+// d/dx of the activation at pre-activation x: GELU' = Phi(x) + x phi(x); ReLU' = [x > 0]
+__device__ __forceinline__ float glds_dact(float x, int act) {
+    if (act == UC_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);      // exp(-x^2/2)
+    const float erf_s = __builtin_copysignf(fmaf(-poly * t, e, 1.0f), x);
+    return fmaf(0.5f, erf_s, 0.5f) + x * e * 0.39894228040143267794f;
+}
+__device__ __forceinline__ float glds_act(float v, int act) {
+    if (act == UC_ACT_GELU_ERF) return glds_gelu(v);
+    if (act == UC_ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ int glds_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+__device__ __forceinline__ uint4 glds_relu_bf16x8(uint4 v) {
+    unsigned* q = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned neg = (q[i] >> 15) & 0x00010001u;
+        q[i] &= ~(neg * 0xffffu);
+    }
+    return v;
+}
+
+// One 1-KiB LDS-DMA piece issued through inline asm.  With the __builtin form hipcc tracks the DMA as an LDS write it
+// cannot disambiguate from the fragment ds_reads of the OTHER stage buffer and inserts `s_waitcnt vmcnt(0)` in front of
+// them — the whole global->LDS latency is then exposed in every K-step (measured: matrix pipe 39 % busy, 57 % of wave
+// cycles parked).  The asm form is invisible to that pass; completion is enforced by hand with counted s_waitcnt
+// vmcnt(N) + s_barrier (see the K-loops).  M0 carries the wave-uniform LDS byte address; it is compiler-reserved, so it
+// is saved and restored inside the statement; s_nop 0 covers the M0-write -> LDS-DMA hazard.
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
+
+// chunk swizzle key of LDS row r: 128-B rows (r>>1)&7, 64-B rows 3*((r>>2)&1) — both make the ds_read_b128 fragment
+// loads (lane = row, lane>>4 = k chunk) conflict-free within the hardware's 16-lane service groups
+template <int BK_>
+__device__ __forceinline__ int glds_swz(int r) { return BK_ == 64 ? ((r >> 1) & 7) : (((r >> 2) & 1) * 3); }
+
+// Buffer-addressed form: source = descriptor base + voff + soff (bytes); a lane whose offset is outside the descriptor's
+// range gets zeros written to its 16 LDS bytes.  s_nop 4 covers SGPR (descriptor / soffset / M0) write -> VMEM read.
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16_buf_to_lds(unsigned voff, uint4_t srd, unsigned soff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff)
+        : "memory");
+}
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// Epilogue of V tiles that are written in the packed VT layout (un-swapped orientation).
+template <int FA, bool LN = false>
+__device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane,
+                                                 char* wbuf) {
+    const int frow = lane & 15;
+    const int g = lane >> 4;
+    // Folded LayerNorm (LN): value = rstd[row] * (acc - mean[row] * colsum[channel]) + bias[channel], rows 16 i + 4 g + r,
+    // channel 16 j + frow.  Lane l holds the statistics of row l (one coalesced load); the four rows of a fragment come
+    // through ds_bpermute.  The correction is applied where a value is consumed: rewriting the 64 accumulators in place
+    // first made the compiler park all of them in scratch.
+    float csj[4] = {0.f, 0.f, 0.f, 0.f};
+    float2 mine = make_float2(0.f, 1.f);
+    static_assert(!LN || FA == 4, "folded LayerNorm: 64-row wave tiles");
+    if constexpr (LN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) csj[j] = p.ln_colsum[wave_n + 16 * j + frow];
+        mine = p.ln_stats[min(wave_m + lane, p.M - 1)];
+    }
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+    auto row_stats = [&](int i) __attribute__((always_inline)) {
+        if constexpr (LN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { mu[r] = __shfl(mine.x, 16 * i + 4 * g + r, 64); rs[r] = __shfl(mine.y, 16 * i + 4 * g + r, 64); }
+        }
+    };
+    auto val = [&](int i, int j, int r, float bc) __attribute__((always_inline)) -> float {
+        if constexpr (LN) return (acc[i][j][r] - mu[r] * csj[j]) * rs[r] + bc;
+        else return acc[i][j][r] + bc;
+    };
+    if (FA == 4 && (p.vt_ntok & 63) == 0 && wave_m + 64 <= p.M && ((uintptr_t)p.vt_out & 15) == 0 && !(p.dbg & 16)) {
+        // The wave's 64 tokens are one aligned 64-position group of one image: 64 channel rows x 128 contiguous bytes of VT.
+        // Bounce [channel d][position] through the wave's LDS block (chunk c of row d at chunk c ^ (d & 7), 8-byte halves
+        // swapped when d & 8) and store whole rows: 8 x dwordx4 instead of 16 x dwordx2 that touch 16 rows x 32 B each.
+        const int head = (int)((wave_n - p.vt_col0) >> 6);
+        const int nheads = (int)((p.N - p.vt_col0) >> 6);
+        float bcj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bcj[j] = p.bias ? p.bias[wave_n + 16 * j + frow] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            row_stats(i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = 16 * j + frow;
+                const uint2 pk = (uint2){pack_bf16x2(val(i, j, 0, bcj[j]), val(i, j, 1, bcj[j])), pack_bf16x2(val(i, j, 2, bcj[j]), val(i, j, 3, bcj[j]))};
+                *reinterpret_cast<uint2*>(wbuf + d * 128 + (((2 * i + (g & 1)) ^ (d & 7)) << 4) + (((g >> 1) ^ ((d >> 3) & 1)) << 3)) = pk;
+            }
+        }
+        const int b = (int)(wave_m / p.vt_ntok);
+        const int tok0 = (int)(wave_m - (int64_t)b * p.vt_ntok);
+        bf16_t* base = p.vt_out + ((int64_t)b * nheads + head) * 64 * (int64_t)p.vt_npad + tok0;
+        const int crow = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int d = 8 * ps + crow;
+            uint4 v = *reinterpret_cast<const uint4*>(wbuf + d * 128 + (pch << 4));
+            if (ps & 1) v = (uint4){v.z, v.w, v.x, v.y};
+            *reinterpret_cast<uint4*>(base + (int64_t)d * p.vt_npad + ((pch ^ (d & 7)) << 3)) = v;
+        }
+        return;
+    }
+    {
+        // acc[i][j][r]: token row m = wave_m + 16i + 4g + r, channel column wave_n + 16j + frow
+        const int head = (int)((wave_n - p.vt_col0) >> 6);
+        const int nheads = (int)((p.N - p.vt_col0) >> 6);
+        const bool aligned = (p.vt_ntok & 15) == 0;
+        float bcol[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bcol[j] = p.bias ? p.bias[wave_n + 16 * j + frow] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int64_t mb = wave_m + 16 * i + 4 * g;
+            row_stats(i);
+            if (aligned) {
+                if (mb >= p.M) continue;
+                const int b = (int)(mb / p.vt_ntok);
+                const int tok = (int)(mb % p.vt_ntok);
+                const int pos = (tok & ~15) + ((g & 1) << 3) + ((g >> 1) << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = 16 * j + frow;
+                    bf16_t* dst = p.vt_out + (((int64_t)b * nheads + head) * 64 + d) * p.vt_npad + pos;
+                    uint2 pk;
+                    pk.x = pack_bf16x2(val(i, j, 0, bcol[j]), val(i, j, 1, bcol[j]));
+                    pk.y = pack_bf16x2(val(i, j, 2, bcol[j]), val(i, j, 3, bcol[j]));
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = mb + r;
+                    if (m >= p.M) continue;
+                    const int b = (int)(m / p.vt_ntok);
+                    const int tok = (int)(m % p.vt_ntok);
+                    const int w = tok & 15;
+                    const int pos = (tok & ~15) + (((w >> 2) & 1) << 3) + (w & 3) + ((w >> 3) << 2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        p.vt_out[(((int64_t)b * nheads + head) * 64 + 16 * j + frow) * p.vt_npad + pos] =
+                            f32_to_bf16(val(i, j, r, bcol[j]));
+                }
+            }
+        }
+    }
+}
+
+// Epilogue of the swapped orientation (bias -> activation -> fused RoPE-2D -> residual(s) -> dact -> store).
+//
+// In the accumulator layout one store instruction touches 16 rows x 32-64 B, and the vector memory path retires about
+// one row segment per 4 cycles per CU whatever its width: a 256x256 tile's store tail took 7 us (bf16 or fp32 output,
+// tools/probes/store_tail.hip) against 1-2 us when every instruction covers whole 128-B lines.  So each wave bounces its
+// 16x64 fragment rows through a private, XOR-swizzled 4-KiB LDS block (the stage buffers are free after the K-loop)
+// and does all global traffic — pre-activation copy, residual reads, dact reads, the store — with a lane owning 4
+// consecutive columns and 16 lanes covering one row (4 rows x 256 B of fp32 or 4 x 128 B of bf16 per instruction).
+// Bias/activation move to that layout too; RoPE (partner channels live in one lane of the accumulator layout) is
+// applied before the bounce.
+//
+// Run-time option tests must not sit inside per-element code: a `p.act` test per value compiled into a scalar compare
+// and branch per ELEMENT (the epilogue then cost as much as six K-steps, half of it instruction fetch: the kernel was
+// 40 k lines of ISA).  The two shapes that carry the forward are specialised at compile time —
+//   glds_epilogue_bf16: bf16 output, no residual (qkv, fc1, kv projections, every convolution), ACT a template parameter,
+//                       bf16 bounce;
+//   glds_epilogue_fast<.., KIND 1>: fp32 output added to one or two fp32 residual streams (proj, fc2), fp32 bounce
+//                       (its KIND 0 form is the fp32-bounce variant of the bf16 store, kept for A/B runs);
+// everything else (split-K slabs, pre-activation copies, dact, bf16 residuals, partial column blocks, unaligned
+// operands) takes a rolled generic drain whose option tests are per 4-column group.
+template <int ACT>
+__device__ __forceinline__ float glds_act_c(float v) {
+    if constexpr (ACT == UC_ACT_GELU_ERF) return glds_gelu(v);
+    else if constexpr (ACT == UC_ACT_RELU) return fmaxf(v, 0.f);
+    else return v;
+}
+
+// LDS bounce block of one wave: 16 rows x 256 B, 16-B chunk c of row r stored at chunk c ^ r (conflict-free for the
+// accumulator-layout ds_write_b128 and the row-contiguous ds_read_b128 alike)
+__device__ __forceinline__ void glds_bounce_write(char* buf, int frow, int g, int j, float4_t v) {
+    *reinterpret_cast<float4_t*>(buf + frow * 256 + (((4 * j + g) ^ frow) << 4)) = v;
+}
+__device__ __forceinline__ float4_t glds_bounce_read(const char* buf, int R, int cchunk) {
+    return *reinterpret_cast<const float4_t*>(buf + R * 256 + ((cchunk ^ R) << 4));
+}
+
+// accumulator rows of fragment row-block i (+ bias and RoPE for mode 1) -> bounce block
+template <int FA>
+__device__ __forceinline__ void glds_stage_rows(glds_pe_t p, float4_t (&acc)[FA][4], int i, int mode, int64_t wave_m,
+                                                int64_t wave_n, int frow, int g, char* buf) {
+    if (mode == 1) {
+        const int64_t m = min(wave_m + 16 * i + frow, p.M - 1);
+        int py = (int)p.rope_pos[m * 2 + 0];
+        int px = (int)p.rope_pos[m * 2 + 1];
+        py = min(max(py, 0), p.rope_npos - 1);
+        px = min(max(px, 0), p.rope_npos - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {      // fragment pair (2h, 2h+1) = channels d, d+16 of the y (h = 0) / x (h = 1) half
+            const float4_t* tb = reinterpret_cast<const float4_t*>(p.rope_table + (h ? px : py) * 16 + 4 * g);
+            const float4_t c0 = tb[0], c1 = tb[1];                               // (cos,sin) x 4
+            const float cs[4] = {c0.x, c0.z, c1.x, c1.z}, sn[4] = {c0.y, c0.w, c1.y, c1.w};
+            float4_t bu = (float4_t){0.f, 0.f, 0.f, 0.f}, bw = bu;
+            if (p.bias) {                  // rope tiles are whole 64-column heads inside N (launcher-checked), bias 16-B aligned or scalar
+                const float* bp = p.bias + wave_n + 32 * h + 4 * g;
+                bu = (float4_t){bp[0], bp[1], bp[2], bp[3]};
+                bw = (float4_t){bp[16], bp[17], bp[18], bp[19]};
+            }
+            float4_t ou, ow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u = acc[i][2 * h][r] + bu[r], w = acc[i][2 * h + 1][r] + bw[r];   // no activation with RoPE (launcher-checked)
+                ou[r] = u * cs[r] - w * sn[r];
+                ow[r] = w * cs[r] + u * sn[r];
+            }
+            glds_bounce_write(buf, frow, g, 2 * h, ou);
+            glds_bounce_write(buf, frow, g, 2 * h + 1, ow);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds_bounce_write(buf, frow, g, j, acc[i][j]);
+    }
+}
+
+template <int FA, int ACT, int KIND, bool NT = false>
+__device__ __forceinline__ void glds_epilogue_fast(glds_pe_t p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                                   int64_t wave_n, int lane, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    // drain layout.  KIND 0 (bf16 out): a lane owns 8 consecutive columns, 8 lanes cover a row, an instruction stores 8
+    // rows x 128 B as dwordx4.  KIND 1 (fp32): 4 columns per lane, 16 lanes per row, 4 rows x 256 B per instruction.
+    constexpr int LPR = KIND == 0 ? 8 : 16;              // lanes per row
+    constexpr int RPP = 64 / LPR;                        // rows per pass
+    constexpr int NPS = 16 / RPP;                        // passes per 16-row block
+    const int crow = lane / LPR, cc = lane % LPR;
+    const int64_t nb = wave_n + (KIND == 0 ? 8 : 4) * cc;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f}, bias4b = bias4;
+    if (mode != 1 && p.bias) {
+        bias4 = *reinterpret_cast<const float4_t*>(p.bias + nb);
+        if constexpr (KIND == 0) bias4b = *reinterpret_cast<const float4_t*>(p.bias + nb + 4);
+    }
+    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;      // row 16i + RPP*ps + crow exists iff 16i + RPP*ps < rows_left
+    constexpr int ESZ = KIND == 0 ? 2 : 4;
+    char* cp = (char*)p.C + ((wave_m + crow) * p.ldc + nb) * ESZ;
+    const int64_t cstep = RPP * p.ldc * ESZ;
+    const char* rp = nullptr; const char* rp2 = nullptr; int64_t rstep = 0;
+    if constexpr (KIND == 1) {
+        rp = (const char*)p.residual + ((wave_m + crow) * p.ldr + nb) * 4;
+        rp2 = p.residual2 ? (const char*)p.residual2 + ((wave_m + crow) * p.ldr + nb) * 4 : nullptr;
+        rstep = RPP * p.ldr * 4;
+    }
+    // the next row block is staged before the current one is drained: its LDS writes overlap this block's global traffic
+    glds_stage_rows<FA>(p, acc, 0, mode, wave_m, wave_n, frow, g, wbuf);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const char* buf = wbuf + (i & 1) * 4096;
+        if (i + 1 < FA) glds_stage_rows<FA>(p, acc, i + 1, mode, wave_m, wave_n, frow, g, wbuf + ((i + 1) & 1) * 4096);
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int R = RPP * ps + crow;
+            if constexpr (KIND == 0) {
+                float4_t v = glds_bounce_read(buf, R, 2 * cc), w = glds_bounce_read(buf, R, 2 * cc + 1);
+                if (16 * i + RPP * ps < rows_left) {
+                    if (mode != 1) {
+                        v += bias4; w += bias4b;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] = glds_act_c<ACT>(v[r]); w[r] = glds_act_c<ACT>(w[r]); }
+                    }
+                    *reinterpret_cast<uint4*>(cp) = (uint4){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w), pack_bf16x2(w.x, w.y), pack_bf16x2(w.z, w.w)};
+                }
+            } else {
+                float4_t v = glds_bounce_read(buf, R, cc);
+                if (16 * i + RPP * ps < rows_left) {
+                    if (mode != 1) v += bias4;
+                    // NT (outputs of more than 128 MB, half the Infinity Cache): the residual stream is read once and written once per
+                    // sub-layer — streaming it keeps the A / W panels of the K-loop in the L2s (+1.2 % on the forward); smaller
+                    // outputs (the decoder's) stay cacheable, their consumer (LayerNorm) finds them on chip
+                    if constexpr (NT) {
+                        v += __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(rp));
+                        if (rp2) v += __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(rp2));
+                        __builtin_nontemporal_store(v, reinterpret_cast<float4_t*>(cp));
+                    } else {
+                        v += *reinterpret_cast<const float4_t*>(rp);
+                        if (rp2) v += *reinterpret_cast<const float4_t*>(rp2);
+                        *reinterpret_cast<float4_t*>(cp) = v;
+                    }
+                }
+            }
+            cp += cstep;
+            if constexpr (KIND == 1) { rp += rstep; if (rp2) rp2 += rstep; }
+        }
+    }
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane
+__device__ __forceinline__ float glds_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    return v;
+}
+
+// fp32 output, optionally added to an fp32 residual stream (proj, fc2, patch / input embeddings; optionally a second addend).
+// The output may alias the residual (in-place accumulate), so the compiler keeps every residual load behind the previous
+// store: written as one load -> add -> store chain per 4-row pass that is 16 HBM round trips per wave, 21 us per 256x256
+// tile — as long as the K-loop of a K = 1024 GEMM.  Here the residual of row block i + 1 is in flight (4 x 16 B per lane)
+// while block i drains; each element is still read before it is written, which is all the in-place form needs.
+//
+// Producer half of the folded LayerNorm: with p.twin the stored rows are also written as bf16 (the A operand of the next
+// GEMM), with p.stats_out every row's (sum, squared deviations from its own mean) over the wave's 64 columns is written
+// — the row's 16 lanes reduce with DPP row rotations; uc_ln_stats_finalize merges the blocks into (mean, rstd).
+template <int FA, bool NT>
+__device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                                    int64_t wave_n, int lane, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    const int crow = lane >> 4, cc = lane & 15;          // drain: 4 columns per lane, 16 lanes per row, 4 rows x 256 B per instruction
+    const int64_t nb = wave_n + 4 * cc;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if (mode != 1 && p.bias) bias4 = *reinterpret_cast<const float4_t*>(p.bias + nb);
+    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;      // row 16i + 4ps + crow exists iff 16i + 4ps < rows_left
+    // wave-uniform 64-bit bases + one 32-bit lane offset per matrix: per-lane 64-bit pointers for C, the residuals, the twin
+    // and the statistics cost 10 registers this epilogue does not have (a spill reload between its stores waits for every
+    // store issued before it)
+    char* cbase = (char*)p.C + (wave_m * p.ldc + wave_n) * 4;
+    const unsigned coff = (unsigned)(crow * (int)p.ldc + 4 * cc) * 4u;
+    const int64_t cstep = 4 * p.ldc * 4;
+    const char* rbase = p.residual ? (const char*)p.residual + (wave_m * p.ldr + wave_n) * 4 : nullptr;
+    const char* rbase2 = p.residual2 ? (const char*)p.residual2 + (wave_m * p.ldr + wave_n) * 4 : nullptr;
+    const unsigned roff = (unsigned)(crow * (int)p.ldr + 4 * cc) * 4u;
+    const int64_t rstep = 4 * p.ldr * 4;
+    char* tbase = p.twin ? (char*)p.twin + (wave_m * p.ldt + wave_n) * 2 : nullptr;
+    const unsigned toff = (unsigned)(crow * (int)p.ldt + 4 * cc) * 2u;
+    const int64_t tstep = 4 * p.ldt * 2;
+    const int nblk = (int)(p.N >> 6);
+    float2* sbase = p.stats_out ? p.stats_out + wave_m * nblk + (wave_n >> 6) : nullptr;
+    // ONE register set for the residual: pass ps of row block i + 1 is requested as soon as pass ps of block i has used
+    // its value (each element is still read before the in-place store of its own row), so 4 loads per lane stay in flight
+    float4_t res[4];
+    auto load_res = [&](int i, int ps) __attribute__((always_inline)) {
+        res[ps] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        if (rbase && 16 * i + 4 * ps < rows_left) {
+            const float4_t* q = reinterpret_cast<const float4_t*>(rbase + (4 * i + ps) * rstep + roff);
+            if constexpr (NT) res[ps] = __builtin_nontemporal_load(q); else res[ps] = *q;
+            if (rbase2) {
+                const float4_t* q2 = reinterpret_cast<const float4_t*>(rbase2 + (4 * i + ps) * rstep + roff);
+                if constexpr (NT) res[ps] += __builtin_nontemporal_load(q2); else res[ps] += *q2;
+            }
+        }
+    };
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) load_res(0, ps);
+    glds_stage_rows<FA>(p, acc, 0, mode, wave_m, wave_n, frow, g, wbuf);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const char* buf = wbuf + (i & 1) * 4096;
+        if (i + 1 < FA) glds_stage_rows<FA>(p, acc, i + 1, mode, wave_m, wave_n, frow, g, wbuf + ((i + 1) & 1) * 4096);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            float4_t v = glds_bounce_read(buf, 4 * ps + crow, cc);
+            if (mode != 1) v += bias4;
+            v += res[ps];
+            if (i + 1 < FA) load_res(i + 1, ps);
+            const bool row_ok = 16 * i + 4 * ps < rows_left;
+            if (row_ok) {
+                // NT (outputs of more than 128 MB, half the Infinity Cache): the residual stream is read once and written once per
+                // sub-layer — streaming it keeps the A / W panels of the K-loop in the L2s (+1.2 % on the forward); smaller
+                // outputs (the decoder's) stay cacheable, their consumer finds them on chip
+                float4_t* cq = reinterpret_cast<float4_t*>(cbase + (4 * i + ps) * cstep + coff);
+                if constexpr (NT) __builtin_nontemporal_store(v, cq); else *cq = v;
+                if (tbase) *reinterpret_cast<uint2*>(tbase + (4 * i + ps) * tstep + toff) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            }
+            if (sbase) {   // all 64 lanes take part in the row reductions (rows past M carry finite garbage and are not stored)
+                const float s = glds_row16_sum((v.x + v.y) + (v.z + v.w));
+                const float mu = s * (1.f / 64.f);
+                const float4_t dv = v - mu;
+                const float q = glds_row16_sum((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w));
+                if (row_ok && cc == 0) sbase[(int64_t)(16 * i + 4 * ps + crow) * nblk] = make_float2(s, q);
+            }
+        }
+    }
+}
+
+// LN: the folded-LayerNorm form — the accumulator holds x . W'^T of the RAW rows; row statistics and the column sums of W'
+// turn it into LN(x) . W^T:  rstd[m] * (acc - mean[m] * colsum[n]) + bias[n].
+template <int FA, int ACT, bool NT = false, bool LN = false>
+__device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                                   int64_t wave_n, int lane, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    // Folded LayerNorm (LN): value = rstd[row] * (acc - mean[row] * colsum[col]) + bias[col], rows 16 i + frow, columns
+    // 16 j + 4 g + r.  Lane l holds the statistics of row l of the wave tile (one coalesced load); a row block's pair comes
+    // through ds_bpermute when the block is staged.  Applied where a value is consumed, never as an in-place pass over acc.
+    // The LN form keeps its two column vectors (column sums, bias) of the wave's 64 columns in LDS behind the bounce
+    // blocks and reads 16 bytes of each per fragment: held in registers (32 of them) next to the accumulators they spilled,
+    // and a spill reload between global stores waits for every store before it (vmcnt counts stores, in order).
+    float2 mine[FA / 4];
+    float* colbuf = reinterpret_cast<float*>(wbuf + 4096);
+    if constexpr (LN) {
+        colbuf[lane] = p.ln_colsum[wave_n + lane];
+        colbuf[64 + lane] = p.bias ? p.bias[wave_n + lane] : 0.f;
+#pragma unroll
+        for (int q = 0; q < FA / 4; ++q) mine[q] = p.ln_stats[min(wave_m + 64 * q + lane, p.M - 1)];
+    }
+    float st_mu = 0.f, st_rs = 1.f;
+    auto row_stats = [&](int i) __attribute__((always_inline)) {
+        if constexpr (LN) { st_mu = __shfl(mine[i / 4].x, 16 * (i & 3) + frow, 64); st_rs = __shfl(mine[i / 4].y, 16 * (i & 3) + frow, 64); }
+    };
+    float4_t b4[4];
+    if constexpr (!LN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b4[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b4[j] = *reinterpret_cast<const float4_t*>(p.bias + wave_n + 16 * j + 4 * g);
+        }
+    }
+    auto val4 = [&](int i, int j) __attribute__((always_inline)) -> float4_t {   // pre-activation values of fragment (i, j)
+        if constexpr (LN) {
+            const float4_t cs = *reinterpret_cast<const float4_t*>(colbuf + 16 * j + 4 * g);
+            const float4_t bb = *reinterpret_cast<const float4_t*>(colbuf + 64 + 16 * j + 4 * g);
+            return (acc[i][j] - st_mu * cs) * st_rs + bb;
+        } else return acc[i][j] + b4[j];
+    };
+    // RoPE tiles: no loads inside the per-row-block code.  The table form (positions -> table address -> cos/sin, per row
+    // block) was four dependent load chains per wave and cost 7 us per tile; here the positions of all row blocks are read up
+    // front and the rotation angles go through the hardware sin/cos (argument in turns, v_fract first): 16 transcendentals
+    // per row block per lane.  Channel 4g + r of a quarter has frequency F0 * base^(-(4g + r) / 16) (kernels.cu:36-81).
+    unsigned pyx[FA];            // (y | x << 16) of row 16 i + frow: positions below 65536 (launcher-checked table size)
+    float turn0 = 0.f;           // turns per unit position of channel 4g; channel 4g + r: turn0 * rope_ratio^r
+    if (mode == 1) {
+        turn0 = p.rope_turn0 * __builtin_amdgcn_exp2f((float)(4 * g) * p.rope_l2ratio);
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int64_t m = min(wave_m + 16 * i + frow, p.M - 1);
+            const longlong2 yx = *reinterpret_cast<const longlong2*>(p.rope_pos + m * 2);
+            pyx[i] = ((unsigned)min(max((int)yx.x, 0), 65535)) | ((unsigned)min(max((int)yx.y, 0), 65535) << 16);
+        }
+    }
+    const int wr_off = frow * 128 + (((g & 1) ^ (frow >> 3)) << 3);       // + ((2j + (g>>1)) ^ (frow & 7)) << 4
+    auto stage = [&](int i, char* buf) {
+        row_stats(i);
+        if (mode == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {      // fragment pair (2h, 2h+1) = channels d, d+16 of the y (h = 0) / x (h = 1) half
+                const float pa = (float)(h ? (pyx[i] >> 16) : (pyx[i] & 0xffffu));
+                const float4_t uu = val4(i, 2 * h), ww = val4(i, 2 * h + 1);
+                float ou[4], ow[4];
+                float turn = turn0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float tfrac = __builtin_amdgcn_fractf(pa * turn);
+                    turn *= p.rope_ratio;
+                    const float cs = __builtin_amdgcn_cosf(tfrac), sn = __builtin_amdgcn_sinf(tfrac);
+                    const float u = uu[r], w = ww[r];   // no activation with RoPE (launcher-checked)
+                    ou[r] = u * cs - w * sn;
+                    ow[r] = w * cs + u * sn;
+                }
+                *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ou[0], ou[1]), pack_bf16x2(ou[2], ou[3])};
+                *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + 2 + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ow[0], ow[1]), pack_bf16x2(ow[2], ow[3])};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4_t v = val4(i, j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = glds_act_c<ACT>(v[r]);
+                *reinterpret_cast<uint2*>(buf + wr_off + (((2 * j + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            }
+        }
+    };
+    const int crow = lane >> 3, pch = lane & 7;              // drain: row 8*ps + crow, physical chunk pch
+    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;
+    char* cp = (char*)p.C + ((wave_m + crow) * p.ldc + wave_n) * 2;
+    const int64_t cstep = 8 * p.ldc * 2;
+    // Plain form: row block i + 1 is staged before block i is drained (its LDS writes overlap the global stores).  Folded-
+    // LayerNorm form: 32 more registers (column sums, statistics) are live while staging, and a spill reload between global
+    // stores waits for ALL of them (vmcnt counts stores, in order): the epilogue took 16 us instead of 6.  It stages all four
+    // row blocks first — the wave's 8-KiB LDS block holds them as bf16 — and drains with no accumulator left alive.
+    constexpr bool ALL_FIRST = false;   // (measured: staging all four row blocks first costs the LDS-write / store overlap: +2.9 us per tile)
+    if constexpr (ALL_FIRST) {
+#pragma unroll
+        for (int i = 0; i < FA; ++i) stage(i, wbuf + i * 2048);
+    } else {
+        stage(0, wbuf);
+    }
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const char* buf = ALL_FIRST ? wbuf + i * 2048 : wbuf + (i & 1) * 2048;
+        if constexpr (!ALL_FIRST) {
+            if (i + 1 < FA) stage(i + 1, wbuf + ((i + 1) & 1) * 2048);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int R = 8 * ps + crow;
+            uint4 v = *reinterpret_cast<const uint4*>(buf + R * 128 + (pch << 4));
+            if (ps) v = (uint4){v.z, v.w, v.x, v.y};         // rows 8..15 store their halves swapped
+            if (16 * i + 8 * ps < rows_left) {
+                if constexpr (NT) {
+                    const uint4_t vv = (uint4_t){v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<uint4_t*>(cp + ((pch ^ (R & 7)) << 4)));
+                } else {
+                    *reinterpret_cast<uint4*>(cp + ((pch ^ (R & 7)) << 4)) = v;
+                }
+            }
+            cp += cstep;
+        }
+    }
+}
+
+// 4 values of row m, columns nb..nb+3 of a [*, ld] matrix of dtype dt: vector access when `full`, else per element inside N
+__device__ __forceinline__ float4_t glds_load4(const void* base, int dt, int64_t idx, bool full, int64_t nb, int64_t N) {
+    float4_t v = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if (full) {
+        if (dt == UC_F32) v = *reinterpret_cast<const float4_t*>((const float*)base + idx);
+        else {
+            const uint2 q = *reinterpret_cast<const uint2*>((const bf16_t*)base + idx);
+            v = (float4_t){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+        }
+    } else {
+        for (int r = 0; r < 4; ++r)
+            if (nb + r < N) v[r] = dt == UC_F32 ? ((const float*)base)[idx + r] : bf16_to_f32(((const bf16_t*)base)[idx + r]);
+    }
+    return v;
+}
+__device__ __forceinline__ void glds_store4(void* base, int dt, int64_t idx, bool full, int64_t nb, int64_t N, float4_t v) {
+    if (full) {
+        if (dt == UC_F32) *reinterpret_cast<float4_t*>((float*)base + idx) = v;
+        else *reinterpret_cast<uint2*>((bf16_t*)base + idx) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    } else {
+        for (int r = 0; r < 4; ++r) {
+            if (nb + r >= N) continue;
+            if (dt == UC_F32) ((float*)base)[idx + r] = v[r]; else ((bf16_t*)base)[idx + r] = f32_to_bf16(v[r]);
+        }
+    }
+}
+
+template <int FA>
+__device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
+                                                      int64_t wave_n, int lane, int ksplit, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    const int crow = lane >> 4, cchunk = lane & 15;
+    const int64_t nb = wave_n + 4 * cchunk;
+    const bool full = p.vec_ok && nb + 3 < p.N;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if (mode != 1 && p.bias && p.split_k <= 1) bias4 = glds_load4(p.bias, UC_F32, nb, full, nb, p.N);
+    float* slab = (float*)p.C + (int64_t)ksplit * p.M * p.ldc;
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        char* buf = wbuf + (i & 1) * 4096;
+        glds_stage_rows<FA>(p, acc, i, mode, wave_m, wave_n, frow, g, buf);
+#pragma unroll 1
+        for (int ps = 0; ps < 4; ++ps) {
+            const int R = 4 * ps + crow;
+            float4_t v = glds_bounce_read(buf, R, cchunk);
+            const int64_t m = wave_m + 16 * i + R;
+            if (m >= p.M || nb >= p.N) continue;
+            const int64_t ci = m * p.ldc + nb;
+            if (p.split_k > 1) { glds_store4(slab, UC_F32, ci, full, nb, p.N, v); continue; }
+            if (mode != 1) {
+                v += bias4;
+                if (p.preact) glds_store4(p.preact, p.out_dtype, ci, full, nb, p.N, v);
+                if (p.act == UC_ACT_GELU_ERF) { for (int r = 0; r < 4; ++r) v[r] = glds_gelu(v[r]); }
+                else if (p.act == UC_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+            }
+            if (p.residual) {
+                v += glds_load4(p.residual, p.res_dtype, m * p.ldr + nb, full, nb, p.N);
+                if (p.residual2) v += glds_load4(p.residual2, p.res_dtype, m * p.ldr + nb, full, nb, p.N);
+            }
+            if (p.dact_u) {   // fused activation backward: out = v * act'(u)
+                const float4_t u = glds_load4(p.dact_u, UC_BF16, ci, full, nb, p.N);
+                if (p.dact_act == UC_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f; }
+                else { for (int r = 0; r < 4; ++r) v[r] *= glds_dact(u[r], UC_ACT_GELU_ERF); }
+            }
+            glds_store4(p.C, p.out_dtype, ci, full, nb, p.N, v);
+        }
+    }
+}
+
+// BK_ = 64 (128-B LDS rows) or 32 (64-B rows: half the LDS per stage, so two 8-wave workgroups share a CU and one's
+// prologue/epilogue runs under the other's K-loop); WGS_PER_CU is the co-residency the register budget is sized for.
+// EPI selects the epilogue family compiled into an instantiation (the launcher picks the instantiation from the descriptor):
+//   GLDS_EPI_BF16: bf16 stores without residual — plain / activation / RoPE tiles, VT tiles, folded LayerNorm (qkv, fc1, q / kv
+//                  projections, convolutions);   GLDS_EPI_F32: fp32 output (+ fp32 residuals, bf16 twin, row statistics: proj,
+//                  fc2, embeddings);   GLDS_EPI_ALL: the generic drain next to the two fast families (everything else).
+// One family per kernel keeps the register allocation of the 128-VGPR K-loop out of reach of epilogue code it never runs:
+// with all of them inlined into one function, every option added to one epilogue spilled DMA pointers inside the K-loop.
+enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2 };
+
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1, int EPI = GLDS_EPI_ALL>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES_N / 4) void gemm_bf16_glds_kernel(GldsParams p) {
+    static_assert(BN_ / WAVES_N == 64, "a wave owns 64 output columns (one 64-wide head)");
+    constexpr int WTM = BM_ / WAVES_M;
+    constexpr int FA = WTM / 16;          // A-row fragments per wave (4 or 8)
+    static_assert(WTM % 16 == 0 && (FA == 4 || FA == 8), "wave tile rows");
+    constexpr int NW = WAVES_M * WAVES_N;
+    static_assert(BK_ == 64 || BK_ == 32, "K-step");
+    constexpr int ROWB = BK_ * 2;         // bytes per LDS row
+    constexpr int CPR = ROWB / 16;        // 16-byte chunks per row (8 or 4)
+    constexpr int RPI = 1024 / ROWB;      // rows per 1-KiB DMA instruction (8 or 16)
+    constexpr int STAGE_BYTES = (BM_ + BN_) * ROWB;
+    constexpr int NI = (BM_ + BN_) / RPI; // 1-KiB DMA instructions per stage
+    constexpr int PER = NI / NW;          // per wave
+    static_assert(NI % NW == 0, "DMA instructions must split evenly over the waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (p.trace) tr0 = __builtin_amdgcn_s_memrealtime();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    if (p.stagger > 0 && blockIdx.x < 256u * WGS_PER_CU) {
+        // De-phase the CUs: every tile of a launch costs the same, so without this all 256 CUs reach their epilogues together
+        // and the store / residual traffic arrives at HBM as one burst while the matrix pipes idle.  The first round of
+        // workgroups (one per CU) starts in 8 phase groups; the offsets persist down each CU's chain of tiles.
+        const unsigned phase = (blockIdx.x >> 3) & 7u;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)phase * (unsigned)p.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int ksplit = p.split_k > 1 ? (int)uc_div(blockIdx.x, p.dNwg) : 0;   // split-K slice
+    const int t = glds_xcd_remap((int)blockIdx.x - ksplit * nwg, nwg);
+    // Tile order inside an XCD's run: groups of GM row panels swept column by column, so the ~32 tiles an XCD runs
+    // concurrently form a GM x (32/GM) block that shares GM A-panels and 32/GM W-panels in its L2 (a plain row-major
+    // order shares 2 A-panels but streams ALL of W through every pair of row panels: 2.4x algorithmic fetch traffic).
+    int tm, tn;
+    {
+        const int GM = p.group_m;
+        const int per_group = GM * p.tiles_n;
+        const int grp = (int)uc_div((unsigned)t, p.dPerGroup), within = t - grp * per_group;
+        const int first_m = grp * GM;
+        const bool last = p.tiles_m - first_m < GM;                        // the ragged last group has tiles_m % GM row panels
+        const int gsz = last ? p.tiles_m - first_m : GM;
+        tn = (int)uc_div((unsigned)within, last ? p.dGmLast : p.dGm);
+        tm = first_m + within - tn * gsz;
+    }
+    const int64_t m0 = (int64_t)tm * BM_;
+    const int64_t n0 = (int64_t)tn * BN_;
+    const int64_t wave_m = m0 + wr * WTM;
+    const int64_t wave_n = n0 + wc * 64;
+
+    // ---- per-wave epilogue mode (wave-uniform) ----
+    const bool is_vt = A_MODE == UC_A_DENSE && p.vt_col0 >= 0 && wave_n >= p.vt_col0;        // conv tiles take neither epilogue
+    const bool is_rope = A_MODE == UC_A_DENSE && !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
+    const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
+
+    // ---- DMA sources: instruction I = wave*PER + q covers combined-tile rows [RPI*I, RPI*(I+1)) ----
+    // Dense: one 64-bit source pointer per instruction, advanced by k0.
+    // Conv: buffer-addressed DMA.  Two wave-uniform descriptors (the input window of this tile, shifted back by one image
+    // row + one pixel so that tap (ky,kx) is a non-negative uniform soffset, and the tile's weight rows); per instruction a
+    // 32-bit byte offset of the lane's row and a 9-bit mask of the taps that fall inside the image.  A tap in the zero
+    // padding sets the lane's offset to 0xffffffff: out of the descriptor's range, and the hardware writes zeros to LDS
+    // (tools/probes/buffer_lds.hip) — no 64-bit per-lane address math, no padding source, half the address registers.
+    const bf16_t* src[A_MODE == UC_A_DENSE ? PER : 1];
+    unsigned st0[A_MODE == UC_A_DENSE ? 1 : PER], st1[A_MODE == UC_A_DENSE ? 1 : PER];
+    uint4_t srd_a = (uint4_t){0u, 0u, 0u, 0u}, srd_w = srd_a;
+    if constexpr (A_MODE != UC_A_DENSE) {
+        const int b0 = (int)uc_div((unsigned)min(m0, p.M - 1), p.dHWo);     // < 2^30 output pixels (launcher-checked)
+        const unsigned long long pa = (unsigned long long)(p.A + ((int64_t)b0 * p.cH * p.cW - (p.cW + 1)) * p.cCin);
+        const unsigned long long pw = (unsigned long long)(p.W + min(n0, p.N - 1) * p.K);
+        srd_a = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
+        srd_w = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pw), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pw >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int rr = (wave * PER + q) * RPI + lane / CPR;
+            const int c = (lane % CPR) ^ glds_swz<BK_>(rr);
+            if (rr < BM_) {
+                const unsigned m = (unsigned)min(m0 + rr, p.M - 1);          // < 2^30 output pixels (launcher-checked)
+                const unsigned mrow = uc_div(m, p.dWo);
+                const int ox = (int)(m - mrow * (unsigned)p.cWo) * p.cStride;
+                const unsigned b = uc_div(mrow, p.dHo);
+                const int oy = (int)(mrow - b * (unsigned)p.cHo) * p.cStride;
+                st0[q] = (unsigned)((((int64_t)((int)b - b0) * p.cH + oy) * p.cW + ox) * p.cCin + c * 8) * 2u;
+                unsigned colmask = 0, mask = 0;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) colmask |= ((unsigned)(ox - 1 + kx) < (unsigned)p.cW ? 1u : 0u) << kx;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) mask |= ((unsigned)(oy - 1 + ky) < (unsigned)p.cH ? colmask : 0u) << (3 * ky);
+                st1[q] = mask;
+            } else {
+                const int64_t n = min(n0 + (rr - BM_), p.N - 1);
+                st0[q] = (unsigned)((n - min(n0, p.N - 1)) * p.K + c * 8) * 2u;
+                st1[q] = 0x1ffu;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int rr = (wave * PER + q) * RPI + lane / CPR;
+            const int c = (lane % CPR) ^ glds_swz<BK_>(rr);   // logical chunk stored at physical chunk (lane % CPR) of row rr
+            if (rr < BM_) src[q] = p.A + min(m0 + rr, p.M - 1) * p.lda + c * 8;
+            else src[q] = p.W + min(n0 + (rr - BM_), p.N - 1) * p.K + c * 8;
+        }
+    }
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;   // LDS byte address of the dynamic region
+    auto issue_stage = [&](int stage, int64_t k0) {
+        int tap = 0;
+        unsigned soff_a = 0, soff_w = 0;
+        if constexpr (A_MODE != UC_A_DENSE) {
+            tap = (int)uc_div((unsigned)k0, p.dCin);
+            const int ch0 = (int)k0 - tap * p.cCin;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            soff_a = (unsigned)(((ky * p.cW + kx) * p.cCin + ch0) * 2);
+            soff_w = (unsigned)(k0 * 2);
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE_BYTES + wave * (PER * 1024) + q * 1024));
+            if constexpr (A_MODE == UC_A_DENSE) {
+                dma16_to_lds(src[q] + k0, dst);
+            } else {
+                const bool is_a = (wave * PER + q) * RPI < BM_;   // wave-uniform: an instruction is all-A or all-W
+                const unsigned vo = ((st1[q] >> tap) & 1u) ? st0[q] : 0xffffffffu;
+                if (is_a) dma16_buf_to_lds(vo, srd_a, soff_a, dst);
+                else dma16_buf_to_lds(vo, srd_w, soff_w, dst);
+            }
+        }
+    };
+
+    // ---- fragment addressing (identity row maps: conflict-free under the (row>>1)&7 chunk swizzle) ----
+    // Row r of fragment i is wr*WTM + 16 i + frow (A) / BM + wc*64 + 16 j + frow (W): the swizzle key (r>>1)&7 only depends
+    // on frow (all other terms are multiples of 16), and the row offsets are one base + compile-time multiples of 2 KiB —
+    // two base registers and two swizzled chunk offsets (one per 32-wide K half) address all 8..12 fragment reads.
+    const int frow = lane & 15;
+    const int fk = lane >> 4;
+    const int f_sw = glds_swz<BK_>(frow);
+    const int a_base = (wr * WTM + frow) * ROWB;
+    const int w_base = (BM_ + wc * 64 + frow) * ROWB;
+    const int ch_off[2] = {((0 * 4 + fk) ^ f_sw) << 4, ((1 * 4 + fk) ^ f_sw) << 4};   // [1] unused when BK_ == 32
+
+    float4_t acc[FA][4];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    // K range of this workgroup (whole K unless split_k > 1)
+    const int nk_total = (int)(p.K / BK_);
+    const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
+    const int kt0 = ksplit * nk_per;
+    int nk = max(0, min(nk_per, nk_total - kt0));
+    if (p.dbg & 8) nk = min(nk, 1);                      // diagnostics: one K-step only (launch + prologue + epilogue cost)
+    const int64_t kbase = (int64_t)kt0 * BK_;
+    // SWAP: first MFMA operand = W rows -> C^T fragments (lane owns 4 consecutive columns of one row);
+    // !SWAP (VT tiles): first operand = A rows (lane owns 4 consecutive tokens of one channel).
+    auto compute_stage = [&](const char* st, auto swap_tag, auto&& mid) {
+        constexpr bool SWAP = decltype(swap_tag)::value;
+#pragma unroll
+        for (int ks = 0; ks < BK_ / 32; ++ks) {
+            bf16x8_t af[FA];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+                uint4 raw = *reinterpret_cast<const uint4*>(st + a_base + ch_off[ks] + i * 16 * ROWB);
+                if constexpr (A_MODE != UC_A_DENSE) {
+                    if (p.relu_a) raw = glds_relu_bf16x8(raw);   // uniform flag: ReLU of the DPT residual conv unit, applied on load
+                }
+                af[i] = __builtin_bit_cast(bf16x8_t, raw);
+            }
+            if constexpr (A_MODE == UC_A_DENSE) {
+                bf16x8_t wf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 16 * ROWB);
+#pragma unroll
+                for (int i = 0; i < FA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                    }
+            } else {
+                // conv tiles carry more loop state (offsets, tap masks, two descriptors): W fragments are read one at a time
+                // (20 instead of 32 fragment registers) so that nothing spills inside the K-loop
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 16 * ROWB);
+#pragma unroll
+                    for (int i = 0; i < FA; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (ks == 0) mid();
+        }
+    };
+    auto main_loop = [&](auto swap_tag) {
+        if constexpr (STAGES == 2) {
+            // 2-stage ring: the DMA of step kt+1 is in flight while the MFMAs of step kt run.
+            if (nk > 0) issue_stage(0, kbase);
+            for (int kt = 0; kt < nk; ++kt) {
+                wait_vmcnt<0>();                 // this wave's pieces of stage kt have landed
+                if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();    // ... and everyone else's; every wave is done reading stage kt-1
+                if (p.trace && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
+                asm volatile("" ::: "memory");
+                // where the next stage's DMA is issued (same-box A/B): dense pieces cost one 64-bit add each and go first
+                // (behind the first MFMA group they lost 0-5 %, split between the wave halves of a SIMD 2-8 %); conv pieces
+                // carry the tap test, s_nop 4 and a descriptor select and go behind the wave's first 16 queued MFMAs (+5 % on
+                // the 256-channel convs)
+                if constexpr (A_MODE == UC_A_DENSE) {
+                    if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
+                    compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag, [] {});
+                } else {
+                    compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag, [&] {
+                        if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
+                    });
+                }
+            }
+        } else {
+            // 3-stage ring, DMA two K-steps ahead: the loads of step kt+1 stay in flight across the barrier of step kt.
+            if (nk > 0) issue_stage(0, kbase);
+            if (nk > 1) issue_stage(1, kbase + BK_);
+            int cur = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (p.trace && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
+                asm volatile("" ::: "memory");
+                int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
+                if (kt + 2 < nk) issue_stage(nxt, kbase + (int64_t)(kt + 2) * BK_);
+                compute_stage(smem + cur * STAGE_BYTES, swap_tag, [] {});
+                cur = (cur == 2) ? 0 : cur + 1;
+            }
+        }
+    };
+    if constexpr (A_MODE == UC_A_DENSE) {
+        if (mode == 2) main_loop(std::false_type{}); else main_loop(std::true_type{});
+    } else {
+        main_loop(std::true_type{});
+    }
+
+    // The epilogue's parameters are re-read from the kernarg segment HERE.  Carried through the K-loop in SGPRs (some 60 of
+    // them: pointers, leading dimensions, option words) they overflowed the scalar file, the overflow went to VGPR lanes, and
+    // the 128-VGPR K-loop answered with scratch reloads of its DMA source pointers inside the loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((opencl_constant)) GldsParams* kp =
+        (const __attribute__((opencl_constant)) GldsParams*)__builtin_amdgcn_kernarg_segment_ptr();   // explicit arguments start at offset 0
+    asm volatile("" : "+s"(kp)::"memory");
+    glds_pe_t pe = *kp;
+#else
+    glds_pe_t pe = p;
+#endif
+    if (pe.dbg & 4) {                                     // diagnostics: no epilogue (keeps the accumulators live)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s == 12345.678f) reinterpret_cast<float*>(pe.C)[0] = s;
+        return;
+    }
+    // every wave is done with the last stage: the ring becomes the epilogue's bounce space (8 KiB per wave)
+    static_assert(STAGES * STAGE_BYTES >= NW * 8192, "bounce space");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (pe.trace) tr2 = __builtin_amdgcn_s_memrealtime();
+    if (wave_n < pe.N) {
+        // a fresh definition of the lane id: keeps the compiler from hoisting the epilogue's per-lane address math above
+        // the K-loop, where it spilled loop-carried registers of the 128-VGPR kernels
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        char* wbuf = smem + wave * 8192;
+        // (the launcher routes a descriptor to the BF16 / F32 family only when every tile of it takes that family's epilogue)
+        const bool plain = pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && !pe.preact && !pe.dact_u && !(pe.dbg & 16);
+        auto bf16_family = [&]() __attribute__((always_inline)) {
+            const bool nt = pe.nt_out & (mode == 1 ? 4 : 2);
+            if (A_MODE == UC_A_DENSE && pe.ln_stats) {   // folded LayerNorm
+                if constexpr (A_MODE == UC_A_DENSE) {
+                    if (nt) {
+                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                        else glds_epilogue_bf16<FA, UC_ACT_NONE, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                    } else {
+                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                        else glds_epilogue_bf16<FA, UC_ACT_NONE, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                    }
+                }
+            } else if (nt) {
+                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_bf16<FA, UC_ACT_NONE, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            } else {
+                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_bf16<FA, UC_ACT_NONE>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            }
+        };
+        auto f32_family = [&]() __attribute__((always_inline)) {
+            if (pe.nt_out & 1) glds_epilogue_resid<FA, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_resid<FA, false>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+        };
+        if constexpr (EPI == GLDS_EPI_BF16) {
+            if (mode == 2) {
+                if (A_MODE == UC_A_DENSE && pe.ln_stats) glds_epilogue_vt<FA, A_MODE == UC_A_DENSE>(pe, acc, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_vt<FA>(pe, acc, wave_m, wave_n, lane, wbuf);
+            } else bf16_family();
+        } else if constexpr (EPI == GLDS_EPI_F32) {
+            f32_family();
+        } else {
+            if (mode == 2) glds_epilogue_vt<FA>(pe, acc, wave_m, wave_n, lane, wbuf);
+            else if (plain && pe.out_dtype == UC_BF16 && !pe.residual) bf16_family();
+            else if (plain && pe.out_dtype == UC_F32 && (!pe.residual || pe.res_dtype == UC_F32) && pe.act == UC_ACT_NONE) f32_family();
+            else glds_epilogue_generic<FA>(pe, acc, mode, wave_m, wave_n, lane, ksplit, wbuf);
+        }
+    }
+    if (pe.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* t = pe.trace + (size_t)blockIdx.x * 6;
+            t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime(); t[4] = hw; t[5] = xcc;
+        }
+    }
+}
+
+template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1, int EPI = GLDS_EPI_ALL>
+static void launch_variant_mode(GldsParams p, hipStream_t st) {
+    p.tiles_m = (int)ceil_div64(p.M, BM_);
+    p.tiles_n = (int)ceil_div64(p.N, BN_);
+    p.dNwg = uc_make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
+    p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
+    p.dGm = uc_make_fastdiv((unsigned)p.group_m);
+    p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
+    auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES, A_MODE, BK_, WGS_PER_CU, EPI>;
+    constexpr int smem = STAGES * (BM_ + BN_) * BK_ * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n * (unsigned)p.split_k), dim3(WM_ * WN_ * 64), smem, st, p);
+}
+
+
+// Tile variants of one (A_MODE, EPI) pair: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2), 2 = 256x256 (4x4), 3 = 256x128x32 with
+// two co-resident workgroups per CU.
+template <int A_MODE, int EPI>
+static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t st) {
+    static int deep = -1;
+    if (deep < 0) { const char* e = getenv("UC_GEMM_SMALL_STAGES"); deep = e ? atoi(e) : 3; }
+    const int64_t sk = p.split_k > 1 ? p.split_k : 1;
+    switch (variant) {
+        case 1:
+            // latency regime (fewer workgroups than CUs: every K-step waits for its own DMA): a 3-stage ring keeps two stages in flight
+            if (deep == 3 && ceil_div64(p.M, 256) * ceil_div64(p.N, 128) * sk <= 256) launch_variant_mode<256, 128, 4, 2, 3, A_MODE, 64, 1, EPI>(p, st);
+            else launch_variant_mode<256, 128, 4, 2, 2, A_MODE, 64, 1, EPI>(p, st);
+            break;
+        case 2: launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI>(p, st); break;
+        case 3: launch_variant_mode<256, 128, 4, 2, 3, A_MODE, 32, 2, EPI>(p, st); break;
+        default:
+            if (deep == 3 && ceil_div64(p.M, 128) * ceil_div64(p.N, 128) * sk <= 512) launch_variant_mode<128, 128, 2, 2, 3, A_MODE, 64, 1, EPI>(p, st);
+            else launch_variant_mode<128, 128, 2, 2, 2, A_MODE, 64, 1, EPI>(p, st);
+            break;
+    }
+}

@@ -267,6 +267,7 @@ extern "C" int uc_splitk_reduce(const float* ws, int split_k, int64_t n, int64_t
                                 uc_stream_t stream) {
     UC_REQUIRE(ws && out && split_k >= 1 && n > 0 && n % 4 == 0 && slab_stride >= n && slab_stride % 4 == 0,
                "uc_splitk_reduce: bad argument (n and slab_stride must be multiples of 4)");
+    UC_REQUIRE(((uintptr_t)ws % 16 == 0) && ((uintptr_t)out % 16 == 0), "uc_splitk_reduce: ws and out must be 16-byte aligned (float4 accesses)");
     const int64_t n4 = n / 4;
     const unsigned grid = (unsigned)min((int64_t)8192, ceil_div64(n4, 256));
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, split_k, n4, slab_stride / 4, out, accumulate);

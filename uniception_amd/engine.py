@@ -83,6 +83,52 @@ def head_dtype() -> torch.dtype:
     return torch.float32 if _head_mode == "fp32" else compute_dtype()
 
 
+# ---------------------------------------------------------------------------------------------
+# LayerNorm folded into the GEMMs around it (bf16 inference): the GEMM that writes the fp32 residual stream also writes a
+# bf16 twin of the rows and their per-row statistics (ops.gemm(emit_ln=True) -> out.uc_ln); the next sub-layer's first GEMM
+# takes the twin as its A operand with gamma folded into the weight and applies rstd * (acc - mean * colsum) + (b + W beta)
+# in its epilogue (ops.gemm(ln=...)).  No LayerNorm kernel, no normalized copy of the stream in HBM.
+# ---------------------------------------------------------------------------------------------
+_ln_fold: bool = os.environ.get("UNICEPTION_AMD_LN_FOLD", "1") != "0"
+
+
+def set_ln_fold(on: bool) -> None:
+    """Switch the fused LayerNorm + GEMM path (default on; off: every LayerNorm is the stand-alone kernel)."""
+    global _ln_fold
+    _ln_fold = bool(on)
+
+
+def fold_ok(dt: torch.dtype, *dims: int) -> bool:
+    """The folded path exists for bf16 operands without autograd; channel counts must be multiples of the 64-wide tile."""
+    return _ln_fold and dt == torch.bfloat16 and not torch.is_grad_enabled() and all(d % 64 == 0 for d in dims)
+
+
+def carry_ln(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """`dst` is a reshaped view of the same rows as `src`: hand the producer's twin / statistics over."""
+    side = getattr(src, "uc_ln", None)
+    if side is not None:
+        dst.uc_ln = side
+    return dst
+
+
+def finalize_ln(x2d: torch.Tensor, ln: nn.Module) -> None:
+    """Materialize the (mean, rstd) rows a later ln_operand(x2d, ln) will use on the CURRENT stream (call before forking
+    work that shares x2d across HIP streams: the lazily built statistics are cached on the tensor)."""
+    side = getattr(x2d, "uc_ln", None)
+    if side is not None and isinstance(ln, nn.LayerNorm):
+        side.stats(ln.eps)
+
+
+def ln_operand(x2d: torch.Tensor, ln: nn.Module, dt: torch.dtype):
+    """A operand of the GEMM behind LayerNorm `ln` of the stream x2d.  Returns (operand, fold): fold is None and operand =
+    LN(x) in dt (stand-alone kernel), or fold = (stats [M,2], ln) and operand = the producer's raw bf16 twin."""
+    side = getattr(x2d, "uc_ln", None)
+    if (side is not None and isinstance(ln, nn.LayerNorm) and ln.elementwise_affine and fold_ok(dt, x2d.shape[-1])
+            and side.twin.shape == x2d.shape):
+        return side.twin, (side.stats(ln.eps), ln)
+    return layernorm(x2d, ln, dt), None
+
+
 def require_inference(*tensors) -> None:
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise UcHipError(
@@ -140,6 +186,31 @@ def kv_weights(projk: nn.Linear, projv: nn.Linear, dtype: torch.dtype):
             b = torch.cat([zk, zv]).float().contiguous()
         return w, b
     return prepared(projk, ("kv", dtype), (projk.weight, projk.bias, projv.weight, projv.bias), build)
+
+
+def _fold_ln(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm, dtype: torch.dtype):
+    """(W * gamma in dtype, b + W beta fp32, row sums of the ROUNDED W * gamma fp32): LN(x) W^T + b = rstd (x W'^T - mean colsum) + b'."""
+    w32 = w.detach().float()
+    wf = (w32 * ln.weight.detach().float()[None, :]).to(dtype).contiguous()
+    bias = w32 @ ln.bias.detach().float()
+    if b is not None:
+        bias = bias + b.detach().float()
+    return wf, bias.contiguous(), wf.float().sum(1).contiguous()
+
+
+def ln_lin_weights(lin: nn.Linear, ln: nn.LayerNorm, dtype: torch.dtype):
+    """Weights of `lin` applied to LayerNorm `ln`'s output, in the folded form (see _fold_ln)."""
+    return prepared(lin, ("lnlin", dtype), (lin.weight, lin.bias, ln.weight, ln.bias),
+                    lambda: _fold_ln(lin.weight, lin.bias, ln, dtype))
+
+
+def ln_kv_weights(projk: nn.Linear, projv: nn.Linear, ln: nn.LayerNorm, dtype: torch.dtype):
+    def build():
+        w = torch.cat([projk.weight.detach(), projv.weight.detach()], 0)
+        zk = projk.bias.detach() if projk.bias is not None else torch.zeros_like(projk.weight[:, 0])
+        zv = projv.bias.detach() if projv.bias is not None else torch.zeros_like(projv.weight[:, 0])
+        return _fold_ln(w, torch.cat([zk, zv]), ln, dtype)
+    return prepared(projk, ("lnkv", dtype), (projk.weight, projk.bias, projv.weight, projv.bias, ln.weight, ln.bias), build)
 
 
 def conv1x1_weights(conv: nn.Conv2d, dtype: torch.dtype):
@@ -237,33 +308,45 @@ def _pos2d(pos: torch.Tensor) -> torch.Tensor:
 # attention sub-graphs on the token stream.  x2d: [B*N, C]; returns the attention-branch output
 # (proj applied) with `residual` added by the proj GEMM epilogue when given.
 # ---------------------------------------------------------------------------------------------
+def _folded(lin: nn.Linear, fold, dtype: torch.dtype):
+    """(W, b, ln-argument of ops.gemm) of `lin` behind a LayerNorm: folded when `fold` = (stats, ln) from ln_operand."""
+    if fold is None:
+        return lin_weights(lin, dtype) + (None,)
+    w, b, cs = ln_lin_weights(lin, fold[1], dtype)
+    return w, b, (fold[0], cs)
+
+
 def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.Linear, num_heads: int, rope, pos,
-                   scale: float, residual: Optional[torch.Tensor], out_dtype: torch.dtype, proj_wb=None) -> torch.Tensor:
-    """proj_wb: optional prepared (W, b) overriding proj's own (e.g. with a LayerScale folded in)."""
+                   scale: float, residual: Optional[torch.Tensor], out_dtype: torch.dtype, proj_wb=None, fold=None,
+                   emit_ln: bool = False) -> torch.Tensor:
+    """proj_wb: optional prepared (W, b) overriding proj's own (e.g. with a LayerScale folded in).
+    fold: from ln_operand — h2d is then the RAW bf16 stream and the LayerNorm is applied by the QKV GEMM's epilogue.
+    emit_ln: the proj GEMM also writes the twin / statistics the next sub-layer's folded LayerNorm consumes."""
     dtype = h2d.dtype
     M, Cd = h2d.shape
     Dh = Cd // num_heads
-    wq, bq = lin_weights(qkv, dtype)
+    wq, bq, lnq = _folded(qkv, fold, dtype)
     wp, bp = proj_wb if proj_wb is not None else lin_weights(proj, dtype)
     native = rope is None or is_native_rope(rope)
     if dtype == torch.bfloat16 and Dh == 64 and native and _fp8_attention():
         ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
-        t5 = ops.gemm(h2d, wq, bq, rope=ep).view(B, N, 3, num_heads, Dh)
+        t5 = ops.gemm(h2d, wq, bq, rope=ep, ln=lnq).view(B, N, 3, num_heads, Dh)
         o = ops.attention_fp8(t5[:, :, 0], t5[:, :, 1], ops.vt_pack_fp8(t5[:, :, 2]), scale)
     elif dtype == torch.bfloat16 and Dh == 64 and native:
         vt = ops.vt_buffer(B, num_heads, N, h2d.device)
         ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
-        qk = ops.gemm(h2d, wq, bq, rope=ep, vt=(2 * Cd, vt, N))
+        qk = ops.gemm(h2d, wq, bq, rope=ep, vt=(2 * Cd, vt, N), ln=lnq)
         qk5 = qk.view(B, N, 2, num_heads, Dh)
         o = ops.attention(qk5[:, :, 0], qk5[:, :, 1], vt, scale, v_packed=True)
     else:
         if dtype == torch.bfloat16 and Dh != 64:
             raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh}); use fp32 precision for this model")
-        t = ops.gemm(h2d, wq, bq).view(B, N, 3, num_heads, Dh)
+        t = ops.gemm(h2d, wq, bq, ln=lnq).view(B, N, 3, num_heads, Dh)
         q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
         q, k = _apply_rope(rope, q, k, pos, pos)
         o = _attention_generic(q, k, v, scale)
-    return ops.gemm(o.view(M, Cd), wp, bp, residual=residual, out_dtype=out_dtype)
+    emit = emit_ln and out_dtype == torch.float32 and fold_ok(dtype, Cd)
+    return ops.gemm(o.view(M, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
 
 def _apply_rope(rope, q, k, qpos, kpos):
@@ -291,44 +374,55 @@ def _attention_generic(q, k, v, scale):
 
 def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk: int, projq: nn.Linear, projk: nn.Linear,
                     projv: nn.Linear, proj: nn.Linear, num_heads: int, rope, qpos, kpos, scale: float,
-                    residual: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+                    residual: Optional[torch.Tensor], out_dtype: torch.dtype, fold_q=None, fold_kv=None,
+                    emit_ln: bool = False) -> torch.Tensor:
+    """fold_q / fold_kv: from ln_operand for the query / key-value streams (see self_attention)."""
     dtype = hq2d.dtype
     Cd = hq2d.shape[1]
     Dh = Cd // num_heads
-    wq, bq = lin_weights(projq, dtype)
-    wkv, bkv = kv_weights(projk, projv, dtype)
+    wq, bq, lnq = _folded(projq, fold_q, dtype)
+    if fold_kv is None:
+        (wkv, bkv), lnkv = kv_weights(projk, projv, dtype), None
+    else:
+        wkv, bkv, cskv = ln_kv_weights(projk, projv, fold_kv[1], dtype)
+        lnkv = (fold_kv[0], cskv)
     wp, bp = lin_weights(proj, dtype)
     native = rope is None or is_native_rope(rope)
     if dtype == torch.bfloat16 and Dh == 64 and native and _fp8_attention():
         epq = _rope_epilogue(rope, _pos2d(qpos), Cd) if rope is not None else None
         epk = _rope_epilogue(rope, _pos2d(kpos), Cd) if rope is not None else None
-        q = ops.gemm(hq2d, wq, bq, rope=epq).view(B, Nq, num_heads, Dh)
-        kv5 = ops.gemm(hkv2d, wkv, bkv, rope=epk).view(B, Nk, 2, num_heads, Dh)
+        q = ops.gemm(hq2d, wq, bq, rope=epq, ln=lnq).view(B, Nq, num_heads, Dh)
+        kv5 = ops.gemm(hkv2d, wkv, bkv, rope=epk, ln=lnkv).view(B, Nk, 2, num_heads, Dh)
         o = ops.attention_fp8(q, kv5[:, :, 0], ops.vt_pack_fp8(kv5[:, :, 1]), scale)
     elif dtype == torch.bfloat16 and Dh == 64 and native:
         vt = ops.vt_buffer(B, num_heads, Nk, hq2d.device)
         epq = _rope_epilogue(rope, _pos2d(qpos), Cd) if rope is not None else None
         epk = _rope_epilogue(rope, _pos2d(kpos), Cd) if rope is not None else None
-        q = ops.gemm(hq2d, wq, bq, rope=epq).view(B, Nq, num_heads, Dh)
-        k = ops.gemm(hkv2d, wkv, bkv, rope=epk, vt=(Cd, vt, Nk)).view(B, Nk, num_heads, Dh)
+        q = ops.gemm(hq2d, wq, bq, rope=epq, ln=lnq).view(B, Nq, num_heads, Dh)
+        k = ops.gemm(hkv2d, wkv, bkv, rope=epk, vt=(Cd, vt, Nk), ln=lnkv).view(B, Nk, num_heads, Dh)
         o = ops.attention(q, k, vt, scale, v_packed=True)
     else:
         if dtype == torch.bfloat16 and Dh != 64:
             raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh}); use fp32 precision for this model")
-        q = ops.gemm(hq2d, wq, bq).view(B, Nq, num_heads, Dh)
-        kv = ops.gemm(hkv2d, wkv, bkv).view(B, Nk, 2, num_heads, Dh)
+        q = ops.gemm(hq2d, wq, bq, ln=lnq).view(B, Nq, num_heads, Dh)
+        kv = ops.gemm(hkv2d, wkv, bkv, ln=lnkv).view(B, Nk, 2, num_heads, Dh)
         k, v = kv[:, :, 0], kv[:, :, 1]
         q, k = _apply_rope(rope, q, k, qpos, kpos)
         o = _attention_generic(q, k, v, scale)
-    return ops.gemm(o.reshape(B * Nq, Cd), wp, bp, residual=residual, out_dtype=out_dtype)
+    emit = emit_ln and out_dtype == torch.float32 and fold_ok(dtype, Cd)
+    return ops.gemm(o.reshape(B * Nq, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
 
 def mlp(h2d: torch.Tensor, fc1: nn.Linear, fc2: nn.Linear, act: str, residual: Optional[torch.Tensor],
-        out_dtype: torch.dtype, fc2_wb=None) -> torch.Tensor:
-    w1, b1 = lin_weights(fc1, h2d.dtype)
+        out_dtype: torch.dtype, fc2_wb=None, fold=None, emit_ln: bool = False) -> torch.Tensor:
+    """fold / emit_ln: see self_attention (fc1 takes the folded LayerNorm, fc2 writes the next one's twin / statistics)."""
+    if fold is not None and act not in ("gelu", "none", None):
+        raise UcHipError("the folded LayerNorm epilogue exists for GELU / no activation")
+    w1, b1, ln1 = _folded(fc1, fold, h2d.dtype)
     w2, b2 = fc2_wb if fc2_wb is not None else lin_weights(fc2, h2d.dtype)
-    g = ops.gemm(h2d, w1, b1, act=act)
-    return ops.gemm(g, w2, b2, residual=residual, out_dtype=out_dtype)
+    g = ops.gemm(h2d, w1, b1, act=act, ln=ln1)
+    emit = emit_ln and out_dtype == torch.float32 and fold_ok(h2d.dtype, w2.shape[0])
+    return ops.gemm(g, w2, b2, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
 
 def act_name(act_module: nn.Module) -> str:

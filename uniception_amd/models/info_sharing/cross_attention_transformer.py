@@ -121,17 +121,22 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
             x2d = nlc.reshape(B * N, self.input_embed_dim)
             if not isinstance(self.proj_embed, nn.Identity):
                 wpe, bpe = engine.lin_weights(self.proj_embed, dt)
-                x2d = ops.gemm(x2d, wpe, bpe, out_dtype=torch.float32)
+                x2d = ops.gemm(x2d, wpe, bpe, out_dtype=torch.float32, emit_ln=engine.fold_ok(dt, self.dim, self.input_embed_dim))
             xs.append(x2d)
         if self.custom_positional_encoding is not None:
             pos = [self.position_getter(B, h, w, f.device) for f in feats]
         else:
             pos = [None] * V
+        if engine.is_native_rope(self.custom_positional_encoding) and dt == torch.bfloat16:
+            # shared caches are filled on the main stream before any branch work is forked to a side stream
+            ops.rope_table(feats[0].device, engine.ROPE_TABLE_NPOS, self.custom_positional_encoding.base, self.custom_positional_encoding.F0)
         taken = []
         for d in range(self.depth):
             if V == 2:   # the two branches of a depth level are independent (Jacobi update): two streams when they are small
                 b0, b1 = self.multi_view_branches[0][d], self.multi_view_branches[1][d]
                 x0, x1 = xs
+                engine.finalize_ln(x0, b0.norm1)   # both branches read both streams' row statistics
+                engine.finalize_ln(x1, b1.norm1)
                 xs = list(engine.run_branches(
                     lambda: b0.forward_tokens(x0, x1, B, N, N, pos[0], pos[1], dt),
                     lambda: b1.forward_tokens(x1, x0, B, N, N, pos[1], pos[0], dt), B * N, inputs1=(x0, x1)))

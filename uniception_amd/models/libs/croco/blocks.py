@@ -55,7 +55,7 @@ def _as_2d(x):
     B, N, C = x.shape
     if x.dtype not in (torch.float32, torch.bfloat16):
         raise engine.UcHipError(f"token dtype {x.dtype} not supported (fp32 or bf16)")
-    return x.reshape(B * N, C) if x.is_contiguous() else x.contiguous().view(B * N, C)
+    return engine.carry_ln(x, x.reshape(B * N, C)) if x.is_contiguous() else x.contiguous().view(B * N, C)
 
 
 class Mlp(nn.Module):
@@ -73,9 +73,9 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features, bias=bias[1])
         self.drop2 = nn.Dropout(drop_probs[1])
 
-    def _run(self, h2d, residual, out_dtype):
+    def _run(self, h2d, residual, out_dtype, fold=None, emit_ln=False):
         _check_no_dropout(self, self.drop1.p, self.drop2.p)
-        return engine.mlp(h2d, self.fc1, self.fc2, engine.act_name(self.act), residual, out_dtype)
+        return engine.mlp(h2d, self.fc1, self.fc2, engine.act_name(self.act), residual, out_dtype, fold=fold, emit_ln=emit_ln)
 
     def forward(self, x):
         engine.require_inference(x, self.fc1.weight)
@@ -102,10 +102,10 @@ class Attention(nn.Module):
         self.torch_attn = torch_attn
         self.dropout_p = attn_drop
 
-    def _run(self, h2d, B, N, xpos, residual, out_dtype):
+    def _run(self, h2d, B, N, xpos, residual, out_dtype, fold=None, emit_ln=False):
         _check_no_dropout(self, self.dropout_p, self.proj_drop.p)
         return engine.self_attention(h2d, B, N, self.qkv, self.proj, self.num_heads, self.rope, xpos, self.scale,
-                                     residual, out_dtype)
+                                     residual, out_dtype, fold=fold, emit_ln=emit_ln)
 
     def forward(self, x, xpos):
         engine.require_inference(x, self.qkv.weight)
@@ -138,10 +138,11 @@ class Block(nn.Module):
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads,
                                               self.attn.rope, xpos, self.attn.scale, dt)
             return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt)
-        h = engine.layernorm(x2d, self.norm1, dt)
-        x2d = self.attn._run(h, B, N, xpos, x2d, x2d.dtype)
-        h = engine.layernorm(x2d, self.norm2, dt)
-        return self.mlp._run(h, x2d, x2d.dtype)
+        # LayerNorm -> GEMM pairs run fused when the stream carries its producer's bf16 twin + row statistics (engine.ln_operand)
+        h, fold = engine.ln_operand(x2d, self.norm1, dt)
+        x2d = self.attn._run(h, B, N, xpos, x2d, x2d.dtype, fold, True)
+        h, fold = engine.ln_operand(x2d, self.norm2, dt)
+        return self.mlp._run(h, x2d, x2d.dtype, fold, True)
 
     def forward(self, x, xpos):
         B, N, C = x.shape

@@ -47,7 +47,9 @@ class PatchEmbedCroCo(nn.Module):
         else:
             cols = ops.patch_gather(img, P, dt)
             w, b = engine.patch_weights(self.proj, dt)
-            tok = ops.gemm(cols, w, b, out_dtype=torch.float32).view(B, (H // P) * (W // P), -1)
+            emit = isinstance(self.norm, nn.Identity) and engine.fold_ok(dt, w.shape[0], w.shape[1])   # first block's LayerNorm folds into its QKV GEMM
+            tok2d = ops.gemm(cols, w, b, out_dtype=torch.float32, emit_ln=emit)
+            tok = engine.carry_ln(tok2d, tok2d.view(B, (H // P) * (W // P), -1))
         pos = self.position_getter(B, H // P, W // P, x.device)
         if not isinstance(self.norm, nn.Identity):
             if train:

@@ -59,7 +59,7 @@ class Attention(nn.Module):
         self.base_token_count_for_entropy_scaling = base_token_count_for_entropy_scaling
         self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
 
-    def _run(self, h2d, B, N, xpos, residual, out_dtype):
+    def _run(self, h2d, B, N, xpos, residual, out_dtype, fold=None, emit_ln=False):
         _check_no_dropout(self, self.attn_drop.p, self.proj_drop.p)
         if not isinstance(self.q_norm, nn.Identity):
             raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
@@ -67,7 +67,7 @@ class Attention(nn.Module):
             assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
         scale = self.scale * _softmax_scale_multiplier(self, N)
         return engine.self_attention(h2d, B, N, self.qkv, self.proj, self.num_heads, self.custom_positional_encoding, xpos,
-                                     scale, residual, out_dtype)
+                                     scale, residual, out_dtype, fold=fold, emit_ln=emit_ln)
 
     def forward(self, x: torch.Tensor, xpos: torch.Tensor = None) -> torch.Tensor:
         engine.require_inference(x, self.qkv.weight)
@@ -105,7 +105,7 @@ class CrossAttention(nn.Module):
         self.base_token_count_for_entropy_scaling = base_token_count_for_entropy_scaling
         self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
 
-    def _run(self, hq2d, hkv2d, B, Nq, Nk, qpos, kpos, residual, out_dtype):
+    def _run(self, hq2d, hkv2d, B, Nq, Nk, qpos, kpos, residual, out_dtype, fold_q=None, fold_kv=None, emit_ln=False):
         _check_no_dropout(self, self.attn_drop.p, self.proj_drop.p)
         if not isinstance(self.q_norm, nn.Identity):
             raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
@@ -114,7 +114,8 @@ class CrossAttention(nn.Module):
             assert kpos is not None, "Positions of keys (kpos) are a required input when using custom positional encoding"
         scale = self.scale * _softmax_scale_multiplier(self, Nq)
         return engine.cross_attention(hq2d, hkv2d, B, Nq, Nk, self.projq, self.projk, self.projv, self.proj, self.num_heads,
-                                      self.custom_positional_encoding, qpos, kpos, scale, residual, out_dtype)
+                                      self.custom_positional_encoding, qpos, kpos, scale, residual, out_dtype,
+                                      fold_q=fold_q, fold_kv=fold_kv, emit_ln=emit_ln)
 
     def forward(self, query, key, value, qpos=None, kpos=None):
         engine.require_inference(query, key, value, self.projq.weight)
@@ -189,16 +190,17 @@ class CrossAttentionBlock(nn.Module):
             assert ypos is not None, "Positions of cross tokens (ypos) are a required input when using custom positional encoding"
         if autograd.grad_needed(x2d, y2d, self.norm1.weight, self.mlp.fc1.weight):
             return self._forward_tokens_train(x2d, y2d, B, Nx, Ny, xpos, ypos, dt)
-        h = engine.layernorm(x2d, self.norm1, dt)
-        x2d = self.attn._run(h, B, Nx, xpos, x2d, x2d.dtype)
+        # LayerNorm -> GEMM pairs run fused when a stream carries its producer's bf16 twin + row statistics (engine.ln_operand)
+        h, fold = engine.ln_operand(x2d, self.norm1, dt)
+        x2d = self.attn._run(h, B, Nx, xpos, x2d, x2d.dtype, fold, True)
         if isinstance(self.norm_y, nn.Identity):
-            yn = y2d if y2d.dtype == dt else engine.ops.convert(y2d, dt)
+            yn, fold_y = (y2d if y2d.dtype == dt else engine.ops.convert(y2d, dt)), None
         else:
-            yn = engine.layernorm(y2d, self.norm_y, dt)
-        h = engine.layernorm(x2d, self.norm2, dt)
-        x2d = self.cross_attn._run(h, yn, B, Nx, Ny, xpos, ypos, x2d, x2d.dtype)
-        h = engine.layernorm(x2d, self.norm3, dt)
-        return self.mlp._run(h, x2d, x2d.dtype)
+            yn, fold_y = engine.ln_operand(y2d, self.norm_y, dt)
+        h, fold = engine.ln_operand(x2d, self.norm2, dt)
+        x2d = self.cross_attn._run(h, yn, B, Nx, Ny, xpos, ypos, x2d, x2d.dtype, fold, fold_y, True)
+        h, fold = engine.ln_operand(x2d, self.norm3, dt)
+        return self.mlp._run(h, x2d, x2d.dtype, fold, True)
 
     def _forward_tokens_train(self, x2d, y2d, B, Nx, Ny, xpos, ypos, dt):
         """Same three sub-layers as autograd Functions (HIP forward + HIP backward)."""

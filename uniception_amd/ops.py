@@ -103,13 +103,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rope: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
          vt: Optional[Tuple[int, torch.Tensor, int]] = None,
          conv: Optional[Tuple[int, int, int, int, int]] = None, preact_out: Optional[torch.Tensor] = None,
-         split_k: int = 1, dact: Optional[Tuple[torch.Tensor, str]] = None) -> torch.Tensor:
+         split_k: int = 1, dact: Optional[Tuple[torch.Tensor, str]] = None,
+         ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, emit_ln: bool = False) -> torch.Tensor:
     """C[M,N] = epilogue(A . W^T).
 
     a    : dense [M,K] (row stride a.stride(0), unit column stride) or, with conv=(B,H,W,Cin,stride), an NHWC image.
     w    : [N,K] contiguous, same dtype as a (fp32 -> exact fp32 kernel, bf16 -> MFMA kernel).
     rope : (positions [M,2] int64, table, rope_cols) -> fused RoPE-2D on the first rope_cols columns (bf16 only).
     vt   : (vt_col0, vt_out [B,H,64,Npad] bf16, ntok) -> V columns written in the packed VT layout (bf16 only).
+    ln   : (stats [M,2] fp32 (mean, rstd), colsum [N] fp32) -> folded LayerNorm: a holds the RAW rows, w has gamma folded in,
+           the epilogue computes rstd * (acc - mean * colsum) + bias (bf16 output only).
+    emit_ln : fp32 output only — also write a bf16 twin of the output and per-row 64-column-block statistics; they ride on the
+           returned tensor as ``out.uc_ln`` (an LnSide: twin, partial, finalized-stats cache) for the consumer's ``ln=``.
     """
     _need_gpu(a, w, bias, residual)
     assert a.dtype == w.dtype and w.is_contiguous() and w.dim() == 2
@@ -173,8 +178,40 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         u, act_name = dact
         assert u.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and u.shape == out.shape and u.stride() == out.stride()
         d.dact_u, d.dact_act = u.data_ptr(), ACT[act_name]
+    if ln is not None:
+        st, cs = ln
+        assert st.dtype == torch.float32 and st.is_contiguous() and st.shape == (M, 2)
+        assert cs.dtype == torch.float32 and cs.is_contiguous() and cs.numel() == N
+        d.ln_stats, d.ln_colsum = st.data_ptr(), cs.data_ptr()
+    side = None
+    if emit_ln:
+        assert out.dtype == torch.float32 and out.dim() == 2 and N % 64 == 0 and vt is None
+        side = LnSide(torch.empty((M, N), dtype=torch.bfloat16, device=a.device),
+                      torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device))
+        d.twin_out, d.ldt, d.stats_out = side.twin.data_ptr(), N, side.partial.data_ptr()
     _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
+    if side is not None:
+        out.uc_ln = side
     return out
+
+
+class LnSide:
+    """What a producer GEMM leaves next to its fp32 output rows for the folded LayerNorm of the consumer: a bf16 copy of the
+    rows and their per-block statistics; (mean, rstd) per row are finalized on first use, per eps."""
+    __slots__ = ("twin", "partial", "_stats")
+
+    def __init__(self, twin, partial):
+        self.twin, self.partial, self._stats = twin, partial, {}
+
+    def stats(self, eps: float) -> torch.Tensor:
+        st = self._stats.get(eps)
+        if st is None:
+            M, nblk, _ = self.partial.shape
+            st = torch.empty((M, 2), dtype=torch.float32, device=self.partial.device)
+            _lib.check(_lib.load().uc_ln_stats_finalize(self.partial.data_ptr(), M, nblk, float(eps), st.data_ptr(), _stream()),
+                       "uc_ln_stats_finalize")
+            self._stats[eps] = st
+        return st
 
 
 def vt_buffer(B: int, H: int, ntok: int, device) -> torch.Tensor:

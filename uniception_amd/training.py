@@ -1,16 +1,25 @@
 """Data-parallel training step for the DUSt3R hot path (BASELINE config 3): flat fp32 parameter / gradient / moment
-buffers, bucketed gradient all-reduce over RCCL (xGMI) overlapped with the backward, one AdamW kernel per step.
+buffers, bucketed gradient all-reduce over RCCL (xGMI) overlapped with the backward, AdamW kernels on contiguous ranges.
 
 Layout (per GPU, 288 GB HBM: a full fp32 replica of the 569 M-parameter model + grads + two moments is 9.1 GB):
-    flat_param [P] fp32   — every trainable nn.Parameter is a view into it (decayed tensors first, then biases/norms)
-    flat_grad  [P] fp32   — every param.grad is a view into it; autograd accumulates in place
+    flat_param [P] fp32   — every trainable nn.Parameter is a view into it
+    flat_grad  [P] fp32   — every param.grad is a view into it; autograd (and the gradient sink) accumulate in place
     exp_avg, exp_avg_sq [P] fp32
-Gradient exchange: parameters are bucketed in reverse registration order (the order the backward produces them); when the
-last gradient of a bucket has been accumulated (post-accumulate-grad hook) the bucket's slice of flat_grad is all-reduced
-asynchronously IN PLACE — no staging copies.  xGMI rings are per-link bound, so buckets are large (default 256 MiB: ~9
-collectives for the whole model) rather than the 25 MiB NVSwitch-era default.  `step()` waits for the handles and applies
-uc_adamw with grad_scale = 1/world_size (the mean) on the two contiguous ranges.
+The flat buffers are laid out in REVERSE registration order — the order in which the backward finishes gradients (heads
+first, patch embedding last) — and cut into buckets of >= bucket_bytes.  Inside a bucket the weight-decayed tensors come
+first and the biases / norm parameters after them, so a bucket is one contiguous all-reduce and two contiguous AdamW ranges;
+no bucket has to wait for parameters from the other end of the network.  Every slot starts on a 64-byte boundary (the
+split-K reduction that writes weight gradients straight into the buffer uses 16-byte accesses).
+
+Gradient exchange: when the last gradient of a bucket has been accumulated (post-accumulate-grad hook) the bucket's slice of
+flat_grad is all-reduced asynchronously IN PLACE — no staging copies.  Collectives are issued strictly in bucket order on
+every rank (a bucket that completes early waits for its predecessors), so ranks can never disagree on the sequence.  The
+producer-side ordering is explicit: an event recorded on the stream that wrote the gradients gates a dedicated
+communication stream, from which the collective is launched.  xGMI rings are per-link bound, so buckets are large (default
+256 MiB: ~9 collectives for the whole model) rather than the 25 MiB NVSwitch-era default.  `step()` waits for the handles
+and applies uc_adamw with grad_scale = 1/world_size (the mean).
 """
+import contextlib
 from typing import List
 
 import torch
@@ -19,15 +28,21 @@ import torch.nn as nn
 
 from . import autograd, engine, ops
 
+SLOT_ALIGN = 16   # elements (64 bytes)
+
 
 def _no_decay(name: str, p: torch.Tensor) -> bool:
     return p.dim() <= 1 or name.endswith(".bias")
 
 
+def _round_up(n: int, a: int) -> int:
+    return (n + a - 1) // a * a
+
+
 class FlatParameters:
     """Re-homes the trainable parameters of `module` into one flat fp32 buffer with a matching gradient buffer."""
 
-    def __init__(self, module: nn.Module):
+    def __init__(self, module: nn.Module, bucket_bytes: int = 256 << 20):
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError("module has no trainable parameters")
@@ -35,23 +50,44 @@ class FlatParameters:
         for n, p in named:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError(f"parameter {n}: expected fp32 on {dev}, got {p.dtype} on {p.device}")
-        decay = [(n, p) for n, p in named if not _no_decay(n, p)]
-        nodecay = [(n, p) for n, p in named if _no_decay(n, p)]
-        self.order = decay + nodecay
-        self.n_decay = sum(p.numel() for _, p in decay)
-        self.numel = sum(p.numel() for _, p in self.order)
-        self.param = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        # buckets: runs of the reversed registration order, each re-ordered decayed-first
+        cap = max(1, bucket_bytes // 4)
+        groups, cur, cur_n = [], [], 0
+        for n, p in reversed(named):
+            cur.append((n, p))
+            cur_n += _round_up(p.numel(), SLOT_ALIGN)
+            if cur_n >= cap:
+                groups.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            groups.append(cur)
+        self.order = []
         self.offsets = {}
+        self.buckets = []        # dicts: lo, split (end of the decayed tensors), hi, names
         off = 0
+        for grp in groups:
+            grp = grp[::-1]   # registration order inside a bucket (keeps e.g. the K and V biases of a fused projection adjacent)
+            decay = [(n, p) for n, p in grp if not _no_decay(n, p)]
+            nodecay = [(n, p) for n, p in grp if _no_decay(n, p)]
+            lo = off
+            for n, p in decay:
+                self.offsets[n] = (off, p.numel())
+                off += _round_up(p.numel(), SLOT_ALIGN)
+            split = off
+            for n, p in nodecay:
+                self.offsets[n] = (off, p.numel())
+                off += _round_up(p.numel(), SLOT_ALIGN)
+            self.buckets.append({"lo": lo, "split": split, "hi": off, "names": [n for n, _ in decay + nodecay]})
+            self.order += decay + nodecay
+        self.numel = off
+        self.param = torch.zeros(self.numel, dtype=torch.float32, device=dev)   # slot padding stays zero (zero gradient, zero update)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         with torch.no_grad():
             for n, p in self.order:
-                k = p.numel()
-                self.param[off:off + k].copy_(p.detach().reshape(-1))
-                p.data = self.param[off:off + k].view(p.shape)
-                p.grad = self.grad[off:off + k].view(p.shape)
-                self.offsets[n] = (off, k)
-                off += k
+                o, k = self.offsets[n]
+                self.param[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.param[o:o + k].view(p.shape)
+                p.grad = self.grad[o:o + k].view(p.shape)
 
     def zero_grad(self) -> None:
         self.grad.zero_()
@@ -62,95 +98,86 @@ class FlatParameters:
 
 
 class GradientBuckets:
-    """Asynchronous in-place all-reduce of slices of the flat gradient buffer, launched from autograd hooks."""
+    """Asynchronous in-place all-reduce of the buckets of the flat gradient buffer, launched from autograd hooks."""
 
-    def __init__(self, flat: FlatParameters, process_group=None, bucket_bytes: int = 256 << 20):
+    def __init__(self, flat: FlatParameters, process_group=None, force_collectives: bool = False):
         self.flat = flat
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_collectives and dist.is_available() and dist.is_initialized())
         self.handles: List = []
-        self.buckets = []        # (lo, hi) element ranges of flat.grad
-        self._pending = []       # gradients still missing per bucket
-        self._bucket_of = {}
-        self._build(bucket_bytes)
+        self.buckets = [(b["lo"], b["hi"]) for b in flat.buckets]
+        self._pending = [len(b["names"]) for b in flat.buckets]
+        self._bucket_of = {n: i for i, b in enumerate(flat.buckets) for n in b["names"]}
+        self.accumulating = False          # inside Trainer.no_sync(): gradients accumulate locally, nothing is reduced
+        self._comm_stream = torch.cuda.Stream(device=flat.grad.device) if flat.grad.is_cuda else None
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for n, p in flat.order:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(n)))
+        self.start_step()
 
-    def _build(self, bucket_bytes: int) -> None:
-        # contiguous runs of the flat buffer, walked from the END (backward produces the last layers first)
-        cap = max(1, bucket_bytes // 4)
-        names = [n for n, _ in self.flat.order]
-        hi = self.flat.numel
-        cur = []
-        for n in reversed(names):
-            off, k = self.flat.offsets[n]
-            cur.append(n)
-            if hi - off >= cap:
-                self._add_bucket(off, hi, cur)
-                hi, cur = off, []
-        if cur:
-            self._add_bucket(0, hi, cur)
-
-    def _add_bucket(self, lo, hi, names) -> None:
-        b = len(self.buckets)
-        self.buckets.append((lo, hi))
-        self._pending.append(len(names))
-        for n in names:
-            self._bucket_of[n] = b
-
-    def _ready(self, name) -> None:
-        if name in self._done:          # a gradient is complete once per step, whoever reports it
-            return
-        self._done.add(name)
-        b = self._bucket_of[name]
-        self._left[b] -= 1
-        if self._left[b] == 0:
-            lo, hi = self.buckets[b]
-            self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+    def start_step(self) -> None:
+        self._left = list(self._pending)
+        self._done = set()
+        self._complete = [False] * len(self.buckets)
+        self._next = 0                     # buckets [0, _next) have been issued
+        self.handles = []
 
     def _make_hook(self, name):
         def hook(_p):
             self._ready(name)
         return hook
 
-    def start_step(self) -> None:
-        self._left = list(self._pending)
-        self._done = set()
-        self.handles = []
-
     def _ready(self, name) -> None:
-        if name in self._done:          # a gradient is complete once per step, whoever reports it
+        if self.accumulating:
             return
+        if name in self._done:
+            # a second backward before step(): the bucket holding this gradient may already be all-reduced, so the new local
+            # contribution would be added to a cross-rank sum — replicas would silently diverge
+            raise RuntimeError(f"gradient of {name} reported twice in one step: for gradient accumulation run the earlier "
+                               "micro-batches under Trainer.no_sync() (only the last backward exchanges gradients)")
         self._done.add(name)
         b = self._bucket_of[name]
         self._left[b] -= 1
         if self._left[b] == 0:
-            lo, hi = self.buckets[b]
-            self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._complete[b] = True
+            self._issue_ready()
 
-    def _make_hook(self, name):
-        def hook(_p):
-            self._ready(name)
-        return hook
+    def _issue_ready(self) -> None:
+        # strictly in bucket order on every rank: a bucket that completes early waits for its predecessors
+        while self._next < len(self.buckets) and self._complete[self._next]:
+            self._issue(self._next)
+            self._next += 1
 
-    def start_step(self) -> None:
-        self._left = list(self._pending)
-        self._done = set()
-        self.handles = []
+    def _issue(self, b: int) -> None:
+        lo, hi = self.buckets[b]
+        g = self.flat.grad[lo:hi]
+        if self._comm_stream is not None:
+            # every kernel that wrote this bucket's gradients (autograd accumulation, uc_splitk_reduce / uc_gemm_tn through
+            # the gradient sink) was launched on the current stream before this point: the event orders the collective
+            # behind them explicitly, whatever stream the process group uses internally
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(g.device))
+            self._comm_stream.wait_event(ev)
+            g.record_stream(self._comm_stream)
+            with torch.cuda.stream(self._comm_stream):
+                self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self) -> None:
-        """Wait for the in-flight buckets; reduce any bucket whose hooks did not all fire (frozen / unused parameters)."""
-        if self.world == 1:
+        """Issue what the hooks could not (frozen / unused parameters leave buckets incomplete) — in bucket order, the same
+        sequence on every rank — and wait for everything."""
+        if not self.active:
             return
-        for b, left in enumerate(self._left):
-            if left > 0:
-                lo, hi = self.buckets[b]
-                self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-                self._left[b] = 0
+        for b in range(self._next, len(self.buckets)):
+            self._issue(b)
+        self._next = len(self.buckets)
         for h in self.handles:
             h.wait()
+        if self._comm_stream is not None:
+            torch.cuda.current_stream(self.flat.grad.device).wait_stream(self._comm_stream)
         self.handles = []
 
 
@@ -158,16 +185,16 @@ class Trainer:
     """zero_grad() -> forward/backward (user code) -> step().  One process per GPU; torch.distributed (RCCL) optional."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
-                 process_group=None, bucket_bytes: int = 256 << 20):
+                 process_group=None, bucket_bytes: int = 256 << 20, force_collectives: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.flat = FlatParameters(model)
-        self.buckets = GradientBuckets(self.flat, process_group, bucket_bytes)
+        self.flat = FlatParameters(model, bucket_bytes)
+        self.buckets = GradientBuckets(self.flat, process_group, force_collectives)
         self.exp_avg = torch.zeros_like(self.flat.param)
         self.exp_avg_sq = torch.zeros_like(self.flat.param)
         self.steps = 0
-        self.buckets.start_step()
         autograd.set_grad_sink(True)   # TN weight gradients are reduced straight into flat.grad
+        engine.bump_weight_epoch()     # the parameters were re-homed: prepared copies keyed on the old storage are stale
 
     @property
     def world_size(self) -> int:
@@ -182,18 +209,31 @@ class Trainer:
         self.flat.zero_grad()
         self.buckets.start_step()
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context only add to the local gradient buffer; the backward
+        that follows outside of it exchanges the accumulated sum."""
+        prev = self.buckets.accumulating
+        self.buckets.accumulating = True
+        try:
+            yield
+        finally:
+            self.buckets.accumulating = prev
+
     def step(self) -> None:
         self.buckets.finish()
         self.steps += 1
-        nd, n = self.flat.n_decay, self.flat.numel
         gs = 1.0 / self.world_size
         b1, b2 = self.betas
-        if nd > 0:
-            ops.adamw_(self.flat.param[:nd], self.flat.grad[:nd], self.exp_avg[:nd], self.exp_avg_sq[:nd], self.lr, b1, b2,
-                       self.eps, self.weight_decay, self.steps, grad_scale=gs)
-        if n > nd:
-            ops.adamw_(self.flat.param[nd:], self.flat.grad[nd:], self.exp_avg[nd:], self.exp_avg_sq[nd:], self.lr, b1, b2,
-                       self.eps, 0.0, self.steps, grad_scale=gs)
+        f = self.flat
+        for b in f.buckets:
+            lo, sp, hi = b["lo"], b["split"], b["hi"]
+            if sp > lo:
+                ops.adamw_(f.param[lo:sp], f.grad[lo:sp], self.exp_avg[lo:sp], self.exp_avg_sq[lo:sp], self.lr, b1, b2,
+                           self.eps, self.weight_decay, self.steps, grad_scale=gs)
+            if hi > sp:
+                ops.adamw_(f.param[sp:hi], f.grad[sp:hi], self.exp_avg[sp:hi], self.exp_avg_sq[sp:hi], self.lr, b1, b2,
+                           self.eps, 0.0, self.steps, grad_scale=gs)
         engine.bump_weight_epoch()   # the kernel wrote through raw pointers: invalidate the prepared-weight cache
 
     # ---- checkpoint / resume -------------------------------------------------------------------
@@ -218,4 +258,3 @@ class Trainer:
         """Call after writing parameters from outside (model.load_state_dict on the flattened model copies INTO the flat
         buffer): invalidates the prepared bf16 / transposed weight copies."""
         engine.bump_weight_epoch()
-
