@@ -143,6 +143,12 @@ typedef struct uc_gemm_desc {
 
 int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);
 
+/* bf16x3 operand split (fp32-class GEMMs on the bf16 matrix pipe): x fp32 [rows, C] -> out bf16 [rows, 3C] = [hi | hi | lo],
+ * hi = bf16(x), lo = bf16(x - hi); relu != 0 clamps x at zero first.  A weight laid out [Wh | Wl | Wh] per K block makes
+ * uc_gemm accumulate xh.wh + xh.wl + xl.wh in fp32 (what the reference computes in fp32 for its prediction heads,
+ * factory/dust3r.py:288-309, to ~2^-16 per product).  C % 8 == 0. */
+int uc_split_bf16x3(const float* x, void* out, int64_t rows, int C, int relu, uc_stream_t stream);
+
 /* Merge the per-block row statistics a producer GEMM wrote (stats_out: [rows][nblk][2] = (sum, squared deviations from the
  * block mean) over 64-column blocks, C = 64 * nblk columns) into LayerNorm statistics: out[row] = (mean, 1/sqrt(var_biased + eps)). */
 int uc_ln_stats_finalize(const float* partial, int64_t rows, int nblk, float eps, float* out, uc_stream_t stream);

@@ -1,0 +1,64 @@
+"""BASELINE configs[4]: ViT-L encoder + decoder at 1024x1024 pairs (N = 4096 tokens per view) with the fp8 MFMA attention path
+running INSIDE the model — dispatch asserted, outputs held against the bf16 run and against the CPU oracle."""
+import pytest
+import torch
+
+from oracle import dust3r_oracle as O
+from tests.golden.cases import GAINS
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+ENC, DEC = 4, 4
+
+
+def test_1024_fp8_attention_inside_the_model(gpu, monkeypatch):
+    from uniception_amd import engine, ops
+    from uniception_amd.models.factory import DUSt3R
+
+    model = DUSt3R(name="c5", img_size=(1024, 1024), pred_head_type="linear").eval()
+    model.encoder.enc_blocks = model.encoder.enc_blocks[:ENC]
+    for br in model.info_sharing.multi_view_branches:
+        del br[DEC:]
+    model.info_sharing.depth = DEC
+    O.fill_state_dict_(model.state_dict(), gains=GAINS)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    img1, img2 = O.make_images(21, 1, 1024, 1024)
+    with torch.no_grad():
+        o1, o2 = O.dust3r_forward(sd, img1, img2, head="linear", enc_depth=ENC, dec_depth=DEC)
+    model = model.to(gpu)
+    v1 = {"img": img1.to(gpu), "instance": ["a"], "data_norm_type": "dust3r"}
+    v2 = {"img": img2.to(gpu), "instance": ["b"], "data_norm_type": "dust3r"}
+    calls = {"fp8": 0, "bf16": 0, "nk": set()}
+    real8, real16 = ops.attention_fp8, ops.attention
+
+    def spy8(q, k, *a, **kw):
+        calls["fp8"] += 1
+        calls["nk"].add(k.shape[1])
+        return real8(q, k, *a, **kw)
+
+    def spy16(*a, **kw):
+        calls["bf16"] += 1
+        return real16(*a, **kw)
+
+    monkeypatch.setattr(ops, "attention_fp8", spy8)
+    monkeypatch.setattr(ops, "attention", spy16)
+    with torch.no_grad(), engine.precision("bf16"):
+        b1, b2 = model(v1, v2)
+        assert calls["fp8"] == 0 and calls["bf16"] == ENC + 2 * 2 * DEC
+        with engine.attention_precision("fp8"):
+            f1, f2 = model(v1, v2)
+    torch.cuda.synchronize()
+    # every attention of the fp8 run went to the e4m3 kernel: encoder self-attention + (self + cross) x 2 views per decoder depth
+    assert calls["fp8"] == ENC + 2 * 2 * DEC and calls["bf16"] == ENC + 2 * 2 * DEC and calls["nk"] == {4096}
+    assert f1["pts3d"].shape == (1, 1024, 1024, 3) and torch.isfinite(f1["pts3d"]).all() and torch.isfinite(f2["conf"]).all()
+    errs = {}
+    for name, got8, got16, ref in (("pts3d_1", f1["pts3d"], b1["pts3d"], o1["pts3d"]), ("conf_1", f1["conf"], b1["conf"], o1["conf"]),
+                                   ("pts3d_2", f2["pts3d_in_other_view"], b2["pts3d_in_other_view"], o2["pts3d_in_other_view"]),
+                                   ("conf_2", f2["conf"], b2["conf"], o2["conf"])):
+        errs[name] = (rel_l2(got8.cpu(), ref), rel_l2(got16.cpu(), ref), rel_l2(got8.cpu(), got16.cpu()))
+    print("\n[config 5, 1024x1024, 4+4 blocks] rel-L2 (fp8 vs oracle, bf16 vs oracle, fp8 vs bf16): " +
+          ", ".join(f"{k}={a:.1e}/{b:.1e}/{c:.1e}" for k, (a, b, c) in errs.items()))
+    for k, (e8, e16, d) in errs.items():
+        assert e16 < 3e-2, (k, e16)
+        assert e8 < 8e-2 and d < 8e-2, (k, e8, d)

@@ -17,6 +17,7 @@ def _small(head):
     for br in m.info_sharing.multi_view_branches:
         del br[2:]
     m.info_sharing.depth = 2
+    m.info_sharing.indices = [0, 1]     # the factory taps blocks 5 and 8 of its 12
     return m
 
 

@@ -491,3 +491,35 @@ def test_attention_ragged_keys_next_to_poisoned_memory(gpu, B, H, Nq, Nk):
     ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v.float())
     assert torch.isfinite(o).all()
     assert rel_l2(o.float().cpu(), ref.cpu()) < 4e-3
+
+
+def test_curope2d_module_and_autograd_function(gpu):
+    """The drop-in for the reference's only native boundary (curope2d.py:12-38): cuRoPE2D on a strided [B,H,N,D] view of a fused
+    qkv buffer rotates in place and returns the same tensor; cuRoPE2D_func's backward applies the inverse rotation to the
+    incoming gradient — also when that gradient is not contiguous — and matches autograd through the oracle's RoPE."""
+    from oracle import dust3r_oracle as O
+    from uniception_amd.models.libs.croco.curope import cuRoPE2D, cuRoPE2D_func
+    B, h, w, H, D = 2, 5, 7, 3, 64
+    N = h * w
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, N, 3, H, D, generator=g)
+    pos = grid_pos(B, h, w)
+    rope = cuRoPE2D(100.0)
+    dev = qkv.to(gpu)
+    q_view = dev[:, :, 0].transpose(1, 2)                      # [B,H,N,D], strides of the fused buffer
+    assert not q_view.is_contiguous()
+    out = rope(q_view, pos.to(gpu))
+    assert out.data_ptr() == q_view.data_ptr()
+    ref = O.rope2d(qkv[:, :, 0].transpose(1, 2), pos, 100.0)   # oracle: [B,H,N,D]
+    assert rel_l2(out.cpu(), ref) < 2e-6
+    assert torch.equal(dev[:, :, 1].cpu(), qkv[:, :, 1]), "k and v of the fused buffer are untouched"
+    # autograd: forward on [B,N,H,D] (the Function's layout), loss through a NON-contiguous consumer of the result
+    x = torch.randn(B, N, H, D, generator=g)
+    wgt = torch.randn(B, H, N, D, generator=g)
+    xr = x.clone().requires_grad_(True)
+    (O.rope2d(xr.transpose(1, 2), pos, 100.0) * wgt).sum().backward()
+    xd = x.to(gpu).requires_grad_(True)
+    y = cuRoPE2D_func.apply(xd.clone(), pos.to(gpu), 100.0, 1.0)
+    assert rel_l2(y.detach().transpose(1, 2).cpu(), O.rope2d(x.transpose(1, 2), pos, 100.0)) < 2e-6
+    (y.transpose(1, 2) * wgt.to(gpu)).sum().backward()         # gradient reaches the Function as a transposed view
+    assert rel_l2(xd.grad.cpu(), xr.grad) < 2e-6

@@ -45,6 +45,7 @@ SIGNATURES = {
     "uc_layernorm": [vp, i32, vp, vp, vp, i32, i64, i32, f32, vp],
     "uc_gemm": [C.POINTER(GemmDesc), vp],
     "uc_ln_stats_finalize": [vp, i64, i32, f32, vp, vp],
+    "uc_split_bf16x3": [vp, vp, i64, i32, i32, vp],
     "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
     "uc_attention_fwd_fp8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [f32, vp],
     "uc_vt_pack_fp8": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],

@@ -185,6 +185,49 @@ extern "C" int uc_convert(const void* src, int sd, void* dst, int dd, int64_t n,
 }
 
 // =======================================================================================
+// bf16x3 operand split: an fp32 row x[0:C] becomes the bf16 row [hi | hi | lo] (3C wide) with hi = bf16(x), lo = bf16(x - hi).
+// Against weights laid out [Wh | Wl | Wh] the ordinary bf16 MFMA GEMM then accumulates xh.wh + xh.wl + xl.wh in fp32 — the
+// three leading terms of the exact product (relative error ~2^-16 per term): fp32-class results at a third of the bf16
+// matrix rate instead of the fp32 vector rate.  relu != 0 clamps x at zero first (the DPT residual units' ReLU-on-load cannot
+// be applied to hi and lo separately).  One work item = 8 channels.
+// =======================================================================================
+__global__ void split_bf16x3_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t rows, int C8, int relu) {
+    const int64_t n = rows * C8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C8;
+        const int c = (int)(i - r * C8);
+        const float4_t* src = reinterpret_cast<const float4_t*>(x + (r * C8 + c) * 8);
+        float v[8];
+        const float4_t a = src[0], b = src[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float p = v[2 * k], q = v[2 * k + 1];
+            if (relu) { p = fmaxf(p, 0.f); q = fmaxf(q, 0.f); }
+            const unsigned h = pack_bf16x2(p, q);
+            hi[k] = h;
+            lo[k] = pack_bf16x2(p - __uint_as_float(h << 16), q - __uint_as_float(h & 0xffff0000u));
+        }
+        bf16_t* dst = out + r * (int64_t)C8 * 24 + c * 8;
+        const uint4 H = (uint4){hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<uint4*>(dst) = H;
+        *reinterpret_cast<uint4*>(dst + (int64_t)C8 * 8) = H;
+        *reinterpret_cast<uint4*>(dst + (int64_t)C8 * 16) = (uint4){lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+
+extern "C" int uc_split_bf16x3(const float* x, void* out, int64_t rows, int C, int relu, uc_stream_t stream) {
+    UC_REQUIRE(x && out && rows >= 0 && C > 0 && C % 8 == 0, "uc_split_bf16x3: C must be a positive multiple of 8");
+    UC_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "uc_split_bf16x3: 16-byte alignment");
+    if (rows == 0) return UC_OK;
+    const int64_t n = rows * (C / 8);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(EW_GRID(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, rows, C / 8, relu);
+    UC_CHECK_LAUNCH("uc_split_bf16x3");
+    return UC_OK;
+}
+
+// =======================================================================================
 // bilinear resize, align_corners=True, NHWC.  src = dst * (in-1)/(out-1); separable weights.
 // (torch: area_pixel_compute_scale -> (in-1)/(out-1) when out>1 else 0; index = scale*dst;
 //  i0 = floor, i1 = min(i0+1, in-1), lambda = index - i0.)  One work item = 8 channels of one output pixel.

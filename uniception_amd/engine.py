@@ -24,29 +24,50 @@ from . import ops
 from ._lib import UcHipError
 
 _forced_dtype: Optional[torch.dtype] = None
-_head_mode: str = os.environ.get("UNICEPTION_AMD_HEAD_PRECISION", "follow")  # "follow" | "fp32"
+_forced_x3: bool = False       # precision("bf16x3"): fp32 tensors, every GEMM / conv on split bf16 operands
+_head_mode: str = os.environ.get("UNICEPTION_AMD_HEAD_PRECISION", "follow")  # "follow" | "fp32" | "fp32_exact"
 ROPE_TABLE_NPOS = 1024  # positions covered by the fused-epilogue cos/sin table (16k px at patch 16)
 
 
 @contextlib.contextmanager
 def precision(name: Optional[str]):
-    """Force the compute dtype of the transformer GEMMs/attention: "fp32" | "bf16" | None (follow autocast)."""
-    global _forced_dtype
-    prev = _forced_dtype
+    """Force the compute precision of the transformer GEMMs/attention: None (follow autocast) or
+    "fp32"   verification mode: exact fp32 kernels (k-ascending FMA chains) everywhere;
+    "bf16"   bf16 MFMA operands, fp32 accumulate — the performance mode;
+    "bf16x3" fp32 tensors, every GEMM / convolution on split bf16 operands (hi.hi + hi.lo + lo.hi, fp32 accumulate: fp32-class
+             results on the matrix pipe, see ops.split_bf16x3), attention in the exact fp32 kernel: the fast 1e-3-grade mode."""
+    global _forced_dtype, _forced_x3
+    prev = (_forced_dtype, _forced_x3)
     _forced_dtype = {None: None, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
-                     "bfloat16": torch.bfloat16}[name]
+                     "bfloat16": torch.bfloat16, "bf16x3": torch.float32}[name]
+    _forced_x3 = name == "bf16x3"
     try:
         yield
     finally:
-        _forced_dtype = prev
+        _forced_dtype, _forced_x3 = prev
 
 
 def set_head_precision(mode: str) -> None:
-    """"follow": prediction heads use the compute dtype; "fp32": heads always run the exact-fp32 kernels
-    (what the reference does by disabling autocast around them, factory/dust3r.py:309)."""
+    """"follow": prediction heads use the compute dtype;
+    "fp32": the reference's policy (it disables autocast around the heads, factory/dust3r.py:288-309): fp32 tensors, GEMMs and
+            convolutions on split bf16 operands (bf16x3, ~1e-6 relative) when the transformer runs bf16, exact kernels in
+            verification mode;
+    "fp32_exact": heads always on the exact fp32 kernels (slow)."""
     global _head_mode
-    assert mode in ("follow", "fp32")
+    assert mode in ("follow", "fp32", "fp32_exact")
     _head_mode = mode
+
+
+def _fp32_matmul() -> str:
+    """How an fp32-operand GEMM runs right now (hook of ops.gemm)."""
+    if _forced_x3:
+        return "bf16x3"
+    if _head_mode == "fp32" and compute_dtype() == torch.bfloat16:
+        return "bf16x3"      # the only fp32 GEMMs next to a bf16 transformer are the heads'
+    return "exact"
+
+
+ops.fp32_matmul_hook = _fp32_matmul
 
 
 _attn_mode: str = os.environ.get("UNICEPTION_AMD_ATTENTION", "bf16")   # "bf16" | "fp8": matrix format of the bf16 path's attention
@@ -70,17 +91,36 @@ def _fp8_attention() -> bool:
     return _attn_mode == "fp8" and not torch.is_grad_enabled()
 
 
+_ambient_dtype: Optional[torch.dtype] = None
+
+
+@contextlib.contextmanager
+def ambient(dt: torch.dtype):
+    """Carry the transformer's compute dtype into a region where autocast is switched off (the factory runs its heads under
+    autocast(enabled=False) like the reference): "follow"-mode heads and the bf16x3 head policy then see the same dtype
+    whether bf16 came from torch.autocast or from engine.precision."""
+    global _ambient_dtype
+    prev = _ambient_dtype
+    _ambient_dtype = dt
+    try:
+        yield
+    finally:
+        _ambient_dtype = prev
+
+
 def compute_dtype() -> torch.dtype:
     if _forced_dtype is not None:
         return _forced_dtype
     if torch.is_autocast_enabled("cuda"):
         # fp16 autocast (the reference's profile_dust3r.py default) is served by the bf16 MFMA path
         return torch.bfloat16
+    if _ambient_dtype is not None:
+        return _ambient_dtype
     return torch.float32
 
 
 def head_dtype() -> torch.dtype:
-    return torch.float32 if _head_mode == "fp32" else compute_dtype()
+    return torch.float32 if _head_mode in ("fp32", "fp32_exact") else compute_dtype()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -152,8 +192,25 @@ def bump_weight_epoch() -> None:
     _weight_epoch += 1
 
 
+_check_weights: bool = os.environ.get("UNICEPTION_AMD_CHECK_WEIGHTS", "0") == "1"
+
+
+def invalidate_prepared(module: Optional[nn.Module] = None) -> None:
+    """Drop prepared weight copies: of `module` and its children, or of everything (None).  Same effect as
+    bump_weight_epoch() but scoped.  REQUIRED after writing parameters through `.data` (`p.data.copy_(ema)`,
+    `p.data.mul_()`), raw pointers or any other route that does not advance the tensors' version counters — the cache cannot
+    see such writes and would keep serving bf16 / transposed / LayerNorm-folded copies of the OLD values."""
+    if module is None:
+        bump_weight_epoch()
+        return
+    for m in module.modules():
+        _prep_cache.pop(m, None)
+
+
 def prepared(owner: nn.Module, tag, sources: Sequence[Optional[torch.Tensor]], build):
     stamp = (_weight_epoch,) + tuple((s.data_ptr(), s._version, s.device, s.dtype) if s is not None else None for s in sources)
+    if _check_weights:   # debug (UNICEPTION_AMD_CHECK_WEIGHTS=1): a content checksum catches `.data` writes, at a sync per call
+        stamp += tuple(float(s.detach().double().abs().sum()) if s is not None else None for s in sources)
     slot = _prep_cache.setdefault(owner, {})
     hit = slot.get(tag)
     if hit is not None and hit[0] == stamp:

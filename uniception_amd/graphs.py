@@ -25,7 +25,15 @@ class GraphedTwoView:
         self.v1 = dict(view1, img=view1["img"].clone())
         self.v2 = dict(view2, img=view2["img"].clone())
         self._warmup = warmup
+        # frozen into the graph: whether the batch is a symmetrized one (the factory then encodes img[::2] only and interleaves,
+        # factory/dust3r.py:227-238) and the normalization tag the encoder checked
+        self._signature = self._view_signature(view1, view2)
         self.recapture()
+
+    @staticmethod
+    def _view_signature(view1: Dict, view2: Dict):
+        from .models.factory.dust3r import is_symmetrized
+        return (bool(is_symmetrized(view1, view2)), view1.get("data_norm_type"), view2.get("data_norm_type"))
 
     def _forward(self):
         with torch.no_grad(), engine.precision(self.precision), engine.attention_precision(self.attention):
@@ -48,6 +56,10 @@ class GraphedTwoView:
         output buffers: they are overwritten by the next call (clone them to keep a result)."""
         if view1["img"].shape != self.v1["img"].shape or view2["img"].shape != self.v2["img"].shape:
             raise ValueError(f"captured for {tuple(self.v1['img'].shape)}, got {tuple(view1['img'].shape)}")
+        sig = self._view_signature(view1, view2)
+        if sig != self._signature:
+            raise ValueError(f"captured for (symmetrized, data_norm_type x2) = {self._signature}, got {sig}: the pair layout and the "
+                             "normalization tag are frozen into the graph — build another GraphedTwoView for these views")
         self.v1["img"].copy_(view1["img"], non_blocking=True)
         self.v2["img"].copy_(view2["img"], non_blocking=True)
         self.graph.replay()

@@ -154,7 +154,7 @@ class DUSt3R(nn.Module):
             outs = {str(v + 1): [(feat1, feat2)[v].float(), inter[0].features[v].float(), inter[1].features[v].float(),
                                  final.features[v].float()] for v in range(2)}
 
-        with torch.autocast("cuda", enabled=False):
+        with torch.autocast("cuda", enabled=False), engine.ambient(engine.compute_dtype()):
             def head(num, shape):
                 ho = self._downstream_head(num, outs, shape)
                 fo = self.adaptor(AdaptorInput(adaptor_feature=ho.decoded_channels, output_shape_hw=shape))

@@ -4,7 +4,6 @@ from typing import List, Optional
 
 import torch.nn as nn
 from torch import Tensor
-from torch.utils.checkpoint import checkpoint
 
 
 @dataclass
@@ -29,14 +28,10 @@ class UniCeptionInfoSharingBase(nn.Module):
         raise NotImplementedError
 
     def wrap_module_with_gradient_checkpointing(self, module: nn.Module):
-        class _CheckpointingWrapper(module.__class__):
-            _restore_cls = module.__class__
-
-            def forward(self, *args, **kwargs):
-                return checkpoint(super().forward, *args, use_reentrant=False, **kwargs)
-
-        module.__class__ = _CheckpointingWrapper
-        return module
+        # 288 GB of HBM hold the activations of every supported batch, and the HIP sub-layer Functions own their saved
+        # tensors: re-computation is not implemented (the reference's own cross-attention transformer cannot enable it
+        # either)
+        raise NotImplementedError("gradient checkpointing is not supported by the HIP path")
 
 
 @dataclass

@@ -5,6 +5,7 @@ hands raw device pointers + sizes/strides to libuc_hip.so.  Nothing in this modu
 torch ops, and nothing falls back to the CPU: tensors must live on a HIP device.
 """
 import ctypes as C
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -120,6 +121,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     assert a.dtype == w.dtype and w.is_contiguous() and w.dim() == 2
     cd = _dt(a.dtype)
     N, K = w.shape
+    if (cd == UC_F32 and fp32_matmul_hook() == "bf16x3" and rope is None and vt is None and preact_out is None and split_k <= 1
+            and dact is None and ln is None and not emit_ln and (K // (9 if conv is not None else 1)) % 8 == 0 and a.is_contiguous()):
+        # fp32-class product on the bf16 matrix pipe: [hi | hi | lo] rows against [Wh | Wl | Wh] weights (uc_split_bf16x3)
+        a3 = split_bf16x3(a, relu=relu_a)
+        conv3 = None if conv is None else (conv[0], conv[1], conv[2], 3 * conv[3], conv[4])
+        return gemm(a3, split_weight_bf16x3(w, 9 if conv is not None else 1), bias, act=act, residual=residual, residual2=residual2,
+                    out_dtype=out_dtype or torch.float32, out=out, conv=conv3)
     d = GemmDesc()
     d.compute_dtype = cd
     d.relu_a = 1 if relu_a else 0
@@ -193,6 +201,42 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if side is not None:
         out.uc_ln = side
     return out
+
+
+# fp32 GEMMs: "exact" (fp32 FMA chain, the verification kernels) or "bf16x3" (split operands on the bf16 MFMA pipe); the
+# engine installs a hook that answers per call (precision context, head policy)
+fp32_matmul_hook = lambda: "exact"   # noqa: E731
+
+
+def split_bf16x3(x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """fp32 [..., C] contiguous -> bf16 [..., 3C] = [hi | hi | lo] (uc_split_bf16x3)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 8 == 0
+    Cn = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (3 * Cn,), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().uc_split_bf16x3(x.data_ptr(), out.data_ptr(), x.numel() // Cn, Cn, 1 if relu else 0, _stream()),
+               "uc_split_bf16x3")
+    return out
+
+
+_w3_cache = {}   # id(weight tensor) -> (weakref, stamp, split copy); entries die with their tensor
+
+
+def split_weight_bf16x3(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
+    """fp32 weight [N, taps*Cin] -> bf16 [N, taps*3*Cin] with every tap's block laid out [Wh | Wl | Wh]; cached per tensor."""
+    key = id(w)
+    hit = _w3_cache.get(key)
+    stamp = (w._version, w.data_ptr(), taps)
+    if hit is not None and hit[0]() is w and hit[1] == stamp:
+        return hit[2]
+    with torch.no_grad():
+        N = w.shape[0]
+        w32 = w.detach().float().view(N, taps, -1)
+        hi = w32.bfloat16()
+        lo = (w32 - hi.float()).bfloat16()
+        w3 = torch.cat([hi, lo, hi], dim=2).reshape(N, -1).contiguous()
+    _w3_cache[key] = (weakref.ref(w, lambda _r, k=key: _w3_cache.pop(k, None)), stamp, w3)
+    return w3
 
 
 class LnSide:
