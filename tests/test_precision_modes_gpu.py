@@ -83,6 +83,6 @@ def test_reference_policy_bf16_transformer_fp32_class_heads(gpu, name):
     compare_to_golden(g, follow, c, tol=4e-2, report=rep_fol)
     # split-operand heads == exact fp32 heads on the same bf16 features, to fp32-class accuracy
     for k in HEAD_OUTPUTS:
-        assert rel_l2(ref_pol[k].cpu(), exact[k].cpu()) < 2e-5, k
+        assert rel_l2(ref_pol[k].cpu(), exact[k].cpu()) < 1e-4, k   # ~2^-16 per product through ~15 chained convolutions
     print(f"\n[reference policy] {name}: bf16 transformer + fp32-class heads " + ", ".join(f"{k}={rep_pol[k]:.1e}" for k in HEAD_OUTPUTS) +
           " | bf16 heads " + ", ".join(f"{k}={rep_fol[k]:.1e}" for k in HEAD_OUTPUTS))
