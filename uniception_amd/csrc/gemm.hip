@@ -580,7 +580,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             { static int nt = -2; if (nt == -2) { const char* e = getenv("UC_GEMM_NT"); nt = e ? atoi(e) : -1; }
               const int64_t out_bytes = d->M * d->N * (d->out_dtype == UC_F32 ? 4 : 2);
               g.nt_out = out_bytes > ((int64_t)128 << 20) ? (nt >= 0 ? nt : 7) : 0; }   // bit 0: fp32 residual stream, 1: bf16 outputs, 2: bf16 RoPE (q, k) tiles
-            { const char* e = getenv("UC_GEMM_STAGGER"); g.stagger = e ? atoi(e) : 0; }
+            { const char* e = getenv("UC_GEMM_STAGGER"); g.stagger = e ? atoi(e) : -1; }   // -1: the launcher's default policy
             static int trace_on = -1;
             if (trace_on < 0) { const char* e = getenv("UC_GEMM_TRACE"); trace_on = e ? atoi(e) : 0; }
             g.trace = nullptr;

@@ -13,7 +13,16 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st) {
     // a descriptor goes to a single-family kernel only when EVERY wave of the launch takes that family's epilogue
     const bool plain = p.vec_ok && p.N % 64 == 0 && p.split_k <= 1 && !p.preact && !p.dact_u && !(p.dbg & 16);
     if (plain && p.out_dtype == UC_BF16 && !p.residual) glds_launch_dense_bf16(p, variant, st);
-    else if (plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0) glds_launch_dense_f32(p, variant, st);
+    else if (plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0) {
+        // The fp32 epilogues (residual read + fp32 store + bf16 twin) move 4-5x the bytes of a bf16 store and all CUs reach
+        // them together: an HBM burst with idle matrix pipes.  Launches long enough to amortise the ramp (>= 6 tiles per CU)
+        // start their first round of workgroups in 8 phase groups 1.5 us apart (by row panel, see the kernel):
+        // encoder proj 480 -> 432 us, fc2 1095 -> 1043 us; neutral-to-worse for shorter launches, hence the threshold.
+        GldsParams q = p;
+        if (q.stagger < 0) q.stagger = (variant == 2 && (int64_t)ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 6 * 256) ? 150 : 0;
+        glds_launch_dense_f32(q, variant, st);
+        return 0;
+    }
     else glds_launch_dense_all(p, variant, st);
     return 0;
 }

@@ -254,6 +254,37 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
 //                       (its KIND 0 form is the fp32-bounce variant of the bf16 store, kept for A/B runs);
 // everything else (split-K slabs, pre-activation copies, dact, bf16 residuals, partial column blocks, unaligned
 // operands) takes a rolled generic drain whose option tests are per 4-column group.
+// erf-GELU of the bf16-store epilogues without transcendentals: GELU(x) = x Phi(x), Phi(x) - 1/2 = x_c Q(x_c^2) with x_c = x clamped
+// to +-4.5 and Q a degree-10 polynomial (least-squares fit in the Chebyshev basis over [0, 4.5^2], evaluated by Horner in
+// t = 2 x_c^2 / 4.5^2 - 1).  |error| <= 1.2e-5 absolute inside the clamp, <= 3e-5 beyond it (Phi(-4.5) = 3.4e-6 instead of -> 0)
+// — two orders below the bf16 output's own rounding.  15 packed-fp32-able operations per element instead of 16 scalar ones plus
+// an exp2 and a reciprocal on the quarter-rate transcendental unit: the GELU epilogue of fc1 cost 7.9 us per 256x256 tile
+// (as much as five K-steps), the VALU being the only unit at work in an epilogue.
+__device__ __forceinline__ float4_t glds_gelu4(float4_t x) {
+    float4_t xc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xc[r] = __builtin_amdgcn_fmed3f(x[r], -4.5f, 4.5f);
+    const float4_t t = xc * xc * (2.0f / 20.25f) - 1.0f;
+    float4_t q = t * 8.660091177e-04f - 2.253821881e-03f;
+    q = q * t + 2.972107097e-03f;
+    q = q * t - 5.424589433e-03f;
+    q = q * t + 1.124217992e-02f;
+    q = q * t - 1.890690569e-02f;
+    q = q * t + 2.834482012e-02f;
+    q = q * t - 4.013649033e-02f;
+    q = q * t + 5.469475207e-02f;
+    q = q * t - 7.719214694e-02f;
+    q = q * t + 1.569050361e-01f;
+    return x * (xc * q + 0.5f);
+}
+
+template <int ACT>
+__device__ __forceinline__ float4_t glds_act4(float4_t v) {
+    if constexpr (ACT == UC_ACT_GELU_ERF) return glds_gelu4(v);
+    else if constexpr (ACT == UC_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); return v; }
+    else return v;
+}
+
 template <int ACT>
 __device__ __forceinline__ float glds_act_c(float v) {
     if constexpr (ACT == UC_ACT_GELU_ERF) return glds_gelu(v);
@@ -544,9 +575,7 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float4_t v = val4(i, j);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = glds_act_c<ACT>(v[r]);
+                const float4_t v = glds_act4<ACT>(val4(i, j));
                 *reinterpret_cast<uint2*>(buf + wr_off + (((2 * j + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
             }
         }
@@ -692,16 +721,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
-    if (p.stagger > 0 && blockIdx.x < 256u * WGS_PER_CU) {
-        // De-phase the CUs: every tile of a launch costs the same, so without this all 256 CUs reach their epilogues together
-        // and the store / residual traffic arrives at HBM as one burst while the matrix pipes idle.  The first round of
-        // workgroups (one per CU) starts in 8 phase groups; the offsets persist down each CU's chain of tiles.
-        const unsigned phase = (blockIdx.x >> 3) & 7u;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long wait = (unsigned long long)phase * (unsigned)p.stagger;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-
     const int nwg = p.tiles_m * p.tiles_n;
     const int ksplit = p.split_k > 1 ? (int)uc_div(blockIdx.x, p.dNwg) : 0;   // split-K slice
     const int t = glds_xcd_remap((int)blockIdx.x - ksplit * nwg, nwg);
@@ -718,6 +737,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
         const int gsz = last ? p.tiles_m - first_m : GM;
         tn = (int)uc_div((unsigned)within, last ? p.dGmLast : p.dGm);
         tm = first_m + within - tn * gsz;
+    }
+    if (p.stagger > 0 && blockIdx.x < 256u * WGS_PER_CU) {
+        // Experiment (UC_GEMM_STAGGER, off by default): de-phase the CUs.  Every tile of a launch costs the same, so all 256 CUs
+        // reach their epilogues together and the store / residual traffic hits HBM as one burst while the matrix pipes idle.
+        // The first round of workgroups (one per CU) starts in 8 phase groups chosen by ROW PANEL, so the column tiles that
+        // share an A panel through their XCD's L2 stay in step; the offsets persist down each CU's chain of tiles.
+        const unsigned phase = (unsigned)tm & 7u;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)phase * (unsigned)p.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
     }
     const int64_t m0 = (int64_t)tm * BM_;
     const int64_t n0 = (int64_t)tn * BN_;
