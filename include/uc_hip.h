@@ -143,6 +143,11 @@ typedef struct uc_gemm_desc {
 
 int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);
 
+/* View positional encoding of the global / alternating multi-view transformers
+ * (info_sharing/global_attention_transformer.py:365-392): x[b, v*T + t, :] += pe[v, :], x fp32 [B, L, C] in place (rows past
+ * V*T untouched), pe fp32 [V, C].  C % 4 == 0. */
+int uc_add_view_pe(float* x, const float* pe, int64_t B, int L, int T, int V, int C, uc_stream_t stream);
+
 /* bf16x3 operand split (fp32-class GEMMs on the bf16 matrix pipe): x fp32 [rows, C] -> out bf16 [rows, 3C] = [hi | hi | lo],
  * hi = bf16(x), lo = bf16(x - hi); relu != 0 clamps x at zero first.  A weight laid out [Wh | Wl | Wh] per K block makes
  * uc_gemm accumulate xh.wh + xh.wl + xl.wh in fp32 (what the reference computes in fp32 for its prediction heads,
@@ -256,6 +261,33 @@ int uc_pixel_shuffle(const void* src, int src_dtype, float* dst, int B, int h, i
 int uc_pointmap_adaptor(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp, float* pts,
                         float* conf, int B, int H, int W, float conf_vmin, float conf_vmax,
                         uc_stream_t stream);
+
+/* Generic adaptor pass (prediction_heads/adaptors.py:25-2300): every adaptor of the reference splits the decoded channels,
+ * transforms each group per pixel and concatenates the results; a list of segments expresses the whole composition in one
+ * kernel.  x: fp32 BCHW-shaped (strides sb, sc, sw in elements; rows dense), out: fp32 NHWC [B,H,W,Cout]. */
+enum uc_adaptor_op {
+    UC_AD_ELEM = 1,          /* n channels: mode 0 x | 1 x^2 | 2 exp(x); clip             (Depth/Scale/SceneFlow, "linear" pointmaps) */
+    UC_AD_NORM = 2,          /* n-vector v: v/max(|v|,1e-8) * f(|v|), f = |v|^2 (mode 1) | expm1|v| (mode 2); clip   (PointMap, RayOrigins, CamTranslation) */
+    UC_AD_ZEXP = 3,          /* (x e^z, y e^z, e^z); clip                                   (PointMap "z_exp") */
+    UC_AD_DIR = 4,           /* clip; flags&1: last channel = max(last, p[0]); flags&2: unit norm; flags&4: divide by the last channel   (RayDirections, Quaternions) */
+    UC_AD_CONF_EXP = 5,      /* vmin + min(exp(x), vmax - vmin)                             (Confidence "exp") */
+    UC_AD_CONF_SIGMOID = 6,  /* sigmoid(x) (vmax - vmin) + vmin                             (Confidence "sigmoid") */
+    UC_AD_MASK = 7,          /* two outputs: (x, sigmoid(x))                                (Mask: logits, mask) */
+    UC_AD_FLOW = 8,          /* (x p[0] + p[1], y p[2] + p[3])                              (Flow: std / mean scaled to the output shape) */
+    UC_AD_FLOWCOORD = 9,     /* 0.5 (x + 1) p[0] + 0.5 - (col + 0.5), same with p[1] and the row   (Flow, output_normalized_coordinate) */
+    UC_AD_COV2D = 10         /* (c1, c2, s) + offset p[0] on c1, c2 -> 7 outputs: covariance (e^c1, e^c2, tanh s e^((c1+c2)/2)), log det, inverse
+                                covariance                                                  (Covariance2D "exp_tanh") */
+};
+#define UC_ADAPTOR_MAX_SEGS 8
+typedef struct uc_adaptor_seg {
+    int op, mode, flags;
+    int c0, n;               /* input channels [c0, c0 + n), n <= 4 */
+    int o0;                  /* first output channel */
+    float p[4];
+    float vmin, vmax;        /* clip bounds (-inf / +inf: none) */
+} uc_adaptor_seg;
+int uc_adaptor_program(const float* x, int64_t sb, int64_t sc, int64_t sw, float* out, int B, int H, int W, int Cout,
+                       const uc_adaptor_seg* segs, int nseg, uc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * DPT regressor tail: ReLU'd features -> Conv1x1(Cin -> 4) + bias -> decoded channels

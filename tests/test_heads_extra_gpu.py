@@ -1,0 +1,69 @@
+"""Widened prediction-head surface against golden vectors of the REAL reference
+(tests/golden/make_golden_heads.py): the adaptor families (flow, scale, depth, scene flow, pointmap modes, ray origins /
+directions, camera translation, quaternions, confidence, mask, 2-D covariance) incl. the generated composites
+(...Plus..., WithConfidence, WithMask, WithConfidenceAndMask), DPTSegmentationProcessor and DPTFeatureDoubleUpsampling."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dust3r_oracle as O
+from tests.golden.heads_cases import AD_H, AD_W, ADAPTOR_CASES, DPT_DOUBLE, DPT_SEG, OUT_FIELDS, adaptor_input
+from tests.helpers import GOLDEN_DIR, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN_DIR, "heads_extra.npz"))
+
+
+@pytest.mark.parametrize("name", list(ADAPTOR_CASES.keys()))
+def test_adaptor_matches_reference(gpu, gold, name):
+    from uniception_amd.models.prediction_heads import adaptors as A
+    from uniception_amd.models.prediction_heads.base import AdaptorInput
+    cls, args, cin = ADAPTOR_CASES[name]
+    ad = getattr(A, cls)(name, *args).to(gpu)
+    x = adaptor_input(name)
+    want = {f: gold[f"ad/{name}/{f}"] for f in OUT_FIELDS if f"ad/{name}/{f}" in gold.files}
+    assert want
+    for layout in ("nchw", "channels_last"):          # contiguous NCHW (reference callers) and the HIP heads' channels-last views
+        xd = x.to(gpu) if layout == "nchw" else x.to(gpu).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        with torch.no_grad():
+            out = ad(AdaptorInput(adaptor_feature=xd, output_shape_hw=(AD_H, AD_W)))
+        for f, w in want.items():
+            got = getattr(out, f)
+            assert tuple(got.shape) == tuple(w.shape), (f, got.shape, w.shape)
+            e = float((got.float().cpu().double() - torch.as_tensor(w).double()).abs().max() / max(1.0, float(np.abs(w).max())))
+            assert e < 2e-6 and rel_l2(got.float().cpu(), w) < 2e-6, f"{name}.{f} ({layout}): {e:.2e}"
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+def test_dpt_segmentation_processor_and_double_upsampling(gpu, gold, mode, tol):
+    from uniception_amd import engine
+    from uniception_amd.models.prediction_heads.base import PredictionHeadLayeredInput
+    from uniception_amd.models.prediction_heads.dpt import DPTFeatureDoubleUpsampling, DPTFeatureInput, DPTSegmentationProcessor
+    c = DPT_SEG
+    seg = DPTSegmentationProcessor(c["input_feature_dim"], c["output_dim"], hidden_dim=c["hidden_dim"]).eval()
+    O.fill_state_dict_(seg.state_dict())
+    seg = seg.to(gpu)
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(c["B"], c["input_feature_dim"], *c["feat_hw"], generator=g)
+    with torch.no_grad(), engine.precision(mode):
+        y = seg(DPTFeatureInput(features_upsampled_8x=x.to(gpu), target_output_shape=c["target"])).decoded_channels
+    assert tuple(y.shape) == tuple(gold["dpt_seg/out"].shape)
+    e1 = rel_l2(y.float().cpu(), gold["dpt_seg/out"])
+    c = DPT_DOUBLE
+    dbl = DPTFeatureDoubleUpsampling(input_feature_dims=c["input_feature_dims"], layer_dims=c["layer_dims"], feature_dim=c["feature_dim"]).eval()
+    O.fill_state_dict_(dbl.state_dict())
+    dbl = dbl.to(gpu)
+    g = torch.Generator().manual_seed(42)
+    feats = [torch.randn(c["B"], d, *c["grid"], generator=g) for d in c["input_feature_dims"]]
+    with torch.no_grad(), engine.precision(mode):
+        z = dbl(PredictionHeadLayeredInput(list_features=[f.to(gpu) for f in feats], target_output_shape=(80, 112))).features_upsampled_8x
+    assert tuple(z.shape) == tuple(gold["dpt_double/out"].shape)
+    e2 = rel_l2(z.float().cpu(), gold["dpt_double/out"])
+    print(f"\n[{mode}] DPTSegmentationProcessor rel-L2 {e1:.2e}, DPTFeatureDoubleUpsampling rel-L2 {e2:.2e}")
+    assert e1 < tol and e2 < tol

@@ -21,6 +21,14 @@ class UcHipError(RuntimeError):
     pass
 
 
+class AdaptorSeg(C.Structure):
+    # field order == struct uc_adaptor_seg in include/uc_hip.h
+    _fields_ = [("op", i32), ("mode", i32), ("flags", i32), ("c0", i32), ("n", i32), ("o0", i32), ("p", f32 * 4), ("vmin", f32), ("vmax", f32)]
+
+
+UC_AD_ELEM, UC_AD_NORM, UC_AD_ZEXP, UC_AD_DIR, UC_AD_CONF_EXP, UC_AD_CONF_SIGMOID, UC_AD_MASK, UC_AD_FLOW, UC_AD_FLOWCOORD, UC_AD_COV2D = range(1, 11)
+
+
 class GemmDesc(C.Structure):
     # field order == struct uc_gemm_desc in include/uc_hip.h
     _fields_ = [
@@ -46,6 +54,7 @@ SIGNATURES = {
     "uc_gemm": [C.POINTER(GemmDesc), vp],
     "uc_ln_stats_finalize": [vp, i64, i32, f32, vp, vp],
     "uc_split_bf16x3": [vp, vp, i64, i32, i32, vp],
+    "uc_add_view_pe": [vp, vp, i64, i32, i32, i32, i32, vp],
     "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
     "uc_attention_fwd_fp8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [f32, vp],
     "uc_vt_pack_fp8": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
@@ -61,6 +70,7 @@ SIGNATURES = {
     "uc_pixel_shuffle": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "uc_pointmap_adaptor": [vp, i64, i64, i64, vp, vp, i32, i32, i32, f32, f32, vp],
     "uc_conv1x1_to4": [vp, i32, vp, vp, vp, i64, i32, vp],
+    "uc_adaptor_program": [vp, i64, i64, i64, vp, i32, i32, i32, i32, vp, i32, vp],
     "uc_assemble_tokens": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "uc_token_slice": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "uc_layernorm_bwd": [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, f32, vp],

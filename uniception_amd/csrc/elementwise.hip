@@ -185,6 +185,34 @@ extern "C" int uc_convert(const void* src, int sd, void* dst, int dd, int64_t n,
 }
 
 // =======================================================================================
+// View positional encoding of the global / alternating multi-view transformers (info_sharing/global_attention_transformer.py
+// :365-392): x[b, v*T + t, :] += pe[v, :] for the V views of T tokens each; rows past V*T (global extra tokens) are untouched.
+// x fp32 [B, L, C] in place, pe fp32 [V, C].  One work item = 4 channels.
+// =======================================================================================
+__global__ void add_view_pe_kernel(float* __restrict__ x, const float* __restrict__ pe, int64_t B, int L, int T, int V, int C4) {
+    const int64_t n = B * (int64_t)V * T * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const int64_t r = i / C4;                 // (b, v, t)
+        const int64_t bv = r / T;
+        const int v = (int)(bv % V);
+        const int64_t b = bv / V;
+        float4_t* px = reinterpret_cast<float4_t*>(x + ((b * L + (int64_t)v * T + (r - bv * T)) * C4 + c) * 4);
+        *px = *px + *reinterpret_cast<const float4_t*>(pe + ((int64_t)v * C4 + c) * 4);
+    }
+}
+
+extern "C" int uc_add_view_pe(float* x, const float* pe, int64_t B, int L, int T, int V, int C, uc_stream_t stream) {
+    UC_REQUIRE(x && pe && B >= 0 && L > 0 && T > 0 && V > 0 && (int64_t)V * T <= L && C > 0 && C % 4 == 0, "uc_add_view_pe: bad argument");
+    UC_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)pe % 16 == 0, "uc_add_view_pe: 16-byte alignment");
+    const int64_t n = B * (int64_t)V * T * (C / 4);
+    if (n == 0) return UC_OK;
+    hipLaunchKernelGGL(add_view_pe_kernel, dim3(EW_GRID(n)), dim3(256), 0, (hipStream_t)stream, x, pe, B, L, T, V, C / 4);
+    UC_CHECK_LAUNCH("uc_add_view_pe");
+    return UC_OK;
+}
+
+// =======================================================================================
 // bf16x3 operand split: an fp32 row x[0:C] becomes the bf16 row [hi | hi | lo] (3C wide) with hi = bf16(x), lo = bf16(x - hi).
 // Against weights laid out [Wh | Wl | Wh] the ordinary bf16 MFMA GEMM then accumulates xh.wh + xh.wl + xl.wh in fp32 — the
 // three leading terms of the exact product (relative error ~2^-16 per term): fp32-class results at a third of the bf16
@@ -534,5 +562,131 @@ extern "C" int uc_token_slice(const float* src, float* dst, int B, int Ns, int N
     hipLaunchKernelGGL(token_slice_kernel, dim3(EW_GRID(items)), dim3(256), 0, (hipStream_t)stream, src, dst, Ns, Nd, src_off, dst_off,
                        n, D / 4, items);
     UC_CHECK_LAUNCH("uc_token_slice");
+    return UC_OK;
+}
+
+
+// =======================================================================================
+// Adaptor "channel programs" (reference: prediction_heads/adaptors.py:25-2300).  Every adaptor of the reference splits the
+// decoded channels, applies a small per-pixel transform to each group and concatenates the results: here the whole
+// composition is ONE pass — a list of up to UC_ADAPTOR_MAX_SEGS segments {op, input channels, output channels, parameters,
+// clip} evaluated per pixel.  x: fp32 BCHW-shaped (strides sb, sc, sw; rows dense), out: fp32 NHWC [B,H,W,Cout].
+// =======================================================================================
+struct AdaptorProgram { uc_adaptor_seg seg[UC_ADAPTOR_MAX_SEGS]; int nseg; };
+
+__device__ __forceinline__ float ad_clip(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+__global__ void adaptor_program_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sw, float* __restrict__ out,
+                                       int64_t npix, int HW, int W, int Cout, AdaptorProgram prog) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int pix = (int)(i - b * HW);
+        const float* px = x + b * sb + (int64_t)pix * sw;
+        float* po = out + i * Cout;
+        for (int s = 0; s < prog.nseg; ++s) {
+            const uc_adaptor_seg g = prog.seg[s];
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < g.n) v[k] = px[(int64_t)(g.c0 + k) * sc];
+            float* o = po + g.o0;
+            switch (g.op) {
+                case UC_AD_ELEM:            // linear / square / exp per channel, then clip
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < g.n) { const float t = g.mode == 1 ? v[k] * v[k] : (g.mode == 2 ? expf(v[k]) : v[k]); o[k] = ad_clip(t, g.vmin, g.vmax); }
+                    break;
+                case UC_AD_NORM: {          // direction x f(distance): f = d^2 ("square") | expm1(d) ("exp"), then clip
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < g.n) d2 += v[k] * v[k];
+                    const float d = sqrtf(d2);
+                    const float f = (g.mode == 1 ? d * d : expm1f(d)) / fmaxf(d, 1e-8f);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < g.n) o[k] = ad_clip(v[k] * f, g.vmin, g.vmax);
+                    break;
+                }
+                case UC_AD_ZEXP: {          // (x e^z, y e^z, e^z), then clip
+                    const float z = expf(v[2]);
+                    o[0] = ad_clip(v[0] * z, g.vmin, g.vmax); o[1] = ad_clip(v[1] * z, g.vmin, g.vmax); o[2] = ad_clip(z, g.vmin, g.vmax);
+                    break;
+                }
+                case UC_AD_DIR: {           // clip, optional clamp of the last channel from below (flag 1), then unit norm (flag 2) or last channel = 1 (flag 4)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < g.n) v[k] = ad_clip(v[k], g.vmin, g.vmax);
+                    if (g.flags & 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k == g.n - 1) v[k] = fmaxf(v[k], g.p[0]);
+                    }
+                    float sc_ = 1.f;
+                    if (g.flags & 2) {
+                        float d2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k < g.n) d2 += v[k] * v[k];
+                        sc_ = 1.f / fmaxf(sqrtf(d2), 1e-8f);
+                    } else if (g.flags & 4) {
+                        float last = 1.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k == g.n - 1) last = v[k];
+                        sc_ = 1.f / last;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < g.n) o[k] = v[k] * sc_;
+                    break;
+                }
+                case UC_AD_CONF_EXP:        // vmin + min(exp(x), vmax - vmin)
+                    o[0] = g.vmin + fminf(expf(v[0]), g.vmax - g.vmin);
+                    break;
+                case UC_AD_CONF_SIGMOID:    // sigmoid(x) (vmax - vmin) + vmin
+                    o[0] = (1.f / (1.f + expf(-v[0]))) * (g.vmax - g.vmin) + g.vmin;
+                    break;
+                case UC_AD_MASK:            // (logits, sigmoid(logits))
+                    o[0] = v[0]; o[1] = 1.f / (1.f + expf(-v[0]));
+                    break;
+                case UC_AD_FLOW:            // x std + mean per channel (already scaled to the output shape by the caller)
+                    o[0] = v[0] * g.p[0] + g.p[1]; o[1] = v[1] * g.p[2] + g.p[3];
+                    break;
+                case UC_AD_FLOWCOORD: {     // 0.5 (x + 1) (W, H) + 0.5 - (pixel centre)
+                    const int yy = pix / W, xx = pix - yy * W;
+                    o[0] = 0.5f * (v[0] + 1.f) * g.p[0] + 0.5f - ((float)xx + 0.5f);
+                    o[1] = 0.5f * (v[1] + 1.f) * g.p[1] + 0.5f - ((float)yy + 0.5f);
+                    break;
+                }
+                case UC_AD_COV2D: {         // (c1, c2, s) -> covariance (3), log det (1), inverse covariance (3); p[0] = offset of c1, c2
+                    const float c1 = v[0] + g.p[0], c2 = v[1] + g.p[0];
+                    const float th = tanhf(v[2]);
+                    const float de = 0.5f * (c1 + c2);
+                    const float om = 1.f - th * th + 1e-8f;
+                    const float ic = 1.f / om;
+                    o[0] = expf(c1); o[1] = expf(c2); o[2] = th * expf(de);
+                    o[3] = c1 + c2 + logf(om);
+                    o[4] = ic * expf(-c1); o[5] = ic * expf(-c2); o[6] = -ic * th * expf(-de);
+                    break;
+                }
+                default: break;
+            }
+        }
+    }
+}
+
+extern "C" int uc_adaptor_program(const float* x, int64_t sb, int64_t sc, int64_t sw, float* out, int B, int H, int W, int Cout,
+                                  const uc_adaptor_seg* segs, int nseg, uc_stream_t stream) {
+    UC_REQUIRE(x && out && segs && B > 0 && H > 0 && W > 0 && Cout > 0, "uc_adaptor_program: bad argument");
+    UC_REQUIRE(nseg > 0 && nseg <= UC_ADAPTOR_MAX_SEGS, "uc_adaptor_program: 1..%d segments", UC_ADAPTOR_MAX_SEGS);
+    AdaptorProgram prog;
+    prog.nseg = nseg;
+    for (int s = 0; s < nseg; ++s) {
+        const uc_adaptor_seg& g = segs[s];
+        const int nout = g.op == UC_AD_MASK ? 2 : (g.op == UC_AD_COV2D ? 7 : g.n);
+        UC_REQUIRE(g.op >= UC_AD_ELEM && g.op <= UC_AD_COV2D && g.n >= 1 && g.n <= 4 && g.c0 >= 0 && g.o0 >= 0 && g.o0 + nout <= Cout,
+                   "uc_adaptor_program: bad segment %d", s);
+        UC_REQUIRE(((g.op != UC_AD_ZEXP && g.op != UC_AD_COV2D) || g.n == 3) && ((g.op != UC_AD_FLOW && g.op != UC_AD_FLOWCOORD) || g.n == 2) &&
+                       ((g.op != UC_AD_CONF_EXP && g.op != UC_AD_CONF_SIGMOID && g.op != UC_AD_MASK) || g.n == 1),
+                   "uc_adaptor_program: segment %d has the wrong channel count for its op", s);
+        prog.seg[s] = g;
+    }
+    const int64_t npix = (int64_t)B * H * W;
+    hipLaunchKernelGGL(adaptor_program_kernel, dim3(EW_GRID(npix)), dim3(256), 0, (hipStream_t)stream, x, sb, sc, sw, out, npix, H * W, W, Cout, prog);
+    UC_CHECK_LAUNCH("uc_adaptor_program");
     return UC_OK;
 }

@@ -60,6 +60,35 @@ class RegressionWithConfidenceAdaptorOutput:
     confidence: Tensor
 
 
+@dataclass
+class MaskAdaptorOutput:
+    logits: Tensor
+    mask: Tensor
+
+
+@dataclass
+class Covariance2DAdaptorOutput:
+    covariance: Tensor
+    log_det: Tensor
+    inv_covariance: Tensor
+    log_representation: Tensor
+
+
+@dataclass
+class RegressionWithMaskAdaptorOutput:
+    value: Tensor
+    logits: Tensor
+    mask: Tensor
+
+
+@dataclass
+class RegressionWithConfidenceAndMaskAdaptorOutput:
+    value: Tensor
+    confidence: Tensor
+    logits: Tensor
+    mask: Tensor
+
+
 class UniCeptionPredictionHeadBase(nn.Module):
     def __init__(self, name: str, *args, **kwargs):
         super().__init__(*args, **kwargs)

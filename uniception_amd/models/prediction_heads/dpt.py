@@ -153,3 +153,124 @@ class DPTRegressionProcessor(nn.Module):
             else:
                 out = ops.gemm(x.view(-1, Cin), wl, bl, out_dtype=torch.float32).view(B, Hh, Ww, -1)
         return PixelTaskOutput(decoded_channels=out.permute(0, 3, 1, 2))
+
+
+class DPTSegmentationProcessor(nn.Module):
+    """8x-upsampled DPT features -> `output_dim` channels at the target resolution (reference: prediction_heads/dpt.py:314-381):
+    conv3x3 (no bias) -> ReLU -> [Dropout, identity in eval] -> conv1x1 -> bilinear (align_corners=True) to the target shape.
+    The 1x1 conv and the resize run in fp32 on a channel count padded to the kernels' 8-channel granule."""
+
+    def __init__(self, input_feature_dim: int, output_dim: int, hidden_dim: Optional[int] = None, use_bn: bool = False,
+                 pretrained_checkpoint_path: str = None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if hidden_dim is None:
+            hidden_dim = input_feature_dim
+        if use_bn:
+            raise engine.UcHipError("BatchNorm in the DPT head is not supported by the HIP path (use_bn=False)")
+        self.output_dim = output_dim
+        self.conv = nn.Sequential(
+            nn.Conv2d(input_feature_dim, hidden_dim, kernel_size=3, padding=1, bias=False),
+            nn.Identity(),
+            nn.ReLU(True),
+            nn.Dropout(0.1, False),
+            nn.Conv2d(hidden_dim, output_dim, kernel_size=1),
+        )
+        self.pretrained_checkpoint_path = pretrained_checkpoint_path
+        if pretrained_checkpoint_path is not None:
+            print(f"Loading pretrained DPT segmentation processor from {pretrained_checkpoint_path}")
+            ckpt = torch.load(pretrained_checkpoint_path, weights_only=False)
+            print(self.load_state_dict(ckpt["model"]))
+
+    def forward(self, dpt_processor_input: DPTFeatureInput):
+        x = dpt_processor_input.features_upsampled_8x
+        H, W = dpt_processor_input.target_output_shape
+        engine.require_inference(x, self.conv[0].weight)
+        if self.training and self.conv[3].p > 0:
+            raise engine.UcHipError("Dropout in training mode is not supported by the HIP path (call .eval())")
+        dt = engine.head_dtype()
+        x = engine.conv3x3(engine.bchw_to_nhwc(x, dt), self.conv[0], act="relu")
+        last = self.conv[4]
+        cpad = (self.output_dim + 7) // 8 * 8
+
+        def padded():   # output channels padded with zero rows to the 8-channel granule of the NHWC kernels
+            w = torch.zeros(cpad, last.in_channels, device=last.weight.device)
+            w[:self.output_dim] = last.weight.detach().reshape(self.output_dim, -1).float()
+            b = torch.zeros(cpad, device=last.weight.device)
+            if last.bias is not None:
+                b[:self.output_dim] = last.bias.detach().float()
+            return w.to(dt).contiguous(), b
+        wl, bl = engine.prepared(last, ("c1pad", dt), (last.weight, last.bias), padded)
+        B, Hh, Ww, Cin = x.shape
+        y = ops.gemm(x.view(-1, Cin), wl, bl, out_dtype=torch.float32).view(B, Hh, Ww, cpad)
+        y = engine.bilinear(y, H, W)
+        return PixelTaskOutput(decoded_channels=y[..., :self.output_dim].permute(0, 3, 1, 2))
+
+
+class DPTFeatureDoubleUpsampling(nn.Module):
+    """Two-level DPT feature head (reference: prediction_heads/dpt.py:385-573): two BCHW token maps -> [1x1 conv | 1x1 conv + 3x3 s2
+    conv] -> 3x3 projections to feature_dim -> refinenet4 (cropped to level-3's size) -> refinenet3 with the skip: a 2x
+    upsampled fused map (returned, like the reference, in the `features_upsampled_8x` field)."""
+
+    def __init__(self, patch_size: Union[int, Tuple[int, int]] = 16, main_tasks: Iterable[str] = ("rgb",), hooks: List[int] = [0, 1],
+                 input_feature_dims: Optional[Union[int, List[int]]] = 768, layer_dims: List[int] = [384, 768],
+                 feature_dim: int = 256, use_bn: bool = False, output_width_ratio=1, pretrained_checkpoint_path: str = None,
+                 checkpoint_gradient: bool = False, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.patch_size = pair(patch_size)
+        self.main_tasks = main_tasks
+        self.hooks = hooks
+        self.layer_dims = layer_dims
+        self.feature_dim = feature_dim
+        self.checkpoint_gradient = checkpoint_gradient
+        if isinstance(input_feature_dims, int):
+            input_feature_dims = 2 * [input_feature_dims]
+        else:
+            assert isinstance(input_feature_dims, List) and len(input_feature_dims) == 2
+        self.input_feature_dims = input_feature_dims
+        self.scratch = self.make_scratch_2(layer_dims, feature_dim, groups=1, expand=False)
+        self.scratch.refinenet3 = make_fusion_block(feature_dim, use_bn, output_width_ratio)
+        self.scratch.refinenet4 = make_fusion_block(feature_dim, use_bn, output_width_ratio)
+        del self.scratch.refinenet4.resConfUnit1      # unused (no skip input); deleted like the reference does for DDP
+        if self.input_feature_dims is not None:
+            self.init(input_feature_dims=input_feature_dims)
+        self.pretrained_checkpoint_path = pretrained_checkpoint_path
+        if pretrained_checkpoint_path is not None:
+            print(f"Loading pretrained DPT dense feature head from {pretrained_checkpoint_path}")
+            ckpt = torch.load(pretrained_checkpoint_path, weights_only=False)
+            print(self.load_state_dict(ckpt["model"]))
+
+    def make_scratch_2(self, in_shape, out_shape, groups=1, expand=False):
+        scratch = nn.Module()
+        o3, o4 = (out_shape * 4, out_shape * 8) if expand else (out_shape, out_shape)
+        scratch.layer3_rn = nn.Conv2d(in_shape[0], o3, kernel_size=3, stride=1, padding=1, bias=False, groups=groups)
+        scratch.layer4_rn = nn.Conv2d(in_shape[1], o4, kernel_size=3, stride=1, padding=1, bias=False, groups=groups)
+        scratch.layer_rn = nn.ModuleList([scratch.layer3_rn, scratch.layer4_rn])
+        return scratch
+
+    def init(self, input_feature_dims: Union[int, List[int]] = 768):
+        if isinstance(input_feature_dims, int):
+            input_feature_dims = 2 * [input_feature_dims]
+        self.input_feature_dims = [dt * len(self.main_tasks) for dt in input_feature_dims]
+        d, L = self.input_feature_dims, self.layer_dims
+        act_postprocess = [
+            nn.Sequential(nn.Conv2d(d[0], L[0], kernel_size=1, stride=1, padding=0)),
+            nn.Sequential(nn.Conv2d(d[1], L[1], kernel_size=1, stride=1, padding=0),
+                          nn.Conv2d(L[1], L[1], kernel_size=3, stride=2, padding=1)),
+        ]
+        self.input_process = nn.ModuleList(
+            [nn.Sequential(act_, layer_rn_) for act_, layer_rn_ in zip(act_postprocess, self.scratch.layer_rn)])
+
+    def forward(self, dpt_input: PredictionHeadLayeredInput) -> DPTFeatureInput:
+        assert self.input_feature_dims is not None, "Need to call init(input_feature_dims) function first"
+        feats = dpt_input.list_features
+        for hook_idx, hook in enumerate(self.hooks):
+            assert feats[hook].shape[1] == self.input_feature_dims[hook_idx], (
+                f"Input feature dimension mismatch at hook {hook}. Expected BCHW")
+        dt = engine.head_dtype()
+        xs = [engine.bchw_to_nhwc(feats[hook], dt) for hook in self.hooks]
+        l0 = engine.conv3x3(engine.conv1x1(xs[0], self.input_process[0][0][0]), self.input_process[0][1])
+        t = engine.conv3x3(engine.conv1x1(xs[1], self.input_process[1][0][0]), self.input_process[1][0][1])
+        l1 = engine.conv3x3(t, self.input_process[1][1])
+        path4 = self.scratch.refinenet4._nhwc(l1, None, crop=(l0.shape[1], l0.shape[2]))
+        out = self.scratch.refinenet3._nhwc(path4, l0)
+        return DPTFeatureInput(features_upsampled_8x=out.permute(0, 3, 1, 2), target_output_shape=dpt_input.target_output_shape)

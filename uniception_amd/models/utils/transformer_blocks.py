@@ -131,7 +131,8 @@ class CrossAttention(nn.Module):
 
 
 class LayerScale(nn.Module):
-    "Per-channel scale; parameter container only — the fused HIP path requires init_values=None (as DUSt3R uses)."
+    """Per-channel scale; parameter container only.  SelfAttentionBlock folds it into the preceding linear's weights
+    (gamma * (x W^T + b) = x (gamma W)^T + gamma b: no kernel work); CrossAttentionBlock requires init_values=None (as DUSt3R uses)."""
 
     def __init__(self, dim: int, init_values: float = 1e-5, inplace: bool = False):
         super().__init__()
@@ -139,7 +140,70 @@ class LayerScale(nn.Module):
         self.gamma = nn.Parameter(init_values * torch.ones(dim))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise engine.UcHipError("LayerScale (init_values != None) is not supported by the HIP path")
+        raise engine.UcHipError("LayerScale is folded into the block's proj / fc2 weights; it is not callable on its own in the HIP path")
+
+
+class SelfAttentionBlock(nn.Module):
+    """x += ls1(attn(norm1(x))); x += ls2(mlp(norm2(x)))  (reference: utils/transformer_blocks.py:415-514) — the block of the
+    global / alternating multi-view transformers.  Same fused pipeline as the CroCo encoder block: LayerNorm folded into the
+    QKV / fc1 GEMMs, RoPE + V-transpose in the QKV epilogue, residual adds in the proj / fc2 epilogues."""
+
+    def __init__(self, dim: int, num_heads: int, latent_attn_dim: Optional[int] = None, mlp_ratio: float = 4.0,
+                 qkv_bias: bool = False, qk_norm: bool = False, proj_drop: float = 0.0, attn_drop: float = 0.0,
+                 init_values: Optional[float] = None, drop_path: float = 0.0, act_layer: nn.Module = nn.GELU,
+                 norm_layer: nn.Module = nn.LayerNorm, mlp_layer: nn.Module = Mlp, custom_positional_encoding: Callable = None,
+                 use_scalable_softmax: bool = False, use_entropy_scaling: bool = False,
+                 base_token_count_for_entropy_scaling: int = 444, entropy_scaling_growth_factor: float = 1.4):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, latent_attn_dim=latent_attn_dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_norm=qk_norm,
+                              attn_drop=attn_drop, proj_drop=proj_drop, norm_layer=norm_layer,
+                              custom_positional_encoding=custom_positional_encoding, use_scalable_softmax=use_scalable_softmax,
+                              use_entropy_scaling=use_entropy_scaling,
+                              base_token_count_for_entropy_scaling=base_token_count_for_entropy_scaling,
+                              entropy_scaling_growth_factor=entropy_scaling_growth_factor)
+        self.ls1 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.drop_path1 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = mlp_layer(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=proj_drop)
+        self.ls2 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
+        self.drop_path2 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.custom_positional_encoding = custom_positional_encoding
+
+    def forward_tokens(self, x2d, B, N, xpos, dt):
+        """[B*N, C] fp32 residual stream in, new residual stream out; attention spans the N tokens of each of the B sequences."""
+        for dp in (self.drop_path1, self.drop_path2):
+            if isinstance(dp, DropPath) and dp.drop_prob > 0 and self.training:
+                raise engine.UcHipError("DropPath with drop_prob > 0 in training mode is not supported by the HIP path")
+        if not isinstance(self.mlp, Mlp):
+            raise engine.UcHipError("only the standard Mlp layer has a fused HIP pipeline")
+        if self.custom_positional_encoding is not None:
+            assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
+        sa = self.attn
+        _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
+        if not isinstance(sa.q_norm, nn.Identity):
+            raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
+        if autograd.grad_needed(x2d, self.norm1.weight, self.mlp.fc1.weight):   # HIP forward + HIP backward sub-layers
+            if not (isinstance(self.ls1, nn.Identity) and isinstance(self.ls2, nn.Identity)):
+                raise engine.UcHipError("LayerScale has no HIP backward: freeze the block or use init_values=None")
+            x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, N, sa.num_heads, sa.custom_positional_encoding,
+                                              xpos, sa.scale * _softmax_scale_multiplier(sa, N), dt)
+            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt)
+        proj_wb = None if isinstance(self.ls1, nn.Identity) else engine.layerscale_lin_weights(sa.proj, self.ls1.gamma, dt)
+        fc2_wb = None if isinstance(self.ls2, nn.Identity) else engine.layerscale_lin_weights(self.mlp.fc2, self.ls2.gamma, dt)
+        h, fold = engine.ln_operand(x2d, self.norm1, dt)
+        x2d = engine.self_attention(h, B, N, sa.qkv, sa.proj, sa.num_heads, sa.custom_positional_encoding, xpos,
+                                    sa.scale * _softmax_scale_multiplier(sa, N), x2d, x2d.dtype, proj_wb=proj_wb, fold=fold, emit_ln=True)
+        h, fold = engine.ln_operand(x2d, self.norm2, dt)
+        return engine.mlp(h, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), x2d, x2d.dtype, fc2_wb=fc2_wb, fold=fold,
+                          emit_ln=True)
+
+    def forward(self, x: torch.Tensor, xpos: torch.Tensor = None) -> torch.Tensor:
+        B, N, C = x.shape
+        x2 = _as_2d(x)
+        if x2.dtype != torch.float32:
+            x2 = x2.float()
+        return self.forward_tokens(x2, B, N, xpos, engine.compute_dtype()).view(B, N, C)
 
 
 class CrossAttentionBlock(nn.Module):

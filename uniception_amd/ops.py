@@ -441,6 +441,21 @@ def pointmap_adaptor(x: torch.Tensor, conf_vmin: float, conf_vmax: float) -> Tup
     return pts, conf
 
 
+def adaptor_program(x: torch.Tensor, segs, cout: int) -> torch.Tensor:
+    """x: fp32 BCHW-shaped map (contiguous NCHW or a channels-last view); segs: list of _lib.AdaptorSeg -> fp32 NHWC [B,H,W,cout]."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.dim() == 4
+    B, _, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    if sh != W * sw:
+        raise UcHipError("adaptor_program: rows of the input map must be densely packed")
+    out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    arr = (_lib.AdaptorSeg * len(segs))(*segs)
+    _lib.check(_lib.load().uc_adaptor_program(x.data_ptr(), sb, sc, sw, out.data_ptr(), B, H, W, cout, arr, len(segs), _stream()),
+               "uc_adaptor_program")
+    return out
+
+
 def conv1x1_to4(feat: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """feat NHWC [B,H,W,Cin]; w fp32 [4,Cin]; b fp32 [4] -> fp32 NHWC [B,H,W,4]."""
     _need_gpu(feat, w, b)
@@ -450,6 +465,15 @@ def conv1x1_to4(feat: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.T
     _lib.check(_lib.load().uc_conv1x1_to4(feat.data_ptr(), _dt(feat.dtype), w.data_ptr(), b.data_ptr(), out.data_ptr(),
                                           B * H * W, Cin, _stream()), "uc_conv1x1_to4")
     return out
+
+
+def add_view_pe_(x: torch.Tensor, pe: torch.Tensor, T: int) -> torch.Tensor:
+    """x fp32 [B, L, C] += pe[v] on the T tokens of each of the V = pe.shape[0] views (in place; rows past V*T untouched)."""
+    _need_gpu(x, pe)
+    assert x.dtype == torch.float32 and pe.dtype == torch.float32 and x.is_contiguous() and pe.is_contiguous() and x.dim() == 3
+    B, L, Cn = x.shape
+    _lib.check(_lib.load().uc_add_view_pe(x.data_ptr(), pe.data_ptr(), B, L, T, pe.shape[0], Cn, _stream()), "uc_add_view_pe")
+    return x
 
 
 def assemble_tokens(tok: torch.Tensor, cls: torch.Tensor, reg: Optional[torch.Tensor], pos: torch.Tensor) -> torch.Tensor:
