@@ -66,7 +66,9 @@ def test_factories_and_registry():
     assert type(enc).__name__ == "CroCoEncoder"
     with pytest.raises(ValueError):
         encoder_factory("nope")
-    assert set(INFO_SHARING_CLASSES) == {"cross_attention"}
+    assert set(INFO_SHARING_CLASSES) == {"cross_attention", "alternating_attention", "global_attention"}
+    for key, (cls, ifr) in INFO_SHARING_CLASSES.items():
+        assert issubclass(ifr, cls), key
     with pytest.raises(AssertionError):  # data-norm check fires before any compute
         enc(ViTEncoderInput(image=torch.zeros(1, 3, 32, 32), data_norm_type="croco"))
 
@@ -83,6 +85,29 @@ def test_no_silent_cpu_compute():
         dec(MultiViewTransformerInput(features=[torch.zeros(1, 64, 2, 2), torch.zeros(1, 64, 2, 2)]))
     with pytest.raises(AssertionError):
         dec(MultiViewTransformerInput(features=[torch.zeros(1, 64, 2, 2)]))
+
+
+def test_multiview_transformers_and_adaptors_construct_and_refuse_cpu_compute():
+    """f2 / f4 constructors carry the reference's parameter names; compute on CPU tensors fails loudly."""
+    from uniception_amd.models.prediction_heads import adaptors as A
+    g_cls, g_ifr = INFO_SHARING_CLASSES["global_attention"]
+    a_cls, _ = INFO_SHARING_CLASSES["alternating_attention"]
+    glob = g_cls(name="g", input_embed_dim=48, max_num_views_for_pe=3, depth=2, dim=64, num_heads=2)
+    alt = a_cls(name="a", input_embed_dim=48, depth=2, dim=64, num_heads=2, distinguish_ref_and_non_ref_views=True)
+    assert len(glob.self_attention_blocks) == 2 and len(alt.self_attention_blocks) == 2
+    feats = [torch.zeros(1, 48, 2, 2) for _ in range(2)]
+    for m in (glob, alt):
+        with torch.no_grad(), pytest.raises(UcHipError):
+            m(MultiViewTransformerInput(features=feats))
+    ifr = g_ifr(name="gi", input_embed_dim=48, max_num_views_for_pe=3, depth=4, dim=64, num_heads=2, indices=[1, 3])
+    assert ifr.indices == [1, 3]
+    # adaptor family: every class of the reference's adaptors module exists and is a UniCeptionAdaptorBase
+    names = ["FlowAdaptor", "DepthAdaptor", "PointMapAdaptor", "RayDirectionsAdaptor", "ConfidenceAdaptor", "MaskAdaptor", "Covariance2DAdaptor",
+             "ValueWithConfidenceAdaptor", "PointMapWithConfidenceAdaptor", "PointMapWithConfidenceAndMaskAdaptor", "RayMapPlusDepthAdaptor",
+             "ScaleAdaptor", "CamTranslationPlusQuatsAdaptor"]
+    from uniception_amd.models.prediction_heads.base import UniCeptionAdaptorBase
+    for n in names:
+        assert issubclass(getattr(A, n), UniCeptionAdaptorBase), n
 
 
 def test_training_inputs_are_rejected_not_mishandled():
