@@ -188,7 +188,7 @@ def test_gemm_bf16_rope_and_vt_epilogue(gpu):
         assert torch.equal(packed.cpu()[:, :, :, posn], v_ref.bfloat16().permute(0, 2, 3, 1))
 
 
-@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3"])
+@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6"])
 def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     """LayerNorm fused into the GEMMs around it (blocks.py:158-161, transformer_blocks.py:643-646): the producer's fp32 epilogue
     emits a bf16 twin + per-row block statistics, the consumer GEMM on the RAW twin with gamma folded into W reproduces
@@ -249,14 +249,14 @@ def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     assert rel_l2(vt.cpu().float()[:, :, :, posn].permute(0, 3, 1, 2), full[:, :, 2]) < 6e-3
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "6"])
 def test_gemm_bf16_tile_variants(gpu, variant, monkeypatch):
     """Every tile variant of the direct-to-LDS kernel (UC_GEMM_VARIANT is read per call) against the fp32 product, through
     each specialised epilogue: bf16 store (+GELU), fp32 residual add, RoPE + VT, the generic drain (ragged N, bf16 residual)."""
     from uniception_amd import ops
     monkeypatch.setenv("UC_GEMM_VARIANT", variant)
     g = torch.Generator().manual_seed(50 + int(variant))
-    for (M, N, K) in [(512, 384, 256), (300, 200, 128), (1024, 768, 64)]:
+    for (M, N, K) in [(512, 384, 256), (300, 200, 128), (1024, 768, 64), (520, 328, 192)]:
         a = torch.randn(M, K, generator=g).bfloat16()
         w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
         bias = torch.randn(N, generator=g)

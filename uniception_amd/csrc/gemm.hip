@@ -487,7 +487,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         int forced_variant;
         {
             const char* e = getenv("UC_GEMM_VARIANT");
-            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..3: glds tile variants
+            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..3, 6: glds tile variants
         }
         if (d->split_k > 1) {
             UC_REQUIRE(d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a, "uc_gemm: split_k needs a dense operand with K %% 64 == 0");
@@ -590,11 +590,11 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 if (!trace_buf) (void)hipMalloc((void**)&trace_buf, trace_cap * 6 * sizeof(unsigned long long));
                 g.trace = trace_buf;
             }
-            uc_launch_gemm_glds(g, variant, st);
+            uc_launch_gemm_glds(g, variant, st, forced_variant < 0);
             UC_CHECK_LAUNCH("uc_gemm(glds)");
             if (trace_on) {   // diagnostics only: per-CU timeline statistics of this launch to stderr
                 (void)hipStreamSynchronize(st);
-                const int bm = variant >= 1 ? 256 : 128, bn = variant == 2 ? 256 : 128;
+                const int bm = variant >= 1 ? 256 : 128, bn = (variant == 2 || variant == 6) ? 256 : 128;
                 size_t nwg = (size_t)ceil_div64(d->M, bm) * ceil_div64(d->N, bn) * (size_t)g.split_k;
                 if (nwg > trace_cap) nwg = trace_cap;
                 unsigned long long* h = (unsigned long long*)malloc(nwg * 6 * sizeof(unsigned long long));

@@ -53,4 +53,5 @@ struct GldsParams {
 };
 
 // variant: 0 = 128x128 tile (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
-int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st);
+// auto_variant: the variant came from the dispatcher's heuristic (not UC_GEMM_VARIANT): the launcher may refine it per epilogue family
+int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool auto_variant = false);

@@ -104,6 +104,20 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_byte
         : "memory");
 }
 
+// saddr form: wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset
+__device__ __forceinline__ void dma16_s_to_lds(unsigned voff, const void* sbase, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+        : "memory");
+}
+
 // chunk swizzle key of LDS row r: 128-B rows (r>>1)&7, 64-B rows 3*((r>>2)&1) — both make the ds_read_b128 fragment
 // loads (lane = row, lane>>4 = k chunk) conflict-free within the hardware's 16-lane service groups
 template <int BK_>
@@ -688,6 +702,90 @@ __device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&ac
     }
 }
 
+enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2 };
+
+// Epilogue dispatch shared by the 16-wave and the 8-wave kernels: picks the drain of this wave's 64-column block from the family
+// compiled into the instantiation (EPI) and the wave's mode (0 plain, 1 RoPE, 2 packed-VT).
+template <int FA, int A_MODE, int EPI>
+__device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&acc)[FA][4], int mode, int64_t wave_m, int64_t wave_n,
+                                                       int tid, int wave, int ksplit, char* smem) {
+    if (wave_n >= pe.N) return;
+    {
+        // a fresh definition of the lane id: keeps the compiler from hoisting the epilogue's per-lane address math above
+        // the K-loop, where it spilled loop-carried registers of the 128-VGPR kernels
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        char* wbuf = smem + wave * 8192;
+        // (the launcher routes a descriptor to the BF16 / F32 family only when every tile of it takes that family's epilogue)
+        const bool plain = pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && !pe.preact && !pe.dact_u && !(pe.dbg & 16);
+        auto bf16_family = [&]() __attribute__((always_inline)) {
+            const bool nt = pe.nt_out & (mode == 1 ? 4 : 2);
+            if (A_MODE == UC_A_DENSE && pe.ln_stats) {   // folded LayerNorm
+                if constexpr (A_MODE == UC_A_DENSE) {
+                    if (nt) {
+                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                        else glds_epilogue_bf16<FA, UC_ACT_NONE, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                    } else {
+                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                        else glds_epilogue_bf16<FA, UC_ACT_NONE, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                    }
+                }
+            } else if (nt) {
+                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_bf16<FA, UC_ACT_NONE, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            } else {
+                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_bf16<FA, UC_ACT_NONE>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            }
+        };
+        auto f32_family = [&]() __attribute__((always_inline)) {
+            if (pe.nt_out & 1) glds_epilogue_resid<FA, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_resid<FA, false>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+        };
+        if constexpr (EPI == GLDS_EPI_BF16) {
+            if (mode == 2) {
+                // (a 128-row wave tile drains as two 64-row halves: the packed-VT fast path is one aligned 64-token group)
+                if constexpr (FA == 4) {
+                    if (A_MODE == UC_A_DENSE && pe.ln_stats) glds_epilogue_vt<4, A_MODE == UC_A_DENSE>(pe, acc, wave_m, wave_n, lane, wbuf);
+                    else glds_epilogue_vt<4>(pe, acc, wave_m, wave_n, lane, wbuf);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < FA / 4; ++h) {
+                        float4_t half[4][4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) half[i][j] = acc[4 * h + i][j];
+                        if (A_MODE == UC_A_DENSE && pe.ln_stats) glds_epilogue_vt<4, A_MODE == UC_A_DENSE>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
+                        else glds_epilogue_vt<4>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
+                    }
+                }
+            } else bf16_family();
+        } else if constexpr (EPI == GLDS_EPI_F32) {
+            f32_family();
+        } else {
+            if (mode == 2) {
+                if constexpr (FA == 4) glds_epilogue_vt<4>(pe, acc, wave_m, wave_n, lane, wbuf);
+                else {
+#pragma unroll
+                    for (int h = 0; h < FA / 4; ++h) {
+                        float4_t half[4][4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) half[i][j] = acc[4 * h + i][j];
+                        glds_epilogue_vt<4>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
+                    }
+                }
+            } else if (plain && pe.out_dtype == UC_BF16 && !pe.residual) bf16_family();
+            else if (plain && pe.out_dtype == UC_F32 && (!pe.residual || pe.res_dtype == UC_F32) && pe.act == UC_ACT_NONE) f32_family();
+            else glds_epilogue_generic<FA>(pe, acc, mode, wave_m, wave_n, lane, ksplit, wbuf);
+        }
+    }
+}
+
 // BK_ = 64 (128-B LDS rows) or 32 (64-B rows: half the LDS per stage, so two 8-wave workgroups share a CU and one's
 // prologue/epilogue runs under the other's K-loop); WGS_PER_CU is the co-residency the register budget is sized for.
 // EPI selects the epilogue family compiled into an instantiation (the launcher picks the instantiation from the descriptor):
@@ -696,7 +794,6 @@ __device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&ac
 //                  fc2, embeddings);   GLDS_EPI_ALL: the generic drain next to the two fast families (everything else).
 // One family per kernel keeps the register allocation of the 128-VGPR K-loop out of reach of epilogue code it never runs:
 // with all of them inlined into one function, every option added to one epilogue spilled DMA pointers inside the K-loop.
-enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2 };
 
 template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1, int EPI = GLDS_EPI_ALL>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES_N / 4) void gemm_bf16_glds_kernel(GldsParams p) {
@@ -964,54 +1061,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (pe.trace) tr2 = __builtin_amdgcn_s_memrealtime();
-    if (wave_n < pe.N) {
-        // a fresh definition of the lane id: keeps the compiler from hoisting the epilogue's per-lane address math above
-        // the K-loop, where it spilled loop-carried registers of the 128-VGPR kernels
-        int lane = tid & 63;
-        asm volatile("" : "+v"(lane));
-        char* wbuf = smem + wave * 8192;
-        // (the launcher routes a descriptor to the BF16 / F32 family only when every tile of it takes that family's epilogue)
-        const bool plain = pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && !pe.preact && !pe.dact_u && !(pe.dbg & 16);
-        auto bf16_family = [&]() __attribute__((always_inline)) {
-            const bool nt = pe.nt_out & (mode == 1 ? 4 : 2);
-            if (A_MODE == UC_A_DENSE && pe.ln_stats) {   // folded LayerNorm
-                if constexpr (A_MODE == UC_A_DENSE) {
-                    if (nt) {
-                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                        else glds_epilogue_bf16<FA, UC_ACT_NONE, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                    } else {
-                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                        else glds_epilogue_bf16<FA, UC_ACT_NONE, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                    }
-                }
-            } else if (nt) {
-                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                else glds_epilogue_bf16<FA, UC_ACT_NONE, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-            } else {
-                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                else glds_epilogue_bf16<FA, UC_ACT_NONE>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-            }
-        };
-        auto f32_family = [&]() __attribute__((always_inline)) {
-            if (pe.nt_out & 1) glds_epilogue_resid<FA, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-            else glds_epilogue_resid<FA, false>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-        };
-        if constexpr (EPI == GLDS_EPI_BF16) {
-            if (mode == 2) {
-                if (A_MODE == UC_A_DENSE && pe.ln_stats) glds_epilogue_vt<FA, A_MODE == UC_A_DENSE>(pe, acc, wave_m, wave_n, lane, wbuf);
-                else glds_epilogue_vt<FA>(pe, acc, wave_m, wave_n, lane, wbuf);
-            } else bf16_family();
-        } else if constexpr (EPI == GLDS_EPI_F32) {
-            f32_family();
-        } else {
-            if (mode == 2) glds_epilogue_vt<FA>(pe, acc, wave_m, wave_n, lane, wbuf);
-            else if (plain && pe.out_dtype == UC_BF16 && !pe.residual) bf16_family();
-            else if (plain && pe.out_dtype == UC_F32 && (!pe.residual || pe.res_dtype == UC_F32) && pe.act == UC_ACT_NONE) f32_family();
-            else glds_epilogue_generic<FA>(pe, acc, mode, wave_m, wave_n, lane, ksplit, wbuf);
-        }
-    }
+    glds_epilogue_dispatch<FA, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n, tid, wave, ksplit, smem);
     if (pe.trace) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1024,6 +1074,240 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime(); t[4] = hw; t[5] = xcc;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Eight-wave form of the dense 256x256x64 tile: 2 x 4 waves of 128x64 (two waves per SIMD, 256 registers each).
+//
+// The 16-wave kernel above has 128 registers per wave: accumulators (64) + one K-half of fragments (32) fill them, so every
+// fragment is read from LDS right before its MFMAs — after each barrier the matrix pipes wait for the first ds_reads of all
+// 16 waves, and a 64x64 wave tile moves 512 B of LDS per MFMA.  Here a wave owns 128x64: 12 fragment reads feed 32 MFMAs
+// (384 B per MFMA), and the registers hold the NEXT 32-deep K-chunk's fragments while the current chunk's MFMAs run:
+//
+//   chunk 0 of stage s:  MFMAs on (a, w)   | ds_read chunk 1 of stage s   -> (a, wn)       (a is refilled row block by row block)
+//   mid-step:            s_waitcnt + s_barrier: everyone has READ stage s, everyone's DMA of stage s+1 has landed
+//                        DMA of stage s+2 -> buffer of stage s
+//   chunk 1 of stage s:  MFMAs on (a, wn)  | ds_read chunk 0 of stage s+1 -> (a, w)
+//
+// One barrier per K-step as before, but every wave arrives at it with 32 MFMAs' worth of operands already in registers.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
+    constexpr int BM_ = 256, BN_ = 256, WAVES_N = 4, FA = 8, ROWB = 128, STAGE_BYTES = (BM_ + BN_) * ROWB, PER = 8, RPI = 8, CPR = 8;
+    constexpr int A_MODE = UC_A_DENSE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (p.trace) tr0 = __builtin_amdgcn_s_memrealtime();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int ksplit = p.split_k > 1 ? (int)uc_div(blockIdx.x, p.dNwg) : 0;
+    const int t = glds_xcd_remap((int)blockIdx.x - ksplit * nwg, nwg);
+    int tm, tn;
+    {   // tile order: see the 16-wave kernel
+        const int GM = p.group_m;
+        const int per_group = GM * p.tiles_n;
+        const int grp = (int)uc_div((unsigned)t, p.dPerGroup), within = t - grp * per_group;
+        const int first_m = grp * GM;
+        const bool last = p.tiles_m - first_m < GM;
+        const int gsz = last ? p.tiles_m - first_m : GM;
+        tn = (int)uc_div((unsigned)within, last ? p.dGmLast : p.dGm);
+        tm = first_m + within - tn * gsz;
+    }
+    if (p.stagger > 0 && blockIdx.x < 256u) {
+        const unsigned phase = (unsigned)tm & 7u;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)phase * (unsigned)p.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+    const int64_t m0 = (int64_t)tm * BM_;
+    const int64_t n0 = (int64_t)tn * BN_;
+    const int64_t wave_m = m0 + wr * 128;
+    const int64_t wave_n = n0 + wc * 64;
+    const bool is_vt = p.vt_col0 >= 0 && wave_n >= p.vt_col0;
+    const bool is_rope = !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
+    const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
+
+    // DMA sources.  Instruction I = wave*8 + q covers combined-tile rows [8 I, 8 I + 8): waves 0-3 stage the A rows, waves 4-7 the
+    // W rows, 64 rows each.  The 8-row groups of a wave are one uniform stride apart, so a piece is addressed as a wave-uniform
+    // 64-bit base (SGPR pair, advanced on the scalar unit) + one of TWO per-lane byte offsets (the chunk swizzle key
+    // (row >> 1) & 7 only depends on the parity of q) — 2 address registers instead of 16.  Row groups past the matrix end are
+    // clamped to its last 8 rows as a group (launcher: M % 8 == 0, N % 8 == 0); their products are never stored.
+    const bool stages_a = wave < 4;
+    const int64_t ld_src = stages_a ? p.lda : p.K;
+    const bf16_t* sbase[PER];
+    {
+        const bf16_t* mat = stages_a ? p.A : p.W;
+        const int64_t row0 = (stages_a ? m0 : n0) + (wave & 3) * 64, lim = (stages_a ? p.M : p.N) - 8;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) sbase[q] = mat + min(row0 + 8 * q, lim) * ld_src;
+    }
+    const unsigned voff_row = (unsigned)((lane >> 3) * (int)ld_src) * 2u;
+    const unsigned voff2[2] = {voff_row + (unsigned)(((lane & 7) ^ (lane >> 4)) << 4), voff_row + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) << 4)};
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    auto issue_piece = [&](int stage, int64_t k0, int q) __attribute__((always_inline)) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE_BYTES + wave * (PER * 1024) + q * 1024));
+        dma16_s_to_lds(voff2[q & 1], sbase[q] + k0, dst);
+    };
+    auto issue_stage = [&](int stage, int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) issue_piece(stage, k0, q);
+    };
+
+    const int frow = lane & 15;
+    const int fk = lane >> 4;
+    const int f_sw = glds_swz<64>(frow);
+    const int a_base = (wr * 128 + frow) * ROWB;
+    const int w_base = (BM_ + wc * 64 + frow) * ROWB;
+    const int ch_off[2] = {((0 * 4 + fk) ^ f_sw) << 4, ((1 * 4 + fk) ^ f_sw) << 4};
+
+    float4_t acc[FA][4];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = (int)(p.K / 64);
+    const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
+    const int kt0 = ksplit * nk_per;
+    int nk = max(0, min(nk_per, nk_total - kt0));
+    if (p.dbg & 8) nk = min(nk, 1);
+    const int64_t kbase = (int64_t)kt0 * 64;
+
+    auto main_loop = [&](auto swap_tag) __attribute__((always_inline)) {
+        constexpr bool SWAP = decltype(swap_tag)::value;
+        if (nk <= 0) return;
+        bf16x8_t a[FA], w[4], wn[4];
+        auto rd_a = [&](const char* st, int ks, int i) __attribute__((always_inline)) {
+            return *reinterpret_cast<const bf16x8_t*>(st + a_base + ch_off[ks] + i * 16 * ROWB);
+        };
+        auto rd_w = [&](const char* st, int ks, int j) __attribute__((always_inline)) {
+            return *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 16 * ROWB);
+        };
+        auto mma = [&](int i, int j, bf16x8_t av, bf16x8_t wv) __attribute__((always_inline)) {
+            if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, av, acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv, acc[i][j], 0, 0, 0);
+        };
+        issue_stage(0, kbase);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (p.trace) tr1 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("" ::: "memory");
+        if (nk > 1) issue_stage(1, kbase + 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = rd_w(smem, 0, j);
+#pragma unroll
+        for (int i = 0; i < FA; ++i) a[i] = rd_a(smem, 0, i);
+        // chunk 0 of a stage: MFMAs on (a, w) while chunk 1 of the same stage streams into (a, wn).  The scheduling fences keep
+        // every refill of a[i] behind the MFMAs that read the old a[i]: hoisted, both generations are live and the loop spills.
+        auto chunk0 = [&](const char* cur) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma(i, j, a[i], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) {      // behind the first MFMA group: in front of it the group would wait for these four reads as well
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wn[j] = rd_w(cur, 1, j);
+                }
+                a[i] = rd_a(cur, 1, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // One K-step but the last: chunk 0, the mid-step synchronisation, chunk 1 with the next stage's first fragments streaming
+        // in.  DMA (compile-time): the DMA of stage kt + 2 goes into the buffer just released, one 1-KiB piece behind each MFMA
+        // group (issued as a block in front of chunk 1 its ~80 scalar instructions hold back both waves of a SIMD right after
+        // the barrier).  The loop bodies are straight-line: with the last steps' DMA-free / prefetch-free forms inside one loop
+        // the accumulators went through phi copies (90 of them parked in scratch) and every join cost an lgkmcnt(0).
+        // (the loops are rotated so that their headers sit at the synchronisation point: hipcc drains lgkmcnt at a loop header
+        // whatever is pending, and there the drain is wanted)
+        auto step = [&](int kt, auto dma_tag) __attribute__((always_inline)) {
+            constexpr bool DMA = decltype(dma_tag)::value;
+            const char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            // every fragment of stage kt is in registers (lgkmcnt(0)), this wave's DMA pieces of the next stage have landed
+            // (vmcnt(0)); after the barrier both hold for the whole workgroup
+            if (p.dbg & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // diagnostics: do not wait for the DMA (wrong results)
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int64_t k2 = kbase + (int64_t)(kt + 2) * 64;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = rd_w(nxt, 0, j);
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma(i, j, a[i], wn[j]);
+                __builtin_amdgcn_sched_barrier(0);
+                a[i] = rd_a(nxt, 0, i);
+                if constexpr (DMA) { if (!(p.dbg & 1)) issue_piece(kt & 1, k2, i); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            chunk0(nxt);
+        };
+        chunk0(smem);
+        for (int kt = 0; kt + 2 < nk; ++kt) step(kt, std::true_type{});
+        if (nk > 1) step(nk - 2, std::false_type{});
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma(i, j, a[i], wn[j]);
+    };
+    if (mode == 2) main_loop(std::false_type{}); else main_loop(std::true_type{});
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((opencl_constant)) GldsParams* kp =
+        (const __attribute__((opencl_constant)) GldsParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp)::"memory");
+    glds_pe_t pe = *kp;
+#else
+    glds_pe_t pe = p;
+#endif
+    if (pe.dbg & 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s == 12345.678f) reinterpret_cast<float*>(pe.C)[0] = s;
+        return;
+    }
+    __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the bounce space (8 KiB per wave)
+    asm volatile("" ::: "memory");
+    if (pe.trace) tr2 = __builtin_amdgcn_s_memrealtime();
+    glds_epilogue_dispatch<FA, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n, tid, wave, ksplit, smem);
+    if (pe.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* t = pe.trace + (size_t)blockIdx.x * 6;
+            t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime(); t[4] = hw; t[5] = xcc;
+        }
+    }
+}
+
+template <int EPI>
+static void launch_glds8(GldsParams p, hipStream_t st) {
+    p.tiles_m = (int)ceil_div64(p.M, 256);
+    p.tiles_n = (int)ceil_div64(p.N, 256);
+    p.dNwg = uc_make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
+    p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
+    p.dGm = uc_make_fastdiv((unsigned)p.group_m);
+    p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
+    auto kfn = gemm_bf16_glds8_kernel<EPI>;
+    constexpr int smem = 2 * 512 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n * (unsigned)p.split_k), dim3(512), smem, st, p);
 }
 
 template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1, int EPI = GLDS_EPI_ALL>
@@ -1060,6 +1344,12 @@ static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t s
             break;
         case 2: launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI>(p, st); break;
         case 3: launch_variant_mode<256, 128, 4, 2, 3, A_MODE, 32, 2, EPI>(p, st); break;
+        case 6:   // 256x256x64 with eight waves of 128x64 and register-resident next-chunk fragments (dense only)
+            // (its DMA addresses row groups of 8 uniformly: matrices whose last group is partial stay on the 16-wave kernel)
+            if (A_MODE == UC_A_DENSE && p.M % 8 == 0 && p.N % 8 == 0) {
+                if constexpr (A_MODE == UC_A_DENSE) launch_glds8<EPI>(p, st);
+            } else launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI>(p, st);
+            break;
         default:
             if (deep == 3 && ceil_div64(p.M, 128) * ceil_div64(p.N, 128) * sk <= 512) launch_variant_mode<128, 128, 2, 2, 3, A_MODE, 64, 1, EPI>(p, st);
             else launch_variant_mode<128, 128, 2, 2, 2, A_MODE, 64, 1, EPI>(p, st);
