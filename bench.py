@@ -82,6 +82,10 @@ def roofline_pass(step_fn, v1, precision, steps):
             nbytes += kw["residual"].numel() * kw["residual"].element_size()            # ... + the residual read by the epilogue
         if kw.get("vt") is not None:
             nbytes += 2.0 * M_ * (N_ - out.shape[1])                                     # ... + the V columns stored as packed VT
+        if getattr(out, "uc_ln", None) is not None:
+            nbytes += 2.0 * M_ * N_ + 8.0 * M_ * (N_ // 64)                              # ... + the bf16 twin and the row statistics of the LayerNorm fold (producer)
+        if kw.get("ln") is not None:
+            nbytes += 8.0 * M_ + 4.0 * N_                                                # ... + (mean, rstd) per row and the column sums (consumer)
         records.append((e0, e1, 2.0 * M_ * N_ * K_, nbytes))
         return out
 

@@ -67,7 +67,8 @@ class ResidualConvUnit_custom(nn.Module):
 
 
 class FeatureFusionBlock_custom(nn.Module):
-    """(path + RCU1(skip)) -> RCU2 -> x2 bilinear (align_corners=True) -> 1x1 conv (dpt_block.py:180-255)."""
+    """(path + RCU1(skip)) -> RCU2 -> x2 bilinear (align_corners=True) -> 1x1 conv (dpt_block.py:180-255); computed as
+    1x1 conv -> x2 bilinear (the two commute)."""
 
     def __init__(self, features, activation, deconv=False, bn=False, expand=False, align_corners=True, width_ratio=1):
         super().__init__()
@@ -89,8 +90,11 @@ class FeatureFusionBlock_custom(nn.Module):
         out = path if skip is None else self.resConfUnit1._nhwc(skip, extra=path)
         out = self.resConfUnit2._nhwc(out)
         B, H, W, _ = out.shape
-        out = engine.bilinear(out, 2 * H, 2 * W, crop)
-        return engine.conv1x1(out, self.out_conv)
+        # The reference upsamples, then applies the 1x1 convolution (dpt_block.py:251-255).  Both are linear and the bilinear
+        # weights of a pixel sum to 1 (bias included), so the two commute exactly in real arithmetic: the 1x1 GEMM runs on the
+        # H x W map — a quarter of the rows — and the x2 resize on its output (same channel count, same resize cost).
+        out = engine.conv1x1(out, self.out_conv)
+        return engine.bilinear(out, 2 * H, 2 * W, crop)
 
     def forward(self, *xs):
         path = _to_nhwc(xs[0])
