@@ -37,7 +37,7 @@ const char* uc_last_error(void);
 /* ABI version; bumped when a signature or the uc_gemm_desc layout changes.
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
  *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added. */
-#define UC_ABI_VERSION 4
+#define UC_ABI_VERSION 5
 int uc_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
@@ -139,6 +139,13 @@ typedef struct uc_gemm_desc {
     float* stats_out;
     const float* ln_stats;
     const float* ln_colsum;
+    /* Fused narrow tail (bf16 direct-to-LDS path, N == 128): the DPT regressor's conv3x3 -> ReLU -> Conv2d(128 -> 4, 1x1)
+       (prediction_heads/dpt.py:271-277, 304-309).  With tail_out non-NULL the [M,128] result is NOT stored (C may be NULL);
+       instead tail_out[m][o] = tail_b[o] + sum_n act(acc[m,n] + bias[n]) * tail_w[o*N + n], o < 4, fp32 [M,4] — the
+       4.3 GB per-head intermediate of a 512x512 batch is never written or read.  No residual / rope / vt / split_k. */
+    const float* tail_w;   /* [4][N] fp32 */
+    const float* tail_b;   /* [4] fp32 or NULL */
+    float* tail_out;       /* [M][4] fp32 */
 } uc_gemm_desc;
 
 int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);

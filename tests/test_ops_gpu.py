@@ -5,6 +5,7 @@ reference runs in fp32 on the SAME rounded inputs, so the tolerance only has to 
 accumulation order + the bf16 rounding of the output.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -286,6 +287,44 @@ def test_gemm_bf16_tile_variants(gpu, variant, monkeypatch):
     wv = n % 16
     posn = (n // 16) * 16 + ((wv >> 2) & 1) * 8 + (wv & 3) + 4 * (wv >> 3)
     assert rel_l2(vt.cpu().float()[:, :, :, posn].permute(0, 3, 1, 2), full[:, :, 2]) < 4e-3
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("geom", [(2, 16, 24, 128, "relu"), (1, 37, 29, 64, "relu"), (3, 8, 8, 32, None), (1, 40, 40, 128, "gelu")])
+def test_conv3x3_fused_tail(gpu, geom, mode):
+    """conv3x3(Cin -> 128) -> act -> Conv2d(128 -> 4, 1x1) in one kernel (uc_gemm_desc.tail_*; dpt.py:271-277): ragged M, every
+    tile variant the dispatcher may pick, plain bf16 and split-operand (fp32-class) arithmetic."""
+    from uniception_amd import engine, ops
+    B, H, W, Cin, act = geom
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    wc = torch.randn(128, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bc = torch.randn(128, generator=g) * 0.3
+    w4 = torch.randn(4, 128, generator=g) / math.sqrt(128)
+    b4 = torch.randn(4, generator=g)
+    xin = x.bfloat16().float() if mode == "bf16" else x
+    win = wc.bfloat16().float() if mode == "bf16" else wc
+    y = F.conv2d(xin.permute(0, 3, 1, 2).double(), win.double(), bc.double(), padding=1)
+    y = {"relu": F.relu, "gelu": F.gelu, None: lambda t: t}[act](y)
+    ref = torch.einsum("bchw,oc->bhwo", y, w4.double()) + b4.double()
+    wg = wc.permute(0, 2, 3, 1).reshape(128, -1).contiguous()
+    for variant in ("auto", "0", "1", "3"):
+        if variant != "auto":
+            os.environ["UC_GEMM_VARIANT"] = variant
+        try:
+            if mode == "bf16":
+                out = ops.gemm(x.bfloat16().to(gpu), wg.bfloat16().to(gpu), bc.to(gpu), act=act, conv=(B, H, W, Cin, 1), tail=(w4.to(gpu), b4.to(gpu)))
+            else:
+                with engine.precision("bf16x3"):
+                    out = ops.gemm(x.to(gpu), wg.to(gpu), bc.to(gpu), act=act, conv=(B, H, W, Cin, 1), tail=(w4.to(gpu), b4.to(gpu)))
+        finally:
+            os.environ.pop("UC_GEMM_VARIANT", None)
+        assert out.shape == (B * H * W, 4) and out.dtype == torch.float32
+        tol = 3e-4 if act == "gelu" else (3e-5 if mode == "bf16" else 1e-5)      # (the epilogue's GELU is a 3e-5-accurate polynomial)
+        assert rel_l2(out.view(B, H, W, 4).cpu(), ref) < tol, (variant, mode)
+    out = ops.gemm(x.bfloat16().to(gpu), wg.bfloat16().to(gpu), None, act=act, conv=(B, H, W, Cin, 1), tail=(w4.to(gpu), None))
+    y0 = {"relu": F.relu, "gelu": F.gelu, None: lambda t: t}[act](F.conv2d(x.bfloat16().double().permute(0, 3, 1, 2), wc.bfloat16().double(), None, padding=1))
+    assert rel_l2(out.view(B, H, W, 4).cpu(), torch.einsum("bchw,oc->bhwo", y0, w4.double())) < (3e-4 if act == "gelu" else 3e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("preact_out", vp), ("split_k", i32), ("dact_u", vp), ("dact_act", i32),
         ("C", vp), ("out_dtype", i32), ("ldc", i64),
         ("twin_out", vp), ("ldt", i64), ("stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
+        ("tail_w", vp), ("tail_b", vp), ("tail_out", vp),
     ]
 
 
@@ -96,7 +97,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 4   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 5   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 // =======================================================================================
 extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     UC_REQUIRE(d, "uc_gemm: null descriptor");
-    UC_REQUIRE(d->A && d->W && d->C, "uc_gemm: null operand pointer");
+    UC_REQUIRE(d->A && d->W && (d->C || d->tail_out), "uc_gemm: null operand pointer");
     UC_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0, "uc_gemm: bad shape M=%lld N=%lld K=%lld", (long long)d->M,
                (long long)d->N, (long long)d->K);
     UC_REQUIRE(d->a_mode == UC_A_DENSE || d->a_mode == UC_A_CONV3X3, "uc_gemm: bad a_mode %d", d->a_mode);
@@ -457,7 +457,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     } else {
         UC_REQUIRE(d->lda >= d->K, "uc_gemm: lda < K");
     }
-    UC_REQUIRE(d->ldc >= (d->vt_col0 >= 0 ? d->vt_col0 : d->N), "uc_gemm: ldc smaller than the columns written to C");
+    if (!d->tail_out) UC_REQUIRE(d->ldc >= (d->vt_col0 >= 0 ? d->vt_col0 : d->N), "uc_gemm: ldc smaller than the columns written to C");
     if (d->residual) UC_REQUIRE(d->ldr >= d->N, "uc_gemm: ldr < N");
 
     hipStream_t st = (hipStream_t)stream;
@@ -522,6 +522,14 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             if (d->twin_out) UC_REQUIRE((uintptr_t)d->twin_out % 8 == 0 && d->ldt % 4 == 0 && d->ldt >= d->N, "uc_gemm: twin_out alignment / ldt");
             if (d->stats_out) UC_REQUIRE((uintptr_t)d->stats_out % 8 == 0, "uc_gemm: stats_out alignment");
         }
+        if (d->tail_out) {
+            UC_REQUIRE(d->tail_w && d->N == 128 && d->a_mode == UC_A_CONV3X3,
+                       "uc_gemm: the fused tail needs tail_w, a 3x3 convolution and N == 128 (one 128-wide tile holds a pixel's channels)");
+            UC_REQUIRE(!d->residual && d->rope_cols <= 0 && d->vt_col0 < 0 && d->split_k <= 1 && !d->preact_out && !d->dact_u && !d->ln_stats &&
+                           !d->twin_out && !d->stats_out, "uc_gemm: the fused tail takes bias + activation only");
+            UC_REQUIRE((uintptr_t)d->tail_out % 16 == 0 && (uintptr_t)d->tail_w % 4 == 0 && (!d->tail_b || (uintptr_t)d->tail_b % 4 == 0),
+                       "uc_gemm: tail_out must be 16-byte aligned");
+        }
         // the conv DMA addresses a tile's input window (the images its 256 output rows touch) with 32-bit byte offsets
         const int64_t conv_window_bytes = d->a_mode == UC_A_CONV3X3
             ? (256 / std::max<int64_t>(1, (int64_t)d->conv_Ho * d->conv_Wo) + 2) * (int64_t)d->conv_H * d->conv_W * d->conv_Cin * 2 : 0;
@@ -549,6 +557,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             g.preact = d->preact_out; g.split_k = d->split_k > 1 ? d->split_k : 1;
             g.ln_stats = (const float2*)d->ln_stats; g.ln_colsum = d->ln_colsum;
             g.twin = (bf16_t*)d->twin_out; g.ldt = d->ldt; g.stats_out = (float2*)d->stats_out;
+            g.tail_w = d->tail_w; g.tail_b = d->tail_b; g.tail_out = d->tail_out;
+            if (d->tail_out) g.vec_ok = 0;     // never one of the single-family kernels
             g.dact_u = (const bf16_t*)d->dact_u; g.dact_act = d->dact_act;
             { static int gm = -1; if (gm < 0) { const char* e = getenv("UC_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } g.group_m = gm; }
             { static int dbg = -1; if (dbg < 0) { const char* e = getenv("UC_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
@@ -577,6 +587,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 if (co < 0) { const char* e = getenv("UC_GEMM_CORESIDENT"); co = e ? atoi(e) : 1; }
                 if (variant == 1 && t256x128 * sk >= 512 && co) variant = 3;
             }
+            if (d->tail_out && (variant == 2 || variant == 6)) variant = 1;    // the tail needs a tile that spans all 128 columns with two wave columns
             { static int nt = -2; if (nt == -2) { const char* e = getenv("UC_GEMM_NT"); nt = e ? atoi(e) : -1; }
               const int64_t out_bytes = d->M * d->N * (d->out_dtype == UC_F32 ? 4 : 2);
               g.nt_out = out_bytes > ((int64_t)128 << 20) ? (nt >= 0 ? nt : 7) : 0; }   // bit 0: fp32 residual stream, 1: bf16 outputs, 2: bf16 RoPE (q, k) tiles
@@ -631,6 +642,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             return UC_OK;
         }
         UC_REQUIRE(!d->ln_stats && !d->twin_out && !d->stats_out, "uc_gemm: the LayerNorm fusion options need the direct-to-LDS kernel (forced off?)");
+        UC_REQUIRE(!d->tail_out, "uc_gemm: the fused tail needs the direct-to-LDS kernel (dense K %% 64 == 0 / conv Cin %% 32 == 0)");
         p.tiles_m = (int)ceil_div64(d->M, BM);
         p.tiles_n = (int)ceil_div64(d->N, BN);
         const unsigned grid = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
@@ -640,7 +652,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         else
             hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_CONV3X3>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);
     } else if (d->compute_dtype == UC_F32) {
-        UC_REQUIRE(!d->ln_stats && !d->twin_out && !d->stats_out, "uc_gemm(f32): the LayerNorm fusion options are bf16-path only");
+        UC_REQUIRE(!d->ln_stats && !d->twin_out && !d->stats_out && !d->tail_out, "uc_gemm(f32): the LayerNorm fusion options and the fused tail are bf16-path only");
         if (d->split_k > 1 || d->dact_u) {
             uc_set_error("uc_gemm(f32): split_k / dact_u are only implemented for the bf16 MFMA path");
             return UC_ERR_UNSUPPORTED;

@@ -34,6 +34,10 @@ struct GldsParams {
     bf16_t* twin;             // [M, ldt] bf16 copy of C, or NULL
     int64_t ldt;
     float2* stats_out;        // [M][N/64] (sum, sum of squared deviations from the block mean), or NULL
+    // fused narrow tail (N == 128): out4[m][o] = tail_b[o] + sum_n act(acc + bias)[m][n] * tail_w[o][n]; C is not stored
+    const float* tail_w;      // [4][N]
+    const float* tail_b;      // [4] or NULL
+    float* tail_out;          // [M][4]
     void* preact;   // optional pre-activation copy (same dtype / ld as C)
     const bf16_t* dact_u;   // optional: multiply the result by act'(u), u bf16 [M, ldc]
     int dact_act;

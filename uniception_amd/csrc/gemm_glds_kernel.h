@@ -704,6 +704,51 @@ __device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&ac
 
 enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2 };
 
+// Fused narrow tail of a 128-wide tile (two wave columns of 64): out4[m][o] = tail_b[o] + sum_n act(acc[m][n] + bias[n]) * tail_w[o][n].
+// The DPT regressor's conv3x3 -> ReLU -> Conv2d(128 -> 4, 1x1): the 128-channel map is never stored.  Per wave: its 64 columns of
+// tail_w (as float4 over the four outputs) and of the bias sit in its LDS block; a lane multiplies its 16 values of a row by
+// them, the four lanes that share a row (lane bits 4, 5) add up through two xor-shuffles, the two wave columns meet through
+// LDS, and the left wave column stores 64 rows x 16 bytes — one contiguous KiB.
+template <int FA, int ACT>
+__device__ __forceinline__ void glds_epilogue_tail4(glds_pe_t p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane,
+                                                    int wave, char* smem) {
+    static_assert(FA == 4, "the fused tail is written for 64-row wave tiles");
+    const int frow = lane & 15, g = lane >> 4;
+    char* wbuf = smem + wave * 8192;
+    float4_t* wl = reinterpret_cast<float4_t*>(wbuf);              // [64 columns] x (o = 0..3)
+    float* bl = reinterpret_cast<float*>(wbuf + 1024);            // [64] bias
+    float4_t* xl = reinterpret_cast<float4_t*>(wbuf + 2048);       // [64 rows] partial sums of this wave column
+    {
+        const int64_t n = wave_n + lane;
+        wl[lane] = (float4_t){p.tail_w[n], p.tail_w[p.N + n], p.tail_w[2 * p.N + n], p.tail_w[3 * p.N + n]};
+        bl[lane] = p.bias ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        float4_t s = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4_t b4 = *reinterpret_cast<const float4_t*>(bl + 16 * j + 4 * g);
+            const float4_t v = glds_act4<ACT>(acc[i][j] + b4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += v[r] * wl[16 * j + 4 * g + r];
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            s[o] += __shfl_xor(s[o], 16, 64);
+            s[o] += __shfl_xor(s[o], 32, 64);
+        }
+        if (g == 0) xl[16 * i + frow] = s;
+    }
+    __syncthreads();                                             // both wave columns of every row block have written their partials
+    if ((wave & 1) == 0) {                                       // wave = 2 * wave_row + wave_column in every 128-wide tile variant
+        const float4_t* other = reinterpret_cast<const float4_t*>(smem + (wave + 1) * 8192 + 2048);
+        float4_t o = xl[lane] + other[lane];
+        if (p.tail_b) o += (float4_t){p.tail_b[0], p.tail_b[1], p.tail_b[2], p.tail_b[3]};
+        if (wave_m + lane < p.M) *reinterpret_cast<float4_t*>(p.tail_out + (wave_m + lane) * 4) = o;
+    }
+}
+
 // Epilogue dispatch shared by the 16-wave and the 8-wave kernels: picks the drain of this wave's 64-column block from the family
 // compiled into the instantiation (EPI) and the wave's mode (0 plain, 1 RoPE, 2 packed-VT).
 template <int FA, int A_MODE, int EPI>
@@ -766,6 +811,14 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
         } else if constexpr (EPI == GLDS_EPI_F32) {
             f32_family();
         } else {
+            if constexpr (A_MODE != UC_A_DENSE && FA == 4) {
+                if (pe.tail_out) {      // (launcher: N == 128 on a 128-wide tile, every wave of the workgroup arrives here)
+                    if (pe.act == UC_ACT_RELU) glds_epilogue_tail4<FA, UC_ACT_RELU>(pe, acc, wave_m, wave_n, lane, wave, smem);
+                    else if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_tail4<FA, UC_ACT_GELU_ERF>(pe, acc, wave_m, wave_n, lane, wave, smem);
+                    else glds_epilogue_tail4<FA, UC_ACT_NONE>(pe, acc, wave_m, wave_n, lane, wave, smem);
+                    return;
+                }
+            }
             if (mode == 2) {
                 if constexpr (FA == 4) glds_epilogue_vt<4>(pe, acc, wave_m, wave_n, lane, wbuf);
                 else {

@@ -530,6 +530,25 @@ def conv3x3(x: torch.Tensor, conv: nn.Conv2d, relu_in: bool = False, act=None, r
     return y.view(B, Ho, Wo, -1)
 
 
+def conv3x3_tail4(x: torch.Tensor, conv: nn.Conv2d, act, last: nn.Conv2d) -> Optional[torch.Tensor]:
+    """conv3x3 (128 output channels) -> act -> Conv2d(128 -> 4, 1x1) in ONE kernel (the regressor tail, dpt.py:271-277): the
+    128-channel map is never stored.  Returns fp32 [B,H,W,4], or None when the fused form does not apply (training, exact fp32
+    kernels, other channel counts): the caller then runs the two layers separately."""
+    if _train(x, conv.weight, last.weight) or conv.out_channels != 128 or last.out_channels != 4 or last.kernel_size != (1, 1):
+        return None
+    B, H, W, Cin = x.shape
+    if conv.stride[0] != 1 or Cin % 32 != 0 or os.environ.get("UNICEPTION_AMD_FUSED_TAIL", "1") == "0":
+        return None
+    if not (x.dtype == torch.bfloat16 or (x.dtype == torch.float32 and ops.fp32_matmul_hook() == "bf16x3")):
+        return None
+    w, b = conv3x3_weights(conv, x.dtype)
+    w4, b4 = prepared(last, "c1x4", (last.weight, last.bias),
+                      lambda: (last.weight.detach().reshape(4, -1).float().contiguous(),
+                               last.bias.detach().float().contiguous() if last.bias is not None
+                               else torch.zeros(4, device=last.weight.device)))
+    return ops.gemm(x, w, b, act=act, conv=(B, H, W, Cin, 1), tail=(w4, b4)).view(B, H, W, 4)
+
+
 def conv_transpose_ks(x: torch.Tensor, ct: nn.ConvTranspose2d) -> torch.Tensor:
     if _train(x, ct.weight):
         from . import autograd

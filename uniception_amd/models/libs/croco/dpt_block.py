@@ -93,6 +93,9 @@ class FeatureFusionBlock_custom(nn.Module):
         # The reference upsamples, then applies the 1x1 convolution (dpt_block.py:251-255).  Both are linear and the bilinear
         # weights of a pixel sum to 1 (bias included), so the two commute exactly in real arithmetic: the 1x1 GEMM runs on the
         # H x W map — a quarter of the rows — and the x2 resize on its output (same channel count, same resize cost).
+        # (inference only: the training path keeps the reference's order, whose backward the gradient fixtures pin)
+        if engine._train(out, self.out_conv.weight):
+            return engine.conv1x1(engine.bilinear(out, 2 * H, 2 * W, crop), self.out_conv)
         out = engine.conv1x1(out, self.out_conv)
         return engine.bilinear(out, 2 * H, 2 * W, crop)
 

@@ -134,8 +134,11 @@ class DPTRegressionProcessor(nn.Module):
         x = engine.bchw_to_nhwc(x, dt)
         x = engine.conv3x3(x, self.conv1)
         x = engine.bilinear(x, H, W)
-        x = engine.conv3x3(x, self.conv2[0], act="relu")
         last = self.conv2[2]
+        fused = engine.conv3x3_tail4(x, self.conv2[0], "relu", last)     # conv2.0 -> ReLU -> conv2.2 in one kernel (inference)
+        if fused is not None:
+            return PixelTaskOutput(decoded_channels=fused.permute(0, 3, 1, 2))
+        x = engine.conv3x3(x, self.conv2[0], act="relu")
         if last.out_channels == 4 and last.in_channels <= 256 and last.in_channels % 8 == 0:
             w = engine.prepared(last, "c1x4", (last.weight, last.bias),
                                 lambda: (last.weight.detach().reshape(4, -1).float().contiguous(),

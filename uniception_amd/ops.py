@@ -105,7 +105,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          vt: Optional[Tuple[int, torch.Tensor, int]] = None,
          conv: Optional[Tuple[int, int, int, int, int]] = None, preact_out: Optional[torch.Tensor] = None,
          split_k: int = 1, dact: Optional[Tuple[torch.Tensor, str]] = None,
-         ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, emit_ln: bool = False) -> torch.Tensor:
+         ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, emit_ln: bool = False,
+         tail: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> torch.Tensor:
     """C[M,N] = epilogue(A . W^T).
 
     a    : dense [M,K] (row stride a.stride(0), unit column stride) or, with conv=(B,H,W,Cin,stride), an NHWC image.
@@ -114,6 +115,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     vt   : (vt_col0, vt_out [B,H,64,Npad] bf16, ntok) -> V columns written in the packed VT layout (bf16 only).
     ln   : (stats [M,2] fp32 (mean, rstd), colsum [N] fp32) -> folded LayerNorm: a holds the RAW rows, w has gamma folded in,
            the epilogue computes rstd * (acc - mean * colsum) + bias (bf16 output only).
+    tail : (w4 [4,N] fp32, b4 [4] fp32 | None) with N == 128 on a 3x3 convolution — the [M,128] result is not stored; returns
+           fp32 [M,4] = b4 + act(acc + bias) . w4^T (the DPT regressor's conv3x3 -> ReLU -> conv1x1(128 -> 4) in one kernel).
     emit_ln : fp32 output only — also write a bf16 twin of the output and per-row 64-column-block statistics; they ride on the
            returned tensor as ``out.uc_ln`` (an LnSide: twin, partial, finalized-stats cache) for the consumer's ``ln=``.
     """
@@ -127,7 +130,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         a3 = split_bf16x3(a, relu=relu_a)
         conv3 = None if conv is None else (conv[0], conv[1], conv[2], 3 * conv[3], conv[4])
         return gemm(a3, split_weight_bf16x3(w, 9 if conv is not None else 1), bias, act=act, residual=residual, residual2=residual2,
-                    out_dtype=out_dtype or torch.float32, out=out, conv=conv3)
+                    out_dtype=out_dtype or torch.float32, out=out, conv=conv3, tail=tail)
     d = GemmDesc()
     d.compute_dtype = cd
     d.relu_a = 1 if relu_a else 0
@@ -166,6 +169,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * M
         d.rope_cols, d.rope_pos, d.rope_table, d.rope_npos = rope_cols, pos.data_ptr(), table.data_ptr(), table.shape[0]
         d.rope_base, d.rope_f0 = table.uc_rope_base, table.uc_rope_f0
+    if tail is not None:
+        w4, b4 = tail
+        assert conv is not None and N == 128 and out is None and residual is None and rope is None and vt is None and split_k <= 1
+        assert w4.dtype == torch.float32 and w4.is_contiguous() and w4.shape == (4, N)
+        assert b4 is None or (b4.dtype == torch.float32 and b4.is_contiguous() and b4.numel() == 4)
+        out4 = torch.empty((M, 4), dtype=torch.float32, device=a.device)
+        d.tail_w, d.tail_b, d.tail_out = w4.data_ptr(), _p(b4), out4.data_ptr()
+        d.C, d.out_dtype, d.ldc = None, UC_BF16, N
+        _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
+        return out4
     if out is None and split_k > 1:
         out = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
         d.C, d.out_dtype, d.ldc = out.data_ptr(), _dt(out.dtype), N
