@@ -64,6 +64,11 @@ int uc_rope_table(float* table, int npos, int Q, float base, float F0, uc_stream
  * ---------------------------------------------------------------------------------- */
 int uc_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
                  int y_dtype, int64_t rows, int C, float eps, uc_stream_t stream);
+/* The same with a second, bf16 copy of y written in the same pass (y_twin_bf16 [rows, C], or NULL): the features a
+ * transformer hands out in fp32 (encoders/croco.py:177-180, cross_attention_transformer.py:497-503) are consumed as bf16
+ * operands by the next module (decoder input projection, DPT heads) — no separate cast pass over them. */
+int uc_layernorm_twin(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                      void* y_twin_bf16, int64_t rows, int C, float eps, uc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * GEMM family: C[M,N] = epilogue( A_op[M,K] . W[N,K]^T )

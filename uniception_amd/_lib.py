@@ -52,6 +52,7 @@ SIGNATURES = {
     "uc_rope2d": [vp, vp, i32, i32, i32, i32, i64, i64, i64, f32, f32, i32, vp],
     "uc_rope_table": [vp, i32, i32, f32, f32, vp],
     "uc_layernorm": [vp, i32, vp, vp, vp, i32, i64, i32, f32, vp],
+    "uc_layernorm_twin": [vp, i32, vp, vp, vp, i32, vp, i64, i32, f32, vp],
     "uc_gemm": [C.POINTER(GemmDesc), vp],
     "uc_ln_stats_finalize": [vp, i64, i32, f32, vp, vp],
     "uc_split_bf16x3": [vp, vp, i64, i32, i32, vp],

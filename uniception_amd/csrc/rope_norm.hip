@@ -162,7 +162,8 @@ template <typename TI, typename TO, int NV, bool NT = false>
 __global__ __launch_bounds__(256) void layernorm_exact_kernel(const typename TI::storage* __restrict__ x,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
-                                                              typename TO::storage* __restrict__ y, int64_t rows, float eps) {
+                                                              typename TO::storage* __restrict__ y, bf16_t* __restrict__ twin,
+                                                              int64_t rows, float eps) {
     constexpr int C = NV * 256;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256) void layernorm_exact_kernel(const typename TI:
         o.z = (v[i].z - mean) * rstd * g[i].z + bb[i].z;
         o.w = (v[i].w - mean) * rstd * g[i].w + bb[i].w;
         ln_store4<TO>(yr + (i * 64 + lane) * 4, o);
+        if (twin) ln_store4<BF16Tag>(twin + row * C + (i * 64 + lane) * 4, o);   // bf16 copy for the consumers that take bf16 operands
     }
 }
 
@@ -208,7 +210,7 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const typename TI::storage* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
-                                                            typename TO::storage* __restrict__ y,
+                                                            typename TO::storage* __restrict__ y, bf16_t* __restrict__ twin,
                                                             int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const typename TI::s
             o.z = (v[i].z - mean) * rstd * g.z + bb.z;
             o.w = (v[i].w - mean) * rstd * g.w + bb.w;
             ln_store4<TO>(yr + c, o);
+            if (twin) ln_store4<BF16Tag>(twin + row * C + c, o);
         }
     }
 }
@@ -257,7 +260,7 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void layernorm_scalar_kernel(const typename TI::storage* __restrict__ x,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
-                                                               typename TO::storage* __restrict__ y,
+                                                               typename TO::storage* __restrict__ y, bf16_t* __restrict__ twin,
                                                                int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -273,18 +276,21 @@ __global__ __launch_bounds__(256) void layernorm_scalar_kernel(const typename TI
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
     typename TO::storage* yr = y + row * C;
-    for (int c = lane; c < C; c += 64)
-        TO::store(yr + c, (TI::load(xr + c) - mean) * rstd * gamma[c] + beta[c]);
+    for (int c = lane; c < C; c += 64) {
+        const float o = (TI::load(xr + c) - mean) * rstd * gamma[c] + beta[c];
+        TO::store(yr + c, o);
+        if (twin) BF16Tag::store(twin + row * C + c, o);
+    }
 }
 
 template <typename TI, typename TO>
-static void launch_ln(const void* x, const float* g, const float* b, void* y, int64_t rows, int C,
+static void launch_ln(const void* x, const float* g, const float* b, void* y, bf16_t* twin, int64_t rows, int C,
                       float eps, hipStream_t st) {
     typedef typename TI::storage SI;
     typedef typename TO::storage SO;
     const unsigned grid = (unsigned)ceil_div64(rows, 4);
     const bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV) && ((uintptr_t)x % 16 == 0) &&
-                     ((uintptr_t)y % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)b % 16 == 0) &&
+                     ((uintptr_t)y % 16 == 0) && ((uintptr_t)twin % 8 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)b % 16 == 0) &&
                      (((int64_t)C * sizeof(SI)) % (4 * sizeof(SI)) == 0);
     const bool exact = vec && (C % 256 == 0);
     static int nt_env = -2;
@@ -293,9 +299,9 @@ static void launch_ln(const void* x, const float* g, const float* b, void* y, in
 #define UC_LN_EXACT(NV_)                                                                                                          \
     do {                                                                                                                          \
         if (nt) hipLaunchKernelGGL((layernorm_exact_kernel<TI, TO, NV_, true>), dim3(grid), dim3(256), 0, st, (const SI*)x, g, b,  \
-                                   (SO*)y, rows, eps);                                                                            \
+                                   (SO*)y, twin, rows, eps);                                                                      \
         else hipLaunchKernelGGL((layernorm_exact_kernel<TI, TO, NV_, false>), dim3(grid), dim3(256), 0, st, (const SI*)x, g, b,    \
-                                (SO*)y, rows, eps);                                                                               \
+                                (SO*)y, twin, rows, eps);                                                                         \
     } while (0)
     if (exact && C == 256) UC_LN_EXACT(1);
     else if (exact && C == 512) UC_LN_EXACT(2);
@@ -306,28 +312,34 @@ static void launch_ln(const void* x, const float* g, const float* b, void* y, in
 #undef UC_LN_EXACT
     else if (vec)
         hipLaunchKernelGGL((layernorm_vec_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const SI*)x, g, b,
-                           (SO*)y, rows, C, eps);
+                           (SO*)y, twin, rows, C, eps);
     else
         hipLaunchKernelGGL((layernorm_scalar_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const SI*)x, g,
-                           b, (SO*)y, rows, C, eps);
+                           b, (SO*)y, twin, rows, C, eps);
 }
 
-extern "C" int uc_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
-                            int y_dtype, int64_t rows, int C, float eps, uc_stream_t stream) {
+extern "C" int uc_layernorm_twin(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                                 void* y_twin_bf16, int64_t rows, int C, float eps, uc_stream_t stream) {
     UC_REQUIRE(x && gamma && beta && y, "uc_layernorm: null pointer");
     UC_REQUIRE(rows >= 0 && C > 0, "uc_layernorm: bad shape rows=%lld C=%d", (long long)rows, C);
     if (rows == 0) return UC_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (x_dtype == UC_F32 && y_dtype == UC_F32) launch_ln<F32Tag, F32Tag>(x, gamma, beta, y, rows, C, eps, st);
-    else if (x_dtype == UC_F32 && y_dtype == UC_BF16) launch_ln<F32Tag, BF16Tag>(x, gamma, beta, y, rows, C, eps, st);
-    else if (x_dtype == UC_BF16 && y_dtype == UC_BF16) launch_ln<BF16Tag, BF16Tag>(x, gamma, beta, y, rows, C, eps, st);
-    else if (x_dtype == UC_BF16 && y_dtype == UC_F32) launch_ln<BF16Tag, F32Tag>(x, gamma, beta, y, rows, C, eps, st);
+    bf16_t* tw = (bf16_t*)y_twin_bf16;
+    if (x_dtype == UC_F32 && y_dtype == UC_F32) launch_ln<F32Tag, F32Tag>(x, gamma, beta, y, tw, rows, C, eps, st);
+    else if (x_dtype == UC_F32 && y_dtype == UC_BF16) launch_ln<F32Tag, BF16Tag>(x, gamma, beta, y, tw, rows, C, eps, st);
+    else if (x_dtype == UC_BF16 && y_dtype == UC_BF16) launch_ln<BF16Tag, BF16Tag>(x, gamma, beta, y, tw, rows, C, eps, st);
+    else if (x_dtype == UC_BF16 && y_dtype == UC_F32) launch_ln<BF16Tag, F32Tag>(x, gamma, beta, y, tw, rows, C, eps, st);
     else {
         uc_set_error("uc_layernorm: unsupported dtypes %d -> %d", x_dtype, y_dtype);
         return UC_ERR_BAD_ARG;
     }
     UC_CHECK_LAUNCH("uc_layernorm");
     return UC_OK;
+}
+
+extern "C" int uc_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                            int y_dtype, int64_t rows, int C, float eps, uc_stream_t stream) {
+    return uc_layernorm_twin(x, x_dtype, gamma, beta, y, y_dtype, nullptr, rows, C, eps, stream);
 }
 
 // ---------------------------------------------------------------------------------------

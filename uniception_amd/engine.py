@@ -316,8 +316,24 @@ def ln_params(ln: nn.LayerNorm):
 # layout helpers at the public BCHW boundary
 # ---------------------------------------------------------------------------------------------
 def nlc_as_bchw(x2d: torch.Tensor, B: int, h: int, w: int) -> torch.Tensor:
-    """[B*h*w, C] -> BCHW-shaped channels-last view (no copy)."""
-    return x2d.view(B, h, w, x2d.shape[-1]).permute(0, 3, 1, 2)
+    """[B*h*w, C] -> BCHW-shaped channels-last view (no copy).  A bf16 twin written by the producing LayerNorm
+    (ops.layernorm(twin=True)) travels with the view as `uc_twin_nhwc` = (NHWC twin, version of the fp32 storage at creation):
+    bchw_to_nhwc hands it out instead of a cast pass as long as nobody has written to the fp32 tensor since."""
+    v = x2d.view(B, h, w, x2d.shape[-1]).permute(0, 3, 1, 2)
+    tw = getattr(x2d, "uc_twin", None)
+    if tw is not None:
+        v.uc_twin_nhwc = (tw.view(B, h, w, x2d.shape[-1]), x2d._version)
+    return v
+
+
+def chunk_bchw(feat: torch.Tensor, n: int):
+    """feat.chunk(n, dim=0) that keeps the bf16 twins of nlc_as_bchw with the pieces."""
+    parts = feat.chunk(n, dim=0)
+    side = getattr(feat, "uc_twin_nhwc", None)
+    if side is not None and len(parts) == n:
+        for p_, t_ in zip(parts, side[0].chunk(n, dim=0)):
+            p_.uc_twin_nhwc = (t_, side[1])
+    return parts
 
 
 def bchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -327,6 +343,10 @@ def bchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if _train(feat):   # differentiable hop: the permute is a view for channels-last features, the cast is a Function
         from . import autograd
         return autograd.convert(nhwc, dtype)
+    side = getattr(feat, "uc_twin_nhwc", None)
+    if (side is not None and dtype == torch.bfloat16 and feat.dtype == torch.float32 and side[1] == feat._version
+            and side[0].shape == nhwc.shape and side[0].is_contiguous()):
+        return side[0]     # the producer's bf16 copy of exactly these values (views share the version counter of their storage)
     if nhwc.is_contiguous():
         return nhwc if nhwc.dtype == dtype else ops.convert(nhwc, dtype)
     if not feat.is_contiguous():
@@ -334,13 +354,15 @@ def bchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return ops.nchw_to_nhwc(feat, dtype)
 
 
-def layernorm(x: torch.Tensor, ln: nn.LayerNorm, out_dtype: torch.dtype) -> torch.Tensor:
+def layernorm(x: torch.Tensor, ln: nn.LayerNorm, out_dtype: torch.dtype, twin: bool = False) -> torch.Tensor:
     if torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad):
         from . import autograd
         x2 = x.reshape(-1, x.shape[-1])
         return autograd.layer_norm(x2, ln, out_dtype).view(x.shape)
     g, b = ln_params(ln)
-    return ops.layernorm(x, g, b, ln.eps, out_dtype)
+    # output features (fp32 by contract) whose consumers take bf16 operands: write the bf16 copy in the same pass
+    want_twin = twin and out_dtype == torch.float32 and compute_dtype() == torch.bfloat16
+    return ops.layernorm(x, g, b, ln.eps, out_dtype, twin=want_twin)
 
 
 # ---------------------------------------------------------------------------------------------

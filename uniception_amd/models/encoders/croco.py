@@ -104,7 +104,7 @@ class CroCoEncoder(UniCeptionViTEncoderBase):
         x2d = _as_2d(tokens)
         for blk in self.enc_blocks:
             x2d = blk.forward_tokens(x2d, B, N, pos, dt)
-        x2d = engine.layernorm(x2d, self.enc_norm, torch.float32)
+        x2d = engine.layernorm(x2d, self.enc_norm, torch.float32, twin=True)
         return self._tokens_to_output(x2d, B, h, w)
 
 
@@ -135,9 +135,9 @@ class CroCoIntermediateFeatureReturner(CroCoEncoder, IntermediateFeatureReturner
         for i, blk in enumerate(blocks):
             x2d = blk.forward_tokens(x2d, B, N, pos, dt)
             if i in take_indices:
-                inter.append(engine.layernorm(x2d, self.enc_norm, torch.float32) if self.norm_intermediate else x2d)
+                inter.append(engine.layernorm(x2d, self.enc_norm, torch.float32, twin=True) if self.norm_intermediate else x2d)
         inter = [self._tokens_to_output(t, B, h, w) for t in inter]
         if self.intermediates_only:
             return inter
-        final = self._tokens_to_output(engine.layernorm(x2d, self.enc_norm, torch.float32), B, h, w)
+        final = self._tokens_to_output(engine.layernorm(x2d, self.enc_norm, torch.float32, twin=True), B, h, w)
         return final, inter

@@ -113,7 +113,7 @@ class DUSt3R(nn.Module):
         "Both views go through the encoder as one batch when their shapes agree (dust3r.py:211-225)."
         if img1.shape[-2:] == img2.shape[-2:]:
             out = self.encoder(ViTEncoderInput(image=torch.cat((img1, img2), dim=0), data_norm_type=data_norm_type)).features
-            return out.chunk(2, dim=0)
+            return engine.chunk_bchw(out, 2)
         # the reference's different-shape branch raises TypeError (ViTEncoderInput built without data_norm_type,
         # dust3r.py:221); here the two views are simply encoded separately
         out1 = self.encoder(ViTEncoderInput(image=img1, data_norm_type=data_norm_type)).features

@@ -141,7 +141,7 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
                     lambda: b0.forward_tokens(x0, x1, B, N, N, pos[0], pos[1], dt),
                     lambda: b1.forward_tokens(x1, x0, B, N, N, pos[1], pos[0], dt), B * N, inputs1=(x0, x1)))
                 if d in take_indices:
-                    taken.append([engine.layernorm(x, self.norm, torch.float32) if norm_intermediate else x for x in xs])
+                    taken.append([engine.layernorm(x, self.norm, torch.float32, twin=True) if norm_intermediate else x for x in xs])
                 continue
             new = []
             for v in range(V):
@@ -155,7 +155,7 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
                 new.append(self.multi_view_branches[v][d].forward_tokens(xs[v], y2d, B, N, Ny, pos[v], ypos, dt))
             xs = new
             if d in take_indices:
-                taken.append([engine.layernorm(x, self.norm, torch.float32) if norm_intermediate else x for x in xs])
+                taken.append([engine.layernorm(x, self.norm, torch.float32, twin=True) if norm_intermediate else x for x in xs])
 
         def out(ts):
             return MultiViewTransformerOutput(features=[engine.nlc_as_bchw(t, B, h, w) for t in ts])
@@ -165,7 +165,7 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
     def forward(self, model_input: MultiViewTransformerInput) -> MultiViewTransformerOutput:
         self._check_input(model_input)
         xs, _, out, *_ = self._run(model_input, (), False)
-        return out([engine.layernorm(x, self.norm, torch.float32) for x in xs])
+        return out([engine.layernorm(x, self.norm, torch.float32, twin=True) for x in xs])
 
 
 class MultiViewCrossAttentionTransformerIFR(MultiViewCrossAttentionTransformer, IntermediateFeatureReturner):
@@ -199,4 +199,4 @@ class MultiViewCrossAttentionTransformerIFR(MultiViewCrossAttentionTransformer, 
         xs, inter, out, *_ = self._run(model_input, take_indices, self.norm_intermediate)
         if self.intermediates_only:
             return inter
-        return out([engine.layernorm(x, self.norm, torch.float32) for x in xs]), inter
+        return out([engine.layernorm(x, self.norm, torch.float32, twin=True) for x in xs]), inter

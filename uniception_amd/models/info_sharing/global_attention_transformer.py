@@ -178,7 +178,7 @@ class _MultiViewSelfAttentionCore(UniCeptionInfoSharingBase):
                 xv = blk.forward_tokens(x3[:, :V * T].reshape(B * V * T, self.dim), B * V, T, None, dt)
                 x2d = torch.cat([xv.view(B, V * T, self.dim), x3[:, V * T:]], dim=1).reshape(B * L, self.dim)
             if d in take_indices:
-                taken.append(engine.layernorm(x2d, self.norm, torch.float32) if norm_intermediate else x2d)
+                taken.append(engine.layernorm(x2d, self.norm, torch.float32, twin=True) if norm_intermediate else x2d)
 
         def out(t2d):
             t4 = t2d.view(B, L, self.dim)[:, :V * T].reshape(B, V, T, self.dim)
@@ -191,14 +191,14 @@ class _MultiViewSelfAttentionCore(UniCeptionInfoSharingBase):
 
     def forward(self, model_input: MultiViewTransformerInput) -> MultiViewTransformerOutput:
         x2d, _, out = self._run(model_input, (), False)
-        return out(engine.layernorm(x2d, self.norm, torch.float32))
+        return out(engine.layernorm(x2d, self.norm, torch.float32, twin=True))
 
     def _forward_ifr(self, model_input: MultiViewTransformerInput):
         take_indices, _ = feature_take_indices(self.depth, self.indices)
         x2d, inter, out = self._run(model_input, take_indices, self.norm_intermediate)
         if self.intermediates_only:
             return inter
-        return out(engine.layernorm(x2d, self.norm, torch.float32)), inter
+        return out(engine.layernorm(x2d, self.norm, torch.float32, twin=True)), inter
 
 
 _CTOR_DOC = """Same constructor as the reference class (all arguments recorded as attributes); dropout / DropPath > 0 in

@@ -85,15 +85,20 @@ def rope_table(device, npos: int, base: float, F0: float = 1.0) -> torch.Tensor:
     return t
 
 
-def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, out_dtype: torch.dtype) -> torch.Tensor:
-    """x [..., C] contiguous (fp32|bf16) -> same shape in out_dtype."""
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, out_dtype: torch.dtype,
+              twin: bool = False) -> torch.Tensor:
+    """x [..., C] contiguous (fp32|bf16) -> same shape in out_dtype.  twin: a bf16 copy of the result is written in the same
+    pass and rides on the returned tensor as ``y.uc_twin`` (for consumers that take bf16 operands)."""
     _need_gpu(x, weight, bias)
     assert x.is_contiguous() and weight.dtype == torch.float32 and bias.dtype == torch.float32
     Cn = x.shape[-1]
     rows = x.numel() // Cn
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    _lib.check(_lib.load().uc_layernorm(x.data_ptr(), _dt(x.dtype), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
-                                        _dt(out_dtype), rows, Cn, float(eps), _stream()), "uc_layernorm")
+    tw = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if twin else None
+    _lib.check(_lib.load().uc_layernorm_twin(x.data_ptr(), _dt(x.dtype), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                             _dt(out_dtype), _p(tw), rows, Cn, float(eps), _stream()), "uc_layernorm")
+    if twin:
+        y.uc_twin = tw
     return y
 
 
