@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-reference-policy", action="store_true",
                     help="skip the extra legs: fp32-class heads beside the bf16 transformer, everything fp32-class, linear-head (enc+dec) run")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="no two-stream execution of independent sub-graphs at large batch (engine.concurrent(False)): what the "
+                         "roofline pass and the committed kernel profiles use — per-kernel durations are only defined without overlap")
     ap.add_argument("--cpu-baseline-max-s", type=float, default=30.0)
     return ap.parse_args()
 
@@ -278,6 +281,8 @@ def main():
                 with torch.no_grad(), engine.precision(args.precision), engine.attention_precision(args.attention):
                     return model(v1, v2)
 
+    if args.single_stream:
+        engine.CONCURRENT = False
     for _ in range(args.warmup):
         step()
 
@@ -304,6 +309,8 @@ def main():
                                 + ", random-init weights"),
                    "pairs_per_gpu": args.pairs, "global_pairs_per_step": world * args.pairs, "img": args.img,
                    "head": args.head, "encoder": args.encoder, "attention": args.attention, "hipgraph": bool(args.graph),
+                   "streams": ("1" if (not engine.CONCURRENT or not fwd) else
+                               "2 (the two views through the encoder, the two decoder branches and the two heads run as concurrent HIP streams)"),
                    "parallelism": (f"dp{world} (independent pairs per rank, no data-path collective)" if fwd else
                                    f"dp{world} (replicated model, bucketed in-place gradient all-reduce over RCCL)")},
         "enc_dec_mfma_frac": round(value / world * gflop_pair * (1 if fwd else 3) / 1e3 / PEAK_BF16_TFLOPS, 4),
@@ -311,10 +318,14 @@ def main():
     if rank == 0 and world == 1 and not fwd and not args.no_roofline and args.precision == "bf16":
         # training: the same kernel family carries the forward and the data-gradient GEMMs (the TN weight-gradient kernel is
         # a separate, smaller share): all dense bf16 uc_gemm launches of a step, forward and backward
-        line["roofline"] = roofline_pass(step, v1, args.precision, min(args.steps, 2))
+        with engine.concurrent(False):
+            line["roofline"] = roofline_pass(step, v1, args.precision, min(args.steps, 2))
     if rank == 0 and world == 1 and fwd:
         if not args.no_roofline and args.precision == "bf16":
-            line["roofline"] = roofline_pass(step, v1, args.precision, min(args.steps, 3))
+            with engine.concurrent(False):   # per-launch durations are only defined when kernels do not overlap
+                line["roofline"] = roofline_pass(step, v1, args.precision, min(args.steps, 3))
+            line["roofline"]["schedule"] = ("single-stream pass (engine.concurrent(False), = bench.py --single-stream, the command of the "
+                                            "committed profiles); the timed region runs two kernel streams")
         if not args.no_reference_policy and args.precision == "bf16" and not args.graph:
             line["reference_policy"] = reference_policy_legs(model, v1, v2, args, dev)
         if not args.no_cpu_baseline:

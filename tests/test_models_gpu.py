@@ -120,3 +120,44 @@ def test_contiguous_nchw_inputs_are_accepted(gpu):
         b = model.info_sharing(MultiViewTransformerInput(features=[f1.contiguous(), f2.contiguous()]))
     assert torch.equal(a.features[0], b.features[0]) and torch.equal(a.features[1], b.features[1])
     assert not f1.is_contiguous() and f1.contiguous().is_contiguous()
+
+
+def test_concurrent_streams_are_bitwise_the_single_stream_forward(gpu):
+    """engine.CONCURRENT (large batches: the two views through the encoder, the two decoder branches and the two heads on
+    concurrent HIP streams) changes the schedule, never a value: bitwise the result of the same sub-graphs run in stream order.  Also on the first calls, when weight-derived caches are built on one stream and read on another
+    (engine.BuiltOn) and shape-keyed ones are built by the sequential warm-up call (run_branches(warm_key=...))."""
+    from oracle import dust3r_oracle as O
+    from tests.golden.cases import GAINS
+    from uniception_amd import engine
+    from uniception_amd.models.factory import DUSt3R
+    model = DUSt3R(name="g", img_size=(64, 96), pred_head_type="dpt").eval()      # the factory model (ViT-L widths) on a 4x6 token grid
+    O.fill_state_dict_(model.state_dict(), gain=1.0, gains=GAINS)
+    model = model.to(gpu)
+    g = torch.Generator().manual_seed(99)
+    B = 12
+    v1 = {"img": torch.randn(B, 3, 64, 96, generator=g).to(gpu), "instance": [str(i) for i in range(B)], "data_norm_type": "dust3r"}
+    v2 = {"img": torch.randn(B, 3, 64, 96, generator=g).to(gpu), "instance": [str(100 + i) for i in range(B)], "data_norm_type": "dust3r"}
+
+    def run(on):
+        prev = engine.BRANCH_TOKENS_MAX
+        engine.BRANCH_TOKENS_MAX = 0 if on else prev       # 12 x 24 tokens count as a "large" batch: every fork goes through CONCURRENT
+        try:
+            with torch.no_grad(), engine.precision("bf16"), engine.concurrent(on):
+                r1, r2 = model(v1, v2)
+        finally:
+            engine.BRANCH_TOKENS_MAX = prev
+        torch.cuda.synchronize()
+        return r1, r2
+
+    engine.invalidate_prepared()
+    first = run(True)          # cold caches; the warm-up call of every fork point
+    second = run(True)         # forked everywhere
+    engine.FORK_STREAMS = False                            # the same decomposition, the halves one after the other on one stream
+    try:
+        ref = run(True)
+    finally:
+        engine.FORK_STREAMS = True
+    for got in (first, second):
+        for a, b in zip(got, ref):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k

@@ -168,7 +168,7 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
         }
     };
     auto val = [&](int i, int j, int r, float bc) __attribute__((always_inline)) -> float {
-        if constexpr (LN) return (acc[i][j][r] - mu[r] * csj[j]) * rs[r] + bc;
+        if constexpr (LN) return __builtin_fmaf(__builtin_fmaf(-mu[r], csj[j], acc[i][j][r]), rs[r], bc);
         else return acc[i][j][r] + bc;
     };
     if (FA == 4 && (p.vt_ntok & 63) == 0 && wave_m + 64 <= p.M && ((uintptr_t)p.vt_out & 15) == 0 && !(p.dbg & 16)) {
@@ -274,22 +274,27 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
 // — two orders below the bf16 output's own rounding.  15 packed-fp32-able operations per element instead of 16 scalar ones plus
 // an exp2 and a reciprocal on the quarter-rate transcendental unit: the GELU epilogue of fc1 cost 7.9 us per 256x256 tile
 // (as much as five K-steps), the VALU being the only unit at work in an epilogue.
+// Explicit fused multiply-adds for the epilogue arithmetic: left to `-ffp-contract`, hipcc contracts each unrolled copy of an
+// expression its own way, and a row's bf16 roundings would depend on where in a tile (or in a batch) the row sits.
+__device__ __forceinline__ float4_t glds_fma4(float4_t a, float4_t b, float4_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float4_t glds_splat4(float v) { return (float4_t){v, v, v, v}; }
+
 __device__ __forceinline__ float4_t glds_gelu4(float4_t x) {
     float4_t xc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) xc[r] = __builtin_amdgcn_fmed3f(x[r], -4.5f, 4.5f);
-    const float4_t t = xc * xc * (2.0f / 20.25f) - 1.0f;
-    float4_t q = t * 8.660091177e-04f - 2.253821881e-03f;
-    q = q * t + 2.972107097e-03f;
-    q = q * t - 5.424589433e-03f;
-    q = q * t + 1.124217992e-02f;
-    q = q * t - 1.890690569e-02f;
-    q = q * t + 2.834482012e-02f;
-    q = q * t - 4.013649033e-02f;
-    q = q * t + 5.469475207e-02f;
-    q = q * t - 7.719214694e-02f;
-    q = q * t + 1.569050361e-01f;
-    return x * (xc * q + 0.5f);
+    const float4_t t = glds_fma4(xc * xc, glds_splat4(2.0f / 20.25f), glds_splat4(-1.0f));
+    float4_t q = glds_fma4(t, glds_splat4(8.660091177e-04f), glds_splat4(-2.253821881e-03f));
+    q = glds_fma4(q, t, glds_splat4(2.972107097e-03f));
+    q = glds_fma4(q, t, glds_splat4(-5.424589433e-03f));
+    q = glds_fma4(q, t, glds_splat4(1.124217992e-02f));
+    q = glds_fma4(q, t, glds_splat4(-1.890690569e-02f));
+    q = glds_fma4(q, t, glds_splat4(2.834482012e-02f));
+    q = glds_fma4(q, t, glds_splat4(-4.013649033e-02f));
+    q = glds_fma4(q, t, glds_splat4(5.469475207e-02f));
+    q = glds_fma4(q, t, glds_splat4(-7.719214694e-02f));
+    q = glds_fma4(q, t, glds_splat4(1.569050361e-01f));
+    return x * glds_fma4(xc, q, glds_splat4(0.5f));
 }
 
 template <int ACT>
@@ -500,6 +505,9 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
                 if (tbase) *reinterpret_cast<uint2*>(tbase + (4 * i + ps) * tstep + toff) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
             }
             if (sbase) {   // all 64 lanes take part in the row reductions (rows past M carry finite garbage and are not stored)
+                // (no FMA contraction here: hipcc contracts each unrolled copy of this block differently, and a row's statistics —
+                // hence the bf16 roundings of everything downstream — must not depend on where in a tile the row sits)
+#pragma clang fp contract(off)
                 const float s = glds_row16_sum((v.x + v.y) + (v.z + v.w));
                 const float mu = s * (1.f / 64.f);
                 const float4_t dv = v - mu;
@@ -546,7 +554,7 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
         if constexpr (LN) {
             const float4_t cs = *reinterpret_cast<const float4_t*>(colbuf + 16 * j + 4 * g);
             const float4_t bb = *reinterpret_cast<const float4_t*>(colbuf + 64 + 16 * j + 4 * g);
-            return (acc[i][j] - st_mu * cs) * st_rs + bb;
+            return glds_fma4(glds_fma4(glds_splat4(-st_mu), cs, acc[i][j]), glds_splat4(st_rs), bb);
         } else return acc[i][j] + b4[j];
     };
     // RoPE tiles: no loads inside the per-row-block code.  The table form (positions -> table address -> cos/sin, per row
@@ -580,8 +588,8 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
                     turn *= p.rope_ratio;
                     const float cs = __builtin_amdgcn_cosf(tfrac), sn = __builtin_amdgcn_sinf(tfrac);
                     const float u = uu[r], w = ww[r];   // no activation with RoPE (launcher-checked)
-                    ou[r] = u * cs - w * sn;
-                    ow[r] = w * cs + u * sn;
+                    ou[r] = __builtin_fmaf(u, cs, -(w * sn));
+                    ow[r] = __builtin_fmaf(w, cs, u * sn);
                 }
                 *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ou[0], ou[1]), pack_bf16x2(ou[2], ou[3])};
                 *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + 2 + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ow[0], ow[1]), pack_bf16x2(ow[2], ow[3])};

@@ -207,6 +207,30 @@ def invalidate_prepared(module: Optional[nn.Module] = None) -> None:
         _prep_cache.pop(m, None)
 
 
+class BuiltOn:
+    """Where and when a cached device object was produced: a consumer on ANOTHER stream waits for the producing stream's event
+    until it has completed (micro-batch streams and two-stream branches share the prepared weights, rope tables, ...)."""
+    __slots__ = ("stream", "event")
+
+    def __init__(self):
+        self.stream = self.event = None
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            self.stream = torch.cuda.current_stream()
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+
+    def sync(self):
+        ev = self.event
+        if ev is None:
+            return
+        if ev.query():
+            self.event = None          # completed: visible to every stream from now on
+            return
+        cur = torch.cuda.current_stream()
+        if cur != self.stream:
+            cur.wait_event(ev)
+
+
 def prepared(owner: nn.Module, tag, sources: Sequence[Optional[torch.Tensor]], build):
     stamp = (_weight_epoch,) + tuple((s.data_ptr(), s._version, s.device, s.dtype) if s is not None else None for s in sources)
     if _check_weights:   # debug (UNICEPTION_AMD_CHECK_WEIGHTS=1): a content checksum catches `.data` writes, at a sync per call
@@ -214,10 +238,11 @@ def prepared(owner: nn.Module, tag, sources: Sequence[Optional[torch.Tensor]], b
     slot = _prep_cache.setdefault(owner, {})
     hit = slot.get(tag)
     if hit is not None and hit[0] == stamp:
+        hit[2].sync()
         return hit[1]
     with torch.no_grad():
         val = build()
-    slot[tag] = (stamp, val)
+    slot[tag] = (stamp, val, BuiltOn())
     return val
 
 
@@ -592,19 +617,49 @@ _side_streams = {}
 BRANCH_TOKENS_MAX = int(os.environ.get("UNICEPTION_AMD_BRANCH_TOKENS_MAX", "16384"))
 
 
-def side_stream(device) -> "torch.cuda.Stream":
-    s = _side_streams.get(device)
+def side_stream(device, index: int = 0) -> "torch.cuda.Stream":
+    s = _side_streams.get((device, index))
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
+        s = _side_streams[(device, index)] = torch.cuda.Stream(device=device)
     return s
 
 
-def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=()):
+# CONCURRENT (UNICEPTION_AMD_CONCURRENT, default on): independent sub-graphs of a LARGE batch also run on two streams.  Every
+# tile of a launch costs the same, so on one stream all 256 CUs reach their HBM-heavy epilogues — and the last, partly filled
+# round of workgroups — together while the matrix pipes idle; with two kernel streams in flight one's epilogue bursts and
+# kernel tails run under the other's MFMA phases: +2 % on the 64-pair forward (two views through the encoder, two decoder
+# branches, two heads).  Per-kernel durations are then not defined (kernels overlap): bench.py's roofline pass and the
+# committed profiles run with concurrent(False).
+CONCURRENT = os.environ.get("UNICEPTION_AMD_CONCURRENT", "1") != "0"
+_branch_warm = set()
+FORK_STREAMS = True      # tests: False keeps every decomposition (two views, two branches, two heads) but runs the halves in stream order
+
+
+@contextlib.contextmanager
+def concurrent(on: bool):
+    "Scoped switch of the large-batch two-stream execution (small batches keep theirs)."
+    global CONCURRENT
+    prev, CONCURRENT = CONCURRENT, bool(on)
+    try:
+        yield
+    finally:
+        CONCURRENT = prev
+
+
+def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None):
     """Runs two independent sub-graphs; when they are small (`rows` tokens/pixels each <= BRANCH_TOKENS_MAX: their kernels
-    launch fewer workgroups than the chip has CUs) and no gradient is recorded, the second one goes to a side HIP stream so
-    both halves of the chip work.  `inputs1` are the tensors fn1 reads that were produced on the current stream (they are
-    recorded on the side stream for the caching allocator); outputs of fn1 are recorded on the current stream."""
-    if torch.is_grad_enabled() or rows > BRANCH_TOKENS_MAX or not inputs1 or not inputs1[0].is_cuda:
+    launch fewer workgroups than the chip has CUs) or CONCURRENT is on, and no gradient is recorded, the second one goes to a
+    side HIP stream.  `inputs1` are the tensors fn1 reads that were produced on the current stream (they are
+    recorded on the side stream for the caching allocator); outputs of fn1 are recorded on the current stream.
+    `warm_key`: the first call with a given key runs the two sub-graphs one after the other on the current stream — whatever
+    they cache by shape (position grids, tables) is then built in stream order; weight-derived caches carry their own event
+    (BuiltOn)."""
+    if torch.is_grad_enabled() or (rows > BRANCH_TOKENS_MAX and not CONCURRENT) or not inputs1 or not inputs1[0].is_cuda:
+        return fn0(), fn1()
+    if warm_key is not None and warm_key not in _branch_warm:
+        _branch_warm.add(warm_key)
+        return fn0(), fn1()
+    if not FORK_STREAMS:
         return fn0(), fn1()
     main = torch.cuda.current_stream()
     side = side_stream(inputs1[0].device)

@@ -3,6 +3,7 @@
 Same constructor, same submodule names (and therefore the same state_dict keys and aliases: `head1.0.* ==
 dpt_feature_head1.*` etc.), same `forward(view1, view2) -> (res1, res2)` contract.
 """
+import os
 from typing import List, Tuple
 
 import torch
@@ -111,6 +112,13 @@ class DUSt3R(nn.Module):
 
     def _encode_image_pairs(self, img1, img2, data_norm_type):
         "Both views go through the encoder as one batch when their shapes agree (dust3r.py:211-225)."
+        if (img1.shape == img2.shape and engine.CONCURRENT and not torch.is_grad_enabled() and img1.is_cuda
+                and img1.shape[0] * (img1.shape[-2] // self.encoder.patch_size) * (img1.shape[-1] // self.encoder.patch_size) > engine.BRANCH_TOKENS_MAX):
+            # large batch: the two views as two concurrent kernel streams instead of one concatenated batch (engine.CONCURRENT);
+            # every row of every kernel depends on its own image only, so the features are those of the concatenated run
+            enc = lambda im: self.encoder(ViTEncoderInput(image=im, data_norm_type=data_norm_type)).features   # noqa: E731
+            return engine.run_branches(lambda: enc(img1), lambda: enc(img2), 0, inputs1=(img2,),
+                                       warm_key=("enc", id(self.encoder), tuple(img1.shape), str(engine.compute_dtype())))
         if img1.shape[-2:] == img2.shape[-2:]:
             out = self.encoder(ViTEncoderInput(image=torch.cat((img1, img2), dim=0), data_norm_type=data_norm_type)).features
             return engine.chunk_bchw(out, 2)
@@ -163,7 +171,8 @@ class DUSt3R(nn.Module):
             # the two heads are independent: on two streams when the batch is too small to fill the chip
             feats2 = outs["2"] if isinstance(outs["2"], list) else [outs["2"]]
             n_tok = feats2[-1].shape[0] * feats2[-1].shape[2] * feats2[-1].shape[3]
-            (p1, c1), (p2, c2) = engine.run_branches(lambda: head(1, shape1), lambda: head(2, shape2), n_tok, inputs1=tuple(feats2))
+            (p1, c1), (p2, c2) = engine.run_branches(lambda: head(1, shape1), lambda: head(2, shape2), n_tok, inputs1=tuple(feats2),
+                                                          warm_key=("heads", id(self), tuple(feats2[-1].shape), shape1, shape2, str(engine.head_dtype())))
             res1 = {"pts3d": p1, "conf": c1}
             res2 = {"pts3d_in_other_view": p2, "conf": c2}
         return res1, res2

@@ -81,7 +81,11 @@ def rope_table(device, npos: int, base: float, F0: float = 1.0) -> torch.Tensor:
         t = torch.empty(npos, 16, 2, dtype=torch.float32, device=device)
         _lib.check(_lib.load().uc_rope_table(t.data_ptr(), npos, 16, float(base), float(F0), _stream()), "uc_rope_table")
         t.uc_rope_base, t.uc_rope_f0 = float(base), float(F0)   # travel with the table into uc_gemm's descriptor
+        from .engine import BuiltOn
+        t.uc_built = BuiltOn()
         _rope_tables[key] = t
+    else:
+        t.uc_built.sync()       # a consumer on another stream waits for the stream that filled the table
     return t
 
 
@@ -246,6 +250,7 @@ def split_weight_bf16x3(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
     hit = _w3_cache.get(key)
     stamp = (w._version, w.data_ptr(), taps)
     if hit is not None and hit[0]() is w and hit[1] == stamp:
+        hit[3].sync()
         return hit[2]
     with torch.no_grad():
         N = w.shape[0]
@@ -253,7 +258,8 @@ def split_weight_bf16x3(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
         hi = w32.bfloat16()
         lo = (w32 - hi.float()).bfloat16()
         w3 = torch.cat([hi, lo, hi], dim=2).reshape(N, -1).contiguous()
-    _w3_cache[key] = (weakref.ref(w, lambda _r, k=key: _w3_cache.pop(k, None)), stamp, w3)
+    from .engine import BuiltOn
+    _w3_cache[key] = (weakref.ref(w, lambda _r, k=key: _w3_cache.pop(k, None)), stamp, w3, BuiltOn())
     return w3
 
 
