@@ -346,7 +346,9 @@ def nlc_as_bchw(x2d: torch.Tensor, B: int, h: int, w: int) -> torch.Tensor:
     bchw_to_nhwc hands it out instead of a cast pass as long as nobody has written to the fp32 tensor since."""
     v = x2d.view(B, h, w, x2d.shape[-1]).permute(0, 3, 1, 2)
     tw = getattr(x2d, "uc_twin", None)
-    if tw is not None:
+    if tw is None and getattr(x2d, "uc_ln", None) is not None:
+        tw = x2d.uc_ln.twin           # un-normed residual-stream rows (norm_intermediate=False): the producer GEMM's bf16 twin
+    if tw is not None and tw.shape == x2d.shape and tw.is_contiguous():
         v.uc_twin_nhwc = (tw.view(B, h, w, x2d.shape[-1]), x2d._version)
     return v
 
