@@ -653,16 +653,18 @@ def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None):
     launch fewer workgroups than the chip has CUs) or CONCURRENT is on, and no gradient is recorded, the second one goes to a
     side HIP stream.  `inputs1` are the tensors fn1 reads that were produced on the current stream (they are
     recorded on the side stream for the caching allocator); outputs of fn1 are recorded on the current stream.
-    `warm_key`: the first call with a given key runs the two sub-graphs one after the other on the current stream — whatever
-    they cache by shape (position grids, tables) is then built in stream order; weight-derived caches carry their own event
-    (BuiltOn)."""
+    `warm_key`: the first call with a given key runs the two sub-graphs one after the other (fn1 on the side stream, fn0 behind
+    it) — whatever they cache by shape (position grids, tables) is then built in order; weight-derived caches carry their own
+    event (BuiltOn)."""
     if torch.is_grad_enabled() or (rows > BRANCH_TOKENS_MAX and not CONCURRENT) or not inputs1 or not inputs1[0].is_cuda:
-        return fn0(), fn1()
-    if warm_key is not None and warm_key not in _branch_warm:
-        _branch_warm.add(warm_key)
         return fn0(), fn1()
     if not FORK_STREAMS:
         return fn0(), fn1()
+    # first call with this key: fn1 still runs on the side stream (its allocator pool fills now, not in somebody's timed
+    # region) but fn0 waits for it — nothing overlaps while shape-keyed caches are being built
+    serialize = warm_key is not None and warm_key not in _branch_warm
+    if serialize:
+        _branch_warm.add(warm_key)
     main = torch.cuda.current_stream()
     side = side_stream(inputs1[0].device)
     side.wait_stream(main)
@@ -670,6 +672,8 @@ def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None):
         t.record_stream(side)
     with torch.cuda.stream(side):
         out1 = fn1()
+    if serialize:
+        main.wait_stream(side)
     out0 = fn0()
     main.wait_stream(side)
     for t in (out1 if isinstance(out1, (tuple, list)) else (out1,)):
