@@ -257,8 +257,12 @@ __device__ __forceinline__ att_uint4_t att_make_srd(const void* base) {
                          (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
 }
 
-__global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE_BYTES];  // 2 stages x (K tile + VT tile)
+// NW waves of 32 queries share every K / VT tile: NW = 8 (256 queries per workgroup) stages each tile once for twice the
+// queries of NW = 4 — half the global->LDS traffic per query — at the same 16 waves per CU (two workgroups of 48 KiB).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn_bf16_dma_kernel(AttnParams p) {
+    // 2 stages x (K tile + VT tile); the Q rows of waves 4..7 (NW = 8) arrive in a third region
+    __shared__ __attribute__((aligned(16))) char smem[(NW == 8 ? 6 : 4) * ATT_TILE_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
     // 1-D grid.  Workgroup w runs on XCD w % 8 (round-robin dispatch): the nq query tiles that share one (batch, head)'s
     // K/VT rows are given ids that differ by multiples of 8, so that they meet in ONE XCD's L2 instead of pulling the
     // same K/VT through all eight.
-    const int nq = (p.Nq + 127) / 128;
+    constexpr int QT = 32 * NW;                 // queries per workgroup
+    const int nq = (p.Nq + QT - 1) / QT;
     const int nbh = p.B * p.H;
     int qt, bh;
     {
@@ -281,30 +286,31 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
         }
     }
     const int b = (int)uc_div((unsigned)bh, p.dH), h = bh - b * p.H;
-    const int q0 = qt * 128 + wave * 32;
+    const int q0 = qt * QT + wave * 32;
 
     const bf16_t* Qb = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const bf16_t* Kb = (const bf16_t*)p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
     const bf16_t* VTb = (const bf16_t*)p.V + ((int64_t)b * p.H + h) * 64 * (int64_t)p.npad;
 
-    // ---- DMA assignment: a tile is 8 instructions of 8 rows x 128 B; wave w issues instructions 2w, 2w+1 of both tiles ----
+    // ---- DMA assignment: a tile is 8 instructions of 8 rows x 128 B; wave w issues instructions PW*w .. PW*w + PW - 1 of both tiles ----
+    constexpr int PW = 8 / NW;                  // 2 (four waves) or 1 (eight waves)
     att_uint4_t srd_k = att_make_srd(Kb);
     srd_k.z = (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)p.Nk - 1) * p.k_sn + 64) * 2));   // key rows >= Nk read as zeros
     const att_uint4_t srd_v = att_make_srd(VTb);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
-    unsigned voff_k[2], voff_v[2];
+    unsigned voff_k[PW], voff_v[PW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rr = (wave * 2 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < PW; ++i) {
+        const int rr = (wave * PW + i) * 8 + (lane >> 3);
         const int cch = (lane & 7) ^ ((rr >> 1) & 7);         // logical chunk stored at physical chunk lane&7 of row rr
         voff_k[i] = (unsigned)(((int64_t)rr * p.k_sn + cch * 8) * 2);
         voff_v[i] = (unsigned)(((int64_t)rr * p.npad + cch * 8) * 2);
     }
     const unsigned kstep = (unsigned)(KV_TILE * p.k_sn * 2);   // bytes between key tiles of K
     auto issue_tile = [&](int t, int buf) {
-        const unsigned dst = lds0 + (unsigned)(buf * 2 * ATT_TILE_BYTES + wave * 2048);
+        const unsigned dst = lds0 + (unsigned)(buf * 2 * ATT_TILE_BYTES + wave * (PW * 1024));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PW; ++i) {
             att_dma16(voff_k[i], srd_k, (unsigned)t * kstep, __builtin_amdgcn_readfirstlane(dst + i * 1024));
             att_dma16(voff_v[i], srd_v, (unsigned)t * (KV_TILE * 2), __builtin_amdgcn_readfirstlane(dst + ATT_TILE_BYTES + i * 1024));
         }
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_dma_kernel(AttnParams p) {
         const int64_t q_rows = min((int64_t)32, (int64_t)p.Nq - q0);
         att_uint4_t srd_q = att_make_srd((const void*)qa);
         srd_q.z = (unsigned)__builtin_amdgcn_readfirstlane((int)(q_rows > 0 ? ((q_rows - 1) * p.q_sn + 64) * 2 : 0));
-        const unsigned dstq = lds0 + (unsigned)(2 * ATT_TILE_BYTES + wave * 4096);
+        const unsigned dstq = lds0 + (unsigned)(2 * ATT_TILE_BYTES + wave * 4096);     // waves 4..7 land behind the second stage
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rr = i * 8 + (lane >> 3);
@@ -609,12 +615,19 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         UC_REQUIRE(o_sb % 4 == 0 && o_sn % 4 == 0 && o_sh % 4 == 0, "uc_attention_fwd(bf16): O strides must be multiples of 4");
         UC_REQUIRE(((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)O % 8 == 0),
                    "uc_attention_fwd(bf16): pointer alignment");
-        p.dGroup = uc_make_fastdiv((unsigned)(8 * ((Nq + 127) / 128))); p.dNq = uc_make_fastdiv((unsigned)((Nq + 127) / 128)); p.dH = uc_make_fastdiv((unsigned)H);
+        // eight waves per workgroup (256 queries share each K / VT tile) when that does not add a mostly empty query tile
+        static int nw_env = -1;
+        if (nw_env < 0) { const char* e = getenv("UC_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
+        const int waste8 = (Nq + 255) / 256 * 256 - Nq, waste4 = (Nq + 127) / 128 * 128 - Nq;
+        const int nw = nw_env == 4 || nw_env == 8 ? nw_env : ((Nq >= 256 && waste8 - waste4 < 64) ? 8 : 4);
+        const int qtile = 32 * nw, nqt = (Nq + qtile - 1) / qtile;
+        p.dGroup = uc_make_fastdiv((unsigned)(8 * nqt)); p.dNq = uc_make_fastdiv((unsigned)nqt); p.dH = uc_make_fastdiv((unsigned)H);
         static int use_dma = -1;
         if (use_dma < 0) { const char* e = getenv("UC_ATTN_DMA"); use_dma = e ? atoi(e) : 1; }
         // DMA-staged kernel: whole 64-key tiles, 32-bit byte offsets inside one (batch, head)'s K rows / VT rows
-        const bool dma_ok = use_dma && (int64_t)((Nq + 127) / 128) * H * B < ((int64_t)1 << 31) && (uintptr_t)O % 16 == 0 && o_sb % 8 == 0 && o_sn % 8 == 0 && o_sh % 8 == 0 && (int64_t)32 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
-        if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
+        const bool dma_ok = use_dma && (int64_t)nqt * H * B < ((int64_t)1 << 31) && (uintptr_t)O % 16 == 0 && o_sb % 8 == 0 && o_sn % 8 == 0 && o_sh % 8 == 0 && (int64_t)32 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
+        if (dma_ok && nw == 8) hipLaunchKernelGGL(attn_bf16_dma_kernel<8>, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
+        else if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel<4>, dim3((unsigned)(nqt * H * B)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
     } else if (dtype == UC_F32) {
         UC_REQUIRE(v_layout == UC_V_ROWMAJOR, "uc_attention_fwd(f32): V must be row-major");
