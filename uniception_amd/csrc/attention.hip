@@ -257,9 +257,18 @@ __device__ __forceinline__ att_uint4_t att_make_srd(const void* base) {
                          (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
 }
 
+// What bounds it (round 2, tools/probe_attn_anatomy.py + tools/pmc_attn.sh, B = 64, H = 16, N = 1024): the costs of the exp2
+// work and of the PV products are ADDITIVE (-18 % without the exps, -20 % without the PV MFMAs, -2 % without the per-tile
+// barrier; static priorities or a start stagger per workgroup slot: nothing).  SQ_ACTIVE_INST_VALU — which includes a matrix
+// instruction for its whole 32 cycles — is 81-86 % of the wave-resident time of a SIMD: matrix and vector instructions of the
+// co-resident waves take turns, they do not overlap.  Per key tile and wave that is 512 cycles of MFMA + ~350 of VALU (three
+// quarters of it the 32 exp2): at head_dim 64 the matrix pipe cannot be more than ~60 % busy, the kernel has it at 48 %.
+// A form software-pipelined INSIDE a wave (S(t+1) MFMAs issued between the exps of tile t, PV(t) per 16-key chunk as soon
+// as its P exists, fragment reads two MFMAs ahead, separate K / VT rings; 160 registers, three waves per SIMD) was built,
+// verified and measured the same per-SIMD time (412 vs 412 us): removed again.
 // NW waves of 32 queries share every K / VT tile: NW = 8 (256 queries per workgroup) stages each tile once for twice the
 // queries of NW = 4 — half the global->LDS traffic per query — at the same 16 waves per CU (two workgroups of 48 KiB).
-template <int NW>
+template <int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64, 4) void attn_bf16_dma_kernel(AttnParams p) {
     // 2 stages x (K tile + VT tile); the Q rows of waves 4..7 (NW = 8) arrive in a third region
     __shared__ __attribute__((aligned(16))) char smem[(NW == 8 ? 6 : 4) * ATT_TILE_BYTES];
@@ -287,6 +296,20 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bf16_dma_kernel(AttnParams p)
     }
     const int b = (int)uc_div((unsigned)bh, p.dH), h = bh - b * p.H;
     const int q0 = qt * QT + wave * 32;
+    if constexpr (DBG & 8) {    // experiment: static priority by (approximate) workgroup slot on the CU
+        const unsigned slot = (blockIdx.x >> 8) & 3u;
+        if (slot == 0) __builtin_amdgcn_s_setprio(0);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+    if constexpr (DBG & 16) {   // experiment: de-phase the first round of workgroups by a quarter of a key tile each
+        if (blockIdx.x < 1024u) {
+            const unsigned slot = (blockIdx.x >> 8) & 3u;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)slot * 15u) __builtin_amdgcn_s_sleep(4);
+        }
+    }
 
     const bf16_t* Qb = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const bf16_t* Kb = (const bf16_t*)p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
@@ -404,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bf16_dma_kernel(AttnParams p)
                 float e[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    e[j] = __builtin_amdgcn_exp2f(fmaf(s[kb][hf * 8 + j], c, -mc));
+                    e[j] = (DBG & 2) ? s[kb][hf * 8 + j] : __builtin_amdgcn_exp2f(fmaf(s[kb][hf * 8 + j], c, -mc));
                     psum += e[j];
                 }
                 union { bf16x8_t v; unsigned u[4]; } pk;
@@ -419,10 +442,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bf16_dma_kernel(AttnParams p)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sv + r_off[g] + db * (32 * 128));
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o[db], 0, 0, 0);
+                if constexpr (!(DBG & 4)) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o[db], 0, 0, 0);
+                else o[db][g] += (float)vf[0] * (float)pf[g][0];
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 have landed
-        __syncthreads();                                      // ... everyone's; and every wave is done reading tile t
+        if constexpr (!(DBG & 1)) __syncthreads();                    // ... everyone's; and every wave is done reading tile t
     }
 
     // ---- normalise; bounce the wave's 32 x 64 outputs through its private 4 KiB of the (now free) ring so that every
@@ -622,11 +646,23 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         const int nw = nw_env == 4 || nw_env == 8 ? nw_env : ((Nq >= 256 && waste8 - waste4 < 64) ? 8 : 4);
         const int qtile = 32 * nw, nqt = (Nq + qtile - 1) / qtile;
         p.dGroup = uc_make_fastdiv((unsigned)(8 * nqt)); p.dNq = uc_make_fastdiv((unsigned)nqt); p.dH = uc_make_fastdiv((unsigned)H);
+        static int dbg = -1;   // diagnostics only (UC_ATTN_DBG; results are wrong): 1 no per-tile barrier, 2 no exp (P = S), 4 no PV MFMAs
+        if (dbg < 0) { const char* e = getenv("UC_ATTN_DBG"); dbg = e ? atoi(e) : 0; }
         static int use_dma = -1;
         if (use_dma < 0) { const char* e = getenv("UC_ATTN_DMA"); use_dma = e ? atoi(e) : 1; }
         // DMA-staged kernel: whole 64-key tiles, 32-bit byte offsets inside one (batch, head)'s K rows / VT rows
         const bool dma_ok = use_dma && (int64_t)nqt * H * B < ((int64_t)1 << 31) && (uintptr_t)O % 16 == 0 && o_sb % 8 == 0 && o_sn % 8 == 0 && o_sh % 8 == 0 && (int64_t)32 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
-        if (dma_ok && nw == 8) hipLaunchKernelGGL(attn_bf16_dma_kernel<8>, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
+        if (dma_ok && nw == 4 && dbg) {
+            const dim3 g((unsigned)(nqt * H * B));
+            if (dbg == 1) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 1>), g, dim3(256), 0, st, p);
+            else if (dbg == 2) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 2>), g, dim3(256), 0, st, p);
+            else if (dbg == 3) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 3>), g, dim3(256), 0, st, p);
+            else if (dbg == 4) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 4>), g, dim3(256), 0, st, p);
+            else if (dbg == 5) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 5>), g, dim3(256), 0, st, p);
+            else if (dbg == 8) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 8>), g, dim3(256), 0, st, p);
+            else if (dbg == 16) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 16>), g, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 24>), g, dim3(256), 0, st, p);
+        } else if (dma_ok && nw == 8) hipLaunchKernelGGL(attn_bf16_dma_kernel<8>, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
         else if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel<4>, dim3((unsigned)(nqt * H * B)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
     } else if (dtype == UC_F32) {
