@@ -265,7 +265,8 @@ __device__ __forceinline__ att_uint4_t att_make_srd(const void* base) {
 // quarters of it the 32 exp2): at head_dim 64 the matrix pipe cannot be more than ~60 % busy, the kernel has it at 48 %.
 // A form software-pipelined INSIDE a wave (S(t+1) MFMAs issued between the exps of tile t, PV(t) per 16-key chunk as soon
 // as its P exists, fragment reads two MFMAs ahead, separate K / VT rings; 160 registers, three waves per SIMD) was built,
-// verified and measured the same per-SIMD time (412 vs 412 us): removed again.
+// verified and measured the same per-SIMD time (412 vs 412 us): removed again.  Packed fp32 (v_pk_fma_f32 for the scale,
+// v_pk_add_f32 for the row sums: 31 instructions instead of 63) measured 5-7 % SLOWER (394 -> 414-421 us): not kept.
 // NW waves of 32 queries share every K / VT tile: NW = 8 (256 queries per workgroup) stages each tile once for twice the
 // queries of NW = 4 — half the global->LDS traffic per query — at the same 16 waves per CU (two workgroups of 48 KiB).
 template <int NW, int DBG = 0>
