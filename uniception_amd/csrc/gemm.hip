@@ -92,11 +92,10 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {  // byte offset ins
 
 __device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
     unsigned* p = reinterpret_cast<unsigned*>(&v);
+    typedef short short2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned neg = (p[i] >> 15) & 0x00010001u;  // sign bits of both halves
-        p[i] &= ~(neg * 0xffffu);
-    }
+    for (int i = 0; i < 4; ++i)      // negative bf16 <=> negative int16: one v_pk_max_i16 per register
+        p[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2_t, p[i]), (short2_t){0, 0}));
     return v;
 }
 

@@ -75,13 +75,15 @@ __device__ __forceinline__ int glds_xcd_remap(int bid, int nwg) {
     return base + k;
 }
 
+// ReLU of eight bf16 values: a bf16 is negative exactly when its bit pattern is negative as an int16, so max(int16, 0) is the
+// ReLU (-0 -> +0): one v_pk_max_i16 per register instead of shift / and / multiply / and-not — the fragment-load ReLU of the
+// residual conv units sits in the K-loop, where vector instructions take their cycles from the matrix pipe.
+typedef short glds_short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 glds_relu_bf16x8(uint4 v) {
     unsigned* q = reinterpret_cast<unsigned*>(&v);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned neg = (q[i] >> 15) & 0x00010001u;
-        q[i] &= ~(neg * 0xffffu);
-    }
+    for (int i = 0; i < 4; ++i)
+        q[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(glds_short2_t, q[i]), (glds_short2_t){0, 0}));
     return v;
 }
 

@@ -55,11 +55,10 @@ __device__ __forceinline__ int tn_swz(int r) { return (r & 3) | (((r >> 3) & 1) 
 __device__ __forceinline__ bf16x4_t tn_relu4(bf16x4_t v) {
     uint2 u = __builtin_bit_cast(uint2, v);
     unsigned* q = reinterpret_cast<unsigned*>(&u);
+    typedef short tn_short2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const unsigned neg = (q[i] >> 15) & 0x00010001u;
-        q[i] &= ~(neg * 0xffffu);
-    }
+    for (int i = 0; i < 2; ++i)      // negative bf16 <=> negative int16: one v_pk_max_i16 per register
+        q[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(tn_short2_t, q[i]), (tn_short2_t){0, 0}));
     return __builtin_bit_cast(bf16x4_t, u);
 }
 
