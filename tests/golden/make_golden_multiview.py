@@ -55,6 +55,40 @@ def main():
         print(name, "ok", {k: v.shape for k, v in store.items() if k.startswith(name + "/")})
     np.savez_compressed(os.path.join(HERE, "multiview.npz"), **store)
     print("wrote", os.path.join(HERE, "multiview.npz"))
+    grads()
+
+
+def grads():
+    """Gradient fixtures (multiview_grads.npz): the reference's own autograd through its global / alternating transformer."""
+    from tests.golden.cases import sample_indices
+    from tests.golden.multiview_cases import MV_GRAD_CASES, grad_weights, output_list
+    store = {}
+    for name in MV_GRAD_CASES:
+        key, extra, V, Tp, G, indices = MV_CASES[name]
+        assert indices is None
+        cls, _ = INFO_SHARING_CLASSES[key]
+        model = cls(name=name, **DIMS, **resolve(extra, RoPE2D)).train()
+        fill(model)
+        feats, per_view, glob = inputs(name)
+        leaves = [t.requires_grad_(True) for t in feats + (per_view or []) + ([glob] if glob is not None else [])]
+        torch.manual_seed(RAND_SEED)
+        out = model(MultiViewTransformerInput(features=feats, additional_input_tokens=glob, additional_input_tokens_per_view=per_view))
+        outs = output_list(out)
+        ws = grad_weights(name, [tuple(t.shape) for t in outs])
+        loss = sum((t * w).sum() for t, w in zip(outs, ws))
+        loss.backward()
+        store[f"{name}/loss"] = np.float64(float(loss.detach()))
+        for i, t in enumerate(leaves):
+            store[f"{name}/din{i}"] = t.grad.detach().numpy()
+        for k, prm in model.named_parameters():
+            if prm.grad is None:
+                continue
+            idx = sample_indices(prm.grad.numel(), 512)
+            store[f"{name}/p/{k}__samples"] = prm.grad.flatten()[idx].float().numpy()
+            store[f"{name}/p/{k}__norm"] = np.float64(prm.grad.double().norm().item())
+        print(name, "grads ok: loss", float(loss.detach()), sum(1 for k in store if k.startswith(name + "/p/")) // 2, "parameter gradients")
+    np.savez_compressed(os.path.join(HERE, "multiview_grads.npz"), **store)
+    print("wrote", os.path.join(HERE, "multiview_grads.npz"))
 
 
 if __name__ == "__main__":

@@ -38,3 +38,24 @@ def resolve(extra, rope_cls):
     if e.get("custom_positional_encoding") == "ROPE_OBJECT":
         e["custom_positional_encoding"] = rope_cls(100.0)
     return e
+
+
+# cases that also have a gradient fixture (multiview_grads.npz): reference autograd of  L = sum_k <out_k, R_k>  over every output
+# tensor (per-view features, extra-token features), R_k seeded
+MV_GRAD_CASES = ("global_rope_v3", "alt_tokens_v2")
+
+
+def grad_weights(name, shapes):
+    """Seeded cotangents, one per output tensor, in the order (features of view 0.., global extra tokens, per-view extra tokens)."""
+    import torch
+    g = torch.Generator().manual_seed(7 + sum(map(ord, name)))
+    return [torch.randn(*s, generator=g) for s in shapes]
+
+
+def output_list(out):
+    ts = list(out.features)
+    if out.additional_token_features is not None:
+        ts.append(out.additional_token_features)
+    if out.additional_token_features_per_view is not None:
+        ts += list(out.additional_token_features_per_view)
+    return ts

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import engine, ops
+from ... import autograd, engine, ops
 from ..libs.croco.pos_embed import RoPE2D
 from ..utils.intermediate_feature_return import IntermediateFeatureReturner, feature_take_indices
 from ..utils.positional_encoding import PositionGetter
@@ -131,7 +131,9 @@ class _MultiViewSelfAttentionCore(UniCeptionInfoSharingBase):
             raise ValueError("Custom positional encoding is not supported when additional_input_tokens or "
                              "additional_input_tokens_per_view are provided. Please set custom_positional_encoding=None "
                              "or remove additional tokens from the input.")
-        engine.require_inference(*feats, self.norm.weight)
+        # training (gradients requested through the features, the extra tokens or the parameters): the blocks switch to their
+        # HIP forward + backward sub-layers themselves; here only the input projection needs the differentiable form
+        train = autograd.grad_needed(*feats, *(per_view or ()), glob, self.norm.weight, *self.proj_embed.parameters())
         T = hw + Tp
         L = V * T + G
         in_dt = torch.float32 if isinstance(self.proj_embed, nn.Identity) else dt
@@ -148,8 +150,11 @@ class _MultiViewSelfAttentionCore(UniCeptionInfoSharingBase):
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
         if not isinstance(self.proj_embed, nn.Identity):
-            wpe, bpe = engine.lin_weights(self.proj_embed, dt)
-            x2d = ops.gemm(x2d, wpe, bpe, out_dtype=torch.float32)
+            if train:
+                x2d = autograd.linear(x2d, self.proj_embed.weight, self.proj_embed.bias, self.proj_embed, dt, torch.float32)
+            else:
+                wpe, bpe = engine.lin_weights(self.proj_embed, dt)
+                x2d = ops.gemm(x2d, wpe, bpe, out_dtype=torch.float32)
         elif x2d.data_ptr() == feats[0].data_ptr():
             x2d = x2d.clone()      # the view encoding below is added in place: never into the caller's features
         pos = None
@@ -164,7 +169,8 @@ class _MultiViewSelfAttentionCore(UniCeptionInfoSharingBase):
                 else:
                     idx += list(range(1, V))
             pe = self.view_pos_table[idx].float().contiguous()      # [1 or V, dim]: reference view only, or every view
-            ops.add_view_pe_(x2d.view(B, L, self.dim), pe, T)
+            # (in place through the raw kernel, also under autograd: d(x + const)/dx = 1 and no Function saved x2d's values)
+            ops.add_view_pe_(x2d.detach().view(B, L, self.dim), pe, T)
         taken = []
         for d, blk in enumerate(self.self_attention_blocks):
             if not self._frame_level(d):
