@@ -985,6 +985,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             } else {
                 const bool is_a = (wave * PER + q) * RPI < BM_;   // wave-uniform: an instruction is all-A or all-W
                 const unsigned vo = ((st1[q] >> tap) & 1u) ? st0[q] : 0xffffffffu;
+                if (is_a && (p.dbg & 64) && tap != 0) continue;   // diagnostics (wrong results): A tiles staged for tap 0 only — what a halo-tiled form could save at most
                 if (is_a) dma16_buf_to_lds(vo, srd_a, soff_a, dst);
                 else dma16_buf_to_lds(vo, srd_w, soff_w, dst);
             }
