@@ -643,6 +643,70 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
     }
 }
 
+// Training forms of the bf16 store (mode 0 tiles, no residual): PRE also stores the value BEFORE the activation (fc1's
+// pre-activation, saved for the backward), DACT multiplies the result by act'(u) of a saved pre-activation u laid out like C
+// (the activation backward fused into the data-gradient GEMM).  Same bounce / whole-row stores as glds_epilogue_bf16; in the
+// generic drain these two cost 60 % on top of the K = 1024 GEMMs that carry them (12 % of a training step).
+template <int FA, int ACT, bool PRE, bool DACT>
+__device__ __forceinline__ void glds_epilogue_bf16_train(glds_pe_t p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane,
+                                                         char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    float4_t b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b4[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4[j] = *reinterpret_cast<const float4_t*>(p.bias + wave_n + 16 * j + 4 * g);
+    }
+    const int wr_off = frow * 128 + (((g & 1) ^ (frow >> 3)) << 3);
+    auto stage = [&](int i, char* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4_t pre = acc[i][j] + b4[j];
+            const int off = wr_off + (((2 * j + (g >> 1)) ^ (frow & 7)) << 4);
+            if constexpr (PRE) *reinterpret_cast<uint2*>(buf + 4096 + off) = (uint2){pack_bf16x2(pre.x, pre.y), pack_bf16x2(pre.z, pre.w)};
+            const float4_t v = glds_act4<ACT>(pre);
+            *reinterpret_cast<uint2*>(buf + off) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+        }
+    };
+    const int crow = lane >> 3, pch = lane & 7;
+    const int rows_left = (int)min((int64_t)(16 * FA), p.M - wave_m) - crow;
+    const int64_t row0 = ((wave_m + crow) * p.ldc + wave_n) * 2;           // byte offset of (row, column block) in C / preact / dact_u
+    const int64_t cstep = 8 * p.ldc * 2;
+    stage(0, wbuf);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const char* buf = wbuf + (i & 1) * 2048;
+        if (i + 1 < FA) stage(i + 1, wbuf + ((i + 1) & 1) * 2048);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int R = 8 * ps + crow;
+            const int64_t off = row0 + (2 * i + ps) * cstep + ((pch ^ (R & 7)) << 4);
+            uint4 v = *reinterpret_cast<const uint4*>(buf + R * 128 + (pch << 4));
+            if (ps) v = (uint4){v.z, v.w, v.x, v.y};         // rows 8..15 keep their halves swapped in the bounce block
+            if (16 * i + 8 * ps < rows_left) {
+                if constexpr (DACT) {
+                    const uint4 u = *reinterpret_cast<const uint4*>((const char*)p.dact_u + off);
+                    const unsigned vv[4] = {v.x, v.y, v.z, v.w}, uu[4] = {u.x, u.y, u.z, u.w};
+                    unsigned oo[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v0 = __uint_as_float(vv[q] << 16), v1 = __uint_as_float(vv[q] & 0xffff0000u);
+                        const float u0 = __uint_as_float(uu[q] << 16), u1 = __uint_as_float(uu[q] & 0xffff0000u);
+                        oo[q] = pack_bf16x2(v0 * glds_dact(u0, p.dact_act), v1 * glds_dact(u1, p.dact_act));
+                    }
+                    v = (uint4){oo[0], oo[1], oo[2], oo[3]};
+                }
+                *reinterpret_cast<uint4*>((char*)p.C + off) = v;
+                if constexpr (PRE) {
+                    uint4 w = *reinterpret_cast<const uint4*>(buf + 4096 + R * 128 + (pch << 4));
+                    if (ps) w = (uint4){w.z, w.w, w.x, w.y};
+                    *reinterpret_cast<uint4*>((char*)p.preact + off) = w;
+                }
+            }
+        }
+    }
+}
+
 // 4 values of row m, columns nb..nb+3 of a [*, ld] matrix of dtype dt: vector access when `full`, else per element inside N
 __device__ __forceinline__ float4_t glds_load4(const void* base, int dt, int64_t idx, bool full, int64_t nb, int64_t N) {
     float4_t v = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -843,6 +907,16 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                     }
                 }
             } else if (plain && pe.out_dtype == UC_BF16 && !pe.residual) bf16_family();
+            else if (mode == 0 && pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && pe.out_dtype == UC_BF16 && !pe.residual &&
+                     !(pe.dbg & 16) && !pe.ln_stats && (pe.preact != nullptr) != (pe.dact_u != nullptr)) {
+                // training: fc1 with its pre-activation copy / a data-gradient GEMM with the activation backward fused
+                if (pe.preact) {
+                    if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16_train<FA, UC_ACT_GELU_ERF, true, false>(pe, acc, wave_m, wave_n, lane, wbuf);
+                    else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16_train<FA, UC_ACT_RELU, true, false>(pe, acc, wave_m, wave_n, lane, wbuf);
+                    else glds_epilogue_bf16_train<FA, UC_ACT_NONE, true, false>(pe, acc, wave_m, wave_n, lane, wbuf);
+                } else if (pe.act == UC_ACT_NONE) glds_epilogue_bf16_train<FA, UC_ACT_NONE, false, true>(pe, acc, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_generic<FA>(pe, acc, mode, wave_m, wave_n, lane, ksplit, wbuf);
+            }
             else if (plain && pe.out_dtype == UC_F32 && (!pe.residual || pe.res_dtype == UC_F32) && pe.act == UC_ACT_NONE) f32_family();
             else glds_epilogue_generic<FA>(pe, acc, mode, wave_m, wave_n, lane, ksplit, wbuf);
         }
