@@ -161,3 +161,39 @@ def test_concurrent_streams_are_bitwise_the_single_stream_forward(gpu):
         for a, b in zip(got, ref):
             for k in a:
                 assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_pairs_are_independent_to_the_bit(gpu, mode):
+    """Every image pair is an independent unit of the path: permuting the pairs of a batch permutes the outputs,
+    and a pair's result does not depend on its batch mates or on where in a kernel's tile its rows land — bit for bit (the
+    epilogue arithmetic is written with explicit FMAs for exactly this; tools/probe_batch_invariance.py)."""
+    from oracle import dust3r_oracle as O
+    from tests.golden.cases import GAINS
+    from uniception_amd import engine
+    from uniception_amd.models.factory import DUSt3R
+    model = DUSt3R(name="g", img_size=(64, 96), pred_head_type="dpt").eval()
+    O.fill_state_dict_(model.state_dict(), gain=1.0, gains=GAINS)
+    model = model.to(gpu)
+    g = torch.Generator().manual_seed(123)
+    B = 5
+    img1 = torch.randn(B, 3, 64, 96, generator=g).to(gpu)
+    img2 = torch.randn(B, 3, 64, 96, generator=g).to(gpu)
+
+    def run(idx):
+        v1 = {"img": img1[idx].contiguous(), "instance": [f"a{i}" for i in idx], "data_norm_type": "dust3r"}
+        v2 = {"img": img2[idx].contiguous(), "instance": [f"b{i}" for i in idx], "data_norm_type": "dust3r"}
+        with torch.no_grad(), engine.precision(mode):
+            r1, r2 = model(v1, v2)
+        torch.cuda.synchronize()
+        return {**{"1" + k: v for k, v in r1.items()}, **{"2" + k: v for k, v in r2.items()}}
+
+    full = run([0, 1, 2, 3, 4])
+    perm = [3, 0, 4, 2, 1]
+    shuffled = run(perm)
+    alone = run([2])
+    pair = run([4, 2])
+    for k, v in full.items():
+        assert torch.equal(shuffled[k], v[perm]), f"{k}: permuting the batch must permute the outputs"
+        assert torch.equal(alone[k][0], v[2]), f"{k}: a pair alone"
+        assert torch.equal(pair[k][1], v[2]) and torch.equal(pair[k][0], v[4]), f"{k}: a pair in another batch"
