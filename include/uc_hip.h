@@ -36,8 +36,9 @@ enum uc_status {
 const char* uc_last_error(void);
 /* ABI version; bumped when a signature or the uc_gemm_desc layout changes.
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
- *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added. */
-#define UC_ABI_VERSION 5
+ *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added.  4/5: see INTEGRATION.md.
+ *   6: uc_adaptor_program_bwd added. */
+#define UC_ABI_VERSION 6
 int uc_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
@@ -372,6 +373,13 @@ int uc_transpose2d(const void* src, int src_dtype, void* dst, int dst_dtype, voi
 int uc_pointmap_adaptor_bwd(const float* x, int64_t x_sb, int64_t x_sc, int64_t x_sp, const float* dpts,
                             const float* dconf, float conf_vmin, float conf_vmax, float* dx, int B, int H, int W,
                             uc_stream_t stream);
+
+/* Backward of uc_adaptor_program for an arbitrary downstream loss (what torch autograd computes through the reference's
+ * adaptors, prediction_heads/adaptors.py:25-2300): dout fp32 NHWC [B,H,W,Cout] -> dx fp32 with the strides of x ([B,Cin,H,W]-shaped).
+ * clip / clamp pass the gradient where the unclipped value lies inside the bounds (bounds included, as torch.clip does);
+ * input channels no segment reads get a zero gradient; two segments may not read the same input channel; Cin <= 64. */
+int uc_adaptor_program_bwd(const float* x, int64_t sb, int64_t sc, int64_t sw, const float* dout, float* dx, int B, int H, int W,
+                           int Cin, int Cout, const uc_adaptor_seg* segs, int nseg, uc_stream_t stream);
 
 /* Confidence-weighted regression loss on adaptor outputs (the DUSt3R training objective; the reference ships no loss):
  *   loss_sum[0] += sum_pix conf*|pts-gt| - alpha*log(conf);  dpts, dconf = its gradients * grad_scale. */

@@ -52,3 +52,10 @@ def adaptor_input(name):
 # DPT extras: (feature dims of the layered inputs, layer dims, feature dim, token grid, target shape, seg classes)
 DPT_SEG = dict(input_feature_dim=32, output_dim=5, hidden_dim=16, feat_hw=(24, 40), target=(35, 61), B=2)
 DPT_DOUBLE = dict(input_feature_dims=[128, 192], layer_dims=[32, 64], feature_dim=32, grid=(5, 7), B=2)
+
+
+def adaptor_grad_weight(name, field, shape):
+    "Weights of the scalar the gradient goldens differentiate: loss = sum over output fields of (field * weight).sum()."
+    import torch
+    g = torch.Generator().manual_seed(sum(map(ord, name + "/" + field)) + 1013)
+    return torch.randn(*shape, generator=g)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import dust3r_oracle as O
-from tests.golden.heads_cases import AD_H, AD_W, ADAPTOR_CASES, DPT_DOUBLE, DPT_SEG, OUT_FIELDS, adaptor_input
+from tests.golden.heads_cases import AD_H, AD_W, ADAPTOR_CASES, DPT_DOUBLE, DPT_SEG, OUT_FIELDS, adaptor_grad_weight, adaptor_input
 from tests.helpers import GOLDEN_DIR, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -38,6 +38,40 @@ def test_adaptor_matches_reference(gpu, gold, name):
             assert tuple(got.shape) == tuple(w.shape), (f, got.shape, w.shape)
             e = float((got.float().cpu().double() - torch.as_tensor(w).double()).abs().max() / max(1.0, float(np.abs(w).max())))
             assert e < 2e-6 and rel_l2(got.float().cpu(), w) < 2e-6, f"{name}.{f} ({layout}): {e:.2e}"
+
+
+@pytest.fixture(scope="module")
+def gold_grads():
+    return np.load(os.path.join(GOLDEN_DIR, "heads_extra_grads.npz"))
+
+
+@pytest.mark.parametrize("name", list(ADAPTOR_CASES.keys()))
+def test_adaptor_gradients_match_reference_autograd(gpu, gold_grads, name):
+    """Every adaptor is trainable: the gradient of a seeded linear functional of all its output fields with respect to the decoded
+    channels equals what torch autograd computes through the REAL reference adaptor (tests/golden/make_golden_heads_grads.py) —
+    clip / clamp masks, the norm's zero gradient at the origin and the composites' channel routing included."""
+    from uniception_amd.models.prediction_heads import adaptors as A
+    from uniception_amd.models.prediction_heads.base import AdaptorInput
+    cls, args, cin = ADAPTOR_CASES[name]
+    ad = getattr(A, cls)(name, *args).to(gpu)
+    want = torch.as_tensor(gold_grads[f"ad/{name}/dx"])
+    for layout in ("nchw", "channels_last"):
+        x0 = adaptor_input(name).to(gpu)
+        leaf = (x0 if layout == "nchw" else x0.permute(0, 2, 3, 1).contiguous()).requires_grad_(True)
+        xd = leaf if layout == "nchw" else leaf.permute(0, 3, 1, 2)
+        out = ad(AdaptorInput(adaptor_feature=xd, output_shape_hw=(AD_H, AD_W)))
+        loss = 0.0
+        for f in OUT_FIELDS:
+            if hasattr(out, f):
+                v = getattr(out, f)
+                loss = loss + (v * adaptor_grad_weight(name, f, v.shape).to(gpu)).sum()
+        loss.backward()
+        got = (leaf.grad if layout == "nchw" else leaf.grad.permute(0, 3, 1, 2)).float().cpu()
+        ref_loss = float(gold_grads[f"ad/{name}/loss"])
+        got_loss = float(loss.detach())
+        assert abs(got_loss - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss)), (name, got_loss, ref_loss)
+        e = float((got.double() - want.double()).abs().max() / max(1.0, float(want.abs().max())))
+        assert e < 5e-6 and rel_l2(got, want) < 5e-6, f"{name} ({layout}): max-abs/scale {e:.2e}, rel-L2 {rel_l2(got, want):.2e}"
 
 
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-5), ("bf16", 2e-2)])

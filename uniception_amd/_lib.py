@@ -82,6 +82,7 @@ SIGNATURES = {
     "uc_act_bwd": [vp, vp, vp, i32, i32, i64, vp],
     "uc_transpose2d": [vp, i32, vp, i32, vp, i64, i64, i64, vp],
     "uc_pointmap_adaptor_bwd": [vp, i64, i64, i64, vp, vp, f32, f32, vp, i32, i32, i32, vp],
+    "uc_adaptor_program_bwd": [vp, i64, i64, i64, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
     "uc_conf_loss": [vp, vp, vp, f32, f32, vp, vp, vp, i64, vp],
     "uc_pointmap_loss": [vp, i64, i64, i64, vp, f32, f32, vp, vp, i32, i32, i32, vp],
     "uc_pixel_unshuffle": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
@@ -98,7 +99,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 5   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 6   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

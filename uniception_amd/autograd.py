@@ -515,6 +515,26 @@ def pointmap_adaptor(x, vmin, vmax):
     return PointmapAdaptorFn.apply(x, vmin, vmax)
 
 
+class AdaptorProgramFn(Function):
+    """A channel program of the generic adaptor pass (ops.adaptor_program) and its gradient with respect to the decoded channels
+    (what torch autograd computes through the reference's adaptor compositions, prediction_heads/adaptors.py:25-2300)."""
+
+    @staticmethod
+    def forward(ctx, x, segs, cout):
+        ctx.save_for_backward(x)
+        ctx.segs = segs
+        return ops.adaptor_program(x, segs, cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        return ops.adaptor_program_bwd(x, _c(dout), ctx.segs), None, None
+
+
+def adaptor_program(x, segs, cout):
+    return AdaptorProgramFn.apply(x, segs, cout)
+
+
 class ConfLossFn(Function):
     """mean_pix(conf * |pts - gt|) - alpha * mean_pix(log conf): the DUSt3R confidence-weighted regression objective
     (the reference ships no loss; SURVEY §8d names this one).  One kernel computes the loss and both gradients."""

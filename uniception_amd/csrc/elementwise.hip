@@ -747,3 +747,169 @@ extern "C" int uc_adaptor_program(const float* x, int64_t sb, int64_t sc, int64_
     UC_CHECK_LAUNCH("uc_adaptor_program");
     return UC_OK;
 }
+
+// Gradient of adaptor_program_kernel with respect to x for an arbitrary downstream loss: dout fp32 NHWC [B,H,W,Cout] -> dx with the
+// strides of x.  The masks follow torch's autograd for the reference's composition of ops: clip / clamp pass the gradient where
+// the unclipped value lies inside [vmin, vmax] (bounds included), norm() has gradient 0 at the origin.  Input channels no segment
+// reads (bit clear in `covered`) get a zero gradient.
+__device__ __forceinline__ float ad_pass(float t, float lo, float hi) { return (t >= lo && t <= hi) ? 1.f : 0.f; }
+
+__global__ void adaptor_program_bwd_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sw, const float* __restrict__ dout,
+                                           float* __restrict__ dx, int64_t npix, int HW, int Cin, int Cout, unsigned long long covered,
+                                           AdaptorProgram prog) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int pix = (int)(i - b * HW);
+        const int64_t base = b * sb + (int64_t)pix * sw;
+        const float* px = x + base;
+        float* pd = dx + base;
+        const float* pg = dout + i * Cout;
+        for (int c = 0; c < Cin; ++c)
+            if (!((covered >> c) & 1ull)) pd[(int64_t)c * sc] = 0.f;
+        for (int s = 0; s < prog.nseg; ++s) {
+            const uc_adaptor_seg sg = prog.seg[s];
+            float v[4] = {0.f, 0.f, 0.f, 0.f}, g[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+            const int nout = sg.op == UC_AD_MASK ? 2 : (sg.op == UC_AD_COV2D ? 7 : sg.n);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < sg.n) v[k] = px[(int64_t)(sg.c0 + k) * sc];
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k < nout) g[k] = pg[sg.o0 + k];
+            switch (sg.op) {
+                case UC_AD_ELEM:
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float e = expf(v[k]);
+                        const float t = sg.mode == 1 ? v[k] * v[k] : (sg.mode == 2 ? e : v[k]);
+                        const float dt = sg.mode == 1 ? 2.f * v[k] : (sg.mode == 2 ? e : 1.f);
+                        d[k] = g[k] * ad_pass(t, sg.vmin, sg.vmax) * dt;
+                    }
+                    break;
+                case UC_AD_NORM: {          // y = v f(r) / max(r, 1e-8): dv = s g' + v (v . g') (f'(r) r - f(r)) / r^3
+                    float r2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < sg.n) r2 += v[k] * v[k];
+                    const float r = sqrtf(r2), rc = fmaxf(r, 1e-8f);
+                    const float em1 = expm1f(r);
+                    const float f = sg.mode == 1 ? r * r : em1;
+                    const float sl = f / rc;
+                    // (f' r - f) / r^2: 1 for r^2; for expm1 the series below 1e-2 (the quotient cancels there)
+                    const float q = sg.mode == 1 ? 1.f : (r > 1e-2f ? ((em1 + 1.f) * r - em1) / (r * r) : 0.5f + r * (1.f / 3.f));
+                    float dot = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < sg.n) { g[k] *= ad_pass(v[k] * sl, sg.vmin, sg.vmax); dot += v[k] * g[k]; }
+                    const float kk = (r >= 1e-8f) ? dot * q / rc : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = sl * g[k] + v[k] * kk;
+                    break;
+                }
+                case UC_AD_ZEXP: {
+                    const float z = expf(v[2]);
+                    const float g0 = g[0] * ad_pass(v[0] * z, sg.vmin, sg.vmax), g1 = g[1] * ad_pass(v[1] * z, sg.vmin, sg.vmax);
+                    const float g2 = g[2] * ad_pass(z, sg.vmin, sg.vmax);
+                    d[0] = g0 * z; d[1] = g1 * z; d[2] = (g0 * v[0] + g1 * v[1] + g2) * z;
+                    break;
+                }
+                case UC_AD_DIR: {
+                    float c[4], m[4];          // clipped values and the pass mask of clip (+ clamp of the last channel)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { m[k] = ad_pass(v[k], sg.vmin, sg.vmax); c[k] = ad_clip(v[k], sg.vmin, sg.vmax); }
+                    if (sg.flags & 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k == sg.n - 1) { m[k] *= (c[k] >= sg.p[0]) ? 1.f : 0.f; c[k] = fmaxf(c[k], sg.p[0]); }
+                    }
+                    float dc[4] = {g[0], g[1], g[2], g[3]};
+                    if (sg.flags & 2) {          // y = c / max(|c|, 1e-8)
+                        float r2 = 0.f, dot = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k < sg.n) { r2 += c[k] * c[k]; dot += c[k] * g[k]; }
+                        const float r = sqrtf(r2), rc = fmaxf(r, 1e-8f);
+                        const float kk = (r >= 1e-8f) ? dot / (rc * rc * r) : 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dc[k] = g[k] / rc - c[k] * kk;
+                    } else if (sg.flags & 4) {   // y = c / c_last
+                        float last = 1.f, dot = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { if (k == sg.n - 1) last = c[k]; if (k < sg.n) dot += c[k] * g[k]; }
+                        const float il = 1.f / last;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dc[k] = g[k] * il - (k == sg.n - 1 ? dot * il * il : 0.f);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = dc[k] * m[k];
+                    break;
+                }
+                case UC_AD_CONF_EXP: {
+                    const float e = expf(v[0]);
+                    d[0] = (e <= sg.vmax - sg.vmin) ? g[0] * e : 0.f;
+                    break;
+                }
+                case UC_AD_CONF_SIGMOID: {
+                    const float sgm = 1.f / (1.f + expf(-v[0]));
+                    d[0] = g[0] * (sg.vmax - sg.vmin) * sgm * (1.f - sgm);
+                    break;
+                }
+                case UC_AD_MASK: {
+                    const float sgm = 1.f / (1.f + expf(-v[0]));
+                    d[0] = g[0] + g[1] * sgm * (1.f - sgm);
+                    break;
+                }
+                case UC_AD_FLOW:
+                    d[0] = g[0] * sg.p[0]; d[1] = g[1] * sg.p[2];
+                    break;
+                case UC_AD_FLOWCOORD:
+                    d[0] = 0.5f * sg.p[0] * g[0]; d[1] = 0.5f * sg.p[1] * g[1];
+                    break;
+                case UC_AD_COV2D: {
+                    const float c1 = v[0] + sg.p[0], c2 = v[1] + sg.p[0];
+                    const float th = tanhf(v[2]);
+                    const float de = 0.5f * (c1 + c2);
+                    const float ic = 1.f / (1.f - th * th + 1e-8f);
+                    const float e1 = expf(c1), e2 = expf(c2), ed = expf(de), n1 = expf(-c1), n2 = expf(-c2), nd = expf(-de);
+                    const float o2 = th * ed, o4 = ic * n1, o5 = ic * n2, o6 = -ic * th * nd;
+                    const float dic = 2.f * th * ic * ic;          // d ic / d th
+                    d[0] = g[0] * e1 + 0.5f * g[2] * o2 + g[3] - g[4] * o4 - 0.5f * g[6] * o6;
+                    d[1] = g[1] * e2 + 0.5f * g[2] * o2 + g[3] - g[5] * o5 - 0.5f * g[6] * o6;
+                    const float dth = g[2] * ed - g[3] * 2.f * th * ic + g[4] * dic * n1 + g[5] * dic * n2 - g[6] * nd * (ic + th * dic);
+                    d[2] = dth * (1.f - th * th);
+                    break;
+                }
+                default: break;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < sg.n) pd[(int64_t)(sg.c0 + k) * sc] = d[k];
+        }
+    }
+}
+
+extern "C" int uc_adaptor_program_bwd(const float* x, int64_t sb, int64_t sc, int64_t sw, const float* dout, float* dx, int B, int H,
+                                      int W, int Cin, int Cout, const uc_adaptor_seg* segs, int nseg, uc_stream_t stream) {
+    UC_REQUIRE(x && dout && dx && segs && B > 0 && H > 0 && W > 0 && Cout > 0, "uc_adaptor_program_bwd: bad argument");
+    UC_REQUIRE(Cin > 0 && Cin <= 64, "uc_adaptor_program_bwd: 1..64 input channels");
+    UC_REQUIRE(nseg > 0 && nseg <= UC_ADAPTOR_MAX_SEGS, "uc_adaptor_program_bwd: 1..%d segments", UC_ADAPTOR_MAX_SEGS);
+    AdaptorProgram prog;
+    prog.nseg = nseg;
+    unsigned long long covered = 0ull;
+    for (int s = 0; s < nseg; ++s) {
+        const uc_adaptor_seg& g = segs[s];
+        const int nout = g.op == UC_AD_MASK ? 2 : (g.op == UC_AD_COV2D ? 7 : g.n);
+        UC_REQUIRE(g.op >= UC_AD_ELEM && g.op <= UC_AD_COV2D && g.n >= 1 && g.n <= 4 && g.c0 >= 0 && g.c0 + g.n <= Cin && g.o0 >= 0 &&
+                       g.o0 + nout <= Cout, "uc_adaptor_program_bwd: bad segment %d", s);
+        UC_REQUIRE(((g.op != UC_AD_ZEXP && g.op != UC_AD_COV2D) || g.n == 3) && ((g.op != UC_AD_FLOW && g.op != UC_AD_FLOWCOORD) || g.n == 2) &&
+                       ((g.op != UC_AD_CONF_EXP && g.op != UC_AD_CONF_SIGMOID && g.op != UC_AD_MASK) || g.n == 1),
+                   "uc_adaptor_program_bwd: segment %d has the wrong channel count for its op", s);
+        const unsigned long long bits = ((1ull << g.n) - 1ull) << g.c0;
+        UC_REQUIRE(!(covered & bits), "uc_adaptor_program_bwd: segment %d reads a channel another segment reads (gradients would have to be summed)", s);
+        covered |= bits;
+        prog.seg[s] = g;
+    }
+    const int64_t npix = (int64_t)B * H * W;
+    hipLaunchKernelGGL(adaptor_program_bwd_kernel, dim3(EW_GRID(npix)), dim3(256), 0, (hipStream_t)stream, x, sb, sc, sw, dout, dx, npix,
+                       H * W, Cin, Cout, covered, prog);
+    UC_CHECK_LAUNCH("uc_adaptor_program_bwd");
+    return UC_OK;
+}

@@ -53,10 +53,14 @@ def _bchw(out_nhwc, a, b):
 
 def _run(adaptor_input: AdaptorInput, segs):
     x = adaptor_input.adaptor_feature
-    if autograd.grad_needed(x):
-        raise engine.UcHipError("this adaptor configuration has no HIP backward (only the DUSt3R pointmap + confidence adaptor does): "
-                                "run it under torch.no_grad()")
     cout = max(s.o0 + (2 if s.op == UC_AD_MASK else (7 if s.op == UC_AD_COV2D else s.n)) for s in segs)
+    return _program(x, segs, cout)
+
+
+def _program(x, segs, cout):
+    "One pass over the decoded channels; with gradients enabled the pass is recorded with its HIP backward (uc_adaptor_program_bwd)."
+    if autograd.grad_needed(x):
+        return autograd.adaptor_program(_as_f32_map(x), segs, cout)
     return ops.adaptor_program(_as_f32_map(x), segs, cout)
 
 
@@ -280,14 +284,13 @@ class Covariance2DAdaptor(UniCeptionAdaptorBase):
 
     @staticmethod
     def _decode(x, offset):
-        out = ops.adaptor_program(_as_f32_map(x), [_seg(UC_AD_COV2D, 0, 3, 0, p=(offset, 0, 0, 0))], 7)
+        out = _program(x, [_seg(UC_AD_COV2D, 0, 3, 0, p=(offset, 0, 0, 0))], 7)
         return Covariance2DAdaptorOutput(covariance=_bchw(out, 0, 3), log_det=_bchw(out, 3, 4), inv_covariance=_bchw(out, 4, 7), log_representation=x)
 
     def forward(self, adaptor_input: AdaptorInput):
         if self.parametrization != "exp_tanh":
             raise ValueError(f"Invalid parametrization: {self.parametrization}")
         x = adaptor_input.adaptor_feature
-        engine.require_inference(x)
         return self._decode(x, 8.0 if self.low_confidence_init else 0.0)
 
     @classmethod

@@ -480,6 +480,22 @@ def adaptor_program(x: torch.Tensor, segs, cout: int) -> torch.Tensor:
     return out
 
 
+def adaptor_program_bwd(x: torch.Tensor, dout: torch.Tensor, segs) -> torch.Tensor:
+    """Gradient of adaptor_program with respect to x: x as in the forward, dout fp32 NHWC [B,H,W,cout] -> dx with x's strides."""
+    _need_gpu(x, dout)
+    assert x.dtype == torch.float32 and x.dim() == 4 and dout.dtype == torch.float32 and dout.is_contiguous() and dout.dim() == 4
+    B, C, H, W = x.shape
+    assert dout.shape[:3] == (B, H, W)
+    sb, sc, sh, sw = x.stride()
+    if sh != W * sw:
+        raise UcHipError("adaptor_program_bwd: rows of the input map must be densely packed")
+    dx = torch.empty_strided(x.shape, x.stride(), dtype=torch.float32, device=x.device)
+    arr = (_lib.AdaptorSeg * len(segs))(*segs)
+    _lib.check(_lib.load().uc_adaptor_program_bwd(x.data_ptr(), sb, sc, sw, dout.data_ptr(), dx.data_ptr(), B, H, W, C, dout.shape[3],
+                                                  arr, len(segs), _stream()), "uc_adaptor_program_bwd")
+    return dx
+
+
 def conv1x1_to4(feat: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """feat NHWC [B,H,W,Cin]; w fp32 [4,Cin]; b fp32 [4] -> fp32 NHWC [B,H,W,4]."""
     _need_gpu(feat, w, b)
