@@ -59,3 +59,9 @@ def adaptor_grad_weight(name, field, shape):
     import torch
     g = torch.Generator().manual_seed(sum(map(ord, name + "/" + field)) + 1013)
     return torch.randn(*shape, generator=g)
+
+
+def dpt_grad_weight(name, shape):
+    import torch
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + 2027)
+    return torch.randn(*shape, generator=g)

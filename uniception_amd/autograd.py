@@ -640,6 +640,55 @@ def conv1x1(x, conv):
     return y.view(B, H, W, -1)
 
 
+def padded_conv1x1_weights(conv, dt, cpad):
+    "Conv2d(k=1) weights with the output channels padded by zero rows to `cpad` (the 8-channel granule of the NHWC kernels)."
+    n = conv.out_channels
+
+    def build():
+        w = torch.zeros(cpad, conv.in_channels, device=conv.weight.device)
+        w[:n] = conv.weight.detach().reshape(n, -1).float()
+        b = torch.zeros(cpad, device=conv.weight.device)
+        if conv.bias is not None:
+            b[:n] = conv.bias.detach().float()
+        return w.to(dt).contiguous(), b
+    return engine.prepared(conv, ("c1pad", dt), (conv.weight, conv.bias), build)
+
+
+class PaddedConv1x1Fn(Function):
+    """A 1x1 convolution to a channel count that is not a multiple of 8 (DPTSegmentationProcessor's class logits, dpt.py:314-381):
+    computed on `cpad` output columns (zero weight rows), fp32 output [M, cpad]; gradients of the real rows only."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, conv, dt, cpad):
+        x2d = _c(x2d)
+        xb = x2d if x2d.dtype == dt else ops.convert(x2d, dt)
+        w, b = padded_conv1x1_weights(conv, dt, cpad)
+        ctx.save_for_backward(xb)
+        ctx.meta = (conv, dt, x2d.dtype, weight.shape, bias is not None, cpad)
+        return ops.gemm(xb, w, b, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xb,) = ctx.saved_tensors
+        conv, dt, x_dtype, wshape, has_b, cpad = ctx.meta
+        n = wshape[0]
+        dyb = _as_dt(_c(dy), dt)
+        dW, db = _wgrad(dyb, xb, dt, has_b)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            def padded32():
+                w = torch.zeros(cpad, conv.in_channels, device=conv.weight.device)
+                w[:n] = conv.weight.detach().reshape(n, -1).float()
+                return w
+            dx = ops.gemm(dyb, _w_t(conv, "c1pad", (conv.weight,), padded32, dt), out_dtype=x_dtype)
+        return dx, dW[:n].reshape(wshape), (db[:n] if has_b else None), None, None, None
+
+
+def padded_conv1x1(x, conv, dt, cpad):
+    B, H, W, Cin = x.shape
+    return PaddedConv1x1Fn.apply(x.reshape(-1, Cin), conv.weight, conv.bias, conv, dt, cpad).view(B, H, W, cpad)
+
+
 class ConvTransposeFn(Function):
     """ConvTranspose2d(kernel = stride, no padding) = GEMM to (u,v,o) columns + pixel scatter (dpt.py:116-140)."""
 

@@ -187,24 +187,19 @@ class DPTSegmentationProcessor(nn.Module):
     def forward(self, dpt_processor_input: DPTFeatureInput):
         x = dpt_processor_input.features_upsampled_8x
         H, W = dpt_processor_input.target_output_shape
-        engine.require_inference(x, self.conv[0].weight)
         if self.training and self.conv[3].p > 0:
-            raise engine.UcHipError("Dropout in training mode is not supported by the HIP path (call .eval())")
+            raise engine.UcHipError("Dropout in training mode is not supported by the HIP path (call .eval(), or build with p = 0)")
         dt = engine.head_dtype()
-        x = engine.conv3x3(engine.bchw_to_nhwc(x, dt), self.conv[0], act="relu")
         last = self.conv[4]
-        cpad = (self.output_dim + 7) // 8 * 8
-
-        def padded():   # output channels padded with zero rows to the 8-channel granule of the NHWC kernels
-            w = torch.zeros(cpad, last.in_channels, device=last.weight.device)
-            w[:self.output_dim] = last.weight.detach().reshape(self.output_dim, -1).float()
-            b = torch.zeros(cpad, device=last.weight.device)
-            if last.bias is not None:
-                b[:self.output_dim] = last.bias.detach().float()
-            return w.to(dt).contiguous(), b
-        wl, bl = engine.prepared(last, ("c1pad", dt), (last.weight, last.bias), padded)
-        B, Hh, Ww, Cin = x.shape
-        y = ops.gemm(x.view(-1, Cin), wl, bl, out_dtype=torch.float32).view(B, Hh, Ww, cpad)
+        train = engine._train(x, self.conv[0].weight, last.weight)
+        x = engine.conv3x3(engine.bchw_to_nhwc(x, dt), self.conv[0], act="relu")
+        cpad = (self.output_dim + 7) // 8 * 8       # output channels padded with zero rows to the 8-channel granule of the NHWC kernels
+        if train:
+            y = autograd.padded_conv1x1(x, last, dt, cpad)
+        else:
+            wl, bl = autograd.padded_conv1x1_weights(last, dt, cpad)
+            B, Hh, Ww, Cin = x.shape
+            y = ops.gemm(x.view(-1, Cin), wl, bl, out_dtype=torch.float32).view(B, Hh, Ww, cpad)
         y = engine.bilinear(y, H, W)
         return PixelTaskOutput(decoded_channels=y[..., :self.output_dim].permute(0, 3, 1, 2))
 
