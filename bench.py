@@ -223,11 +223,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # UNICEPTION_AMD_BENCH_SHARE_GPU=1: a dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
+    # devices, gloo instead of RCCL — two ranks cannot open one device in an RCCL communicator); the line it prints is marked
+    share = os.environ.get("UNICEPTION_AMD_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from uniception_amd import _lib, engine
     from uniception_amd.models.factory import DUSt3R
@@ -315,6 +322,8 @@ def main():
                                    f"dp{world} (replicated model, bucketed in-place gradient all-reduce over RCCL)")},
         "enc_dec_mfma_frac": round(value / world * gflop_pair * (1 if fwd else 3) / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
+    if share:
+        line["config"]["shared_gpu_dry_run"] = "ranks share devices, gloo process group: control-flow check only, not a measurement"
     if rank == 0 and world == 1 and not fwd and not args.no_roofline and args.precision == "bf16":
         # training: the same kernel family carries the forward and the data-gradient GEMMs (the TN weight-gradient kernel is
         # a separate, smaller share): all dense bf16 uc_gemm launches of a step, forward and backward
