@@ -1,0 +1,40 @@
+"""DINOv2 cases pinned to an independent implementation (HuggingFace transformers' Dinov2Model / Dinov2WithRegistersModel) — shared
+by the golden generator (make_golden_dinov2_hf.py), the oracle test and the GPU test.  Native 37x37 grids only (518 / 14): the two
+implementations resize the position embedding differently for other grids (hub: 0.1-offset scale factor / antialias; HF: plain
+size-based bicubic), so only the native grid is a common ground."""
+import torch
+
+SIZES = {"small": (384, 6), "base": (768, 12), "large": (1024, 16)}   # embed dim, heads
+GAINS = {"pos_embed": 300.0, "cls_token": 10.0, "register_tokens": 20.0}
+DINOV2_HF_CASES = {
+    "small_noreg": dict(size="small", regs=False, layers=2, hw=(518, 518), B=1, seed=11),
+    "small_reg": dict(size="small", regs=True, layers=3, hw=(518, 518), B=1, seed=12),
+    "base_reg": dict(size="base", regs=True, layers=1, hw=(518, 518), B=1, seed=13),
+}
+
+
+def dinov2_image(c):
+    g = torch.Generator().manual_seed(c["seed"])
+    return torch.randn(c["B"], 3, *c["hw"], generator=g)
+
+
+def dinov2_hub_state_dict(c, prefix="model."):
+    "Hub-named parameters (the names DINOv2Encoder / the oracle read) filled by the name-keyed filler."
+    from oracle import dust3r_oracle as O
+    D, _ = SIZES[c["size"]]
+    R = 4 if c["regs"] else 0
+    sd = {"cls_token": torch.empty(1, 1, D), "pos_embed": torch.empty(1, 1 + 37 * 37, D),
+          "patch_embed.proj.weight": torch.empty(D, 3, 14, 14), "patch_embed.proj.bias": torch.empty(D),
+          "norm.weight": torch.empty(D), "norm.bias": torch.empty(D)}
+    if R:
+        sd["register_tokens"] = torch.empty(1, R, D)
+    for i in range(c["layers"]):
+        b = f"blocks.{i}."
+        for n, shp in (("norm1.weight", (D,)), ("norm1.bias", (D,)), ("attn.qkv.weight", (3 * D, D)), ("attn.qkv.bias", (3 * D,)),
+                       ("attn.proj.weight", (D, D)), ("attn.proj.bias", (D,)), ("ls1.gamma", (D,)), ("norm2.weight", (D,)),
+                       ("norm2.bias", (D,)), ("mlp.fc1.weight", (4 * D, D)), ("mlp.fc1.bias", (4 * D,)), ("mlp.fc2.weight", (D, 4 * D)),
+                       ("mlp.fc2.bias", (D,)), ("ls2.gamma", (D,))):
+            sd[b + n] = torch.empty(*shp)
+    sd = {prefix + k: v for k, v in sd.items()}
+    O.fill_state_dict_(sd, gains=GAINS)
+    return sd

@@ -138,3 +138,35 @@ def test_config4_pipeline_matches_oracle_composition_and_trains_with_frozen_enco
     assert all(p.grad is None for p in m.encoder.parameters())
     gnorm = sum(float(p.grad.norm()) for p in m.info_sharing.parameters())
     assert gnorm > 0 and torch.isfinite(torch.tensor(gnorm))
+
+
+@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg"])
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2)])
+def test_matches_huggingface_transformers_golden(gpu, name, mode, tol):
+    """The HIP DINOv2 encoder against goldens of an INDEPENDENT implementation of the published network (transformers'
+    Dinov2Model / Dinov2WithRegistersModel, tests/golden/make_golden_dinov2_hf.py) at the native 518x518 / 37x37 grid of config 3 —
+    the pin this module has in place of the unavailable torch.hub code."""
+    import os
+
+    import numpy as np
+
+    from tests.golden.cases import sample_indices
+    from tests.golden.dinov2_cases import DINOV2_HF_CASES, dinov2_hub_state_dict, dinov2_image
+    from tests.helpers import GOLDEN_DIR
+    from uniception_amd import engine
+    from uniception_amd.models.encoders import encoder_factory
+    from uniception_amd.models.encoders.base import ViTEncoderInput
+    gold = np.load(os.path.join(GOLDEN_DIR, "dinov2_hf.npz"))
+    c = DINOV2_HF_CASES[name]
+    enc = encoder_factory("dinov2", name="d", size=c["size"], with_registers=c["regs"], keep_first_n_layers=c["layers"]).eval()
+    missing = enc.load_state_dict(dinov2_hub_state_dict(c), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    with torch.no_grad(), engine.precision(mode):
+        out = enc.to(gpu)(ViTEncoderInput(image=dinov2_image(c).to(gpu), data_norm_type="dinov2"))
+    feats, regs = out.features.float().cpu().contiguous(), out.registers.float().cpu()
+    assert tuple(feats.shape) == tuple(gold[f"{name}/features__shape"])
+    e_f = rel_l2(feats.flatten()[sample_indices(feats.numel())], gold[f"{name}/features__samples"])
+    e_n = abs(float(feats.double().norm()) - float(gold[f"{name}/features__norm"])) / float(gold[f"{name}/features__norm"])
+    e_r = rel_l2(regs, gold[f"{name}/registers"])
+    print(f"\n[dinov2 {mode} vs transformers {gold['transformers_version']}] {name}: features {e_f:.2e} (norm {e_n:.1e}), cls/registers {e_r:.2e}")
+    assert e_f < tol and e_n < tol and e_r < tol

@@ -47,3 +47,29 @@ def test_rope_roundtrip_and_quarters():
     assert torch.equal(r[:, :, 0], t[:, :, 0])  # token (0,0)
     # the x-half is untouched for tokens in column 0, the y-half for tokens in row 0
     assert torch.equal(r[:, :, 3, 32:], t[:, :, 3, 32:]) and torch.equal(r[:, :, 1, :32], t[:, :, 1, :32])
+
+
+@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg"])
+def test_oracle_dinov2_matches_huggingface_transformers(name):
+    """The oracle's restatement of the DINOv2 ViT (cls token, registers inserted after the position embedding, LayerScale, erf-GELU,
+    final LayerNorm) against an independent implementation of the same published network: transformers' Dinov2Model /
+    Dinov2WithRegistersModel (tests/golden/make_golden_dinov2_hf.py).  The hub code the reference loads is not available here."""
+    import os
+
+    import numpy as np
+
+    from tests.golden.cases import sample_indices
+    from tests.golden.dinov2_cases import DINOV2_HF_CASES, SIZES, dinov2_hub_state_dict, dinov2_image
+    from tests.helpers import GOLDEN_DIR, rel_l2
+    gold = np.load(os.path.join(GOLDEN_DIR, "dinov2_hf.npz"))
+    c = DINOV2_HF_CASES[name]
+    with torch.no_grad():
+        feats, regs = O.dinov2_encoder(dinov2_image(c), dinov2_hub_state_dict(c), "model.", num_heads=SIZES[c["size"]][1],
+                                       num_registers=4 if c["regs"] else 0)
+    assert tuple(feats.shape) == tuple(gold[f"{name}/features__shape"])
+    idx = sample_indices(feats.numel())
+    e_f = rel_l2(feats.flatten()[idx], gold[f"{name}/features__samples"])
+    e_n = abs(float(feats.double().norm()) - float(gold[f"{name}/features__norm"])) / float(gold[f"{name}/features__norm"])
+    e_r = rel_l2(regs, gold[f"{name}/registers"])
+    print(f"\n[oracle vs transformers {gold['transformers_version']}] {name}: features {e_f:.2e} (norm {e_n:.1e}), cls/registers {e_r:.2e}")
+    assert e_f < 2e-5 and e_n < 2e-5 and e_r < 2e-5
