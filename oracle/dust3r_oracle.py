@@ -276,12 +276,14 @@ def pointmap_adaptor(x: Tensor, conf_vmin: float = 1.0, conf_vmax: float = float
 
 
 # ---------------------------------------------------------------------------------------------
-# DINOv2 ViT-S/B/L-14 encoder (BASELINE config 4).  PARITY UNPINNED: the reference loads this network from torch.hub
+# DINOv2 ViT-S/B/L-14 encoder (BASELINE config 4).  The reference loads this network from torch.hub
 # ("facebookresearch/dinov2", encoders/dinov2.py:91-102) — third-party, not vendored, no pinned revision, not fetchable
 # here — so this is a restatement of the PUBLISHED architecture (prepare_tokens_with_masks / interpolate_pos_encoding /
-# NestedTensorBlock without drop-path / forward_features), anchored only on the reference's call sites
-# (encoders/dinov2.py:140-163 SDPA attention, :188-216 output split).  It checks the HIP module against the same reading
-# of the architecture, nothing more.
+# NestedTensorBlock without drop-path / forward_features), anchored on the reference's call sites
+# (encoders/dinov2.py:140-163 SDPA attention, :188-216 output split) and PINNED at the native 37x37 grid to an independent
+# implementation of the same network: HuggingFace transformers 5.15.0's Dinov2Model / Dinov2WithRegistersModel
+# (tests/golden/make_golden_dinov2_hf.py -> dinov2_hf.npz; agreement ~1e-7).  PARITY UNPINNED for other grids: the hub's
+# position-embedding resize (dinov2_pos_embed below) is restated from the published code only — transformers resizes differently.
 # ---------------------------------------------------------------------------------------------
 def dinov2_pos_embed(sd: SD, prefix: str, h0: int, w0: int, num_registers: int) -> Tensor:
     pe = sd[prefix + "pos_embed"].float()

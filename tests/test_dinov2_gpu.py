@@ -1,7 +1,8 @@
-"""DINOv2 encoder (BASELINE config 4) on the HIP kernels vs the oracle's restatement of the published architecture.
-PARITY UNPINNED: the reference fetches this network from torch.hub (not vendored, no network here), so there is no reference
-output to pin either side to; these tests only prove that the HIP module and the CPU restatement implement the same
-reading of the architecture (cls token, resized position embedding, registers, LayerScale, output split)."""
+"""DINOv2 encoder (BASELINE config 4) on the HIP kernels.  The reference fetches this network from torch.hub (not vendored, no network
+here): at the native 37x37 grid the module is pinned to goldens of an independent implementation (transformers' Dinov2Model /
+Dinov2WithRegistersModel, test_matches_huggingface_transformers_golden); for other grids (resized position embedding — PARITY
+UNPINNED) the tests prove that the HIP module and the oracle's restatement implement the same reading of the published code (cls
+token, resized position embedding, registers, LayerScale, output split)."""
 import pytest
 import torch
 

@@ -5,8 +5,9 @@ The reference obtains the network itself from `torch.hub.load("facebookresearch/
 `DinoVisionTransformerParams` below therefore restates the PUBLISHED DINOv2 ViT architecture (ViT-S/B/L-14: patch 14,
 cls token, learned position embedding stored for a 37x37 grid and bicubically resized to other grids, optional 4 register
 tokens, pre-LN blocks with LayerScale, erf-GELU MLP, final LayerNorm eps 1e-6) with the hub checkpoints' parameter names so
-their `state_dict`s load unchanged.  PARITY UNPINNED: there is no reference output to compare against in this container;
-the GPU tests check this module against oracle/dust3r_oracle.py's restatement of the same published architecture only.
+their `state_dict`s load unchanged.  Pinned, at the native 37x37 grid, to an independent implementation of the same network
+(HuggingFace transformers' Dinov2Model / Dinov2WithRegistersModel: tests/golden/dinov2_hf.npz); PARITY UNPINNED for resized
+position embeddings (other grids), where the GPU tests check this module against the oracle's restatement of the hub code only.
 
 Kernel mapping: patch gather + GEMM (K = 588: fp32 GEMM, 0.1 % of the FLOPs) -> uc_assemble_tokens (cls + pos, registers,
 patches + pos) -> per block: LayerNorm -> QKV GEMM with the VT epilogue (no RoPE) -> flash attention -> proj GEMM with
