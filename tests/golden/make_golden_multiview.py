@@ -61,10 +61,10 @@ def main():
 def grads():
     """Gradient fixtures (multiview_grads.npz): the reference's own autograd through its global / alternating transformer."""
     from tests.golden.cases import sample_indices
-    from tests.golden.multiview_cases import MV_GRAD_CASES, grad_weights, output_list
+    from tests.golden.multiview_cases import MV_GRAD_CASES, case, grad_weights, output_list
     store = {}
     for name in MV_GRAD_CASES:
-        key, extra, V, Tp, G, indices = MV_CASES[name]
+        key, extra, V, Tp, G, indices = case(name)
         assert indices is None
         cls, _ = INFO_SHARING_CLASSES[key]
         model = cls(name=name, **DIMS, **resolve(extra, RoPE2D)).train()
@@ -92,4 +92,7 @@ def grads():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["grads"]:      # only the gradient fixtures (multiview.npz untouched)
+        grads()
+    else:
+        main()

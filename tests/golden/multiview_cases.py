@@ -12,13 +12,24 @@ MV_CASES = {
     "alt_tokens_v2": ("alternating_attention", dict(use_pe_for_non_reference_views=True, use_rand_idx_pe_for_non_reference_views=True), 2, 2, 3, None),
     "alt_ifr_v4": ("alternating_attention", dict(custom_positional_encoding="ROPE_OBJECT", init_values=0.5), 4, 0, 0, 2),
 }
+# gradient-fixture-only cases (no forward golden in multiview.npz): LayerScale blocks (init_values) under training
+MV_GRAD_ONLY_CASES = {
+    "alt_ls_v2": ("alternating_attention", dict(custom_positional_encoding="ROPE_OBJECT", init_values=0.5), 2, 0, 0, None),
+    "global_ls_tokens_v2": ("global_attention", dict(use_rand_idx_pe_for_non_reference_views=False, init_values=0.7), 2, 1, 2, None),
+}
+
+
+def case(name):
+    return MV_CASES[name] if name in MV_CASES else MV_GRAD_ONLY_CASES[name]
+
+
 # "ROPE_OBJECT": a RoPE2D(100.0) instance of the side that builds the model (only the global transformer resolves the string "rope")
 RAND_SEED = 1234      # torch.manual_seed before every forward: the random view-index draw (global_attention_transformer.py:378-380)
 
 
 def inputs(name):
     import torch
-    _, _, V, Tp, G, _ = MV_CASES[name]
+    _, _, V, Tp, G, _ = case(name)
     g = torch.Generator().manual_seed(sum(map(ord, name)))
     feats = [torch.randn(B, DIMS["input_embed_dim"], H, W, generator=g) for _ in range(V)]
     per_view = [torch.randn(B, DIMS["input_embed_dim"], Tp, generator=g) for _ in range(V)] if Tp else None
@@ -42,7 +53,7 @@ def resolve(extra, rope_cls):
 
 # cases that also have a gradient fixture (multiview_grads.npz): reference autograd of  L = sum_k <out_k, R_k>  over every output
 # tensor (per-view features, extra-token features), R_k seeded
-MV_GRAD_CASES = ("global_rope_v3", "alt_tokens_v2")
+MV_GRAD_CASES = ("global_rope_v3", "alt_tokens_v2", "alt_ls_v2", "global_ls_tokens_v2")
 
 
 def grad_weights(name, shapes):

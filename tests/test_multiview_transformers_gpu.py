@@ -64,19 +64,19 @@ def test_multiview_transformer_parity(gpu, name, mode, tol):
     print(f"\n[{mode}] {name}: worst rel-L2 {worst:.2e} over {len(want)} tensors")
 
 
-@pytest.mark.parametrize("name", ["global_rope_v3", "alt_tokens_v2"])
+@pytest.mark.parametrize("name", ["global_rope_v3", "alt_tokens_v2", "alt_ls_v2", "global_ls_tokens_v2"])   # = multiview_cases.MV_GRAD_CASES
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_multiview_transformer_gradients_match_reference_autograd(gpu, name, mode):
     """Training through the global / alternating transformers: HIP forward + backward sub-layers against the reference's own
     autograd (tests/golden/multiview_grads.npz: L = sum of <output, seeded cotangent> over every output tensor) — gradients of the
     input features, of the extra tokens and of every parameter.  fp32 mode: rel-L2 < 1e-3; bf16 mode: cosine > 0.999."""
     from tests.golden.cases import sample_indices
-    from tests.golden.multiview_cases import grad_weights, output_list
+    from tests.golden.multiview_cases import case, grad_weights, output_list
     from uniception_amd import engine
     from uniception_amd.models.info_sharing import INFO_SHARING_CLASSES, MultiViewTransformerInput
     from uniception_amd.models.libs.croco.pos_embed import RoPE2D
     gold = np.load(os.path.join(GOLDEN_DIR, "multiview_grads.npz"))
-    key, extra, V, Tp, G, indices = MV_CASES[name]
+    key, extra, V, Tp, G, indices = case(name)
     cls, _ = INFO_SHARING_CLASSES[key]
     model = cls(name=name, **DIMS, **resolve(extra, RoPE2D)).train()
     fill(model)

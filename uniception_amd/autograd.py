@@ -289,6 +289,26 @@ def patch_embed(img, conv, P, dt):
     return PatchEmbedFn.apply(img, conv.weight, conv.bias, conv, P, dt)
 
 
+# LayerScale behind a sub-layer's output linear (DINOv2 blocks, SelfAttentionBlock(init_values=...)): the forward runs the linear with
+# the folded weights W_f = gamma[:,None] W, b_f = gamma b (engine.layerscale_lin_weights — zero kernel work); the backward takes the
+# gradients of the FOLDED parameters from the usual weight-gradient GEMM and unfolds them:
+#   dW = gamma[:,None] dW_f,  db = gamma db_f,  dgamma = rowsum(dW_f * W) + db_f * b.
+def _folded_weight_t(lin, gamma, dt):
+    return _w_t(lin, "ls", (lin.weight, gamma),
+                lambda: (lin.weight.detach().float() * gamma.detach().float()[:, None]).contiguous(), dt)
+
+
+def _unfold_layerscale(lin, gamma, dWf, dbf):
+    W = lin.weight.detach().float()
+    g = gamma.detach().float()
+    dgamma = (dWf * W).sum(1)
+    db = None
+    if dbf is not None:
+        dgamma = dgamma + dbf * lin.bias.detach().float()
+        db = dbf * g
+    return dWf * g[:, None], db, dgamma.to(gamma.dtype)
+
+
 # =================================================================================================================
 # pre-LN sub-layers of the transformer blocks
 # =================================================================================================================
@@ -296,7 +316,7 @@ class SelfAttnSubLayerFn(Function):
     """x + proj(SDPA(rope(q), rope(k), v)),  q,k,v = qkv(LN(x))   (blocks.py:105-125,154-158; transformer_blocks.py:214-260)."""
 
     @staticmethod
-    def forward(ctx, x2d, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, ln, qkv, proj, B, N, H, rope, pos, scale, dt):
+    def forward(ctx, x2d, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None):
         x2d = _c(x2d)
         M, C = x2d.shape
         Dh = C // H
@@ -304,7 +324,8 @@ class SelfAttnSubLayerFn(Function):
         g, bta = engine.ln_params(ln)
         h = ops.layernorm(x2d, g, bta, ln.eps, dt)
         wq, bq = engine.lin_weights(qkv, dt)
-        wp, bp = engine.lin_weights(proj, dt)
+        wp, bp = engine.lin_weights(proj, dt) if gamma is None else engine.layerscale_lin_weights(proj, gamma, dt)
+        ctx.gamma = gamma
         if dt == torch.bfloat16 and rope is not None:
             if Dh != 64:
                 raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh})")
@@ -331,8 +352,14 @@ class SelfAttnSubLayerFn(Function):
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
-        do = ops.gemm(dyb, lin_weight_t(proj, dt))
+        dgamma = None
+        if ctx.gamma is None:
+            dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
+            do = ops.gemm(dyb, lin_weight_t(proj, dt))
+        else:
+            dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp)
+            dWp, dbp, dgamma = _unfold_layerscale(proj, ctx.gamma, dWp, dbp)
+            do = ops.gemm(dyb, _folded_weight_t(proj, ctx.gamma, dt))
         dt3 = torch.empty_like(t)
         d5, t5 = dt3.view(B, N, 3, H, Dh), t.view(B, N, 3, H, Dh)
         ops.attention_bwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale,
@@ -343,12 +370,13 @@ class SelfAttnSubLayerFn(Function):
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
-        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10
+        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10 + (dgamma,)
 
 
-def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt):
+def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None):
+    "gamma: LayerScale on the sub-layer's output (x + gamma * proj(...)), or None."
     return SelfAttnSubLayerFn.apply(x2d, ln.weight, ln.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, ln, qkv, proj,
-                                    B, N, H, rope, pos, scale, dt)
+                                    B, N, H, rope, pos, scale, dt, gamma)
 
 
 class CrossAttnSubLayerFn(Function):
@@ -442,12 +470,13 @@ class MlpSubLayerFn(Function):
     """x + fc2(act(fc1(LN(x))))   (blocks.py:64-86,159; transformer_blocks.py:517-560)."""
 
     @staticmethod
-    def forward(ctx, x2d, ln_w, ln_b, w1_, b1_, w2_, b2_, ln, fc1, fc2, act, dt):
+    def forward(ctx, x2d, ln_w, ln_b, w1_, b1_, w2_, b2_, ln, fc1, fc2, act, dt, gamma=None):
         x2d = _c(x2d)
         g, bta = engine.ln_params(ln)
         h = ops.layernorm(x2d, g, bta, ln.eps, dt)
         w1, b1 = engine.lin_weights(fc1, dt)
-        w2, b2 = engine.lin_weights(fc2, dt)
+        w2, b2 = engine.lin_weights(fc2, dt) if gamma is None else engine.layerscale_lin_weights(fc2, gamma, dt)
+        ctx.gamma = gamma
         u = torch.empty((x2d.shape[0], w1.shape[0]), dtype=dt, device=x2d.device)
         a = ops.gemm(h, w1, b1, act=act, preact_out=u)
         out = ops.gemm(a, w2, b2, residual=x2d, out_dtype=x2d.dtype)
@@ -461,8 +490,14 @@ class MlpSubLayerFn(Function):
         ln, fc1, fc2, act, dt, has_b1, has_b2 = ctx.meta
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
-        dW2, db2 = _wgrad(dyb, a, dt, has_b2, sink=[(fc2.weight, 0, fc2.weight.shape[0])], bias_sink=[fc2.bias])
-        w2t = lin_weight_t(fc2, dt)
+        dgamma = None
+        if ctx.gamma is None:
+            dW2, db2 = _wgrad(dyb, a, dt, has_b2, sink=[(fc2.weight, 0, fc2.weight.shape[0])], bias_sink=[fc2.bias])
+            w2t = lin_weight_t(fc2, dt)
+        else:
+            dW2, db2 = _wgrad(dyb, a, dt, has_b2)
+            dW2, db2, dgamma = _unfold_layerscale(fc2, ctx.gamma, dW2, db2)
+            w2t = _folded_weight_t(fc2, ctx.gamma, dt)
         if act != "none" and dt == torch.bfloat16 and w2t.shape[1] % 64 == 0:
             du = ops.gemm(dyb, w2t, dact=(u, act))          # act'(u) applied in the data-gradient GEMM's epilogue
         else:
@@ -472,11 +507,12 @@ class MlpSubLayerFn(Function):
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
         dg, db = torch.zeros_like(g), torch.zeros_like(g)
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
-        return (dx, dg, db, dW1, db1, dW2, db2) + (None,) * 5
+        return (dx, dg, db, dW1, db1, dW2, db2) + (None,) * 5 + (dgamma,)
 
 
-def mlp_sublayer(x2d, ln, fc1, fc2, act, dt):
-    return MlpSubLayerFn.apply(x2d, ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln, fc1, fc2, act, dt)
+def mlp_sublayer(x2d, ln, fc1, fc2, act, dt, gamma=None):
+    "gamma: LayerScale on the sub-layer's output (x + gamma * fc2(...)), or None."
+    return MlpSubLayerFn.apply(x2d, ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln, fc1, fc2, act, dt, gamma)
 
 
 # =================================================================================================================

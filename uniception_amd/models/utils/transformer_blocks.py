@@ -184,11 +184,11 @@ class SelfAttentionBlock(nn.Module):
         if not isinstance(sa.q_norm, nn.Identity):
             raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
         if autograd.grad_needed(x2d, self.norm1.weight, self.mlp.fc1.weight):   # HIP forward + HIP backward sub-layers
-            if not (isinstance(self.ls1, nn.Identity) and isinstance(self.ls2, nn.Identity)):
-                raise engine.UcHipError("LayerScale has no HIP backward: freeze the block or use init_values=None")
+            g1 = None if isinstance(self.ls1, nn.Identity) else self.ls1.gamma       # LayerScale: folded weights forward, unfolded gradients
+            g2 = None if isinstance(self.ls2, nn.Identity) else self.ls2.gamma
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, N, sa.num_heads, sa.custom_positional_encoding,
-                                              xpos, sa.scale * _softmax_scale_multiplier(sa, N), dt)
-            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt)
+                                              xpos, sa.scale * _softmax_scale_multiplier(sa, N), dt, gamma=g1)
+            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, gamma=g2)
         proj_wb = None if isinstance(self.ls1, nn.Identity) else engine.layerscale_lin_weights(sa.proj, self.ls1.gamma, dt)
         fc2_wb = None if isinstance(self.ls2, nn.Identity) else engine.layerscale_lin_weights(self.mlp.fc2, self.ls2.gamma, dt)
         h, fold = engine.ln_operand(x2d, self.norm1, dt)
