@@ -38,3 +38,12 @@ def dinov2_hub_state_dict(c, prefix="model."):
     sd = {prefix + k: v for k, v in sd.items()}
     O.fill_state_dict_(sd, gains=GAINS)
     return sd
+
+
+# cases that also carry gradients (transformers' autograd): loss = <features, Wf> + <cls/registers, Wr>, seeded cotangents
+DINOV2_HF_GRAD_CASES = ("small_noreg", "small_reg")
+
+
+def dinov2_grad_weights(name, f_shape, r_shape):
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + 4099)
+    return torch.randn(*f_shape, generator=g), torch.randn(*r_shape, generator=g)

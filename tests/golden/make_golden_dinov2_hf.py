@@ -7,7 +7,9 @@ compatible with the hub weights through a key map).
 
 The hub-named parameters of tests/golden/dinov2_cases.py are mapped onto the transformers module (qkv split into query / key / value,
 ls*.gamma -> layer_scale*.lambda1, ...), loaded strictly, and the final-norm token stream of a seeded 518x518 image is stored:
-strided samples + norm of the patch-feature map, the class / register tokens in full (data only)."""
+strided samples + norm of the patch-feature map, the class / register tokens in full; for DINOV2_HF_GRAD_CASES also the gradients
+(transformers' autograd) of loss = <features, Wf> + <class / register tokens, Wr> with respect to every parameter, mapped back to the
+hub names (query / key / value -> attn.qkv, lambda1 -> gamma): 512 strided samples + norm each (data only)."""
 import os
 import sys
 
@@ -20,7 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from tests.golden.cases import sample_indices  # noqa: E402
-from tests.golden.dinov2_cases import DINOV2_HF_CASES, SIZES, dinov2_hub_state_dict, dinov2_image  # noqa: E402
+from tests.golden.dinov2_cases import (DINOV2_HF_CASES, DINOV2_HF_GRAD_CASES, SIZES, dinov2_grad_weights, dinov2_hub_state_dict,  # noqa: E402
+                                       dinov2_image)
 
 
 def hub_to_hf(sd, prefix, layers, D, regs):
@@ -71,6 +74,36 @@ def main():
         store[f"{name}/features__shape"] = np.array(feats.shape)
         store[f"{name}/registers"] = regs.numpy()
         print(name, tuple(feats.shape), tuple(regs.shape), f"|features| {feats.norm().item():.4f}")
+        if name in DINOV2_HF_GRAD_CASES:
+            tok = model(pixel_values=dinov2_image(c)).last_hidden_state
+            feats = tok[:, 1 + R:].permute(0, 2, 1).reshape(c["B"], D, h0, w0)
+            regs = tok[:, :1 + R].permute(0, 2, 1)
+            wf, wr = dinov2_grad_weights(name, feats.shape, regs.shape)
+            loss = (feats * wf).sum() + (regs * wr).sum()
+            loss.backward()
+            hf = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+            hub = {"cls_token": hf["embeddings.cls_token"], "pos_embed": hf["embeddings.position_embeddings"],
+                   "patch_embed.proj.weight": hf["embeddings.patch_embeddings.projection.weight"],
+                   "patch_embed.proj.bias": hf["embeddings.patch_embeddings.projection.bias"],
+                   "norm.weight": hf["layernorm.weight"], "norm.bias": hf["layernorm.bias"]}
+            if c["regs"]:
+                hub["register_tokens"] = hf["embeddings.register_tokens"]
+            for i in range(c["layers"]):
+                b, h = f"blocks.{i}.", f"encoder.layer.{i}."
+                a = h + "attention.attention."
+                hub[b + "attn.qkv.weight"] = torch.cat([hf[a + "query.weight"], hf[a + "key.weight"], hf[a + "value.weight"]], 0)
+                hub[b + "attn.qkv.bias"] = torch.cat([hf[a + "query.bias"], hf[a + "key.bias"], hf[a + "value.bias"]], 0)
+                for hub_k, hf_k in (("norm1.weight", "norm1.weight"), ("norm1.bias", "norm1.bias"), ("attn.proj.weight", "attention.output.dense.weight"),
+                                    ("attn.proj.bias", "attention.output.dense.bias"), ("ls1.gamma", "layer_scale1.lambda1"),
+                                    ("norm2.weight", "norm2.weight"), ("norm2.bias", "norm2.bias"), ("mlp.fc1.weight", "mlp.fc1.weight"),
+                                    ("mlp.fc1.bias", "mlp.fc1.bias"), ("mlp.fc2.weight", "mlp.fc2.weight"), ("mlp.fc2.bias", "mlp.fc2.bias"),
+                                    ("ls2.gamma", "layer_scale2.lambda1")):
+                    hub[b + hub_k] = hf[h + hf_k]
+            store[f"{name}/loss"] = np.float64(float(loss.detach()))
+            for k, gr in hub.items():
+                store[f"{name}/grad/model.{k}__samples"] = gr.flatten()[sample_indices(gr.numel(), 512)].float().numpy()
+                store[f"{name}/grad/model.{k}__norm"] = np.float64(gr.double().norm().item())
+            print(name, "gradients of", len(hub), "parameters; loss", float(loss.detach()))
     np.savez_compressed(os.path.join(HERE, "dinov2_hf.npz"), **store)
     print("wrote", os.path.join(HERE, "dinov2_hf.npz"))
 

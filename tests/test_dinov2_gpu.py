@@ -171,3 +171,59 @@ def test_matches_huggingface_transformers_golden(gpu, name, mode, tol):
     e_r = rel_l2(regs, gold[f"{name}/registers"])
     print(f"\n[dinov2 {mode} vs transformers {gold['transformers_version']}] {name}: features {e_f:.2e} (norm {e_n:.1e}), cls/registers {e_r:.2e}")
     assert e_f < tol and e_n < tol and e_r < tol
+
+
+@pytest.mark.parametrize("name", ["small_noreg", "small_reg"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gradients_match_huggingface_transformers_autograd(gpu, name, mode):
+    """The DINOv2 encoder is trainable: gradients of  <features, Wf> + <class / register tokens, Wr>  with respect to every
+    parameter (patch embedding, cls / register tokens, position embedding, LayerScale gammas, all block weights, final norm) against
+    transformers' autograd on the same weights (tests/golden/make_golden_dinov2_hf.py).  fp32 kernels: rel-L2 < 1e-3 per parameter
+    (samples + norm); bf16: cosine over all sampled gradients > 0.999."""
+    import os
+
+    import numpy as np
+
+    from tests.golden.cases import sample_indices
+    from tests.golden.dinov2_cases import DINOV2_HF_CASES, dinov2_grad_weights, dinov2_hub_state_dict, dinov2_image
+    from tests.helpers import GOLDEN_DIR
+    from uniception_amd import engine
+    from uniception_amd.models.encoders import encoder_factory
+    from uniception_amd.models.encoders.base import ViTEncoderInput
+    gold = np.load(os.path.join(GOLDEN_DIR, "dinov2_hf.npz"))
+    c = DINOV2_HF_CASES[name]
+    enc = encoder_factory("dinov2", name="d", size=c["size"], with_registers=c["regs"], keep_first_n_layers=c["layers"]).train()
+    enc.load_state_dict(dinov2_hub_state_dict(c), strict=True)
+    enc = enc.to(gpu)
+    with engine.precision(mode):
+        out = enc(ViTEncoderInput(image=dinov2_image(c).to(gpu), data_norm_type="dinov2"))
+        wf, wr = dinov2_grad_weights(name, out.features.shape, out.registers.shape)
+        loss = (out.features * wf.to(gpu)).sum() + (out.registers * wr.to(gpu)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    want_loss = float(gold[f"{name}/loss"])
+    if mode == "fp32":
+        assert abs(float(loss.detach()) - want_loss) <= 1e-4 * max(1.0, abs(want_loss)), (float(loss.detach()), want_loss)
+    got_all, ref_all, worst, n = [], [], ("", 0.0), 0
+    for k, p in enc.named_parameters():
+        key = f"{name}/grad/{k}__samples"
+        assert key in gold.files, k
+        assert p.grad is not None, k
+        idx = torch.from_numpy(sample_indices(p.grad.numel(), 512)).to(gpu)
+        got = p.grad.flatten()[idx].double().cpu()
+        ref = torch.from_numpy(gold[key]).double()
+        want_n, got_n = float(gold[f"{name}/grad/{k}__norm"]), float(p.grad.double().norm())
+        e = max(rel_l2(got, ref), abs(got_n - want_n) / max(want_n, 1e-30))
+        if e > worst[1]:
+            worst = (k, e)
+        got_all.append(got)
+        ref_all.append(ref)
+        n += 1
+    got_all, ref_all = torch.cat(got_all), torch.cat(ref_all)
+    cos = float(torch.dot(got_all, ref_all) / (got_all.norm() * ref_all.norm()))
+    print(f"\n[dinov2 {mode} grads vs transformers autograd] {name}: {n} parameters, worst {worst[0]} {worst[1]:.2e}, cosine {cos:.6f}")
+    assert n == sum(1 for f in gold.files if f.startswith(f"{name}/grad/") and f.endswith("__samples"))
+    if mode == "fp32":
+        assert worst[1] < 1e-3, worst
+    else:
+        assert cos > 0.999, cos

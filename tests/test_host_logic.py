@@ -115,8 +115,12 @@ def test_training_inputs_are_rejected_not_mishandled():
     one go to the HIP autograd path, which needs a device."""
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    dino = encoder_factory("dinov2", name="d", size="small", keep_first_n_layers=1)   # LayerScale folding: inference only
+    from uniception_amd.models.libs.croco.blocks import Mlp
+    mlp = Mlp(64, 128)            # a bare layer module (the trainable pipelines are the blocks'): inference only
     with pytest.raises(UcHipError, match="backward"):
+        mlp(torch.zeros(2, 3, 64))
+    dino = encoder_factory("dinov2", name="d", size="small", keep_first_n_layers=1)   # trainable: HIP autograd path, needs a device
+    with pytest.raises(UcHipError, match="HIP device only"):
         dino(ViTEncoderInput(image=torch.zeros(1, 3, 28, 28), data_norm_type="dinov2"))
     dino.requires_grad_(False)
     with pytest.raises(UcHipError, match="HIP device only"):

@@ -12,7 +12,11 @@ position embeddings (other grids), where the GPU tests check this module against
 Kernel mapping: patch gather + GEMM (K = 588: fp32 GEMM, 0.1 % of the FLOPs) -> uc_assemble_tokens (cls + pos, registers,
 patches + pos) -> per block: LayerNorm -> QKV GEMM with the VT epilogue (no RoPE) -> flash attention -> proj GEMM with
 LayerScale folded into its weights + residual -> LayerNorm -> fc1 GEMM + GELU -> fc2 GEMM (LayerScale folded) + residual
--> final LayerNorm -> uc_token_slice (patch tokens / cls+registers).  Inference only (LayerScale folding has no backward).
+-> final LayerNorm -> uc_token_slice (patch tokens / cls+registers).
+Training (gradients requested through any parameter): the blocks run as HIP forward + backward sub-layers (autograd.py; LayerScale
+folded forward, unfolded gradients), the patch embedding as autograd.patch_embed; the token assembly (cls / registers / position
+embedding, incl. its bicubic resize) and the output split are a handful of torch ops on small tensors, so that cls_token,
+register_tokens and pos_embed receive their gradients from autograd.
 """
 import math
 from typing import List, Optional, Union
@@ -21,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import engine, ops
+from ... import autograd, engine, ops
 from ..utils.intermediate_feature_return import IntermediateFeatureReturner, feature_take_indices
 from .base import UniCeptionViTEncoderBase, ViTEncoderInput, ViTEncoderOutput
 
@@ -64,6 +68,10 @@ class _Block(nn.Module):
         self.ls2 = _LayerScale(dim)
 
     def forward_tokens(self, x2d, B, N, dt):
+        if autograd.grad_needed(x2d, self.norm1.weight, self.attn.qkv.weight, self.mlp.fc1.weight, self.ls1.gamma):
+            x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads, None, None,
+                                              self.attn.scale, dt, gamma=self.ls1.gamma)
+            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, "gelu", dt, gamma=self.ls2.gamma)
         h = engine.layernorm(x2d, self.norm1, dt)
         x2d = engine.self_attention(h, B, N, self.attn.qkv, self.attn.proj, self.attn.num_heads, None, None, self.attn.scale,
                                     x2d, x2d.dtype, proj_wb=engine.layerscale_lin_weights(self.attn.proj, self.ls1.gamma, dt))
@@ -99,24 +107,26 @@ class DinoVisionTransformerParams(nn.Module):
         if self.register_tokens is not None:
             nn.init.normal_(self.register_tokens, std=1e-6)
 
+    def _resized_pos_embed(self, pe: torch.Tensor, h0: int, w0: int) -> torch.Tensor:
+        "[1+h0*w0, D]: class position + the patch grid resized bicubically (published `interpolate_pos_encoding`); differentiable."
+        N = pe.shape[1] - 1
+        M = int(math.sqrt(N))
+        assert N == M * M
+        if (h0, w0) == (M, M):
+            return pe[0]
+        grid = pe[:, 1:].reshape(1, M, M, -1).permute(0, 3, 1, 2)
+        if self.interpolate_offset:
+            kw = dict(scale_factor=(float(h0 + self.interpolate_offset) / M, float(w0 + self.interpolate_offset) / M))
+        else:
+            kw = dict(size=(h0, w0))
+        grid = F.interpolate(grid, mode="bicubic", antialias=self.interpolate_antialias, **kw)
+        assert tuple(grid.shape[-2:]) == (h0, w0)
+        return torch.cat([pe[0, :1], grid.permute(0, 2, 3, 1).reshape(h0 * w0, -1)], 0)
+
     def interpolated_pos_embed(self, h0: int, w0: int) -> torch.Tensor:
-        """[1+h0*w0, D] fp32: class position + the patch grid resized bicubically (published `interpolate_pos_encoding`)."""
-        def build():
-            pe = self.pos_embed.detach().float()
-            N = pe.shape[1] - 1
-            M = int(math.sqrt(N))
-            assert N == M * M
-            if (h0, w0) == (M, M):
-                return pe[0].contiguous()
-            grid = pe[:, 1:].reshape(1, M, M, -1).permute(0, 3, 1, 2)
-            if self.interpolate_offset:
-                kw = dict(scale_factor=(float(h0 + self.interpolate_offset) / M, float(w0 + self.interpolate_offset) / M))
-            else:
-                kw = dict(size=(h0, w0))
-            grid = F.interpolate(grid, mode="bicubic", antialias=self.interpolate_antialias, **kw)
-            assert tuple(grid.shape[-2:]) == (h0, w0)
-            return torch.cat([pe[0, :1], grid.permute(0, 2, 3, 1).reshape(h0 * w0, -1)], 0).contiguous()
-        return engine.prepared(self, ("pos", h0, w0), (self.pos_embed,), build)
+        "Inference: the resized table, cached per grid and per version of pos_embed."
+        return engine.prepared(self, ("pos", h0, w0), (self.pos_embed,),
+                               lambda: self._resized_pos_embed(self.pos_embed.detach().float(), h0, w0).contiguous())
 
 
 class DINOv2Encoder(UniCeptionViTEncoderBase):
@@ -158,8 +168,10 @@ class DINOv2Encoder(UniCeptionViTEncoderBase):
         assert C == 3, "Input must have 3 channels"
         assert H % self.patch_size == 0 and W % self.patch_size == 0, \
             f"Input shape must be divisible by patch size: {self.patch_size}"
-        engine.require_inference(encoder_input.image, self.model.cls_token)
         return B, H // self.patch_size, W // self.patch_size
+
+    def _train(self, image) -> bool:
+        return autograd.grad_needed(image, *self.model.parameters())
 
     def _tokens(self, image, h0, w0):
         m = self.model
@@ -167,6 +179,15 @@ class DINOv2Encoder(UniCeptionViTEncoderBase):
         dt = engine.compute_dtype()
         pdt = dt if (3 * P * P) % 8 == 0 else torch.float32
         img = image.float().contiguous() if (image.dtype != torch.float32 or not image.is_contiguous()) else image
+        if self._train(image):
+            B = image.shape[0]
+            tok = autograd.patch_embed(img, m.patch_embed.proj, P, pdt).view(B, h0 * w0, -1)
+            pe = m._resized_pos_embed(m.pos_embed.float(), h0, w0)
+            parts = [(m.cls_token.float() + pe[:1]).expand(B, -1, -1)]
+            if m.register_tokens is not None:          # registers are inserted AFTER the position embedding was added: none for them
+                parts.append(m.register_tokens.float().expand(B, -1, -1))
+            parts.append(tok + pe[1:])
+            return torch.cat(parts, dim=1).contiguous(), dt
         cols = ops.patch_gather(img, P, pdt)
         w, b = engine.patch_weights(m.patch_embed.proj, pdt)
         tok = ops.gemm(cols, w, b, out_dtype=torch.float32).view(image.shape[0], h0 * w0, -1)
@@ -184,6 +205,8 @@ class DINOv2Encoder(UniCeptionViTEncoderBase):
     def _split(self, xn, B, h0, w0):
         "normed [B,Nt,D] -> (features BCHW view, registers [B,D,1+R])"
         R = self.model.num_register_tokens
+        if xn.requires_grad:      # training: plain (differentiable) slices
+            return xn[:, 1 + R:].reshape(B, h0, w0, -1).permute(0, 3, 1, 2), xn[:, :1 + R].permute(0, 2, 1).contiguous()
         patches = ops.token_slice(xn, 1 + R, h0 * w0)
         extra = ops.token_slice(xn, 0, 1 + R)
         return engine.nlc_as_bchw(patches.view(B * h0 * w0, -1), B, h0, w0), extra.permute(0, 2, 1).contiguous()
@@ -230,6 +253,10 @@ class DINOv2IntermediateFeatureReturner(DINOv2Encoder, IntermediateFeatureReturn
             x2d = blk.forward_tokens(x2d, B, Nt, dt)
             if i in take:
                 xn = (self._final_norm(x2d) if self.norm_intermediate else x2d).view(B, Nt, D)
+                if xn.requires_grad:
+                    outs.append(ViTEncoderOutput(features=xn[:, 1 + R:].reshape(B, h0, w0, D).permute(0, 3, 1, 2),
+                                                 registers=xn[:, :1].permute(0, 2, 1).contiguous()))
+                    continue
                 patches = ops.token_slice(xn, 1 + R, h0 * w0)
                 cls = ops.token_slice(xn, 0, 1)
                 outs.append(ViTEncoderOutput(features=engine.nlc_as_bchw(patches.view(B * h0 * w0, D), B, h0, w0),
