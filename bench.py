@@ -85,8 +85,11 @@ def roofline_pass(step_fn, v1, precision, steps):
             nbytes += kw["residual"].numel() * kw["residual"].element_size()            # ... + the residual read by the epilogue
         if kw.get("vt") is not None:
             nbytes += 2.0 * M_ * (N_ - out.shape[1])                                     # ... + the V columns stored as packed VT
-        if getattr(out, "uc_ln", None) is not None:
-            nbytes += 2.0 * M_ * N_ + 8.0 * M_ * (N_ // 64)                              # ... + the bf16 twin and the row statistics of the LayerNorm fold (producer)
+        side = getattr(out, "uc_ln", None)
+        if side is not None:
+            nbytes += 8.0 * M_ * (N_ // 64)                                              # ... + the row statistics of the LayerNorm fold (producer)
+            if side.twin is not out:
+                nbytes += 2.0 * M_ * N_                                                  # ... + the bf16 twin of an fp32 stream (a bf16 stream is its own twin)
         if kw.get("ln") is not None:
             nbytes += 8.0 * M_ + 4.0 * N_                                                # ... + (mean, rstd) per row and the column sums (consumer)
         records.append((e0, e1, 2.0 * M_ * N_ * K_, nbytes))
@@ -318,6 +321,9 @@ def main():
                    "head": args.head, "encoder": args.encoder, "attention": args.attention, "hipgraph": bool(args.graph),
                    "streams": ("1" if (not engine.CONCURRENT or not fwd) else
                                "2 (the two views through the encoder, the two decoder branches and the two heads run as concurrent HIP streams)"),
+                   "residual_stream": ("bf16 (the reference's stream under autocast: bf16 sub-layer outputs added to a bf16 x)"
+                                       if (fwd and args.precision == "bf16" and args.encoder == "croco" and engine.bf16_stream_enabled())
+                                       else "fp32"),
                    "parallelism": (f"dp{world} (independent pairs per rank, no data-path collective)" if fwd else
                                    f"dp{world} (replicated model, bucketed in-place gradient all-reduce over RCCL)")},
         "enc_dec_mfma_frac": round(value / world * gflop_pair * (1 if fwd else 3) / 1e3 / PEAK_BF16_TFLOPS, 4),

@@ -236,3 +236,19 @@ def test_bench_sized_batch_reproduces_the_golden_pair_to_the_bit(gpu):
     report = {}
     compare_to_golden(load_golden("vitl_dpt_512"), {k: v[13:14] for k, v in batch.items()}, c, tol=BF16_TOL["default"], report=report)
     print("\n[bf16] golden pair inside a 20-pair 512x512 batch: " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(report.items())))
+
+
+@pytest.mark.parametrize("name", ["tiny_dpt", "vitl_dpt_512"])
+def test_bf16_mode_with_an_fp32_residual_stream(gpu, name):
+    """engine.bf16_stream(False): bf16 operands with the residual stream kept in fp32 (round 1's policy, more accurate than the
+    reference's bf16 stream) still meets the bf16 bar, and lands closer to the fp32 reference than the default on the features."""
+    from uniception_amd import engine
+    rep = {}
+    for on in (True, False):
+        with engine.bf16_stream(on):
+            tensors, c = run_case(name, gpu, "bf16")
+        r = {}
+        compare_to_golden(load_golden(name), tensors, c, tol=BF16_TOL["default"], report=r)
+        rep[on] = r
+    keys = sorted(rep[True])
+    print(f"\n[bf16 stream vs fp32 stream] {name}: " + ", ".join(f"{k}={rep[True][k]:.1e}/{rep[False][k]:.1e}" for k in keys))

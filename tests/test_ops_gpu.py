@@ -250,6 +250,50 @@ def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     assert rel_l2(vt.cpu().float()[:, :, :, posn].permute(0, 3, 1, 2), full[:, :, 2]) < 6e-3
 
 
+@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6"])
+def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
+    """The producer GEMM of a bf16 residual stream (the reference's stream under autocast): bf16 output = round(acc + bias + bf16
+    residual [+ second residual]) in ONE rounding, row statistics of the STORED (rounded) rows, the output its own twin; ragged M;
+    and the consumer's folded LayerNorm on it."""
+    from uniception_amd import ops
+    if variant != "auto":
+        monkeypatch.setenv("UC_GEMM_VARIANT", variant)
+    g = torch.Generator().manual_seed(78)
+    for M in (520, 256):
+        C, K = 192, 128
+        a = torch.randn(M, K, generator=g).bfloat16()
+        wp = (torch.randn(C, K, generator=g) / math.sqrt(K)).bfloat16()
+        bp = torch.randn(C, generator=g) + 0.7
+        res = (torch.randn(M, C, generator=g) * 2 + 0.5).bfloat16()
+        res2 = torch.randn(M, C, generator=g).bfloat16()
+        for r2 in (None, res2):
+            want = a.float() @ wp.float().t() + bp + res.float() + (0 if r2 is None else r2.float())
+            x = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), residual=res.to(gpu), residual2=None if r2 is None else r2.to(gpu),
+                         out_dtype=torch.bfloat16, emit_ln=True)
+            assert x.dtype == torch.bfloat16 and x.uc_ln.twin is x
+            # one rounding of the fp32 sum: equal to the bf16 of the reference up to the accumulation-order noise at rounding ties
+            xd = x.cpu().float()
+            assert rel_l2(xd, want) < 3e-3
+            assert ((xd - want).abs() <= want.abs() * 2.0 ** -8 + 1e-6).all()
+            st = x.uc_ln.stats(1e-6).cpu().double()
+            assert (st[:, 0] - xd.double().mean(1)).abs().max() < 1e-5, "statistics are those of the stored rows"
+            assert ((st[:, 1] - 1 / torch.sqrt(xd.double().var(1, unbiased=False) + 1e-6)) / st[:, 1]).abs().max() < 1e-5
+        # without a residual (embedding GEMMs)
+        x0 = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), out_dtype=torch.bfloat16, emit_ln=True)
+        assert rel_l2(x0.cpu().float(), a.float() @ wp.float().t() + bp) < 3e-3 and x0.uc_ln.twin is x0
+        # bf16 residual without statistics (the last sub-layer of a stack)
+        x1 = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), residual=res.to(gpu), out_dtype=torch.bfloat16)
+        assert torch.equal(x1.cpu(), ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), residual=res.to(gpu), out_dtype=torch.bfloat16, emit_ln=True).cpu())
+        # consumer: folded LayerNorm on the stream
+        gamma, beta = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+        wq = torch.randn(2 * C, C, generator=g) / math.sqrt(C)
+        bq = torch.randn(2 * C, generator=g)
+        wf = (wq * gamma[None, :]).bfloat16()
+        y = ops.gemm(x, wf.to(gpu), (wq @ beta + bq).to(gpu), ln=(x.uc_ln.stats(1e-6), wf.float().sum(1).to(gpu)))
+        y_ref = F.layer_norm(x.cpu().float(), (C,), gamma, beta, 1e-6) @ wq.t() + bq
+        assert rel_l2(y.cpu().float(), y_ref) < 6e-3
+
+
 @pytest.mark.parametrize("variant", ["0", "1", "2", "3", "6"])
 def test_gemm_bf16_tile_variants(gpu, variant, monkeypatch):
     """Every tile variant of the direct-to-LDS kernel (UC_GEMM_VARIANT is read per call) against the fp32 product, through

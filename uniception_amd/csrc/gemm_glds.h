@@ -47,7 +47,7 @@ struct GldsParams {
     uc_fastdiv dNwg, dPerGroup, dGm, dGmLast;   // exact fast division by tiles_m*tiles_n, group_m*tiles_n, group_m, tiles_m % group_m
     int vec_ok;   // C / residual / bias satisfy the alignment needed by the 4-wide vector epilogue
     // implicit-GEMM 3x3 convolution over an NHWC image (a_mode == UC_A_CONV3X3): K = 9*Cin, Cin % 64 == 0
-    int dbg;      // diagnostics only (UC_GEMM_DBG): 1 skip the in-loop DMA, 2 skip the in-loop barrier, 4 no epilogue, 8 one K-step, 16 generic epilogue only, 32 (eight-wave kernel) no wait for the DMA, 64 (conv) A tiles staged for tap 0 only
+    int dbg;      // diagnostics only (UC_GEMM_DBG): 1 skip the in-loop DMA, 2 skip the in-loop barrier, 4 no epilogue, 8 one K-step, 16 generic epilogue only, 32 (eight-wave kernel) no wait for the DMA, 64 (conv) A tiles staged for tap 0 only, 128 / 256 (fp32 residual epilogue) no residual read / no twin write
     int stagger;  // experiment: 100-MHz ticks of start delay per phase group for the first round of workgroups (0 = off)
     int nt_out;   // output (+ residual) streams of more than half the 256 MB Infinity Cache: non-temporal epilogue loads / stores
     unsigned long long* trace;   // diagnostics (UC_GEMM_TRACE): per-workgroup {start, loop start, loop end, end} 100-MHz ticks + HW id

@@ -5,6 +5,7 @@
 
 void glds_launch_dense_bf16(const GldsParams& p, int variant, hipStream_t st);
 void glds_launch_dense_f32(const GldsParams& p, int variant, hipStream_t st);
+void glds_launch_dense_bs(const GldsParams& p, int variant, hipStream_t st);
 void glds_launch_dense_all(const GldsParams& p, int variant, hipStream_t st);
 void glds_launch_conv(const GldsParams& p, int variant, hipStream_t st);
 
@@ -16,17 +17,21 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool a
     // UC_GEMM_8WAVE: 0 off, 1 bf16-store family (default), 2 every family.
     static int eight = -1;
     if (eight < 0) { const char* e = getenv("UC_GEMM_8WAVE"); eight = e ? atoi(e) : 1; }
-    const bool bf16_fam = plain && p.out_dtype == UC_BF16 && !p.residual;
+    // bf16 residual stream (out bf16 + bf16 residual and / or row statistics): the residual family's drain, 2 + 2 bytes per element
+    const bool bf16_stream = plain && p.out_dtype == UC_BF16 && p.act == UC_ACT_NONE && p.vt_col0 < 0 && p.rope_cols <= 0 && !p.ln_stats &&
+                             ((p.residual && p.res_dtype == UC_BF16) || p.stats_out);
+    const bool bf16_fam = plain && p.out_dtype == UC_BF16 && !p.residual && !bf16_stream;
     if (auto_variant && variant == 2 && p.M % 8 == 0 && p.N % 8 == 0 && (eight == 2 || (eight == 1 && bf16_fam))) variant = 6;
     if (bf16_fam) glds_launch_dense_bf16(p, variant, st);
-    else if (plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0) {
+    else if (bf16_stream || (plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0)) {
         // The fp32 epilogues (residual read + fp32 store + bf16 twin) move 4-5x the bytes of a bf16 store and all CUs reach
         // them together: an HBM burst with idle matrix pipes.  Launches long enough to amortise the ramp (>= 6 tiles per CU)
         // start their first round of workgroups in 8 phase groups 1.5 us apart (by row panel, see the kernel):
         // encoder proj 480 -> 432 us, fc2 1095 -> 1043 us; neutral-to-worse for shorter launches, hence the threshold.
         GldsParams q = p;
         if (q.stagger < 0) q.stagger = ((variant == 2 || variant == 6) && (int64_t)ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 6 * 256) ? 150 : 0;
-        glds_launch_dense_f32(q, variant, st);
+        if (bf16_stream) glds_launch_dense_bs(q, variant, st);
+        else glds_launch_dense_f32(q, variant, st);
         return 0;
     }
     else glds_launch_dense_all(p, variant, st);

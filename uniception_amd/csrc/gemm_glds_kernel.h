@@ -446,9 +446,14 @@ __device__ __forceinline__ float glds_row16_sum(float v) {
 // Producer half of the folded LayerNorm: with p.twin the stored rows are also written as bf16 (the A operand of the next
 // GEMM), with p.stats_out every row's (sum, squared deviations from its own mean) over the wave's 64 columns is written
 // — the row's 16 lanes reduce with DPP row rotations; uc_ln_stats_finalize merges the blocks into (mean, rstd).
-template <int FA, bool NT>
+//
+// BS (bf16 residual stream, the reference's own policy under autocast): C and the residual(s) are bf16 — 2 + 2 bytes per element
+// instead of 4 + 4 + 2; the stored rows ARE the next GEMM's A operand (no twin) and the statistics are those of the ROUNDED values
+// the consumer will normalise.
+template <int FA, bool NT, bool BS = false>
 __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
                                                     int64_t wave_n, int lane, char* wbuf) {
+    constexpr int ES = BS ? 2 : 4;                       // bytes per element of C and of the residual(s)
     const int frow = lane & 15, g = lane >> 4;
     const int crow = lane >> 4, cc = lane & 15;          // drain: 4 columns per lane, 16 lanes per row, 4 rows x 256 B per instruction
     const int64_t nb = wave_n + 4 * cc;
@@ -458,14 +463,16 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
     // wave-uniform 64-bit bases + one 32-bit lane offset per matrix: per-lane 64-bit pointers for C, the residuals, the twin
     // and the statistics cost 10 registers this epilogue does not have (a spill reload between its stores waits for every
     // store issued before it)
-    char* cbase = (char*)p.C + (wave_m * p.ldc + wave_n) * 4;
-    const unsigned coff = (unsigned)(crow * (int)p.ldc + 4 * cc) * 4u;
-    const int64_t cstep = 4 * p.ldc * 4;
-    const char* rbase = p.residual ? (const char*)p.residual + (wave_m * p.ldr + wave_n) * 4 : nullptr;
-    const char* rbase2 = p.residual2 ? (const char*)p.residual2 + (wave_m * p.ldr + wave_n) * 4 : nullptr;
-    const unsigned roff = (unsigned)(crow * (int)p.ldr + 4 * cc) * 4u;
-    const int64_t rstep = 4 * p.ldr * 4;
-    char* tbase = p.twin ? (char*)p.twin + (wave_m * p.ldt + wave_n) * 2 : nullptr;
+    char* cbase = (char*)p.C + (wave_m * p.ldc + wave_n) * ES;
+    const unsigned coff = (unsigned)(crow * (int)p.ldc + 4 * cc) * (unsigned)ES;
+    const int64_t cstep = 4 * p.ldc * ES;
+    // diagnostics (wrong results): dbg & 128 never reads the residual(s), dbg & 256 never writes the twin — together the HBM bytes of
+    // a bf16 residual stream (4 per element instead of 10)
+    const char* rbase = (p.residual && !(p.dbg & 128)) ? (const char*)p.residual + (wave_m * p.ldr + wave_n) * ES : nullptr;
+    const char* rbase2 = (p.residual2 && !(p.dbg & 128)) ? (const char*)p.residual2 + (wave_m * p.ldr + wave_n) * ES : nullptr;
+    const unsigned roff = (unsigned)(crow * (int)p.ldr + 4 * cc) * (unsigned)ES;
+    const int64_t rstep = 4 * p.ldr * ES;
+    char* tbase = (!BS && p.twin && !(p.dbg & 256)) ? (char*)p.twin + (wave_m * p.ldt + wave_n) * 2 : nullptr;
     const unsigned toff = (unsigned)(crow * (int)p.ldt + 4 * cc) * 2u;
     const int64_t tstep = 4 * p.ldt * 2;
     const int nblk = (int)(p.N >> 6);
@@ -476,11 +483,25 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
     auto load_res = [&](int i, int ps) __attribute__((always_inline)) {
         res[ps] = (float4_t){0.f, 0.f, 0.f, 0.f};
         if (rbase && 16 * i + 4 * ps < rows_left) {
-            const float4_t* q = reinterpret_cast<const float4_t*>(rbase + (4 * i + ps) * rstep + roff);
-            if constexpr (NT) res[ps] = __builtin_nontemporal_load(q); else res[ps] = *q;
-            if (rbase2) {
-                const float4_t* q2 = reinterpret_cast<const float4_t*>(rbase2 + (4 * i + ps) * rstep + roff);
-                if constexpr (NT) res[ps] += __builtin_nontemporal_load(q2); else res[ps] += *q2;
+            if constexpr (BS) {
+                typedef unsigned glds_u2_t __attribute__((ext_vector_type(2)));
+                auto up = [](glds_u2_t u) __attribute__((always_inline)) {
+                    return (float4_t){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                      __uint_as_float(u.y & 0xffff0000u)};
+                };
+                const glds_u2_t* q = reinterpret_cast<const glds_u2_t*>(rbase + (4 * i + ps) * rstep + roff);
+                res[ps] = up(NT ? __builtin_nontemporal_load(q) : *q);
+                if (rbase2) {
+                    const glds_u2_t* q2 = reinterpret_cast<const glds_u2_t*>(rbase2 + (4 * i + ps) * rstep + roff);
+                    res[ps] += up(NT ? __builtin_nontemporal_load(q2) : *q2);
+                }
+            } else {
+                const float4_t* q = reinterpret_cast<const float4_t*>(rbase + (4 * i + ps) * rstep + roff);
+                if constexpr (NT) res[ps] = __builtin_nontemporal_load(q); else res[ps] = *q;
+                if (rbase2) {
+                    const float4_t* q2 = reinterpret_cast<const float4_t*>(rbase2 + (4 * i + ps) * rstep + roff);
+                    if constexpr (NT) res[ps] += __builtin_nontemporal_load(q2); else res[ps] += *q2;
+                }
             }
         }
     };
@@ -498,7 +519,17 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
             v += res[ps];
             if (i + 1 < FA) load_res(i + 1, ps);
             const bool row_ok = 16 * i + 4 * ps < rows_left;
-            if (row_ok) {
+            if constexpr (BS) {
+                typedef unsigned glds_u2_t __attribute__((ext_vector_type(2)));
+                const glds_u2_t pk = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+                if (row_ok) {
+                    glds_u2_t* cq = reinterpret_cast<glds_u2_t*>(cbase + (4 * i + ps) * cstep + coff);
+                    if constexpr (NT) __builtin_nontemporal_store(pk, cq); else *cq = pk;
+                }
+                // the statistics below are those of the stored (rounded) row
+                v = (float4_t){__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
+                               __uint_as_float(pk.y & 0xffff0000u)};
+            } else if (row_ok) {
                 // NT (outputs of more than 128 MB, half the Infinity Cache): the residual stream is read once and written once per
                 // sub-layer — streaming it keeps the A / W panels of the K-loop in the L2s (+1.2 % on the forward); smaller
                 // outputs (the decoder's) stay cacheable, their consumer finds them on chip
@@ -776,7 +807,7 @@ __device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&ac
     }
 }
 
-enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2 };
+enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2, GLDS_EPI_BS = 3 };
 
 // Fused narrow tail of a 128-wide tile (two wave columns of 64): out4[m][o] = tail_b[o] + sum_n act(acc[m][n] + bias[n]) * tail_w[o][n].
 // The DPT regressor's conv3x3 -> ReLU -> Conv2d(128 -> 4, 1x1): the 128-channel map is never stored.  Per wave: its 64 columns of
@@ -884,6 +915,9 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
             } else bf16_family();
         } else if constexpr (EPI == GLDS_EPI_F32) {
             f32_family();
+        } else if constexpr (EPI == GLDS_EPI_BS) {          // bf16 residual stream: bf16 output + bf16 residual(s) + row statistics
+            if (pe.nt_out & 1) glds_epilogue_resid<FA, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_resid<FA, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
         } else {
             if constexpr (A_MODE != UC_A_DENSE && FA == 4) {
                 if (pe.tail_out) {      // (launcher: N == 128 on a 128-wide tile, every wave of the workgroup arrives here)
@@ -928,7 +962,8 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
 // EPI selects the epilogue family compiled into an instantiation (the launcher picks the instantiation from the descriptor):
 //   GLDS_EPI_BF16: bf16 stores without residual — plain / activation / RoPE tiles, VT tiles, folded LayerNorm (qkv, fc1, q / kv
 //                  projections, convolutions);   GLDS_EPI_F32: fp32 output (+ fp32 residuals, bf16 twin, row statistics: proj,
-//                  fc2, embeddings);   GLDS_EPI_ALL: the generic drain next to the two fast families (everything else).
+//                  fc2, embeddings);   GLDS_EPI_BS: the same sub-layers on a bf16 residual stream (bf16 output + bf16 residuals +
+//                  row statistics);   GLDS_EPI_ALL: the generic drain next to the fast families (everything else).
 // One family per kernel keeps the register allocation of the 128-VGPR K-loop out of reach of epilogue code it never runs:
 // with all of them inlined into one function, every option added to one epilogue spilled DMA pointers inside the K-loop.
 

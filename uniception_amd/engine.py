@@ -2,8 +2,10 @@
 token-stream / NHWC pipelines that the nn.Module shells in ``uniception_amd.models`` call.
 
 Data layout in HBM
-  * token stream  : [B*N, C] row-major ("NLC"), residual stream fp32 (as the reference keeps it under autocast:
-                    LayerNorm outputs fp32, residual adds promote to fp32), GEMM operands in the compute dtype.
+  * token stream  : [B*N, C] row-major ("NLC"), GEMM operands in the compute dtype.  Residual stream: bf16 in bf16 inference (the
+                    reference's stream under autocast: the patch embedding and every sub-layer's output linear produce bf16, and
+                    bf16 + bf16 stays bf16; only LayerNorm outputs are fp32) — `set_bf16_stream(False)` keeps it in fp32 —
+                    and fp32 in verification mode and in training.
   * q|k buffer    : [B*N, 2C] compute dtype, RoPE already applied by the QKV GEMM epilogue (bf16 mode);
                     V is written by the same GEMM in the packed "VT" layout [B,H,64,Npad] the attention kernel wants.
   * dense maps    : NHWC in the compute dtype inside the DPT head; BCHW-shaped tensors at the public API are
@@ -141,6 +143,39 @@ def set_ln_fold(on: bool) -> None:
 def fold_ok(dt: torch.dtype, *dims: int) -> bool:
     """The folded path exists for bf16 operands without autograd; channel counts must be multiples of the 64-wide tile."""
     return _ln_fold and dt == torch.bfloat16 and not torch.is_grad_enabled() and all(d % 64 == 0 for d in dims)
+
+
+# bf16 residual stream (bf16 inference with the folded LayerNorm): the stream between the sub-layers is stored in bf16 — what the
+# reference's stream is under torch.autocast (bf16 linear outputs added to a bf16 x) — 2 + 2 bytes per element in the residual
+# epilogues instead of 4 + 4 + 2 (fp32 read + fp32 write + bf16 twin): the stored rows ARE the next GEMM's A operand and the row
+# statistics are those of the rounded rows.  Off: the fp32 stream of round 1 (more accurate than the reference's policy).
+_bf16_stream: bool = os.environ.get("UNICEPTION_AMD_BF16_STREAM", "1") != "0"
+
+
+def set_bf16_stream(on: bool) -> None:
+    global _bf16_stream
+    _bf16_stream = bool(on)
+
+
+def bf16_stream_enabled() -> bool:
+    return _bf16_stream and _ln_fold
+
+
+@contextlib.contextmanager
+def bf16_stream(on: bool):
+    "Scoped switch of the residual-stream dtype of bf16 inference (True: bf16, the default; False: fp32)."
+    global _bf16_stream
+    prev = _bf16_stream
+    _bf16_stream = bool(on)
+    try:
+        yield
+    finally:
+        _bf16_stream = prev
+
+
+def stream_dtype(dt: torch.dtype, *dims: int) -> torch.dtype:
+    "dtype of the residual stream a sub-layer pipeline in compute dtype `dt` starts: bf16 where the folded-LayerNorm path runs."
+    return torch.bfloat16 if (_bf16_stream and fold_ok(dt, *dims)) else torch.float32
 
 
 def carry_ln(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
@@ -451,7 +486,7 @@ def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.L
         q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
         q, k = _apply_rope(rope, q, k, pos, pos)
         o = _attention_generic(q, k, v, scale)
-    emit = emit_ln and out_dtype == torch.float32 and fold_ok(dtype, Cd)
+    emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cd)
     return ops.gemm(o.view(M, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
 
@@ -515,7 +550,7 @@ def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk
         k, v = kv[:, :, 0], kv[:, :, 1]
         q, k = _apply_rope(rope, q, k, qpos, kpos)
         o = _attention_generic(q, k, v, scale)
-    emit = emit_ln and out_dtype == torch.float32 and fold_ok(dtype, Cd)
+    emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cd)
     return ops.gemm(o.reshape(B * Nq, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
 
@@ -527,7 +562,7 @@ def mlp(h2d: torch.Tensor, fc1: nn.Linear, fc2: nn.Linear, act: str, residual: O
     w1, b1, ln1 = _folded(fc1, fold, h2d.dtype)
     w2, b2 = fc2_wb if fc2_wb is not None else lin_weights(fc2, h2d.dtype)
     g = ops.gemm(h2d, w1, b1, act=act, ln=ln1)
-    emit = emit_ln and out_dtype == torch.float32 and fold_ok(h2d.dtype, w2.shape[0])
+    emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(h2d.dtype, w2.shape[0])
     return ops.gemm(g, w2, b2, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
 

@@ -154,13 +154,16 @@ class DUSt3R(nn.Module):
 
         feat1, feat2 = self._encode_symmetrized(view1, view2)
         info_in = MultiViewTransformerInput(features=[feat1, feat2])
+
+        def f32(t):      # the reference hands fp32 features to its heads (dust3r.py:288-309); rows of a bf16 residual stream that a bf16
+            return t if (t.dtype == torch.bfloat16 and engine.head_dtype() == torch.bfloat16) else t.float()   # head reads as they are
         if self.pred_head_type == "linear":
             final = self.info_sharing(info_in)
-            outs = {"1": final.features[0].float(), "2": final.features[1].float()}
+            outs = {"1": f32(final.features[0]), "2": f32(final.features[1])}
         else:
             final, inter = self.info_sharing(info_in)
-            outs = {str(v + 1): [(feat1, feat2)[v].float(), inter[0].features[v].float(), inter[1].features[v].float(),
-                                 final.features[v].float()] for v in range(2)}
+            outs = {str(v + 1): [f32((feat1, feat2)[v]), f32(inter[0].features[v]), f32(inter[1].features[v]),
+                                 f32(final.features[v])] for v in range(2)}
 
         with torch.autocast("cuda", enabled=False), engine.ambient(engine.compute_dtype()):
             def head(num, shape):

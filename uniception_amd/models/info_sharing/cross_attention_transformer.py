@@ -121,7 +121,8 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
             x2d = nlc.reshape(B * N, self.input_embed_dim)
             if not isinstance(self.proj_embed, nn.Identity):
                 wpe, bpe = engine.lin_weights(self.proj_embed, dt)
-                x2d = ops.gemm(x2d, wpe, bpe, out_dtype=torch.float32, emit_ln=engine.fold_ok(dt, self.dim, self.input_embed_dim))
+                x2d = ops.gemm(x2d, wpe, bpe, out_dtype=engine.stream_dtype(dt, self.dim, self.input_embed_dim),
+                               emit_ln=engine.fold_ok(dt, self.dim, self.input_embed_dim))
             xs.append(x2d)
         if self.custom_positional_encoding is not None:
             pos = [self.position_getter(B, h, w, f.device) for f in feats]

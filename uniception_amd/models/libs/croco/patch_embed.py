@@ -48,7 +48,7 @@ class PatchEmbedCroCo(nn.Module):
             cols = ops.patch_gather(img, P, dt)
             w, b = engine.patch_weights(self.proj, dt)
             emit = isinstance(self.norm, nn.Identity) and engine.fold_ok(dt, w.shape[0], w.shape[1])   # first block's LayerNorm folds into its QKV GEMM
-            tok2d = ops.gemm(cols, w, b, out_dtype=torch.float32, emit_ln=emit)
+            tok2d = ops.gemm(cols, w, b, out_dtype=engine.stream_dtype(dt, w.shape[0], w.shape[1]) if emit else torch.float32, emit_ln=emit)
             tok = engine.carry_ln(tok2d, tok2d.view(B, (H // P) * (W // P), -1))
         pos = self.position_getter(B, H // P, W // P, x.device)
         if not isinstance(self.norm, nn.Identity):

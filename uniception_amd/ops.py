@@ -126,8 +126,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
            the epilogue computes rstd * (acc - mean * colsum) + bias (bf16 output only).
     tail : (w4 [4,N] fp32, b4 [4] fp32 | None) with N == 128 on a 3x3 convolution — the [M,128] result is not stored; returns
            fp32 [M,4] = b4 + act(acc + bias) . w4^T (the DPT regressor's conv3x3 -> ReLU -> conv1x1(128 -> 4) in one kernel).
-    emit_ln : fp32 output only — also write a bf16 twin of the output and per-row 64-column-block statistics; they ride on the
-           returned tensor as ``out.uc_ln`` (an LnSide: twin, partial, finalized-stats cache) for the consumer's ``ln=``.
+    emit_ln : also write per-row 64-column-block statistics and, for an fp32 output, a bf16 twin of it (a bf16 output — the bf16
+           residual stream — is its own twin); they ride on the returned tensor as ``out.uc_ln`` (an LnSide: twin, partial,
+           finalized-stats cache) for the consumer's ``ln=``.
     """
     _need_gpu(a, w, bias, residual)
     assert a.dtype == w.dtype and w.is_contiguous() and w.dim() == 2
@@ -215,10 +216,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         d.ln_stats, d.ln_colsum = st.data_ptr(), cs.data_ptr()
     side = None
     if emit_ln:
-        assert out.dtype == torch.float32 and out.dim() == 2 and N % 64 == 0 and vt is None
-        side = LnSide(torch.empty((M, N), dtype=torch.bfloat16, device=a.device),
-                      torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device))
-        d.twin_out, d.ldt, d.stats_out = side.twin.data_ptr(), N, side.partial.data_ptr()
+        assert out.dim() == 2 and N % 64 == 0 and vt is None
+        partial = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
+        if out.dtype == torch.bfloat16:      # bf16 residual stream: the stored rows are their own twin
+            assert out.is_contiguous() and (residual is None or residual.dtype == torch.bfloat16)
+            side = LnSide(out, partial)
+            d.stats_out = partial.data_ptr()
+        else:
+            assert out.dtype == torch.float32
+            side = LnSide(torch.empty((M, N), dtype=torch.bfloat16, device=a.device), partial)
+            d.twin_out, d.ldt, d.stats_out = side.twin.data_ptr(), N, side.partial.data_ptr()
     _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
     if side is not None:
         out.uc_ln = side
