@@ -253,7 +253,7 @@ def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
 @pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6"])
 def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
     """The producer GEMM of a bf16 residual stream (the reference's stream under autocast): bf16 output = round(acc + bias + bf16
-    residual [+ second residual]) in ONE rounding, row statistics of the STORED (rounded) rows, the output its own twin; ragged M;
+    residual) in ONE rounding, row statistics of the STORED (rounded) rows, the output its own twin; ragged M;
     and the consumer's folded LayerNorm on it."""
     from uniception_amd import ops
     if variant != "auto":
@@ -265,11 +265,9 @@ def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
         wp = (torch.randn(C, K, generator=g) / math.sqrt(K)).bfloat16()
         bp = torch.randn(C, generator=g) + 0.7
         res = (torch.randn(M, C, generator=g) * 2 + 0.5).bfloat16()
-        res2 = torch.randn(M, C, generator=g).bfloat16()
-        for r2 in (None, res2):
-            want = a.float() @ wp.float().t() + bp + res.float() + (0 if r2 is None else r2.float())
-            x = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), residual=res.to(gpu), residual2=None if r2 is None else r2.to(gpu),
-                         out_dtype=torch.bfloat16, emit_ln=True)
+        for _ in range(1):
+            want = a.float() @ wp.float().t() + bp + res.float()
+            x = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), residual=res.to(gpu), out_dtype=torch.bfloat16, emit_ln=True)
             assert x.dtype == torch.bfloat16 and x.uc_ln.twin is x
             # one rounding of the fp32 sum: equal to the bf16 of the reference up to the accumulation-order noise at rounding ties
             xd = x.cpu().float()

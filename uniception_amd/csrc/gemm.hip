@@ -513,11 +513,11 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         }
         if (d->twin_out || d->stats_out) {
             const bool f32_stream = d->out_dtype == UC_F32 && (!d->residual || d->res_dtype == UC_F32);
-            const bool bf16_stream = d->out_dtype == UC_BF16 && (!d->residual || d->res_dtype == UC_BF16) && !d->twin_out;   // C is its own twin
+            const bool bf16_stream = d->out_dtype == UC_BF16 && (!d->residual || d->res_dtype == UC_BF16) && !d->residual2 && !d->twin_out;   // C is its own twin
             UC_REQUIRE(glds_dense && (f32_stream || bf16_stream) && d->act == UC_ACT_NONE && !d->preact_out && !d->dact_u && d->split_k <= 1 &&
                            d->vt_col0 < 0 && d->rope_cols <= 0 && d->N % 64 == 0,
                        "uc_gemm: twin_out / stats_out need the dense direct-to-LDS kernel, an fp32 stream (fp32 output + fp32 residual) or a bf16 "
-                       "stream (bf16 output + bf16 residual, no twin), N %% 64 == 0");
+                       "stream (bf16 output + ONE bf16 residual, no twin), N %% 64 == 0");
             UC_REQUIRE((uintptr_t)d->C % 16 == 0 && d->ldc % 8 == 0 && (!d->bias || (uintptr_t)d->bias % 16 == 0) &&
                            (!d->residual || ((uintptr_t)d->residual % 16 == 0 && d->ldr % 4 == 0 && (!d->residual2 || (uintptr_t)d->residual2 % 16 == 0))),
                        "uc_gemm: twin_out / stats_out need 16-byte aligned C / bias / residual");

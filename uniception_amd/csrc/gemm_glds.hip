@@ -14,14 +14,15 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool a
     // a descriptor goes to a single-family kernel only when EVERY wave of the launch takes that family's epilogue
     const bool plain = p.vec_ok && p.N % 64 == 0 && p.split_k <= 1 && !p.preact && !p.dact_u && !(p.dbg & 16);
     // 256x256 tiles: the eight-wave form (variant 6, 128x64 per wave, next K-chunk's fragments register-resident) where it wins.
-    // UC_GEMM_8WAVE: 0 off, 1 bf16-store family (default), 2 every family.
+    // UC_GEMM_8WAVE: 0 off, 1 bf16-store family (default), 2 every family, 3 bf16-store family + bf16 residual stream.
     static int eight = -1;
     if (eight < 0) { const char* e = getenv("UC_GEMM_8WAVE"); eight = e ? atoi(e) : 1; }
     // bf16 residual stream (out bf16 + bf16 residual and / or row statistics): the residual family's drain, 2 + 2 bytes per element
     const bool bf16_stream = plain && p.out_dtype == UC_BF16 && p.act == UC_ACT_NONE && p.vt_col0 < 0 && p.rope_cols <= 0 && !p.ln_stats &&
-                             ((p.residual && p.res_dtype == UC_BF16) || p.stats_out);
+                             !p.residual2 && ((p.residual && p.res_dtype == UC_BF16) || p.stats_out);
     const bool bf16_fam = plain && p.out_dtype == UC_BF16 && !p.residual && !bf16_stream;
-    if (auto_variant && variant == 2 && p.M % 8 == 0 && p.N % 8 == 0 && (eight == 2 || (eight == 1 && bf16_fam))) variant = 6;
+    if (auto_variant && variant == 2 && p.M % 8 == 0 && p.N % 8 == 0 &&
+        (eight == 2 || ((eight == 1 || eight == 3) && bf16_fam) || (eight == 3 && bf16_stream))) variant = 6;
     if (bf16_fam) glds_launch_dense_bf16(p, variant, st);
     else if (bf16_stream || (plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0)) {
         // The fp32 epilogues (residual read + fp32 store + bf16 twin) move 4-5x the bytes of a bf16 store and all CUs reach

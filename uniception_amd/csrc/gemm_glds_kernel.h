@@ -478,24 +478,21 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
     const int nblk = (int)(p.N >> 6);
     float2* sbase = p.stats_out ? p.stats_out + wave_m * nblk + (wave_n >> 6) : nullptr;
     // ONE register set for the residual: pass ps of row block i + 1 is requested as soon as pass ps of block i has used
-    // its value (each element is still read before the in-place store of its own row), so 4 loads per lane stay in flight
-    float4_t res[4];
+    // its value (each element is still read before the in-place store of its own row), so 4 loads per lane stay in flight.
+    // (BS: the four bf16 values stay packed — 2 registers — until they are used; one residual only, see the launcher)
+    typedef unsigned glds_u2_t __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<BS, glds_u2_t, float4_t>::type res_t;
+    res_t res[4];
     auto load_res = [&](int i, int ps) __attribute__((always_inline)) {
-        res[ps] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        if (rbase && 16 * i + 4 * ps < rows_left) {
-            if constexpr (BS) {
-                typedef unsigned glds_u2_t __attribute__((ext_vector_type(2)));
-                auto up = [](glds_u2_t u) __attribute__((always_inline)) {
-                    return (float4_t){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                                      __uint_as_float(u.y & 0xffff0000u)};
-                };
+        if constexpr (BS) {
+            res[ps] = (glds_u2_t){0u, 0u};
+            if (rbase && 16 * i + 4 * ps < rows_left) {
                 const glds_u2_t* q = reinterpret_cast<const glds_u2_t*>(rbase + (4 * i + ps) * rstep + roff);
-                res[ps] = up(NT ? __builtin_nontemporal_load(q) : *q);
-                if (rbase2) {
-                    const glds_u2_t* q2 = reinterpret_cast<const glds_u2_t*>(rbase2 + (4 * i + ps) * rstep + roff);
-                    res[ps] += up(NT ? __builtin_nontemporal_load(q2) : *q2);
-                }
-            } else {
+                if constexpr (NT) res[ps] = __builtin_nontemporal_load(q); else res[ps] = *q;
+            }
+        } else {
+            res[ps] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (rbase && 16 * i + 4 * ps < rows_left) {
                 const float4_t* q = reinterpret_cast<const float4_t*>(rbase + (4 * i + ps) * rstep + roff);
                 if constexpr (NT) res[ps] = __builtin_nontemporal_load(q); else res[ps] = *q;
                 if (rbase2) {
@@ -516,11 +513,13 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
         for (int ps = 0; ps < 4; ++ps) {
             float4_t v = glds_bounce_read(buf, 4 * ps + crow, cc);
             if (mode != 1) v += bias4;
-            v += res[ps];
+            if constexpr (BS) {
+                v += (float4_t){__uint_as_float(res[ps].x << 16), __uint_as_float(res[ps].x & 0xffff0000u), __uint_as_float(res[ps].y << 16),
+                                __uint_as_float(res[ps].y & 0xffff0000u)};
+            } else v += res[ps];
             if (i + 1 < FA) load_res(i + 1, ps);
             const bool row_ok = 16 * i + 4 * ps < rows_left;
             if constexpr (BS) {
-                typedef unsigned glds_u2_t __attribute__((ext_vector_type(2)));
                 const glds_u2_t pk = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
                 if (row_ok) {
                     glds_u2_t* cq = reinterpret_cast<glds_u2_t*>(cbase + (4 * i + ps) * cstep + coff);
