@@ -72,12 +72,15 @@ class _Block(nn.Module):
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads, None, None,
                                               self.attn.scale, dt, gamma=self.ls1.gamma)
             return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, "gelu", dt, gamma=self.ls2.gamma)
-        h = engine.layernorm(x2d, self.norm1, dt)
+        # (the same pipeline as utils/transformer_blocks.SelfAttentionBlock: LayerNorms folded into the QKV / fc1 GEMMs once a producer
+        # GEMM has left the row statistics — from the first proj on —, LayerScale folded into the proj / fc2 weights)
+        h, fold = engine.ln_operand(x2d, self.norm1, dt)
         x2d = engine.self_attention(h, B, N, self.attn.qkv, self.attn.proj, self.attn.num_heads, None, None, self.attn.scale,
-                                    x2d, x2d.dtype, proj_wb=engine.layerscale_lin_weights(self.attn.proj, self.ls1.gamma, dt))
-        h = engine.layernorm(x2d, self.norm2, dt)
+                                    x2d, x2d.dtype, proj_wb=engine.layerscale_lin_weights(self.attn.proj, self.ls1.gamma, dt),
+                                    fold=fold, emit_ln=True)
+        h, fold = engine.ln_operand(x2d, self.norm2, dt)
         return engine.mlp(h, self.mlp.fc1, self.mlp.fc2, "gelu", x2d, x2d.dtype,
-                          fc2_wb=engine.layerscale_lin_weights(self.mlp.fc2, self.ls2.gamma, dt))
+                          fc2_wb=engine.layerscale_lin_weights(self.mlp.fc2, self.ls2.gamma, dt), fold=fold, emit_ln=True)
 
 
 class _PatchEmbed(nn.Module):
@@ -195,11 +198,14 @@ class DINOv2Encoder(UniCeptionViTEncoderBase):
         reg = None
         if m.register_tokens is not None:
             reg = engine.prepared(m, "reg", (m.register_tokens,), lambda: m.register_tokens.detach().float()[0].contiguous())
-        return ops.assemble_tokens(tok, cls, reg, m.interpolated_pos_embed(h0, w0)), dt
+        x = ops.assemble_tokens(tok, cls, reg, m.interpolated_pos_embed(h0, w0))
+        if engine.stream_dtype(dt, self.enc_embed_dim) == torch.bfloat16:      # bf16 residual stream (engine.stream_dtype): one cast here,
+            x = ops.convert(x, torch.bfloat16)                                  # 4 instead of 10 bytes per element in every sub-layer after it
+        return x, dt
 
     def _final_norm(self, x2d):
         if isinstance(self.model.norm, nn.Identity):
-            return x2d
+            return x2d if (x2d.dtype == torch.float32 or x2d.requires_grad) else ops.convert(x2d, torch.float32)
         return engine.layernorm(x2d, self.model.norm, torch.float32)
 
     def _split(self, xn, B, h0, w0):
@@ -252,7 +258,10 @@ class DINOv2IntermediateFeatureReturner(DINOv2Encoder, IntermediateFeatureReturn
         for i, blk in enumerate(self.model.blocks):
             x2d = blk.forward_tokens(x2d, B, Nt, dt)
             if i in take:
-                xn = (self._final_norm(x2d) if self.norm_intermediate else x2d).view(B, Nt, D)
+                xn = self._final_norm(x2d) if self.norm_intermediate else x2d
+                if xn.dtype != torch.float32 and not xn.requires_grad:
+                    xn = ops.convert(xn, torch.float32)
+                xn = xn.view(B, Nt, D)
                 if xn.requires_grad:
                     outs.append(ViTEncoderOutput(features=xn[:, 1 + R:].reshape(B, h0, w0, D).permute(0, 3, 1, 2),
                                                  registers=xn[:, :1].permute(0, 2, 1).contiguous()))
