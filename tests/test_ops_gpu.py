@@ -265,17 +265,16 @@ def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
         wp = (torch.randn(C, K, generator=g) / math.sqrt(K)).bfloat16()
         bp = torch.randn(C, generator=g) + 0.7
         res = (torch.randn(M, C, generator=g) * 2 + 0.5).bfloat16()
-        for _ in range(1):
-            want = a.float() @ wp.float().t() + bp + res.float()
-            x = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), residual=res.to(gpu), out_dtype=torch.bfloat16, emit_ln=True)
-            assert x.dtype == torch.bfloat16 and x.uc_ln.twin is x
-            # one rounding of the fp32 sum: equal to the bf16 of the reference up to the accumulation-order noise at rounding ties
-            xd = x.cpu().float()
-            assert rel_l2(xd, want) < 3e-3
-            assert ((xd - want).abs() <= want.abs() * 2.0 ** -8 + 1e-6).all()
-            st = x.uc_ln.stats(1e-6).cpu().double()
-            assert (st[:, 0] - xd.double().mean(1)).abs().max() < 1e-5, "statistics are those of the stored rows"
-            assert ((st[:, 1] - 1 / torch.sqrt(xd.double().var(1, unbiased=False) + 1e-6)) / st[:, 1]).abs().max() < 1e-5
+        want = a.float() @ wp.float().t() + bp + res.float()
+        x = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), residual=res.to(gpu), out_dtype=torch.bfloat16, emit_ln=True)
+        assert x.dtype == torch.bfloat16 and x.uc_ln.twin is x
+        # one rounding of the fp32 sum: equal to the bf16 of the reference up to the accumulation-order noise at rounding ties
+        xd = x.cpu().float()
+        assert rel_l2(xd, want) < 3e-3
+        assert ((xd - want).abs() <= want.abs() * 2.0 ** -8 + 1e-6).all()
+        st = x.uc_ln.stats(1e-6).cpu().double()
+        assert (st[:, 0] - xd.double().mean(1)).abs().max() < 1e-5, "statistics are those of the stored rows"
+        assert ((st[:, 1] - 1 / torch.sqrt(xd.double().var(1, unbiased=False) + 1e-6)) / st[:, 1]).abs().max() < 1e-5
         # without a residual (embedding GEMMs)
         x0 = ops.gemm(a.to(gpu), wp.to(gpu), bp.to(gpu), out_dtype=torch.bfloat16, emit_ln=True)
         assert rel_l2(x0.cpu().float(), a.float() @ wp.float().t() + bp) < 3e-3 and x0.uc_ln.twin is x0
