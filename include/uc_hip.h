@@ -131,9 +131,7 @@ typedef struct uc_gemm_desc {
     int64_t ldc;
     /* LayerNorm fused into the GEMMs around it (bf16 direct-to-LDS path, N % 64 == 0) — the "fused LayerNorm + QKV / fc1" of
        the pre-LN sub-layers (libs/croco/blocks.py:158-161, utils/transformer_blocks.py:643-646):
-       producer (the GEMM that writes the residual stream: proj, fc2, patch / input embedding).  fp32 stream: out_dtype UC_F32 (+ fp32
-       residuals);  bf16 stream (the reference's own under autocast): out_dtype UC_BF16 + at most ONE bf16 residual, twin_out NULL —
-       C = one bf16 rounding of acc + bias + residual, is its own twin, and the statistics are those of the rounded rows:
+       producer (the GEMM that writes the fp32 residual stream: proj, fc2, patch / input embedding; out_dtype UC_F32):
          twin_out : if non-NULL, the stored rows are also written as bf16 to twin_out [M, ldt] — the A operand of the consumer;
          stats_out: if non-NULL, [M][N/64][2] fp32: per row and 64-column block (sum, sum of squared deviations from the block
                     mean) of the stored values; uc_ln_stats_finalize merges the blocks into (mean, rstd) per row;
