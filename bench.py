@@ -179,7 +179,8 @@ def reference_policy_legs(model, v1, v2, args, dev):
     fp32-class heads (split bf16 operands on the matrix pipe) at the headline batch; (b) EVERYTHING fp32-class
     (engine.precision("bf16x3"): split-operand GEMMs / convolutions, exact fp32 attention) — the mode that meets the
     1e-3 / 1e-2 gate (tests/test_precision_modes_gpu.py) — on a bounded batch; (c) the encoder + decoder alone (linear
-    head, 0.15 % of the FLOPs), the quantity the 40 % MFMA target is defined on."""
+    head, 0.15 % of the FLOPs), the quantity the 40 % MFMA target is defined on; (d) the headline forward with an fp32 residual
+    stream instead of the reference's bf16 one."""
     from uniception_amd import engine
     from uniception_amd.models.factory import DUSt3R
     out = {}
@@ -199,6 +200,15 @@ def reference_policy_legs(model, v1, v2, args, dev):
                                                    "pairs_per_gpu": args.pairs, "heads": "bf16x3 split-operand MFMA, fp32 tensors"}
     finally:
         engine.set_head_precision("follow")
+    if engine.bf16_stream_enabled() and args.encoder == "croco":
+        # the same bf16 forward with the residual stream kept in fp32 (round 1's policy: more accurate than the reference's own bf16
+        # stream under autocast, 10 instead of 4 bytes per element in the residual epilogues)
+        with engine.bf16_stream(False):
+            f = fwd(v1, v2, "bf16")
+            f(); f()
+            dt, _ = timed(f, steps, 1)
+        out["bf16_operands_fp32_residual_stream"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
+                                                     "pairs_per_gpu": args.pairs}
     nb = min(args.pairs, 4)
     s1 = {k: (v[:nb] if k != "data_norm_type" else v) for k, v in v1.items()}
     s2 = {k: (v[:nb] if k != "data_norm_type" else v) for k, v in v2.items()}
