@@ -171,6 +171,8 @@ class _MultiViewSelfAttentionCore(UniCeptionInfoSharingBase):
             pe = self.view_pos_table[idx].float().contiguous()      # [1 or V, dim]: reference view only, or every view
             # (in place through the raw kernel, also under autograd: d(x + const)/dx = 1 and no Function saved x2d's values)
             ops.add_view_pe_(x2d.detach().view(B, L, self.dim), pe, T)
+        if not train and engine.stream_dtype(dt, self.dim) == torch.bfloat16:
+            x2d = ops.convert(x2d, torch.bfloat16)      # bf16 residual stream (engine.stream_dtype): one cast, then 4 bytes per element per sub-layer
         taken = []
         for d, blk in enumerate(self.self_attention_blocks):
             if not self._frame_level(d):
