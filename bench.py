@@ -3,6 +3,7 @@
 cross-attention decoder + DPT pointmap heads + adaptor, 512x512 pairs, bf16 MFMA operands (BASELINE.json configs[1]).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3         (no torchrun: bench.py starts its own ranks, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One process per GPU; every rank runs `--pairs` independent image pairs per step (weak scaling, no data-path
@@ -155,7 +156,8 @@ def cpu_baseline(model, H, W, head, max_s):
         m = timer.blocked_autorange(min_run_time=min(max_s, 20.0))
     t = m.median
     return {"value": round(1.0 / t, 4), "unit": "image-pairs/s", "cores": cores, "cpu": cpu_model_name(), "kind": "port",
-            "sample": f"1 pair (2x{H}x{W}) fp32 forward incl. heads, Timer.blocked_autorange median of {len(m.times)} runs, "
+            "n_samples": len(m.times),
+            "sample": f"1 pair (2x{H}x{W}) fp32 forward incl. heads, Timer.blocked_autorange, n={len(m.times)} run(s) (median), "
                       f"{t:.2f}s each, torch CPU {cores} threads"}
 
 
@@ -230,12 +232,56 @@ def reference_policy_legs(model, v1, v2, args, dev):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell (no torchrun): start the N ranks ourselves — one process per GPU through
+    torch.distributed.run on 127.0.0.1 and a free port, this very command line behind it — and pass the children's output (rank 0's
+    ONE JSON line) and exit status through.  Under torchrun (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(rank, world):
+    """UNICEPTION_AMD_BENCH_LAUNCH_CHECK=1 (tests, no GPU needed): rendezvous over gloo, the fences and the max-over-ranks reduction of
+    the timing contract, rank 0's line — everything of the N > 1 control flow but the model.  The line says what it is."""
+    from uniception_amd.distributed import max_over_ranks
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = max_over_ranks(time.perf_counter() - t0)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "max_rank_s": round(dt, 4), "note": "control flow only: not a measurement"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("UNICEPTION_AMD_BENCH_LAUNCH_CHECK", "0") == "1":
+        return launch_check(rank, world)
+    if not (os.environ.get("UNICEPTION_AMD_BENCH_SHARE_GPU", "0") == "1") and torch.cuda.device_count() < min(world, local_rank + 1):
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local_rank} but this node shows {torch.cuda.device_count()} GPU(s)")
     # UNICEPTION_AMD_BENCH_SHARE_GPU=1: a dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
     # devices, gloo instead of RCCL — two ranks cannot open one device in an RCCL communicator); the line it prints is marked
     share = os.environ.get("UNICEPTION_AMD_BENCH_SHARE_GPU", "0") == "1"

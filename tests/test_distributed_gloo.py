@@ -172,3 +172,32 @@ def test_flat_parameters_keep_module_semantics():
     assert end == flat.numel
     flat.param.mul_(2.0)   # parameters are views of the flat buffer
     assert torch.equal(model[0].weight, sd0["0.weight"] * 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py starts its own ranks: `python bench.py --gpus N` from a plain shell
+# ---------------------------------------------------------------------------------------------------------------
+def _run_bench(args, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_self_launches_two_ranks_from_plain_python():
+    """No torchrun, no WORLD_SIZE in the environment: bench.py spawns the ranks, they rendezvous on 127.0.0.1, rank 0 prints
+    ONE line with n_gpus == 2 (the launch check replaces the model, which needs a GPU)."""
+    r, lines = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"UNICEPTION_AMD_BENCH_LAUNCH_CHECK": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["launch_check"] is True
+    assert lines[0]["max_rank_s"] >= 0.02          # the slowest rank's time (rank 1 sleeps 20 ms)
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    r, lines = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "UNICEPTION_AMD_BENCH_LAUNCH_CHECK": "1"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and not lines
