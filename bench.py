@@ -53,6 +53,10 @@ def parse():
                     help="no two-stream execution of independent sub-graphs at large batch (engine.concurrent(False)): what the "
                          "roofline pass and the committed kernel profiles use — per-kernel durations are only defined without overlap")
     ap.add_argument("--cpu-baseline-max-s", type=float, default=30.0)
+    ap.add_argument("--sweep", default=None,
+                    help="comma-separated batch sizes (pairs), e.g. 1,2,4,8,16,64: adds `batch_sweep` to the JSON line — the forward at each "
+                         "size, timed like the reference's own harness (examples/models/dust3r/profile_dust3r.py:31-46: randn images, "
+                         "no_grad, Timer.blocked_autorange().mean), eager and (up to 16 pairs) replayed from a hipGraph")
     return ap.parse_args()
 
 
@@ -269,6 +273,34 @@ def launch_check(rank, world):
         dist.destroy_process_group()
 
 
+def batch_sweep(model, sizes, args, dev):
+    """The reference's benchmark loop (profile_dust3r.py:31-46, utils/profile.py:4-6) over this build: batch sizes {1, 2, 4, 8} there."""
+    import torch.utils.benchmark as tbench
+    from uniception_amd import engine
+    out = []
+    for b in sizes:
+        v1, v2 = make_views(b, args.img, args.img, 0, dev)
+
+        def f():
+            with torch.no_grad(), engine.precision(args.precision), engine.attention_precision(args.attention):
+                return model(v1, v2)
+        f(); f()
+        m = tbench.Timer(stmt="f()", globals={"f": f}).blocked_autorange(min_run_time=1.0)
+        e = {"pairs": b, "ms_per_batch": round(m.mean * 1e3, 3), "pairs_per_s": round(b / m.mean, 2)}
+        if b <= 16:
+            from uniception_amd.graphs import GraphedTwoView
+            g = GraphedTwoView(model, v1, v2, precision=args.precision, attention=args.attention)
+            g(v1, v2)
+            mg = tbench.Timer(stmt="g(v1, v2)", globals={"g": g, "v1": v1, "v2": v2}).blocked_autorange(min_run_time=1.0)
+            e["hipgraph_ms_per_batch"] = round(mg.mean * 1e3, 3)
+            e["hipgraph_pairs_per_s"] = round(b / mg.mean, 2)
+            del g
+        out.append(e)
+        del v1, v2
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -399,6 +431,8 @@ def main():
                                             "committed profiles); the timed region runs two kernel streams")
         if not args.no_reference_policy and args.precision == "bf16" and not args.graph:
             line["reference_policy"] = reference_policy_legs(model, v1, v2, args, dev)
+        if args.sweep:
+            line["batch_sweep"] = batch_sweep(model, [int(x) for x in args.sweep.split(",")], args, dev)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.img, args.img, args.head, args.cpu_baseline_max_s)
     if rank == 0:

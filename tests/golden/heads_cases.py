@@ -39,6 +39,8 @@ ADAPTOR_CASES = {
     "pointmap_conf_mask": ("PointMapWithConfidenceAndMaskAdaptor", ("exp", -INF, INF, "exp", 1, INF), 5),
     "rd_depth_flow_conf_mask": ("RayDirectionsPlusDepthPlusSceneFlowWithConfidenceAndMaskAdaptor", RD + ("exp", 0, INF) + ("linear", -INF, INF) + ("sigmoid", 0.0, 2.0), 9),
 }
+# the pose heads hand [B, C] vectors to their adaptors (reference pose_head.py:157-179): name -> case of ADAPTOR_CASES run on a 2-D input
+ADAPTOR_CASES_2D = {"camtrans_quats_2d": "camtrans_quats", "camtrans_2d": "camtrans_square", "quats_2d": "quats_norm", "scale_2d": "scale_exp"}
 AD_B, AD_H, AD_W = 2, 5, 7
 OUT_FIELDS = ("value", "confidence", "logits", "mask", "covariance", "log_det", "inv_covariance")
 
@@ -47,6 +49,12 @@ def adaptor_input(name):
     import torch
     g = torch.Generator().manual_seed(sum(map(ord, name)) + 7)
     return torch.randn(AD_B, ADAPTOR_CASES[name][2], AD_H, AD_W, generator=g)
+
+
+def adaptor_input_2d(name):
+    import torch
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + 11)
+    return torch.randn(3, ADAPTOR_CASES[ADAPTOR_CASES_2D[name]][2], generator=g)
 
 
 # DPT extras: (feature dims of the layered inputs, layer dims, feature dim, token grid, target shape, seg classes)

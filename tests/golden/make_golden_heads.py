@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import dust3r_oracle as O  # noqa: E402
-from tests.golden.heads_cases import AD_H, AD_W, ADAPTOR_CASES, DPT_DOUBLE, DPT_SEG, OUT_FIELDS, adaptor_input  # noqa: E402
+from tests.golden.heads_cases import (AD_H, AD_W, ADAPTOR_CASES, ADAPTOR_CASES_2D, DPT_DOUBLE, DPT_SEG, OUT_FIELDS, adaptor_input,  # noqa: E402
+                                      adaptor_input_2d)
 
 from uniception.models.prediction_heads import adaptors as RA  # noqa: E402
 from uniception.models.prediction_heads.base import AdaptorInput, PredictionHeadLayeredInput  # noqa: E402
@@ -31,6 +32,12 @@ def main():
             if hasattr(out, f):
                 store[f"ad/{name}/{f}"] = getattr(out, f).numpy()
         print(name, [k.split("/")[-1] for k in store if k.startswith(f"ad/{name}/")])
+    for name, base in ADAPTOR_CASES_2D.items():      # [B, C] inputs (pose heads)
+        cls, args, _ = ADAPTOR_CASES[base]
+        with torch.no_grad():
+            out = getattr(RA, cls)(name, *args)(AdaptorInput(adaptor_feature=adaptor_input_2d(name), output_shape_hw=(AD_H, AD_W)))
+        store[f"ad2d/{name}/value"] = out.value.numpy()
+        print(name, store[f"ad2d/{name}/value"].shape)
     c = DPT_SEG
     seg = DPTSegmentationProcessor(c["input_feature_dim"], c["output_dim"], hidden_dim=c["hidden_dim"]).eval()
     O.fill_state_dict_(seg.state_dict())

@@ -133,6 +133,37 @@ def _grad_worker(rank, world, port, bucket_bytes):
             raised = "no_sync" in str(e)
         assert raised
         buckets.finish()
+        # Gradient sink (autograd._wgrad under the Trainer): a Function that adds its weight gradient straight into p.grad and hands
+        # autograd None.  The AccumulateGrad node of such a parameter still runs (undefined gradient) and fires the post-accumulate
+        # hook on this PyTorch build, so the bucket is issued DURING the backward, not in finish() (if a build skipped the
+        # hook, finish() would still reduce it — this assertion is what tells the two apart).
+        class Sunk(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.save_for_backward(x, w)
+                return x @ w.t()
+
+            @staticmethod
+            def backward(ctx, g):
+                x, w = ctx.saved_tensors
+                w.grad.add_(g.t() @ x)
+                return g @ w, None
+        flat.zero_grad()
+        buckets.start_step()
+        h = model[:-1](data[rank])
+        Sunk.apply(h, model[-1].weight).square().mean().backward()     # (the last layer's bias gets no gradient: frozen-like)
+        issued_in_backward = buckets._next
+        buckets.finish()
+        first = flat.buckets[0]["names"]
+        if all(n == "5.weight" or n == "5.bias" for n in first):        # many-small-buckets layout: bucket 0 = the last layer's weight (+ bias)
+            assert issued_in_backward >= (1 if "5.bias" not in first else 0)
+        ref_model = _toy_model()
+        tot = torch.zeros_like(ref_model[-1].weight)
+        for r in range(world):
+            ref_model.zero_grad()
+            (ref_model[:-1](data[r]) @ ref_model[-1].weight.t()).square().mean().backward()
+            tot += ref_model[-1].weight.grad
+        assert torch.allclose(model[-1].weight.grad, tot, rtol=1e-5, atol=1e-6)
     finally:
         dist.destroy_process_group()
 

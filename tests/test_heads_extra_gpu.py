@@ -9,7 +9,8 @@ import pytest
 import torch
 
 from oracle import dust3r_oracle as O
-from tests.golden.heads_cases import AD_H, AD_W, ADAPTOR_CASES, DPT_DOUBLE, DPT_SEG, OUT_FIELDS, adaptor_grad_weight, adaptor_input
+from tests.golden.heads_cases import (AD_H, AD_W, ADAPTOR_CASES, ADAPTOR_CASES_2D, DPT_DOUBLE, DPT_SEG, OUT_FIELDS, adaptor_grad_weight, adaptor_input,
+                                      adaptor_input_2d)
 from tests.helpers import GOLDEN_DIR, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -38,6 +39,27 @@ def test_adaptor_matches_reference(gpu, gold, name):
             assert tuple(got.shape) == tuple(w.shape), (f, got.shape, w.shape)
             e = float((got.float().cpu().double() - torch.as_tensor(w).double()).abs().max() / max(1.0, float(np.abs(w).max())))
             assert e < 2e-6 and rel_l2(got.float().cpu(), w) < 2e-6, f"{name}.{f} ({layout}): {e:.2e}"
+
+
+@pytest.mark.parametrize("name", list(ADAPTOR_CASES_2D.keys()))
+def test_adaptor_takes_pose_head_vectors(gpu, gold, name):
+    """(B x C) inputs — what the reference's pose heads hand to CamTranslation / Quaternions / CamTranslationPlusQuats / Scale adaptors
+    (pose_head.py:157-179) — against the reference's outputs; also under autograd (the composite crashed on 2-D input)."""
+    from uniception_amd.models.prediction_heads import adaptors as A
+    from uniception_amd.models.prediction_heads.base import AdaptorInput
+    cls, args, cin = ADAPTOR_CASES[ADAPTOR_CASES_2D[name]]
+    ad = getattr(A, cls)(name, *args).to(gpu)
+    want = gold[f"ad2d/{name}/value"]
+    x = adaptor_input_2d(name).to(gpu)
+    with torch.no_grad():
+        got = ad(AdaptorInput(adaptor_feature=x, output_shape_hw=(AD_H, AD_W))).value
+    assert tuple(got.shape) == tuple(want.shape)
+    assert rel_l2(got.float().cpu(), want) < 2e-6
+    leaf = x.clone().requires_grad_(True)
+    out = ad(AdaptorInput(adaptor_feature=leaf, output_shape_hw=(AD_H, AD_W))).value
+    assert rel_l2(out.detach().float().cpu(), want) < 2e-6
+    out.sum().backward()
+    assert leaf.grad is not None and leaf.grad.shape == x.shape and torch.isfinite(leaf.grad).all()
 
 
 @pytest.fixture(scope="module")

@@ -1,8 +1,9 @@
 """GPU parity of the nn.Module mirror against the golden vectors of the real reference.
 
 fp32 mode (exact-fp32 kernels) must meet the north-star bar: 1e-3 relative on every captured tensor (it lands
-around 1e-6..1e-5).  bf16 mode (MFMA operands bf16, fp32 accumulate, fp32 residual stream) is held to the error the
-reference itself shows under bf16 autocast (~1e-2 rel-L2 on encoder/decoder features)."""
+around 1e-6..1e-5).  bf16 mode (MFMA operands bf16, fp32 accumulate, bf16 residual stream — the reference's own stream under
+autocast) is held, tensor class by tensor class, to the error the reference itself shows under bf16 autocast (~1e-2 rel-L2 on
+encoder/decoder features): features <= 1e-2, everything behind the heads' exp / expm1 <= 3e-2."""
 import pytest
 import torch
 
@@ -14,7 +15,11 @@ pytestmark = pytest.mark.gpu
 FP32_TOL = 1e-3
 FP32_MAX_ABS = 1e-2   # the reference's own gate asks for both (examples/models/dust3r/dust3r.py:230)
 # bf16: encoder/decoder features ~1e-2; decoded channels pass through exp/expm1, which amplifies absolute error
-BF16_TOL = {"default": 4e-2}
+BF16_TOL = {"enc_feat": 1e-2, "dec_final": 1e-2, "dec_take": 1e-2, "dpt_up8": 1.5e-2, "decoded": 2e-2, "default": 3e-2}
+
+
+def bf16_tol(key):
+    return next((v for k, v in BF16_TOL.items() if key.startswith(k)), BF16_TOL["default"])
 
 
 def run_case(name, gpu, mode):
@@ -56,7 +61,11 @@ def test_bf16_parity(gpu, name):
     tensors, c = run_case(name, gpu, "bf16")
     report = {}
     abs_report = {}
-    worst = compare_to_golden(load_golden(name), tensors, c, tol=BF16_TOL["default"], report=report, abs_report=abs_report)
+    gold = load_golden(name)
+    worst = ("", 0.0)
+    for k, t in tensors.items():          # one bar per tensor class (not one loose bar for everything)
+        w = compare_to_golden(gold, {k: t}, c, tol=bf16_tol(k), report=report, abs_report=abs_report)
+        worst = max(worst, w, key=lambda x: x[1])
     print(f"\n[bf16] {name}: worst {worst[0]} {worst[1]:.2e}; " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(report.items())) +
           "; head outputs max-abs " + ", ".join(f"{k}={abs_report[k]:.1e}" for k in HEAD_OUTPUTS if k in abs_report))
 
@@ -76,6 +85,42 @@ def test_autocast_selects_bf16_and_heads_follow_reference_policy(gpu):
         with engine.precision("bf16"):
             b1, _ = model(img1, img2, {})
     assert torch.equal(a1["pts3d"], b1["pts3d"])
+
+
+@pytest.mark.parametrize("name", ["vitl_linear_224", "vitl_dpt_512"])
+def test_factory_under_autocast_equals_precision_bf16(gpu, name):
+    """The FACTORY runs its heads under autocast(enabled=False) like the reference (factory/dust3r.py:288-309) and carries the
+    transformer's dtype into that region (engine.ambient): bf16 that comes from torch.autocast must give the very kernels — and
+    bits — of engine.precision('bf16'), for the DPT and the linear heads (the ambient dtype used to be read after
+    autocast was already off, and the heads silently fell back to the exact-fp32 kernels)."""
+    from uniception_amd import engine, ops
+
+    model, c = build_case_model(name)
+    model = model.to(gpu)
+    img1, img2 = (t.to(gpu) for t in case_images(c))
+    v1 = {"img": img1, "instance": [str(i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+    v2 = {"img": img2, "instance": [str(100 + i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+    seen = {"precision": [], "autocast": []}
+    orig = ops.gemm
+
+    def spy(tag):
+        def f(a, w, *args, **kw):
+            seen[tag].append((a.dtype, tuple(w.shape)))
+            return orig(a, w, *args, **kw)
+        return f
+    try:
+        with torch.no_grad():
+            ops.gemm = spy("precision")
+            with engine.precision("bf16"):
+                b1, b2 = model(v1, v2)
+            ops.gemm = spy("autocast")
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                a1, a2 = model(v1, v2)
+    finally:
+        ops.gemm = orig
+    assert seen["precision"] and seen["autocast"] == seen["precision"], "autocast(bf16) took other GEMM kernels than precision('bf16'): the heads lost the ambient dtype"
+    assert torch.equal(a1["pts3d"], b1["pts3d"]) and torch.equal(a1["conf"], b1["conf"])
+    assert torch.equal(a2["pts3d_in_other_view"], b2["pts3d_in_other_view"]) and torch.equal(a2["conf"], b2["conf"])
 
 
 def test_symmetrized_batch_shortcut(gpu):

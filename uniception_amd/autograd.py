@@ -325,7 +325,6 @@ class SelfAttnSubLayerFn(Function):
         h = ops.layernorm(x2d, g, bta, ln.eps, dt)
         wq, bq = engine.lin_weights(qkv, dt)
         wp, bp = engine.lin_weights(proj, dt) if gamma is None else engine.layerscale_lin_weights(proj, gamma, dt)
-        ctx.gamma = gamma
         if dt == torch.bfloat16 and rope is not None:
             if Dh != 64:
                 raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh})")
@@ -340,26 +339,28 @@ class SelfAttnSubLayerFn(Function):
         lse = torch.empty((B, H, N), dtype=torch.float32, device=x2d.device)
         o = _attention_fwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], scale, lse)
         out = ops.gemm(o.view(M, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
-        ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0))
+        # (gamma goes through save_for_backward: autograd's version check then catches an in-place edit between forward and backward)
+        ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0), *(() if gamma is None else (gamma,)))
         ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
-        x2d, g, h, t, o, lse, pos = ctx.saved_tensors
+        x2d, g, h, t, o, lse, pos, *rest = ctx.saved_tensors
+        gamma = rest[0] if rest else None
         ln, qkv, proj, B, N, H, rope, scale, dt, has_bq, has_bp = ctx.meta
         M, C = x2d.shape
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
         dgamma = None
-        if ctx.gamma is None:
+        if gamma is None:
             dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
             do = ops.gemm(dyb, lin_weight_t(proj, dt))
         else:
             dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp)
-            dWp, dbp, dgamma = _unfold_layerscale(proj, ctx.gamma, dWp, dbp)
-            do = ops.gemm(dyb, _folded_weight_t(proj, ctx.gamma, dt))
+            dWp, dbp, dgamma = _unfold_layerscale(proj, gamma, dWp, dbp)
+            do = ops.gemm(dyb, _folded_weight_t(proj, gamma, dt))
         dt3 = torch.empty_like(t)
         d5, t5 = dt3.view(B, N, 3, H, Dh), t.view(B, N, 3, H, Dh)
         ops.attention_bwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale,
@@ -476,28 +477,28 @@ class MlpSubLayerFn(Function):
         h = ops.layernorm(x2d, g, bta, ln.eps, dt)
         w1, b1 = engine.lin_weights(fc1, dt)
         w2, b2 = engine.lin_weights(fc2, dt) if gamma is None else engine.layerscale_lin_weights(fc2, gamma, dt)
-        ctx.gamma = gamma
         u = torch.empty((x2d.shape[0], w1.shape[0]), dtype=dt, device=x2d.device)
         a = ops.gemm(h, w1, b1, act=act, preact_out=u)
         out = ops.gemm(a, w2, b2, residual=x2d, out_dtype=x2d.dtype)
-        ctx.save_for_backward(x2d, g, h, u, a)
+        ctx.save_for_backward(x2d, g, h, u, a, *(() if gamma is None else (gamma,)))
         ctx.meta = (ln, fc1, fc2, act, dt, b1_ is not None, b2_ is not None)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
-        x2d, g, h, u, a = ctx.saved_tensors
+        x2d, g, h, u, a, *rest = ctx.saved_tensors
+        gamma = rest[0] if rest else None
         ln, fc1, fc2, act, dt, has_b1, has_b2 = ctx.meta
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
         dgamma = None
-        if ctx.gamma is None:
+        if gamma is None:
             dW2, db2 = _wgrad(dyb, a, dt, has_b2, sink=[(fc2.weight, 0, fc2.weight.shape[0])], bias_sink=[fc2.bias])
             w2t = lin_weight_t(fc2, dt)
         else:
             dW2, db2 = _wgrad(dyb, a, dt, has_b2)
-            dW2, db2, dgamma = _unfold_layerscale(fc2, ctx.gamma, dW2, db2)
-            w2t = _folded_weight_t(fc2, ctx.gamma, dt)
+            dW2, db2, dgamma = _unfold_layerscale(fc2, gamma, dW2, db2)
+            w2t = _folded_weight_t(fc2, gamma, dt)
         if act != "none" and dt == torch.bfloat16 and w2t.shape[1] % 64 == 0:
             du = ops.gemm(dyb, w2t, dact=(u, act))          # act'(u) applied in the data-gradient GEMM's epilogue
         else:

@@ -668,7 +668,8 @@ def side_stream(device, index: int = 0) -> "torch.cuda.Stream":
 # branches, two heads).  Per-kernel durations are then not defined (kernels overlap): bench.py's roofline pass and the
 # committed profiles run with concurrent(False).
 CONCURRENT = os.environ.get("UNICEPTION_AMD_CONCURRENT", "1") != "0"
-_branch_warm = set()
+_branch_warm = set()                          # warm keys without an owner
+_branch_warm_by_owner = weakref.WeakKeyDictionary()   # owner module -> its warm keys (dropped with the module: no id() reuse, no growth)
 FORK_STREAMS = True      # tests: False keeps every decomposition (two views, two branches, two heads) but runs the halves in stream order
 
 
@@ -683,23 +684,25 @@ def concurrent(on: bool):
         CONCURRENT = prev
 
 
-def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None):
+def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None, owner=None):
     """Runs two independent sub-graphs; when they are small (`rows` tokens/pixels each <= BRANCH_TOKENS_MAX: their kernels
     launch fewer workgroups than the chip has CUs) or CONCURRENT is on, and no gradient is recorded, the second one goes to a
     side HIP stream.  `inputs1` are the tensors fn1 reads that were produced on the current stream (they are
     recorded on the side stream for the caching allocator); outputs of fn1 are recorded on the current stream.
     `warm_key`: the first call with a given key runs the two sub-graphs one after the other (fn1 on the side stream, fn0 behind
     it) — whatever they cache by shape (position grids, tables) is then built in order; weight-derived caches carry their own
-    event (BuiltOn)."""
+    event (BuiltOn).  `owner`: the module the warm state belongs to (kept in a WeakKeyDictionary — a key built from id(module)
+    would outlive the module and be inherited by whatever object reuses the id)."""
     if torch.is_grad_enabled() or (rows > BRANCH_TOKENS_MAX and not CONCURRENT) or not inputs1 or not inputs1[0].is_cuda:
         return fn0(), fn1()
     if not FORK_STREAMS:
         return fn0(), fn1()
     # first call with this key: fn1 still runs on the side stream (its allocator pool fills now, not in somebody's timed
     # region) but fn0 waits for it — nothing overlaps while shape-keyed caches are being built
-    serialize = warm_key is not None and warm_key not in _branch_warm
+    warm = _branch_warm if owner is None else _branch_warm_by_owner.setdefault(owner, set())
+    serialize = warm_key is not None and warm_key not in warm
     if serialize:
-        _branch_warm.add(warm_key)
+        warm.add(warm_key)
     main = torch.cuda.current_stream()
     side = side_stream(inputs1[0].device)
     side.wait_stream(main)

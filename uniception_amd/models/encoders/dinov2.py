@@ -68,7 +68,7 @@ class _Block(nn.Module):
         self.ls2 = _LayerScale(dim)
 
     def forward_tokens(self, x2d, B, N, dt):
-        if autograd.grad_needed(x2d, self.norm1.weight, self.attn.qkv.weight, self.mlp.fc1.weight, self.ls1.gamma):
+        if autograd.grad_needed(x2d, *self.parameters()):
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads, None, None,
                                               self.attn.scale, dt, gamma=self.ls1.gamma)
             return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, "gelu", dt, gamma=self.ls2.gamma)

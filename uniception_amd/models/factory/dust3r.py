@@ -118,7 +118,7 @@ class DUSt3R(nn.Module):
             # every row of every kernel depends on its own image only, so the features are those of the concatenated run
             enc = lambda im: self.encoder(ViTEncoderInput(image=im, data_norm_type=data_norm_type)).features   # noqa: E731
             return engine.run_branches(lambda: enc(img1), lambda: enc(img2), 0, inputs1=(img2,),
-                                       warm_key=("enc", id(self.encoder), tuple(img1.shape), str(engine.compute_dtype())))
+                                       warm_key=("enc", tuple(img1.shape), str(engine.compute_dtype())), owner=self.encoder)
         if img1.shape[-2:] == img2.shape[-2:]:
             out = self.encoder(ViTEncoderInput(image=torch.cat((img1, img2), dim=0), data_norm_type=data_norm_type)).features
             return engine.chunk_bchw(out, 2)
@@ -165,7 +165,10 @@ class DUSt3R(nn.Module):
             outs = {str(v + 1): [f32((feat1, feat2)[v]), f32(inter[0].features[v]), f32(inter[1].features[v]),
                                  f32(final.features[v])] for v in range(2)}
 
-        with torch.autocast("cuda", enabled=False), engine.ambient(engine.compute_dtype()):
+        # (with-items are entered left to right: read the transformer's dtype BEFORE autocast is switched off, or bf16 that came from
+        # torch.autocast would reach the heads as fp32)
+        transformer_dtype = engine.compute_dtype()
+        with torch.autocast("cuda", enabled=False), engine.ambient(transformer_dtype):
             def head(num, shape):
                 ho = self._downstream_head(num, outs, shape)
                 fo = self.adaptor(AdaptorInput(adaptor_feature=ho.decoded_channels, output_shape_hw=shape))
@@ -175,7 +178,7 @@ class DUSt3R(nn.Module):
             feats2 = outs["2"] if isinstance(outs["2"], list) else [outs["2"]]
             n_tok = feats2[-1].shape[0] * feats2[-1].shape[2] * feats2[-1].shape[3]
             (p1, c1), (p2, c2) = engine.run_branches(lambda: head(1, shape1), lambda: head(2, shape2), n_tok, inputs1=tuple(feats2),
-                                                          warm_key=("heads", id(self), tuple(feats2[-1].shape), shape1, shape2, str(engine.head_dtype())))
+                                                          warm_key=("heads", tuple(feats2[-1].shape), shape1, shape2, str(engine.head_dtype())), owner=self)
             res1 = {"pts3d": p1, "conf": c1}
             res2 = {"pts3d_in_other_view": p2, "conf": c2}
         return res1, res2

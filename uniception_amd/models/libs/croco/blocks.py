@@ -133,7 +133,7 @@ class Block(nn.Module):
         """[B*N, C] residual stream in, new residual stream out (same dtype)."""
         if isinstance(self.drop_path, DropPath):
             self.drop_path(x2d)  # raises in training with rate > 0
-        if autograd.grad_needed(x2d, self.norm1.weight, self.mlp.fc1.weight):
+        if autograd.grad_needed(x2d, *self.parameters()):
             _check_no_dropout(self, self.attn.dropout_p, self.attn.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads,
                                               self.attn.rope, xpos, self.attn.scale, dt)

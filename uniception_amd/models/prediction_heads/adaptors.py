@@ -6,7 +6,11 @@ whole composition, fp32); composite adaptors concatenate the segments of their p
 NHWC buffer, so the factory's `.permute(0, 2, 3, 1).contiguous()` is free.
 
 `PointMapWithConfidenceAdaptor` in the DUSt3R setting ("exp" pointmap without bounds, "exp" confidence) keeps its dedicated
-fused kernel (`uc_pointmap_adaptor`) and its HIP backward; every other configuration is inference-only.
+fused kernel (`uc_pointmap_adaptor`) and its HIP backward; every other configuration trains through the gradient of the same
+channel program (`uc_adaptor_program_bwd`).
+
+The reference's adaptors take any (B x C x ...) tensor (the pose heads hand over [B, 7], pose_head.py:157-179): inputs that are
+not 4-D maps are viewed as [B, C, -1, 1], run through the program and reshaped back.
 
 The named composite classes of the reference differ only in which parts they combine; their constructors take the parts'
 parameters as prefixed groups in a fixed order (`pointmap_*`, `ray_origins_*`, `ray_directions_*`, `depth_*`, `scene_flow_*`,
@@ -76,6 +80,11 @@ class _ProgramAdaptor(UniCeptionAdaptorBase):
     def forward(self, adaptor_input: AdaptorInput):
         x = adaptor_input.adaptor_feature
         assert x.shape[1] == self.required_channels, f"{type(self).__name__} needs {self.required_channels} channels, got {x.shape[1]}"
+        if x.dim() != 4:      # (B x C ...) that is not a map — the pose heads' [B, 3 | 4 | 7]: a [B, C, n, 1] map, reshaped back
+            shp = tuple(x.shape)
+            as_map = AdaptorInput(adaptor_feature=x.reshape(shp[0], shp[1], -1, 1), output_shape_hw=adaptor_input.output_shape_hw)
+            out = _run(as_map, self.segments(0, 0, adaptor_input.output_shape_hw))
+            return self._output_cls(value=_bchw(out, 0, self.out_channels).reshape((shp[0], self.out_channels) + shp[2:]))
         out = _run(adaptor_input, self.segments(0, 0, adaptor_input.output_shape_hw))
         return self._output_cls(value=_bchw(out, 0, self.out_channels))
 
@@ -101,14 +110,6 @@ class ScaleAdaptor(_Elementwise):
 
     def __init__(self, name: str, mode: str, vmin: float = 0, vmax: float = np.inf, *args, **kwargs):
         super().__init__(name, mode, vmin, vmax, *args, **kwargs)
-
-    def forward(self, adaptor_input: AdaptorInput):
-        x = adaptor_input.adaptor_feature
-        if x.dim() != 4:      # the reference accepts any (B x 1 x ...) tensor: view it as a map
-            shp = x.shape
-            r = super().forward(AdaptorInput(adaptor_feature=x.reshape(shp[0], 1, -1, 1).float(), output_shape_hw=adaptor_input.output_shape_hw))
-            return AdaptorOutput(value=r.value.reshape(shp))
-        return super().forward(adaptor_input)
 
 
 class DepthAdaptor(_Elementwise):
@@ -153,13 +154,6 @@ class RayOriginsAdaptor(_Radial):
 class CamTranslationAdaptor(_Radial):
     _output_cls = AdaptorOutput
 
-    def forward(self, adaptor_input: AdaptorInput):
-        x = adaptor_input.adaptor_feature
-        if x.dim() == 2:      # pose heads hand over [B, 3]
-            r = super().forward(AdaptorInput(adaptor_feature=x.reshape(x.shape[0], 3, 1, 1).float(), output_shape_hw=adaptor_input.output_shape_hw))
-            return AdaptorOutput(value=r.value.reshape(x.shape))
-        return super().forward(adaptor_input)
-
 
 class RayDirectionsAdaptor(_ProgramAdaptor):
     def __init__(self, name: str, mode: str, normalize_to_unit_sphere: bool, normalize_to_unit_image_plane: bool,
@@ -194,13 +188,6 @@ class QuaternionsAdaptor(_ProgramAdaptor):
         if self.mode != "linear":
             raise ValueError(f"Invalid mode: {self.mode}")
         return [_seg(UC_AD_DIR, c0, 4, o0, flags=2 if self.normalize else 0, vmin=self.vmin, vmax=self.vmax)]
-
-    def forward(self, adaptor_input: AdaptorInput):
-        x = adaptor_input.adaptor_feature
-        if x.dim() == 2:
-            r = super().forward(AdaptorInput(adaptor_feature=x.reshape(x.shape[0], 4, 1, 1).float(), output_shape_hw=adaptor_input.output_shape_hw))
-            return AdaptorOutput(value=r.value.reshape(x.shape))
-        return super().forward(adaptor_input)
 
 
 class FlowAdaptor(_ProgramAdaptor):

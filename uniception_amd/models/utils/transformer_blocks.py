@@ -183,7 +183,7 @@ class SelfAttentionBlock(nn.Module):
         _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
         if not isinstance(sa.q_norm, nn.Identity):
             raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
-        if autograd.grad_needed(x2d, self.norm1.weight, self.mlp.fc1.weight):   # HIP forward + HIP backward sub-layers
+        if autograd.grad_needed(x2d, *self.parameters()):   # HIP forward + HIP backward sub-layers
             g1 = None if isinstance(self.ls1, nn.Identity) else self.ls1.gamma       # LayerScale: folded weights forward, unfolded gradients
             g2 = None if isinstance(self.ls2, nn.Identity) else self.ls2.gamma
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, N, sa.num_heads, sa.custom_positional_encoding,
@@ -252,7 +252,7 @@ class CrossAttentionBlock(nn.Module):
         if self.custom_positional_encoding is not None:
             assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
             assert ypos is not None, "Positions of cross tokens (ypos) are a required input when using custom positional encoding"
-        if autograd.grad_needed(x2d, y2d, self.norm1.weight, self.mlp.fc1.weight):
+        if autograd.grad_needed(x2d, y2d, *self.parameters()):
             return self._forward_tokens_train(x2d, y2d, B, Nx, Ny, xpos, ypos, dt)
         # LayerNorm -> GEMM pairs run fused when a stream carries its producer's bf16 twin + row statistics (engine.ln_operand)
         h, fold = engine.ln_operand(x2d, self.norm1, dt)

@@ -235,6 +235,9 @@ class Trainer:
                 ops.adamw_(f.param[sp:hi], f.grad[sp:hi], self.exp_avg[sp:hi], self.exp_avg_sq[sp:hi], self.lr, b1, b2,
                            self.eps, 0.0, self.steps, grad_scale=gs)
         engine.bump_weight_epoch()   # the kernel wrote through raw pointers: invalidate the prepared-weight cache
+        # the exchange of this step is over: a backward that follows without zero_grad() (gradients then accumulate on top of the
+        # reduced ones, as with torch optimizers) starts a new round of bookkeeping instead of tripping the double-backward check
+        self.buckets.start_step()
 
     # ---- checkpoint / resume -------------------------------------------------------------------
     def state_dict(self) -> dict:
