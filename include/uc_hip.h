@@ -5,8 +5,13 @@
  * Boundary rules:
  *   - extern "C", plain pointers + explicit sizes/strides, no torch types.
  *   - every entry point is asynchronous on the hipStream_t it is given, allocates
- *     nothing, keeps no mutable global state (except the thread-local last-error text)
+ *     nothing, keeps no mutable global state (except the thread-local last-error text and
+ *     the tuning knobs below: environment read ONCE under std::call_once, two run-time
+ *     switchable atomics — all of them choose between correct code paths)
  *     and returns 0 on success or a negative uc_status.
+ *   - the shipped (release) build contains no diagnostics: the wrong-result anatomy
+ *     switches and the allocating / synchronising timeline trace of the kernel work exist
+ *     only in a -DUC_DIAG build (libuc_hip_diag.so, uc_build_flavor() == "diag").
  *   - all pointers are DEVICE pointers unless the name says "host".
  *
  * Each entry point cites the reference interface (file:line under the UniCeption tree)
@@ -37,9 +42,19 @@ const char* uc_last_error(void);
 /* ABI version; bumped when a signature or the uc_gemm_desc layout changes.
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
  *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added.  4/5: see INTEGRATION.md.
- *   6: uc_adaptor_program_bwd added. */
-#define UC_ABI_VERSION 6
+ *   6: uc_adaptor_program_bwd added.  7: uc_build_flavor, uc_tuning_set / uc_tuning_get (environment knobs read once; no
+ *      diagnostics in the release build). */
+#define UC_ABI_VERSION 7
 int uc_abi_version(void);
+/* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
+const char* uc_build_flavor(void);
+/* Tuning knobs switchable at run time (process-wide atomics; every value selects a correct kernel):
+ *   "gemm_variant": -3 automatic (default), -1 register-staged kernel, 0 128x128, 1 256x128, 2 256x256, 3 256x128x32 co-resident,
+ *                   6 eight-wave 256x256 tile of the direct-to-LDS bf16 GEMM;  "gemm_stagger": -1 launcher policy, >= 0 ticks.
+ * Their initial values come from UC_GEMM_VARIANT / UC_GEMM_STAGGER; every other UC_* environment knob (csrc/knobs.h) is read
+ * once, on first use. */
+int uc_tuning_set(const char* name, int value);
+int uc_tuning_get(const char* name, int* value);
 
 /* ------------------------------------------------------------------------------------
  * RoPE-2D, in place — drop-in for the reference's only native entry point

@@ -19,3 +19,14 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _automatic_gemm_variant():
+    """Tests that force a tile variant of the bf16 GEMM (ops.tuning_set) leave the library on its automatic choice."""
+    yield
+    import torch
+    if torch.cuda.is_available():
+        from uniception_amd import ops
+        ops.tuning_set("gemm_variant", -3)
+        ops.tuning_set("gemm_stagger", -1)

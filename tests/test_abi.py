@@ -31,10 +31,36 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in uc_hip.h but not exported: {missing}"
     # the ctypes signature table covers the same set
-    assert sorted(list(_lib.SIGNATURES.keys()) + ["uc_last_error"]) == declared_symbols()
+    assert sorted(list(_lib.SIGNATURES.keys()) + ["uc_last_error", "uc_build_flavor"]) == declared_symbols()
     loaded = _lib.load()
     assert loaded.uc_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define UC_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
     assert loaded.uc_last_error() is not None
+
+
+def test_shipped_library_is_the_release_build_without_diagnostics():
+    """no wrong-result / allocating path is reachable in the shipped library.  The release build says so, its
+    sources read the environment in exactly one place (under std::call_once), and the diagnostics names do not even occur in the
+    binary's strings."""
+    from uniception_amd import _lib
+
+    lib = _lib.load()
+    assert lib.uc_build_flavor() == b"release"
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"UC_GEMM_DBG", b"UC_ATTN_DBG", b"UC_GEMM_TRACE"):
+        assert name not in blob, f"{name.decode()} is still compiled into the release library"
+    assert b"UC_GEMM_GROUP_M" in blob            # (the tuning knobs are there)
+    csrc = os.path.join(ROOT, "uniception_amd", "csrc")
+    users = [f for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h")) and re.search(r"\bgetenv\s*\(", open(os.path.join(csrc, f)).read())]
+    assert users == ["error.hip"], users
+    assert "std::call_once" in open(os.path.join(csrc, "error.hip")).read()
+    # run-time switchable knobs: validated, round-trip
+    import ctypes as C
+    v = C.c_int(0)
+    assert lib.uc_tuning_get(b"gemm_variant", C.byref(v)) == 0 and v.value == int(os.environ.get("UC_GEMM_VARIANT", "-3"))
+    assert lib.uc_tuning_set(b"gemm_variant", 2) == 0 and lib.uc_tuning_get(b"gemm_variant", C.byref(v)) == 0 and v.value == 2
+    assert lib.uc_tuning_set(b"gemm_variant", 5) != 0 and b"gemm_variant" in lib.uc_last_error()
+    assert lib.uc_tuning_set(b"gemm_dbg", 64) != 0            # diagnostics are not tuning knobs
+    assert lib.uc_tuning_set(b"gemm_variant", -3) == 0
 
 
 def test_gemm_descriptor_layout_matches_header():

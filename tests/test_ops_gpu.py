@@ -196,7 +196,7 @@ def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     LN(x) W^T + b through its epilogue — plain, GELU, RoPE and VT tiles, with a non-zero row mean."""
     from uniception_amd import ops
     if variant != "auto":
-        monkeypatch.setenv("UC_GEMM_VARIANT", variant)
+        ops.tuning_set("gemm_variant", int(variant))       # (reset to automatic after every test: conftest.py)
     g = torch.Generator().manual_seed(77)
     B, h, w_, H = 2, 8, 16, 3
     N, C = h * w_, H * 64
@@ -257,7 +257,7 @@ def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
     and the consumer's folded LayerNorm on it."""
     from uniception_amd import ops
     if variant != "auto":
-        monkeypatch.setenv("UC_GEMM_VARIANT", variant)
+        ops.tuning_set("gemm_variant", int(variant))       # (reset to automatic after every test: conftest.py)
     g = torch.Generator().manual_seed(78)
     for M in (520, 256):
         C, K = 192, 128
@@ -293,10 +293,10 @@ def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
 
 @pytest.mark.parametrize("variant", ["0", "1", "2", "3", "6"])
 def test_gemm_bf16_tile_variants(gpu, variant, monkeypatch):
-    """Every tile variant of the direct-to-LDS kernel (UC_GEMM_VARIANT is read per call) against the fp32 product, through
+    """Every tile variant of the direct-to-LDS kernel (uc_tuning_set "gemm_variant") against the fp32 product, through
     each specialised epilogue: bf16 store (+GELU), fp32 residual add, RoPE + VT, the generic drain (ragged N, bf16 residual)."""
     from uniception_amd import ops
-    monkeypatch.setenv("UC_GEMM_VARIANT", variant)
+    ops.tuning_set("gemm_variant", int(variant))           # (reset to automatic after every test: conftest.py)
     g = torch.Generator().manual_seed(50 + int(variant))
     for (M, N, K) in [(512, 384, 256), (300, 200, 128), (1024, 768, 64), (520, 328, 192)]:
         a = torch.randn(M, K, generator=g).bfloat16()
@@ -350,8 +350,7 @@ def test_conv3x3_fused_tail(gpu, geom, mode):
     ref = torch.einsum("bchw,oc->bhwo", y, w4.double()) + b4.double()
     wg = wc.permute(0, 2, 3, 1).reshape(128, -1).contiguous()
     for variant in ("auto", "0", "1", "3"):
-        if variant != "auto":
-            os.environ["UC_GEMM_VARIANT"] = variant
+        ops.tuning_set("gemm_variant", -3 if variant == "auto" else int(variant))
         try:
             if mode == "bf16":
                 out = ops.gemm(x.bfloat16().to(gpu), wg.bfloat16().to(gpu), bc.to(gpu), act=act, conv=(B, H, W, Cin, 1), tail=(w4.to(gpu), b4.to(gpu)))
@@ -359,7 +358,7 @@ def test_conv3x3_fused_tail(gpu, geom, mode):
                 with engine.precision("bf16x3"):
                     out = ops.gemm(x.to(gpu), wg.to(gpu), bc.to(gpu), act=act, conv=(B, H, W, Cin, 1), tail=(w4.to(gpu), b4.to(gpu)))
         finally:
-            os.environ.pop("UC_GEMM_VARIANT", None)
+            ops.tuning_set("gemm_variant", -3)
         assert out.shape == (B * H * W, 4) and out.dtype == torch.float32
         tol = 3e-4 if act == "gelu" else (3e-5 if mode == "bf16" else 1e-5)      # (the epilogue's GELU is a 3e-5-accurate polynomial)
         assert rel_l2(out.view(B, H, W, 4).cpu(), ref) < tol, (variant, mode)

@@ -53,9 +53,9 @@ for tag, Bimg, C, H in (("enc", 2 * B, 1024, 16), ("dec", B, 768, 12)):
     if tag not in which: continue
     for name, fl, fn in cases(tag, Bimg, C, H):
         for v in variants:
-            if v == "auto": os.environ.pop("UC_GEMM_VARIANT", None)
-            else: os.environ["UC_GEMM_VARIANT"] = v
+            if v == "auto": ops.tuning_set("gemm_variant", -3)
+            else: ops.tuning_set("gemm_variant", int(v))
             t = timeit(fn)
             res[(name, v)] = (t, fl)
         print(f"{name}: " + " | ".join(f"v{v} {res[(name, v)][0]*1e6:7.1f}us {fl/res[(name, v)][0]/1e12:6.1f}TF" for v in variants), flush=True)
-os.environ.pop("UC_GEMM_VARIANT", None)
+ops.tuning_set("gemm_variant", -3)

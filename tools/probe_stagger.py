@@ -23,5 +23,5 @@ for tag, M, C in (("enc", 131072, 1024), ("dec", 65536, 768)):
               (f"{tag} fc2 +res32 emit", lambda hid=hid, w2=w2, bp=bp, x=x, o=out32: ops.gemm(hid, w2, bp, residual=x, out=o, emit_ln=True)),
               (f"{tag} fc1 gelu", lambda h=h, w1=w1, b1=b1: ops.gemm(h, w1, b1, act="gelu"))]
 for st in (0, 150, 300, 500):
-    os.environ["UC_GEMM_STAGGER"] = str(st)
+    ops.tuning_set("gemm_stagger", int(st))
     print(f"stagger {st:4d}: " + " | ".join(f"{n} {timeit(f):7.1f}" for n, f in cases), flush=True)

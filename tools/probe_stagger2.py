@@ -27,5 +27,5 @@ for tag, Bimg, C, H in (("enc", 128, 1024, 16), ("dec", 64, 768, 12)):
               (f"{tag} fc1 gelu", lambda h=h, w1=w1, b1=b1: ops.gemm(h, w1, b1, act="gelu"))]
 for rep in range(2):
     for st in (0, 50, 100, 200):
-        os.environ["UC_GEMM_STAGGER"] = str(st)
+        ops.tuning_set("gemm_stagger", int(st))
         print(f"stagger {st:4d}: " + " | ".join(f"{n} {timeit(f):7.1f}" for n, f in cases), flush=True)

@@ -10,9 +10,9 @@ b = torch.randn(N, generator=g).to(dev); res = torch.randn(M, N, generator=g).to
 pos = torch.cartesian_prod(torch.arange(32), torch.arange(32)).to(dev).contiguous()
 table = ops.rope_table(dev, 1024, 100.0, 1.0)
 def run(var, fn):
-    os.environ["UC_GEMM_VARIANT"] = var
+    ops.tuning_set("gemm_variant", int(var))
     try: return fn()
-    finally: os.environ.pop("UC_GEMM_VARIANT")
+    finally: ops.tuning_set("gemm_variant", -3)
 cases = {
  "f32 plain": lambda: ops.gemm(a, w, out_dtype=torch.float32),
  "f32 bias+res": lambda: ops.gemm(a, w, b, residual=res, out_dtype=torch.float32),

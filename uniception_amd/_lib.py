@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("UC_HIP_LIB") or os.path.join(_HERE, "libuc_hip.so")   # UC_HIP_LIB: A/B-test another build
+# UC_HIP_LIB: A/B-test another build; UNICEPTION_AMD_DIAG_LIB=1: the diagnostics build (python -m uniception_amd.build --diag), tools only
+LIB_PATH = os.environ.get("UC_HIP_LIB") or os.path.join(_HERE, "libuc_hip_diag.so" if os.environ.get("UNICEPTION_AMD_DIAG_LIB") == "1"
+                                                        else "libuc_hip.so")
 
 UC_F32, UC_BF16, UC_F16 = 0, 1, 2
 UC_A_DENSE, UC_A_CONV3X3 = 0, 1
@@ -49,6 +51,8 @@ class GemmDesc(C.Structure):
 # name -> argtypes (every function returns int except uc_last_error)
 SIGNATURES = {
     "uc_abi_version": [],
+    "uc_tuning_set": [C.c_char_p, i32],
+    "uc_tuning_get": [C.c_char_p, C.POINTER(i32)],
     "uc_rope2d": [vp, vp, i32, i32, i32, i32, i64, i64, i64, f32, f32, i32, vp],
     "uc_rope_table": [vp, i32, i32, f32, f32, vp],
     "uc_layernorm": [vp, i32, vp, vp, vp, i32, i64, i32, f32, vp],
@@ -99,7 +103,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 6   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 7   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():
@@ -115,6 +119,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.uc_last_error.restype = C.c_char_p
     lib.uc_last_error.argtypes = []
+    lib.uc_build_flavor.restype = C.c_char_p
+    lib.uc_build_flavor.argtypes = []
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = i32

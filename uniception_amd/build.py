@@ -60,15 +60,15 @@ def hipcc_path():
     return "hipcc"
 
 
-def _compile_one(src, hdr, force, verbose):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+def _compile_one(src, hdr, force, verbose, extra=(), objdir=None):
+    obj = os.path.join(objdir or OBJ, src.replace(".hip", ".o"))
     stamp = obj + ".stamp"
     fp = hashlib.sha256(hdr.encode() + _read(os.path.join(CSRC, src))).hexdigest()
     if not force and os.path.exists(obj) and os.path.exists(stamp):
         with open(stamp) as f:
             if f.read().strip() == fp:
                 return obj, False
-    cmd = [hipcc_path()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [hipcc_path()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print("[uniception_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -97,6 +97,26 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_diag(verbose=True):
+    """The diagnostics flavour (-DUC_DIAG): libuc_hip_diag.so next to the product library, with the anatomy switches (UC_GEMM_DBG,
+    UC_ATTN_DBG: WRONG results by construction) and the per-workgroup timeline (UC_GEMM_TRACE: allocates, synchronises) compiled
+    in.  Tools load it with UNICEPTION_AMD_DIAG_LIB=1; it is git-ignored and never the library the package ships or tests."""
+    objdir = os.path.join(HERE, "_obj_diag")
+    os.makedirs(objdir, exist_ok=True)
+    hdr = _headers_digest() + "+diag"
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = [o for o, _ in ex.map(lambda s: _compile_one(s, hdr, False, verbose, ("-DUC_DIAG",), objdir), SOURCES)]
+    lib = os.path.join(HERE, "libuc_hip_diag.so")
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", lib]
+    if verbose:
+        print("[uniception_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--diag" in sys.argv:
+        print(build_diag())
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

@@ -14,6 +14,7 @@
 //
 // attn_f32_kernel — verification mode: one thread per query row, fp32 FMA chains, expf.
 #include "common.h"
+#include "knobs.h"
 #include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -641,18 +642,16 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         UC_REQUIRE(((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)O % 8 == 0),
                    "uc_attention_fwd(bf16): pointer alignment");
         // eight waves per workgroup (256 queries share each K / VT tile) when that does not add a mostly empty query tile
-        static int nw_env = -1;
-        if (nw_env < 0) { const char* e = getenv("UC_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
+        const int nw_env = uc_knobs().attn_nw;
         const int waste8 = (Nq + 255) / 256 * 256 - Nq, waste4 = (Nq + 127) / 128 * 128 - Nq;
         const int nw = nw_env == 4 || nw_env == 8 ? nw_env : ((Nq >= 256 && waste8 - waste4 < 64) ? 8 : 4);
         const int qtile = 32 * nw, nqt = (Nq + qtile - 1) / qtile;
         p.dGroup = uc_make_fastdiv((unsigned)(8 * nqt)); p.dNq = uc_make_fastdiv((unsigned)nqt); p.dH = uc_make_fastdiv((unsigned)H);
-        static int dbg = -1;   // diagnostics only (UC_ATTN_DBG; results are wrong): 1 no per-tile barrier, 2 no exp (P = S), 4 no PV MFMAs
-        if (dbg < 0) { const char* e = getenv("UC_ATTN_DBG"); dbg = e ? atoi(e) : 0; }
-        static int use_dma = -1;
-        if (use_dma < 0) { const char* e = getenv("UC_ATTN_DMA"); use_dma = e ? atoi(e) : 1; }
+        const int use_dma = uc_knobs().attn_dma;
         // DMA-staged kernel: whole 64-key tiles, 32-bit byte offsets inside one (batch, head)'s K rows / VT rows
         const bool dma_ok = use_dma && (int64_t)nqt * H * B < ((int64_t)1 << 31) && (uintptr_t)O % 16 == 0 && o_sb % 8 == 0 && o_sn % 8 == 0 && o_sh % 8 == 0 && (int64_t)32 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)Nk * k_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * p.npad * 2 < ((int64_t)1 << 31);
+#ifdef UC_DIAG
+        const int dbg = uc_knobs().attn_dbg;   // diag build only (results are wrong): 1 no per-tile barrier, 2 no exp (P = S), 4 no PV MFMAs
         if (dma_ok && nw == 4 && dbg) {
             const dim3 g((unsigned)(nqt * H * B));
             if (dbg == 1) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 1>), g, dim3(256), 0, st, p);
@@ -663,7 +662,9 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
             else if (dbg == 8) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 8>), g, dim3(256), 0, st, p);
             else if (dbg == 16) hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 16>), g, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 24>), g, dim3(256), 0, st, p);
-        } else if (dma_ok && nw == 8) hipLaunchKernelGGL(attn_bf16_dma_kernel<8>, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
+        } else
+#endif
+        if (dma_ok && nw == 8) hipLaunchKernelGGL(attn_bf16_dma_kernel<8>, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
         else if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel<4>, dim3((unsigned)(nqt * H * B)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
     } else if (dtype == UC_F32) {

@@ -4,6 +4,7 @@
 // All are single-pass streaming kernels; channel-last (NHWC) tensors are moved 8 elements per lane
 // (16 B bf16 / 2x16 B fp32).
 #include "common.h"
+#include "knobs.h"
 
 // ---- generic 8-element vector load/store with fp32 math in between --------------------------
 struct V8 { float v[8]; };
@@ -342,8 +343,7 @@ extern "C" int uc_bilinear_nhwc(const void* src, void* dst, int dtype, int B, in
     UC_REQUIRE(crop_h <= 65535 && B <= 65535 && (int64_t)crop_w * (C / 8) < ((int64_t)1 << 31), "uc_bilinear_nhwc: shape exceeds the launch grid");
     const dim3 grid((unsigned)(((int64_t)crop_w * (C / 8) + 255) / 256), (unsigned)crop_h, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    static int rows2 = -1;
-    if (rows2 < 0) { const char* e = getenv("UC_BILINEAR_ROWS2"); rows2 = e ? atoi(e) : 4; }   // rows per work item of the upsampling form: 4 (default), 2, 0 = one-row kernel
+    const int rows2 = uc_knobs().bilinear_rows2;   // rows per work item of the upsampling form: 4 (default), 2, 0 = one-row kernel
     // (bf16 only: the fp32 kernels are the verification path — its gradient fixtures sit on ReLU boundaries of the tiny test models,
     // where a 1e-7 change of the forward's rounding flips a mask and moves a small gradient tensor by 1e-3)
     if (rows2 && dtype == UC_BF16 && sy <= 0.5f) {

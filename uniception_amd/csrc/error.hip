@@ -1,5 +1,10 @@
-// Thread-local error text + ABI version for libuc_hip.so.
+// Thread-local error text, ABI version, build flavour and the tuning knobs of libuc_hip.so.
 #include "common.h"
+#include "knobs.h"
+
+#include <mutex>
+#include <stdlib.h>
+#include <string.h>
 
 static thread_local char g_uc_err[512] = {0};
 
@@ -12,3 +17,68 @@ void uc_set_error(const char* fmt, ...) {
 
 extern "C" const char* uc_last_error(void) { return g_uc_err; }
 extern "C" int uc_abi_version(void) { return UC_ABI_VERSION; }
+
+#ifdef UC_DIAG
+extern "C" const char* uc_build_flavor(void) { return "diag"; }
+#else
+extern "C" const char* uc_build_flavor(void) { return "release"; }
+#endif
+
+static UcKnobs g_knobs;
+static std::once_flag g_knobs_once;
+std::atomic<int> g_uc_gemm_variant{-3};
+std::atomic<int> g_uc_gemm_stagger{-1};
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+const UcKnobs& uc_knobs() {
+    std::call_once(g_knobs_once, [] {
+        g_knobs.gemm_group_m = env_int("UC_GEMM_GROUP_M", 4);
+        if (g_knobs.gemm_group_m < 1) g_knobs.gemm_group_m = 1;
+        g_knobs.gemm_coresident = env_int("UC_GEMM_CORESIDENT", 1);
+        g_knobs.gemm_nt = env_int("UC_GEMM_NT", -1);
+        g_knobs.gemm_8wave = env_int("UC_GEMM_8WAVE", 1);
+        g_knobs.gemm_small_stages = env_int("UC_GEMM_SMALL_STAGES", 3);
+        g_knobs.attn_nw = env_int("UC_ATTN_NW", 0);
+        g_knobs.attn_dma = env_int("UC_ATTN_DMA", 1);
+        g_knobs.bilinear_rows2 = env_int("UC_BILINEAR_ROWS2", 4);
+        g_knobs.ln_nt = env_int("UC_LN_NT", -1);
+        g_knobs.gemm_splitk_small = env_int("UC_GEMM_SMALLM", 1);
+#ifdef UC_DIAG
+        g_knobs.gemm_dbg = env_int("UC_GEMM_DBG", 0);
+        g_knobs.attn_dbg = env_int("UC_ATTN_DBG", 0);
+        g_knobs.gemm_trace = env_int("UC_GEMM_TRACE", 0);
+#endif
+        g_uc_gemm_variant.store(env_int("UC_GEMM_VARIANT", -3));
+        g_uc_gemm_stagger.store(env_int("UC_GEMM_STAGGER", -1));
+    });
+    return g_knobs;
+}
+
+extern "C" int uc_tuning_set(const char* name, int value) {
+    UC_REQUIRE(name, "uc_tuning_set: null name");
+    (void)uc_knobs();   // the environment's initial values first, so that a later first use does not overwrite this call
+    if (!strcmp(name, "gemm_variant")) {
+        UC_REQUIRE(value == -3 || value == -1 || (value >= 0 && value <= 3) || value == 6, "uc_tuning_set: gemm_variant must be -3 (automatic), -1, 0..3 or 6 (got %d)", value);
+        g_uc_gemm_variant.store(value);
+    } else if (!strcmp(name, "gemm_stagger")) {
+        UC_REQUIRE(value >= -1 && value <= 100000, "uc_tuning_set: gemm_stagger out of range (%d)", value);
+        g_uc_gemm_stagger.store(value);
+    } else {
+        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger; everything else is read from the environment once, see csrc/knobs.h)", name);
+        return UC_ERR_BAD_ARG;
+    }
+    return UC_OK;
+}
+
+extern "C" int uc_tuning_get(const char* name, int* value) {
+    UC_REQUIRE(name && value, "uc_tuning_get: null argument");
+    (void)uc_knobs();
+    if (!strcmp(name, "gemm_variant")) *value = g_uc_gemm_variant.load();
+    else if (!strcmp(name, "gemm_stagger")) *value = g_uc_gemm_stagger.load();
+    else { uc_set_error("uc_tuning_get: unknown knob '%s'", name); return UC_ERR_BAD_ARG; }
+    return UC_OK;
+}

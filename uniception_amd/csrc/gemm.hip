@@ -18,6 +18,7 @@
 // row: fragment ni and ni+1 of the SAME lane and register, so the rotation needs no cross-lane traffic.
 #include "common.h"
 #include "gemm_glds.h"
+#include "knobs.h"
 #include <stdlib.h>
 #include <algorithm>
 
@@ -481,13 +482,10 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             UC_REQUIRE((uintptr_t)d->vt_out % 8 == 0, "uc_gemm: vt_out must be 8-byte aligned");
         }
         // dense operands with K % 64 == 0 take the direct-to-LDS kernel (gemm_glds.hip)
-        // re-read on every call (a linear scan of environ, far below the launch cost) so that tests and micro-benchmarks can
-        // switch tile variants inside one process
-        int forced_variant;
-        {
-            const char* e = getenv("UC_GEMM_VARIANT");
-            forced_variant = e ? atoi(e) : -3;   // -3: automatic, -1: register-staged kernel, 0..3, 6: glds tile variants
-        }
+        // (initial value from UC_GEMM_VARIANT, switchable at run time through uc_tuning_set: tests and micro-benchmarks run every
+        // tile variant inside one process)
+        const UcKnobs& knobs = uc_knobs();
+        const int forced_variant = g_uc_gemm_variant.load(std::memory_order_relaxed);   // -3: automatic, -1: register-staged kernel, 0..3, 6: glds tile variants
         if (d->split_k > 1) {
             UC_REQUIRE(d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a, "uc_gemm: split_k needs a dense operand with K %% 64 == 0");
             UC_REQUIRE(d->out_dtype == UC_F32 && !d->bias && d->act == UC_ACT_NONE && !d->residual && d->rope_cols <= 0 && d->vt_col0 < 0 && !d->preact_out,
@@ -562,8 +560,12 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             g.tail_w = d->tail_w; g.tail_b = d->tail_b; g.tail_out = d->tail_out;
             if (d->tail_out) g.vec_ok = 0;     // never one of the single-family kernels
             g.dact_u = (const bf16_t*)d->dact_u; g.dact_act = d->dact_act;
-            { static int gm = -1; if (gm < 0) { const char* e = getenv("UC_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } g.group_m = gm; }
-            { static int dbg = -1; if (dbg < 0) { const char* e = getenv("UC_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+            g.group_m = knobs.gemm_group_m;
+#ifdef UC_DIAG
+            g.dbg = knobs.gemm_dbg;     // (diag build only; the release build has no code behind these bits)
+#else
+            g.dbg = 0;
+#endif
             g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
             g.cStride = d->conv_stride; g.cHo = d->conv_Ho; g.cWo = d->conv_Wo;
             if (d->a_mode == UC_A_CONV3X3) {
@@ -585,27 +587,27 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 if (variant == 2 && waste256 - waste128 >= 128 && t256x128 * sk >= 160) variant = 1;
                 // 256x128 tiles with enough workgroups for two per CU: the 32-deep K-step form (72 KiB of LDS, two co-resident
                 // 8-wave workgroups) keeps 16 waves on a CU where the 64-deep form (96 KiB) leaves 8
-                static int co = -1;
-                if (co < 0) { const char* e = getenv("UC_GEMM_CORESIDENT"); co = e ? atoi(e) : 1; }
-                if (variant == 1 && t256x128 * sk >= 512 && co) variant = 3;
+                if (variant == 1 && t256x128 * sk >= 512 && knobs.gemm_coresident) variant = 3;
             }
             if (d->tail_out && (variant == 2 || variant == 6)) variant = 1;    // the tail needs a tile that spans all 128 columns with two wave columns
-            { static int nt = -2; if (nt == -2) { const char* e = getenv("UC_GEMM_NT"); nt = e ? atoi(e) : -1; }
+            { const int nt = knobs.gemm_nt;
               const int64_t out_bytes = d->M * d->N * (d->out_dtype == UC_F32 ? 4 : 2);
               g.nt_out = out_bytes > ((int64_t)128 << 20) ? (nt >= 0 ? nt : 7) : 0; }   // bit 0: fp32 residual stream, 1: bf16 outputs, 2: bf16 RoPE (q, k) tiles
-            { const char* e = getenv("UC_GEMM_STAGGER"); g.stagger = e ? atoi(e) : -1; }   // -1: the launcher's default policy
-            static int trace_on = -1;
-            if (trace_on < 0) { const char* e = getenv("UC_GEMM_TRACE"); trace_on = e ? atoi(e) : 0; }
+            g.stagger = g_uc_gemm_stagger.load(std::memory_order_relaxed);   // -1: the launcher's default policy
             g.trace = nullptr;
+#ifdef UC_DIAG
+            const int trace_on = knobs.gemm_trace;
             static unsigned long long* trace_buf = nullptr;
             const size_t trace_cap = 1 << 16;
             if (trace_on) {
                 if (!trace_buf) (void)hipMalloc((void**)&trace_buf, trace_cap * 6 * sizeof(unsigned long long));
                 g.trace = trace_buf;
             }
+#endif
             uc_launch_gemm_glds(g, variant, st, forced_variant < 0);
             UC_CHECK_LAUNCH("uc_gemm(glds)");
-            if (trace_on) {   // diagnostics only: per-CU timeline statistics of this launch to stderr
+#ifdef UC_DIAG
+            if (trace_on) {   // diagnostics only (diag build): per-CU timeline statistics of this launch to stderr
                 (void)hipStreamSynchronize(st);
                 const int bm = variant >= 1 ? 256 : 128, bn = (variant == 2 || variant == 6) ? 256 : 128;
                 size_t nwg = (size_t)ceil_div64(d->M, bm) * ceil_div64(d->N, bn) * (size_t)g.split_k;
@@ -641,6 +643,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                         pro / nwg * 0.01, loop / nwg * 0.01, epi / nwg * 0.01, ngap ? gap / ngap * 0.01 : 0.0, ngap, overlap);
                 free(h); free(r);
             }
+#endif
             return UC_OK;
         }
         UC_REQUIRE(!d->ln_stats && !d->twin_out && !d->stats_out, "uc_gemm: the LayerNorm fusion options need the direct-to-LDS kernel (forced off?)");

@@ -2,6 +2,7 @@
 // mode and epilogue family in separate translation units (gemm_glds_*.hip): they compile in parallel and each kernel carries
 // only the epilogue code its launches can reach.
 #include "gemm_glds.h"
+#include "knobs.h"
 
 void glds_launch_dense_bf16(const GldsParams& p, int variant, hipStream_t st);
 void glds_launch_dense_f32(const GldsParams& p, int variant, hipStream_t st);
@@ -12,11 +13,10 @@ void glds_launch_conv(const GldsParams& p, int variant, hipStream_t st);
 int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool auto_variant) {
     if (p.a_mode == UC_A_CONV3X3) { glds_launch_conv(p, variant, st); return 0; }
     // a descriptor goes to a single-family kernel only when EVERY wave of the launch takes that family's epilogue
-    const bool plain = p.vec_ok && p.N % 64 == 0 && p.split_k <= 1 && !p.preact && !p.dact_u && !(p.dbg & 16);
+    const bool plain = p.vec_ok && p.N % 64 == 0 && p.split_k <= 1 && !p.preact && !p.dact_u && !UC_DBG(p, 16);
     // 256x256 tiles: the eight-wave form (variant 6, 128x64 per wave, next K-chunk's fragments register-resident) where it wins.
     // UC_GEMM_8WAVE: 0 off, 1 bf16-store family (default), 2 every family, 3 bf16-store family + bf16 residual stream.
-    static int eight = -1;
-    if (eight < 0) { const char* e = getenv("UC_GEMM_8WAVE"); eight = e ? atoi(e) : 1; }
+    const int eight = uc_knobs().gemm_8wave;
     // bf16 residual stream (out bf16 + bf16 residual and / or row statistics): the residual family's drain, 2 + 2 bytes per element
     const bool bf16_stream = plain && p.out_dtype == UC_BF16 && p.act == UC_ACT_NONE && p.vt_col0 < 0 && p.rope_cols <= 0 && !p.ln_stats &&
                              !p.residual2 && ((p.residual && p.res_dtype == UC_BF16) || p.stats_out);

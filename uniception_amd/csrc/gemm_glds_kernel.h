@@ -21,6 +21,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 #include "gemm_glds.h"
+#include "knobs.h"
 #include <stdlib.h>
 
 // How the epilogues see the kernel parameters: through the kernarg segment (scalar loads at the point of use), see the
@@ -173,7 +174,7 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
         if constexpr (LN) return __builtin_fmaf(__builtin_fmaf(-mu[r], csj[j], acc[i][j][r]), rs[r], bc);
         else return acc[i][j][r] + bc;
     };
-    if (FA == 4 && (p.vt_ntok & 63) == 0 && wave_m + 64 <= p.M && ((uintptr_t)p.vt_out & 15) == 0 && !(p.dbg & 16)) {
+    if (FA == 4 && (p.vt_ntok & 63) == 0 && wave_m + 64 <= p.M && ((uintptr_t)p.vt_out & 15) == 0 && !UC_DBG(p, 16)) {
         // The wave's 64 tokens are one aligned 64-position group of one image: 64 channel rows x 128 contiguous bytes of VT.
         // Bounce [channel d][position] through the wave's LDS block (chunk c of row d at chunk c ^ (d & 7), 8-byte halves
         // swapped when d & 8) and store whole rows: 8 x dwordx4 instead of 16 x dwordx2 that touch 16 rows x 32 B each.
@@ -468,11 +469,11 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
     const int64_t cstep = 4 * p.ldc * ES;
     // diagnostics (wrong results): dbg & 128 never reads the residual(s), dbg & 256 never writes the twin — together the HBM bytes of
     // a bf16 residual stream (4 per element instead of 10)
-    const char* rbase = (p.residual && !(p.dbg & 128)) ? (const char*)p.residual + (wave_m * p.ldr + wave_n) * ES : nullptr;
-    const char* rbase2 = (p.residual2 && !(p.dbg & 128)) ? (const char*)p.residual2 + (wave_m * p.ldr + wave_n) * ES : nullptr;
+    const char* rbase = (p.residual && !UC_DBG(p, 128)) ? (const char*)p.residual + (wave_m * p.ldr + wave_n) * ES : nullptr;
+    const char* rbase2 = (p.residual2 && !UC_DBG(p, 128)) ? (const char*)p.residual2 + (wave_m * p.ldr + wave_n) * ES : nullptr;
     const unsigned roff = (unsigned)(crow * (int)p.ldr + 4 * cc) * (unsigned)ES;
     const int64_t rstep = 4 * p.ldr * ES;
-    char* tbase = (!BS && p.twin && !(p.dbg & 256)) ? (char*)p.twin + (wave_m * p.ldt + wave_n) * 2 : nullptr;
+    char* tbase = (!BS && p.twin && !UC_DBG(p, 256)) ? (char*)p.twin + (wave_m * p.ldt + wave_n) * 2 : nullptr;
     const unsigned toff = (unsigned)(crow * (int)p.ldt + 4 * cc) * 2u;
     const int64_t tstep = 4 * p.ldt * 2;
     const int nblk = (int)(p.N >> 6);
@@ -866,7 +867,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
         asm volatile("" : "+v"(lane));
         char* wbuf = smem + wave * 8192;
         // (the launcher routes a descriptor to the BF16 / F32 family only when every tile of it takes that family's epilogue)
-        const bool plain = pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && !pe.preact && !pe.dact_u && !(pe.dbg & 16);
+        const bool plain = pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && !pe.preact && !pe.dact_u && !UC_DBG(pe, 16);
         auto bf16_family = [&]() __attribute__((always_inline)) {
             const bool nt = pe.nt_out & (mode == 1 ? 4 : 2);
             if (A_MODE == UC_A_DENSE && pe.ln_stats) {   // folded LayerNorm
@@ -941,7 +942,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                 }
             } else if (plain && pe.out_dtype == UC_BF16 && !pe.residual) bf16_family();
             else if (mode == 0 && pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && pe.out_dtype == UC_BF16 && !pe.residual &&
-                     !(pe.dbg & 16) && !pe.ln_stats && (pe.preact != nullptr) != (pe.dact_u != nullptr)) {
+                     !UC_DBG(pe, 16) && !pe.ln_stats && (pe.preact != nullptr) != (pe.dact_u != nullptr)) {
                 // training: fc1 with its pre-activation copy / a data-gradient GEMM with the activation backward fused
                 if (pe.preact) {
                     if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16_train<FA, UC_ACT_GELU_ERF, true, false>(pe, acc, wave_m, wave_n, lane, wbuf);
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-    if (p.trace) tr0 = __builtin_amdgcn_s_memrealtime();
+    if (UC_TRACE(p)) tr0 = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             } else {
                 const bool is_a = (wave * PER + q) * RPI < BM_;   // wave-uniform: an instruction is all-A or all-W
                 const unsigned vo = ((st1[q] >> tap) & 1u) ? st0[q] : 0xffffffffu;
-                if (is_a && (p.dbg & 64) && tap != 0) continue;   // diagnostics (wrong results): A tiles staged for tap 0 only — what a halo-tiled form could save at most
+                if (is_a && UC_DBG(p, 64) && tap != 0) continue;   // diagnostics (wrong results): A tiles staged for tap 0 only — what a halo-tiled form could save at most
                 if (is_a) dma16_buf_to_lds(vo, srd_a, soff_a, dst);
                 else dma16_buf_to_lds(vo, srd_w, soff_w, dst);
             }
@@ -1122,7 +1123,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
     const int kt0 = ksplit * nk_per;
     int nk = max(0, min(nk_per, nk_total - kt0));
-    if (p.dbg & 8) nk = min(nk, 1);                      // diagnostics: one K-step only (launch + prologue + epilogue cost)
+    if UC_DBG(p, 8) nk = min(nk, 1);                      // diagnostics: one K-step only (launch + prologue + epilogue cost)
     const int64_t kbase = (int64_t)kt0 * BK_;
     // SWAP: first MFMA operand = W rows -> C^T fragments (lane owns 4 consecutive columns of one row);
     // !SWAP (VT tiles): first operand = A rows (lane owns 4 consecutive tokens of one channel).
@@ -1169,19 +1170,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             if (nk > 0) issue_stage(0, kbase);
             for (int kt = 0; kt < nk; ++kt) {
                 wait_vmcnt<0>();                 // this wave's pieces of stage kt have landed
-                if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();    // ... and everyone else's; every wave is done reading stage kt-1
-                if (p.trace && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
+                if (!UC_DBG(p, 2)) __builtin_amdgcn_s_barrier();    // ... and everyone else's; every wave is done reading stage kt-1
+                if (UC_TRACE(p) && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
                 asm volatile("" ::: "memory");
                 // where the next stage's DMA is issued (same-box A/B): dense pieces cost one 64-bit add each and go first
                 // (behind the first MFMA group they lost 0-5 %, split between the wave halves of a SIMD 2-8 %); conv pieces
                 // carry the tap test, s_nop 4 and a descriptor select and go behind the wave's first 16 queued MFMAs (+5 % on
                 // the 256-channel convs)
                 if constexpr (A_MODE == UC_A_DENSE) {
-                    if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
+                    if (kt + 1 < nk && !UC_DBG(p, 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
                     compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag, [] {});
                 } else {
                     compute_stage(smem + (kt & 1) * STAGE_BYTES, swap_tag, [&] {
-                        if (kt + 1 < nk && !(p.dbg & 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
+                        if (kt + 1 < nk && !UC_DBG(p, 1)) issue_stage((kt + 1) & 1, kbase + (int64_t)(kt + 1) * BK_);
                     });
                 }
             }
@@ -1193,7 +1194,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             for (int kt = 0; kt < nk; ++kt) {
                 if (kt + 1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
-                if (p.trace && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
+                if (UC_TRACE(p) && kt == 0) tr1 = __builtin_amdgcn_s_memrealtime();
                 asm volatile("" ::: "memory");
                 int nxt = cur + 2; if (nxt >= 3) nxt -= 3;
                 if (kt + 2 < nk) issue_stage(nxt, kbase + (int64_t)(kt + 2) * BK_);
@@ -1219,7 +1220,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
 #else
     glds_pe_t pe = p;
 #endif
-    if (pe.dbg & 4) {                                     // diagnostics: no epilogue (keeps the accumulators live)
+    if UC_DBG(pe, 4) {                                     // diagnostics: no epilogue (keeps the accumulators live)
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < FA; ++i)
@@ -1232,9 +1233,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     static_assert(STAGES * STAGE_BYTES >= NW * 8192, "bounce space");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (pe.trace) tr2 = __builtin_amdgcn_s_memrealtime();
+    if (UC_TRACE(pe)) tr2 = __builtin_amdgcn_s_memrealtime();
     glds_epilogue_dispatch<FA, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n, tid, wave, ksplit, smem);
-    if (pe.trace) {
+    if (UC_TRACE(pe)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tid == 0) {
@@ -1242,7 +1243,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* t = pe.trace + (size_t)blockIdx.x * 6;
+            unsigned long long* t = UC_TRACE(pe) + (size_t)blockIdx.x * 6;
             t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime(); t[4] = hw; t[5] = xcc;
         }
     }
@@ -1268,7 +1269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
     constexpr int A_MODE = UC_A_DENSE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-    if (p.trace) tr0 = __builtin_amdgcn_s_memrealtime();
+    if (UC_TRACE(p)) tr0 = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1344,7 +1345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
     const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
     const int kt0 = ksplit * nk_per;
     int nk = max(0, min(nk_per, nk_total - kt0));
-    if (p.dbg & 8) nk = min(nk, 1);
+    if UC_DBG(p, 8) nk = min(nk, 1);
     const int64_t kbase = (int64_t)kt0 * 64;
 
     auto main_loop = [&](auto swap_tag) __attribute__((always_inline)) {
@@ -1364,7 +1365,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
         issue_stage(0, kbase);
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (p.trace) tr1 = __builtin_amdgcn_s_memrealtime();
+        if (UC_TRACE(p)) tr1 = __builtin_amdgcn_s_memrealtime();
         asm volatile("" ::: "memory");
         if (nk > 1) issue_stage(1, kbase + 64);
 #pragma unroll
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
             const char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
             // every fragment of stage kt is in registers (lgkmcnt(0)), this wave's DMA pieces of the next stage have landed
             // (vmcnt(0)); after the barrier both hold for the whole workgroup
-            if (p.dbg & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // diagnostics: do not wait for the DMA (wrong results)
+            if UC_DBG(p, 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // diagnostics: do not wait for the DMA (wrong results)
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1414,7 +1415,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
                 for (int j = 0; j < 4; ++j) mma(i, j, a[i], wn[j]);
                 __builtin_amdgcn_sched_barrier(0);
                 a[i] = rd_a(nxt, 0, i);
-                if constexpr (DMA) { if (!(p.dbg & 1)) issue_piece(kt & 1, k2, i); }
+                if constexpr (DMA) { if (!UC_DBG(p, 1)) issue_piece(kt & 1, k2, i); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             chunk0(nxt);
@@ -1437,7 +1438,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
 #else
     glds_pe_t pe = p;
 #endif
-    if (pe.dbg & 4) {
+    if UC_DBG(pe, 4) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < FA; ++i)
@@ -1448,9 +1449,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
     }
     __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the bounce space (8 KiB per wave)
     asm volatile("" ::: "memory");
-    if (pe.trace) tr2 = __builtin_amdgcn_s_memrealtime();
+    if (UC_TRACE(pe)) tr2 = __builtin_amdgcn_s_memrealtime();
     glds_epilogue_dispatch<FA, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n, tid, wave, ksplit, smem);
-    if (pe.trace) {
+    if (UC_TRACE(pe)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tid == 0) {
@@ -1458,7 +1459,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* t = pe.trace + (size_t)blockIdx.x * 6;
+            unsigned long long* t = UC_TRACE(pe) + (size_t)blockIdx.x * 6;
             t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime(); t[4] = hw; t[5] = xcc;
         }
     }
@@ -1505,8 +1506,7 @@ static void launch_variant_mode(GldsParams p, hipStream_t st) {
 // two co-resident workgroups per CU.
 template <int A_MODE, int EPI>
 static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t st) {
-    static int deep = -1;
-    if (deep < 0) { const char* e = getenv("UC_GEMM_SMALL_STAGES"); deep = e ? atoi(e) : 3; }
+    const int deep = uc_knobs().gemm_small_stages;
     const int64_t sk = p.split_k > 1 ? p.split_k : 1;
     switch (variant) {
         case 1:

@@ -1,0 +1,44 @@
+// Tuning knobs of libuc_hip.so.
+//
+// Every environment variable the library honours is read ONCE, on first use, under std::call_once (uc_knobs()): no lazily
+// initialised function-local statics, no getenv on a launch path.  All of them choose between CORRECT code paths (tile variants,
+// cache policies, workgroup sizes); none changes results beyond what the chosen kernel's own arithmetic order does.
+// Two of them can also be switched at run time through the C ABI (uc_tuning_set: atomics) — tests and micro-benchmarks run every
+// tile variant inside one process.
+//
+// Diagnostics that produce WRONG results or allocate / synchronise (UC_GEMM_DBG, UC_ATTN_DBG, UC_GEMM_TRACE) exist only in a
+// build with -DUC_DIAG (python -m uniception_amd.build --diag -> libuc_hip_diag.so, never the shipped library): in the release
+// build UC_DBG(...) / UC_TRACE(...) are compile-time constants and the code behind them is not in the binary.
+#pragma once
+#include <atomic>
+
+struct UcKnobs {
+    int gemm_group_m;        // UC_GEMM_GROUP_M      row panels per L2-sharing tile group (default 4)
+    int gemm_coresident;     // UC_GEMM_CORESIDENT   256x128x32 tiles with two workgroups per CU for narrow outputs (default 1)
+    int gemm_nt;             // UC_GEMM_NT           non-temporal epilogue mask override (-1: policy)
+    int gemm_8wave;          // UC_GEMM_8WAVE        eight-wave 256x256 kernel: 0 off, 1 bf16-store family (default), 2 all, 3 + bf16 stream
+    int gemm_small_stages;   // UC_GEMM_SMALL_STAGES 3-stage ring for launches with fewer workgroups than CUs (default 3)
+    int attn_nw;             // UC_ATTN_NW           waves per attention workgroup: 0 policy, 4, 8
+    int attn_dma;            // UC_ATTN_DMA          LDS-DMA attention kernel (default 1)
+    int bilinear_rows2;      // UC_BILINEAR_ROWS2    output rows per work item of the upsampling form (default 4)
+    int ln_nt;               // UC_LN_NT             non-temporal LayerNorm loads override (-1: policy)
+    int gemm_splitk_small;   // UC_GEMM_SMALLM       small-M policy of the dense GEMM (default 1: fill the CUs with split-K slices / smaller tiles)
+#ifdef UC_DIAG
+    int gemm_dbg;            // UC_GEMM_DBG          (diag build only) wrong-result anatomy switches of the GEMM kernels
+    int attn_dbg;            // UC_ATTN_DBG          (diag build only) wrong-result anatomy switches of the attention kernel
+    int gemm_trace;          // UC_GEMM_TRACE        (diag build only) per-workgroup timeline: allocates, synchronises, prints
+#endif
+};
+const UcKnobs& uc_knobs();
+
+// run-time switchable (uc_tuning_set): -3 / -1 mean "automatic / launcher policy"
+extern std::atomic<int> g_uc_gemm_variant;   // UC_GEMM_VARIANT: -3 automatic, -1 register-staged kernel, 0..3, 6 direct-to-LDS tile variants
+extern std::atomic<int> g_uc_gemm_stagger;   // UC_GEMM_STAGGER: -1 launcher policy, >= 0 ticks per phase group
+
+#ifdef UC_DIAG
+#define UC_DBG(p, bits) ((p).dbg & (bits))
+#define UC_TRACE(p) ((p).trace)
+#else
+#define UC_DBG(p, bits) (0)
+#define UC_TRACE(p) ((unsigned long long*)nullptr)
+#endif

@@ -3,6 +3,7 @@
 // the layout allows, trig hoisted out of the per-head loop (the reference recomputes nothing per
 // head either: kernels.cu:47-50 computes cos/sin once per (token, channel) and loops over heads).
 #include "common.h"
+#include "knobs.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -293,8 +294,7 @@ static void launch_ln(const void* x, const float* g, const float* b, void* y, bf
                      ((uintptr_t)y % 16 == 0) && ((uintptr_t)twin % 8 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)b % 16 == 0) &&
                      (((int64_t)C * sizeof(SI)) % (4 * sizeof(SI)) == 0);
     const bool exact = vec && (C % 256 == 0);
-    static int nt_env = -2;
-    if (nt_env == -2) { const char* e = getenv("UC_LN_NT"); nt_env = e ? atoi(e) : -1; }
+    const int nt_env = uc_knobs().ln_nt;
     const bool nt = nt_env >= 0 ? nt_env != 0 : (rows * (int64_t)C * (int64_t)sizeof(SI) > ((int64_t)128 << 20));
 #define UC_LN_EXACT(NV_)                                                                                                          \
     do {                                                                                                                          \

@@ -8,6 +8,8 @@ import ctypes as C
 import weakref
 from typing import Optional, Tuple
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -40,6 +42,31 @@ def _stream():
 
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
+
+
+def tuning_set(name: str, value: int) -> None:
+    """Run-time switchable tuning knobs of libuc_hip.so (uc_tuning_set): "gemm_variant" (-3 automatic, -1 register-staged kernel,
+    0..3 / 6 tile variants of the direct-to-LDS bf16 GEMM), "gemm_stagger" (-1 launcher policy).  Every value selects a correct
+    kernel; everything else the library reads from the environment, once (csrc/knobs.h)."""
+    _lib.check(_lib.load().uc_tuning_set(name.encode(), int(value)), f"uc_tuning_set({name})")
+
+
+def tuning_get(name: str) -> int:
+    import ctypes
+    v = ctypes.c_int(0)
+    _lib.check(_lib.load().uc_tuning_get(name.encode(), ctypes.byref(v)), f"uc_tuning_get({name})")
+    return v.value
+
+
+@contextlib.contextmanager
+def tuning(name: str, value: int):
+    "Scoped tuning_set (tests, micro-benchmarks: run one tile variant, then restore)."
+    prev = tuning_get(name)
+    tuning_set(name, value)
+    try:
+        yield
+    finally:
+        tuning_set(name, prev)
 
 
 # --------------------------------------------------------------------------------------------
