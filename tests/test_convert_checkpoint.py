@@ -113,3 +113,31 @@ def test_key_map_equals_the_reference_scripts():
     mods = cc.split_modules(conv)
     for h in ("1", "2"):
         _same_map(mods[f"linear_feature_head{h}"]["model"], fx["modules"][f"linear_feature_head{h}"], names)
+
+
+def test_original_dpt_weights_through_the_converter_match_the_original_module_on_cpu():
+    """CPU half of the numeric pin of the DPT key map (the GPU half: test_convert_checkpoint_gpu.py): the weights of
+    tests/golden/dpt_original.npz — ORIGINAL checkpoint names, output of the reference's `DPTOutputAdapter`
+    (libs/croco/dpt_block.py:326-530) — converted and evaluated by the oracle's DPT restatement (which is keyed by the UniCeption
+    names) reproduce that output.  A wrong map entry cannot pass: the oracle reads every converted key by name."""
+    import os
+
+    import numpy as np
+
+    from oracle import dust3r_oracle as O
+    from tests.golden.dpt_original_case import DPT_ORIGINAL as C
+    from tests.helpers import GOLDEN_DIR, rel_l2
+    gold = np.load(os.path.join(GOLDEN_DIR, "dpt_original.npz"))
+    orig = {k[2:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w/")}
+    conv, dropped = cc.original_to_uniception(orig)
+    assert len(dropped) == 4 and all("refinenet4.resConfUnit1" in k for k in dropped)
+    h, w = C["img"][0] // C["patch"], C["img"][1] // C["patch"]
+    feats = [torch.from_numpy(gold[f"tokens{i}"]).transpose(1, 2).reshape(C["B"], -1, h, w) for i in range(4)]
+    with torch.no_grad():
+        up8 = O.dpt_feature(feats, conv, "dpt_feature_head1.")
+        out = O.dpt_regressor(up8, tuple(C["img"]), conv, "dpt_regressor_head1.")
+    assert rel_l2(out, gold["out"]) < 1e-5
+    # ... and through the alias names the factory registers (head1.0.* / head1.1.*)
+    with torch.no_grad():
+        out2 = O.dpt_regressor(O.dpt_feature(feats, conv, "head1.0."), tuple(C["img"]), conv, "head1.1.")
+    assert torch.equal(out, out2)

@@ -1,0 +1,77 @@
+"""uniception_amd/tools/verify_outputs.py — the counterpart of the reference's real-weights check
+(examples/models/dust3r/dust3r.py:198-230).  CPU: the metric definitions and the gate; GPU: the whole command on an `.npz` the
+ORACLE wrote (real DUSt3R reference outputs are external files the build environment cannot fetch)."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from uniception_amd.tools import verify_outputs as V
+
+
+def test_metrics_are_the_references():
+    g = np.random.default_rng(0)
+    x = g.standard_normal((2, 8, 8, 3))
+    y = x + 1e-4 * g.standard_normal(x.shape)
+    a, r = V.abs_and_rel_error(x, y)
+    assert a == np.abs(x - y).max() and r == np.linalg.norm(x - y) / np.linalg.norm(x)      # dust3r.py:223: relative to the OUTPUT's norm
+    out = {k: x if "pts3d" in k else x[..., 0] for k in V.KEYS}
+    ref = {k: y if "pts3d" in k else y[..., 0] for k in V.KEYS}
+    rep, ok = V.compare(out, ref)
+    assert ok and all(v[2] for v in rep.values())
+    ref["head2_conf"] = ref["head2_conf"].copy()
+    ref["head2_conf"][0, 0, 0] += 0.02                                                      # one pixel off by 2e-2: max-abs gate
+    rep, ok = V.compare(out, ref)
+    assert not ok and not rep["head2_conf"][2] and rep["head1_conf"][2]
+    ref["head2_conf"] = (1.0 + 2e-3) * out["head2_conf"]                                    # uniformly 0.2 % off: rel gate only
+    rep, ok = V.compare(out, ref)
+    assert not ok and rep["head2_conf"][0] < 1e-2 and rep["head2_conf"][1] > 1e-3
+    with pytest.raises(ValueError):
+        V.compare(out, dict(ref, head1_conf=ref["head1_conf"][:1]))
+    with pytest.raises(KeyError):
+        V.compare(out, {k: v for k, v in ref.items() if k != "head1_pts3d"})
+
+
+def test_image_normalisation_follows_the_reference():
+    u8 = (np.arange(4 * 6 * 4) % 256).astype(np.uint8).reshape(4, 6, 4)                     # RGBA like the reference's PNGs: alpha dropped
+    t = V.normalise_image(u8)
+    assert t.shape == (3, 4, 6) and torch.allclose(t, ((torch.from_numpy(u8[..., :3]).float() / 255 - 0.5) / 0.5).permute(2, 0, 1))
+    f = np.random.default_rng(1).random((4, 6, 3)).astype(np.float32)
+    assert torch.allclose(V.normalise_image(f), ((torch.from_numpy(f) - 0.5) / 0.5).permute(2, 0, 1))
+    chw = np.random.default_rng(2).standard_normal((3, 4, 6)).astype(np.float32)
+    assert torch.equal(V.normalise_image(chw), torch.from_numpy(chw))
+    v1, v2 = V.symmetrized_views(torch.zeros(3, 4, 6), torch.ones(3, 4, 6), "cpu")
+    assert v1["instance"] == [0, 1] and v2["instance"] == [1, 0] and torch.equal(v2["img"], v1["img"][[1, 0]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("head", ["dpt", "linear"])
+def test_command_on_an_oracle_written_reference(gpu, tmp_path, head):
+    """Original-layout checkpoint -> converter -> factory model -> forward -> both metrics, both heads, through main()."""
+    from oracle import dust3r_oracle as O
+    from tests.golden.cases import GAINS
+    from uniception_amd.models.factory import DUSt3R
+    from uniception_amd.tools import convert_checkpoint as cc
+    size = (224, 224)
+    torch.manual_seed(0)
+    src = DUSt3R(name="v", img_size=size, pred_head_type=head).eval()
+    O.fill_state_dict_(src.state_dict(), gains=GAINS)
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    torch.save({"model": cc.uniception_to_original(sd)}, tmp_path / "orig.pth")
+    g = np.random.default_rng(5)
+    img0, img1 = (g.integers(0, 256, size=(224, 224, 3), dtype=np.uint8) for _ in range(2))
+    np.savez(tmp_path / "pair.npz", img0=img0, img1=img1)
+    a, b = V.normalise_image(img0), V.normalise_image(img1)
+    with torch.no_grad():      # the oracle (CPU restatement of the reference path, pinned to it by tests/golden) on the symmetrized pair
+        o1, o2 = O.dust3r_forward(sd, torch.stack([a, b]), torch.stack([b, a]), head=head)
+    np.savez(tmp_path / "ref.npz", head1_pts3d=o1["pts3d"].numpy(), head2_pts3d=o2["pts3d_in_other_view"].numpy(),
+             head1_conf=o1["conf"].squeeze(-1).numpy(), head2_conf=o2["conf"].squeeze(-1).numpy())
+    base = ["--checkpoint", str(tmp_path / "orig.pth"), "--original", "--images", str(tmp_path / "pair.npz"), "--head", head, "--img", "224"]
+    assert V.main(base + ["--reference", str(tmp_path / "ref.npz"), "--precision", "fp32"]) == 0
+    assert V.main(base + ["--reference", str(tmp_path / "ref.npz"), "--precision", "bf16x3"]) == 0
+    bad = dict(np.load(tmp_path / "ref.npz"))
+    bad["head2_pts3d"] = bad["head2_pts3d"] * 1.01
+    np.savez(tmp_path / "bad.npz", **bad)
+    assert V.main(base + ["--reference", str(tmp_path / "bad.npz"), "--precision", "fp32"]) == 1
