@@ -183,8 +183,8 @@ def timed(step, steps, world):
 def reference_policy_legs(model, v1, v2, args, dev):
     """Beside the bf16 headline: the reference keeps its heads in fp32 (factory/dust3r.py:288-309).  (a) bf16 transformer +
     fp32-class heads (split bf16 operands on the matrix pipe) at the headline batch; (b) EVERYTHING fp32-class
-    (engine.precision("bf16x3"): split-operand GEMMs / convolutions, exact fp32 attention) — the mode that meets the
-    1e-3 / 1e-2 gate (tests/test_precision_modes_gpu.py) — on a bounded batch; (c) the encoder + decoder alone (linear
+    (engine.precision("bf16x3"): split-operand GEMMs / convolutions / attention products on the matrix pipe) — the mode that meets
+    the 1e-3 / 1e-2 gate (tests/test_precision_modes_gpu.py) — at the headline batch; (c) the encoder + decoder alone (linear
     head, 0.15 % of the FLOPs), the quantity the 40 % MFMA target is defined on; (d) the headline forward with an fp32 residual
     stream instead of the reference's bf16 one."""
     from uniception_amd import engine
@@ -215,14 +215,14 @@ def reference_policy_legs(model, v1, v2, args, dev):
             dt, _ = timed(f, steps, 1)
         out["bf16_operands_fp32_residual_stream"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
                                                      "pairs_per_gpu": args.pairs}
-    nb = min(args.pairs, 4)
-    s1 = {k: (v[:nb] if k != "data_norm_type" else v) for k, v in v1.items()}
-    s2 = {k: (v[:nb] if k != "data_norm_type" else v) for k, v in v2.items()}
-    f = fwd(s1, s2, "bf16x3")
+    f = fwd(v1, v2, "bf16x3")
     f(); f()
     dt, _ = timed(f, 2, 1)
-    out["everything_fp32class"] = {"pairs_per_s": round(nb * 2 / dt, 2), "ms_per_step": round(dt / 2 * 1e3, 2), "pairs_per_gpu": nb,
-                                   "mode": "bf16x3 GEMMs/convs + exact fp32 attention (VALU)", "meets": "rel-L2 < 1e-3 and max-abs < 1e-2 vs reference"}
+    out["everything_fp32class"] = {"pairs_per_s": round(args.pairs * 2 / dt, 2), "ms_per_step": round(dt / 2 * 1e3, 2), "pairs_per_gpu": args.pairs,
+                                   "mode": "bf16x3: every GEMM / convolution and both products of the attention as three bf16 MFMA products of "
+                                           "split operands, fp32 accumulate, fp32 softmax, fp32 tensors",
+                                   "meets": "rel-L2 < 1e-3 and max-abs < 1e-2 vs reference (tests/test_precision_modes_gpu.py)"}
+    torch.cuda.empty_cache()
     if args.head == "dpt" and args.encoder == "croco":
         torch.manual_seed(0)
         lin = DUSt3R(name="bench_linear", img_size=(args.img, args.img), pred_head_type="linear").to(dev).eval()

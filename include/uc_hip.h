@@ -43,7 +43,7 @@ const char* uc_last_error(void);
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
  *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added.  4/5: see INTEGRATION.md.
  *   6: uc_adaptor_program_bwd added.  7: uc_build_flavor, uc_tuning_set / uc_tuning_get (environment knobs read once; no
- *      diagnostics in the release build). */
+ *      diagnostics in the release build), uc_attention_fwd_x3. */
 #define UC_ABI_VERSION 7
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
@@ -185,6 +185,20 @@ int uc_split_bf16x3(const float* x, void* out, int64_t rows, int C, int relu, uc
 /* Merge the per-block row statistics a producer GEMM wrote (stats_out: [rows][nblk][2] = (sum, squared deviations from the
  * block mean) over 64-column blocks, C = 64 * nblk columns) into LayerNorm statistics: out[row] = (mean, 1/sqrt(var_biased + eps)). */
 int uc_ln_stats_finalize(const float* partial, int64_t rows, int nblk, float eps, float* out, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * fp32-class attention on the matrix pipe (head_dim 64; engine.precision("bf16x3")): softmax(scale Q K^T) V with both products as
+ * THREE bf16 MFMA products of split operands (x = hi + lo; hi.hi + hi.lo + lo.hi, fp32 accumulate), fp32 softmax — ~1e-5 relative
+ * on the output, the arithmetic of F.scaled_dot_product_attention in fp32 (libs/croco/blocks.py:123-125,
+ * models/utils/transformer_blocks.py:244-246, 373-375) at MFMA rate.  Q / K / V: fp32 [B, N, H, 64] addressed by element strides
+ * (unit channel stride); O: fp32, same addressing; lse: optional fp32 [B, H, Nq].  `workspace`: device scratch of
+ * uc_attention_x3_workspace_bytes(B, H, Nq, Nk) bytes (the split bf16 operands; the call allocates nothing).
+ * ---------------------------------------------------------------------------------- */
+int64_t uc_attention_x3_workspace_bytes(int B, int H, int Nq, int Nk);
+int uc_attention_fwd_x3(const float* Q, const float* K, const float* V, float* O, void* workspace, int B, int H, int Nq, int Nk,
+                        int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                        int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale, float* lse,
+                        uc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Scaled-dot-product attention, no mask, no dropout:  O = softmax(Q K^T * scale) V

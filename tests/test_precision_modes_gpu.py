@@ -43,6 +43,34 @@ def test_split_gemm_and_conv_match_fp32(gpu):
         assert rel_l2(yc.view(refc.shape).cpu(), refc) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 196, 196), (1, 2, 1024, 1024), (2, 2, 150, 333), (1, 1, 64, 4096), (3, 2, 40, 8)])
+def test_split_operand_attention_matches_fp64(gpu, shape):
+    """uc_attention_fwd_x3 — both products of softmax(QK^T)V as three bf16 MFMA products of split operands, fp32 softmax — against
+    the fp64 product: fp32-class (<= 3e-5), where the bf16 kernel is at 4e-3; strided q / k / v views of one fused qkv buffer, ragged
+    and cross-attention key counts, peaked scores (a large scale), and agreement with the exact fp32 VALU kernel it replaces in
+    engine.precision("bf16x3") (libs/croco/blocks.py:123-125, utils/transformer_blocks.py:244-246, 373-375)."""
+    from uniception_amd import ops
+    B, H, Nq, Nk = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    if Nq == Nk:
+        qkv = torch.randn(B, Nq, 3, H, 64, generator=g).to(gpu)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    else:
+        q = torch.randn(B, Nq, H, 64, generator=g).to(gpu)
+        kv = torch.randn(B, Nk, 2, H, 64, generator=g).to(gpu)
+        k, v = kv[:, :, 0], kv[:, :, 1]
+    for scale in (0.125, 1.0):          # 1.0: softmax dominated by a few keys (scores ~ N(0, 64))
+        o = ops.attention_x3(q, k, v, scale)
+        assert o.shape == (B, Nq, H, 64) and o.dtype == torch.float32 and o.is_contiguous()
+        qd, kd, vd = (t.double().permute(0, 2, 1, 3) for t in (q, k, v))
+        ref = (torch.softmax(qd @ kd.transpose(-1, -2) * scale, -1) @ vd).permute(0, 2, 1, 3)
+        err = rel_l2(o.cpu(), ref.cpu())
+        exact = ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), scale)
+        print(f"[x3 attention] {shape} scale {scale}: rel-L2 {err:.2e} (exact fp32 kernel {rel_l2(exact.cpu(), ref.cpu()):.2e})")
+        assert err < 3e-5
+        assert float((o - ref.float()).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
 def _run(name, gpu, mode, head_mode):
     from uniception_amd import engine
     model, c = build_case_model(name)

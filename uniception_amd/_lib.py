@@ -62,6 +62,8 @@ SIGNATURES = {
     "uc_split_bf16x3": [vp, vp, i64, i32, i32, vp],
     "uc_add_view_pe": [vp, vp, i64, i32, i32, i32, i32, vp],
     "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
+    "uc_attention_x3_workspace_bytes": [i32, i32, i32, i32],
+    "uc_attention_fwd_x3": [vp, vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
     "uc_attention_fwd_fp8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [f32, vp],
     "uc_vt_pack_fp8": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
     "uc_attention_fwd_fp8_k8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 6 + [f32, vp],
@@ -123,7 +125,7 @@ def load():
     lib.uc_build_flavor.argtypes = []
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
-        fn.restype = i32
+        fn.restype = i64 if name.endswith("_bytes") else i32
         fn.argtypes = args
     if lib.uc_abi_version() != ABI_VERSION:
         raise UcHipError(f"{LIB_PATH} has ABI version {lib.uc_abi_version()}, this binding expects {ABI_VERSION}: rebuild it "

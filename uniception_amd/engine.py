@@ -36,8 +36,9 @@ def precision(name: Optional[str]):
     """Force the compute precision of the transformer GEMMs/attention: None (follow autocast) or
     "fp32"   verification mode: exact fp32 kernels (k-ascending FMA chains) everywhere;
     "bf16"   bf16 MFMA operands, fp32 accumulate — the performance mode;
-    "bf16x3" fp32 tensors, every GEMM / convolution on split bf16 operands (hi.hi + hi.lo + lo.hi, fp32 accumulate: fp32-class
-             results on the matrix pipe, see ops.split_bf16x3), attention in the exact fp32 kernel: the fast 1e-3-grade mode."""
+    "bf16x3" fp32 tensors, every GEMM / convolution AND both products of the attention on split bf16 operands (hi.hi + hi.lo +
+             lo.hi, fp32 accumulate: fp32-class results on the matrix pipe, see ops.split_bf16x3 / ops.attention_x3), fp32 softmax:
+             the fast 1e-3-grade mode."""
     global _forced_dtype, _forced_x3
     prev = (_forced_dtype, _forced_x3)
     _forced_dtype = {None: None, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
@@ -72,6 +73,7 @@ def _fp32_matmul() -> str:
 ops.fp32_matmul_hook = _fp32_matmul
 
 
+_x3_attention: bool = os.environ.get("UNICEPTION_AMD_X3_ATTENTION", "1") != "0"   # bf16x3 mode: MFMA split-operand attention (0: the exact fp32 VALU kernel)
 _attn_mode: str = os.environ.get("UNICEPTION_AMD_ATTENTION", "bf16")   # "bf16" | "fp8": matrix format of the bf16 path's attention
 
 
@@ -510,6 +512,9 @@ def _attention_generic(q, k, v, scale):
     q = q if q.stride(3) == 1 else q.contiguous()
     k = k if k.stride(3) == 1 else k.contiguous()
     v = v if v.stride(3) == 1 else v.contiguous()
+    if _forced_x3 and q.shape[-1] == 64 and _x3_attention and not torch.is_grad_enabled():
+        # precision("bf16x3"): the two products of the attention as three bf16 MFMA products of split operands each, fp32 softmax
+        return ops.attention_x3(q, k, v, scale)
     return ops.attention(q, k, v, scale)
 
 

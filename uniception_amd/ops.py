@@ -410,6 +410,26 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, v
     return out
 
 
+def attention_x3(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None,
+                 lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32-class attention on the matrix pipe (uc_attention_fwd_x3: split bf16 operands, three MFMA products per product, fp32
+    softmax).  q [B,Nq,H,64], k / v [B,Nk,H,64]: fp32 strided views with stride(3) == 1.  Returns fp32 O [B,Nq,H,64] contiguous."""
+    _need_gpu(q, k, v)
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    assert D == 64 and q.dtype == k.dtype == v.dtype == torch.float32
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and k.shape == v.shape
+    if out is None:
+        out = torch.empty((B, Nq, H, D), dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    ws = torch.empty(int(lib.uc_attention_x3_workspace_bytes(B, H, Nq, Nk)), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.uc_attention_fwd_x3(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), ws.data_ptr(), B, H, Nq, Nk,
+                                       q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                       v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2), float(scale),
+                                       _p(lse), _stream()), "uc_attention_fwd_x3")
+    return out
+
+
 def patch_gather(img: torch.Tensor, P: int, out_dtype: torch.dtype) -> torch.Tensor:
     _need_gpu(img)
     assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4
