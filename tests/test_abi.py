@@ -91,3 +91,25 @@ def test_product_path_fails_loudly_without_gpu():
         ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-6, torch.float32)
     with pytest.raises(RuntimeError):
         ops.rope_2d_(torch.zeros(1, 2, 1, 64), torch.zeros(1, 2, 2, dtype=torch.int64), 100.0, 1.0)
+
+
+def test_four_wave_gemm_hands_its_accumulators_over_in_untouched_agprs():
+    """gemm_bf16_glds4_kernel: the asm K-loop leaves its accumulators in a0..a255 and 256 single-register asm statements read them
+    back for the C++ epilogues.  Sound only if the compiler itself never allocates an AGPR in that kernel — checked on the generated
+    code of the two instantiations the forward uses (tools/check_glds4_agprs.py); also: the committed loop text is what the generator
+    produces."""
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_glds4_agprs as chk
+    with ThreadPoolExecutor(2) as ex:
+        reports = list(ex.map(chk.check, ["gemm_glds_dense_bf16.hip", "gemm_glds_dense_bs.hip"]))
+    seen = 0
+    for rep in reports:
+        for name, (blocks, bad) in rep.items():
+            seen += 1
+            assert blocks >= 257 and not bad, (name, blocks, bad[:3])
+    assert seen == 2
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "uniception_amd", "csrc", "gen", "gen_glds4_loop.py")], capture_output=True, text=True, check=True).stdout
+    assert gen == open(os.path.join(ROOT, "uniception_amd", "csrc", "gemm_glds4_loop.inc")).read(), "regenerate gemm_glds4_loop.inc"

@@ -189,7 +189,7 @@ def test_gemm_bf16_rope_and_vt_epilogue(gpu):
         assert torch.equal(packed.cpu()[:, :, :, posn], v_ref.bfloat16().permute(0, 2, 3, 1))
 
 
-@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6"])
+@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6", "7"])
 def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     """LayerNorm fused into the GEMMs around it (blocks.py:158-161, transformer_blocks.py:643-646): the producer's fp32 epilogue
     emits a bf16 twin + per-row block statistics, the consumer GEMM on the RAW twin with gamma folded into W reproduces
@@ -250,7 +250,7 @@ def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     assert rel_l2(vt.cpu().float()[:, :, :, posn].permute(0, 3, 1, 2), full[:, :, 2]) < 6e-3
 
 
-@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6"])
+@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6", "7"])
 def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
     """The producer GEMM of a bf16 residual stream (the reference's stream under autocast): bf16 output = round(acc + bias + bf16
     residual) in ONE rounding, row statistics of the STORED (rounded) rows, the output its own twin; ragged M;
@@ -291,7 +291,7 @@ def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
         assert rel_l2(y.cpu().float(), y_ref) < 6e-3
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "6"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "6", "7"])
 def test_gemm_bf16_tile_variants(gpu, variant, monkeypatch):
     """Every tile variant of the direct-to-LDS kernel (uc_tuning_set "gemm_variant") against the fp32 product, through
     each specialised epilogue: bf16 store (+GELU), fp32 residual add, RoPE + VT, the generic drain (ragged N, bf16 residual)."""
@@ -602,3 +602,31 @@ def test_curope2d_module_and_autograd_function(gpu):
     assert rel_l2(y.detach().transpose(1, 2).cpu(), O.rope2d(x.transpose(1, 2), pos, 100.0)) < 2e-6
     (y.transpose(1, 2) * wgt.to(gpu)).sum().backward()         # gradient reaches the Function as a transposed view
     assert rel_l2(xd.grad.cpu(), xr.grad) < 2e-6
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 1024])
+def test_gemm_four_wave_kernel_is_bitwise_the_sixteen_wave_kernel(gpu, K):
+    """gemm_bf16_glds4_kernel (variant 7: 128x128 wave tiles, accumulators pinned in AGPRs, hand-scheduled inline-asm K-loop) adds up
+    the same MFMA products in the same order as the 16-wave kernel: every epilogue family must agree with it to the bit, for 1, 2, 3
+    (the three loop forms: last / no-DMA / full) and many K-steps, several tiles, a ragged last row panel and a partial column tile."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(900 + K)
+    for (M, N) in [(512, 512), (776, 640), (256, 264)]:
+        a = torch.randn(M, K, generator=g).bfloat16().to(gpu)
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(gpu)
+        bias = torch.randn(N, generator=g).to(gpu)
+        res16 = torch.randn(M, N, generator=g).bfloat16().to(gpu)
+        res32 = torch.randn(M, N, generator=g).to(gpu)
+        outs = {}
+        for variant in (2, 7):
+            with ops.tuning("gemm_variant", variant):
+                outs[variant] = [ops.gemm(a, w, bias), ops.gemm(a, w, bias, act="gelu"), ops.gemm(a, w, out_dtype=torch.float32),
+                                 ops.gemm(a, w, bias, residual=res32, out_dtype=torch.float32),
+                                 ops.gemm(a, w, bias, residual=res16, out_dtype=torch.bfloat16, emit_ln=(N % 64 == 0))]
+        ref = a.float() @ w.float().t() + bias
+        assert rel_l2(outs[7][0].float().cpu(), ref.cpu()) < 4e-3
+        for i, (x, y) in enumerate(zip(outs[2], outs[7])):
+            assert torch.equal(x, y), (M, N, K, i, float((x.float() - y.float()).abs().max()))
+        if N % 64 == 0:
+            s2, s7 = outs[2][4].uc_ln, outs[7][4].uc_ln
+            assert torch.equal(s2.stats(1e-6), s7.stats(1e-6))

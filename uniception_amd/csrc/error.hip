@@ -42,6 +42,7 @@ const UcKnobs& uc_knobs() {
         g_knobs.gemm_nt = env_int("UC_GEMM_NT", -1);
         g_knobs.gemm_8wave = env_int("UC_GEMM_8WAVE", 1);
         g_knobs.gemm_small_stages = env_int("UC_GEMM_SMALL_STAGES", 3);
+        g_knobs.gemm_4wave = env_int("UC_GEMM_4WAVE", 0);
         g_knobs.attn_nw = env_int("UC_ATTN_NW", 0);
         g_knobs.attn_dma = env_int("UC_ATTN_DMA", 1);
         g_knobs.bilinear_rows2 = env_int("UC_BILINEAR_ROWS2", 4);
@@ -62,7 +63,7 @@ extern "C" int uc_tuning_set(const char* name, int value) {
     UC_REQUIRE(name, "uc_tuning_set: null name");
     (void)uc_knobs();   // the environment's initial values first, so that a later first use does not overwrite this call
     if (!strcmp(name, "gemm_variant")) {
-        UC_REQUIRE(value == -3 || value == -1 || (value >= 0 && value <= 3) || value == 6, "uc_tuning_set: gemm_variant must be -3 (automatic), -1, 0..3 or 6 (got %d)", value);
+        UC_REQUIRE(value == -3 || value == -1 || (value >= 0 && value <= 3) || value == 6 || value == 7, "uc_tuning_set: gemm_variant must be -3 (automatic), -1, 0..3, 6 or 7 (got %d)", value);
         g_uc_gemm_variant.store(value);
     } else if (!strcmp(name, "gemm_stagger")) {
         UC_REQUIRE(value >= -1 && value <= 100000, "uc_tuning_set: gemm_stagger out of range (%d)", value);

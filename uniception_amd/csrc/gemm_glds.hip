@@ -23,6 +23,12 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool a
     const bool bf16_fam = plain && p.out_dtype == UC_BF16 && !p.residual && !bf16_stream;
     if (auto_variant && variant == 2 && p.M % 8 == 0 && p.N % 8 == 0 &&
         (eight == 2 || ((eight == 1 || eight == 3) && bf16_fam) || (eight == 3 && bf16_stream))) variant = 6;
+    // ... or the four-wave form (variant 7: 128x128 wave tiles, accumulators in AGPRs, hand-scheduled K-loop).
+    // UC_GEMM_4WAVE: 0 off, 1 bf16-store family, 2 + bf16 residual stream, 3 every family.
+    const int four = uc_knobs().gemm_4wave;
+    const bool f32_fam = plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0;
+    if (auto_variant && (variant == 2 || variant == 6) && four > 0 &&
+        (four >= 3 || (bf16_fam && four >= 1) || (bf16_stream && four >= 2) || (f32_fam && four >= 3))) variant = 7;
     if (bf16_fam) glds_launch_dense_bf16(p, variant, st);
     else if (bf16_stream || (plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0)) {
         // The fp32 epilogues (residual read + fp32 store + bf16 twin) move 4-5x the bytes of a bf16 store and all CUs reach

@@ -1465,6 +1465,130 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Four-wave form of the dense 256x256x64 tile: 2 x 2 waves of 128x128, ONE wave per SIMD, 256 accumulators per lane pinned in
+// a0..a255 and a hand-scheduled K-loop (gemm_glds4_loop.inc, generated by gen/gen_glds4_loop.py) — the layout of the vendor's
+// hand-written kernels: 32 ds_read_b128 feed 128 MFMAs per wave per K-step (256 B of LDS per MFMA against 512 B for the 64x64 wave
+// tiles of the 16-wave kernel), so the same FLOPs cost less LDS traffic — less energy, on a part that runs this kernel at its power
+// cap.  hipcc cannot schedule this form (accumulator copies and scratch in the loop), hence the inline-asm loop; the
+// prologue (tile order, DMA source set-up) and the epilogues are the shared C++ ones: after the loop each wave drains its 128x128
+// tile as two 128x64 halves through glds_epilogue_dispatch<8, ...>.
+//
+// LDS image, stage ring, chunk swizzle and DMA piece addressing are those of the eight-wave kernel; waves 0-1 stage the A rows, waves
+// 2-3 the W rows (128 rows = 16 pieces of 1 KiB each per stage).  The accumulators cross from the asm statement to the epilogue in
+// the physical registers a0..a255 (read out by the v_accvgpr_read statements of UC_GLDS4_READ_HALF*): nothing between the loop and
+// the last read-out may allocate an AGPR — tools/check_glds4_agprs.py verifies that on the compiled code (build.py runs it).
+#include "gemm_glds4_loop.inc"
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GldsParams p) {
+    constexpr int BM_ = 256, BN_ = 256, ROWB = 128, A_MODE = UC_A_DENSE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int t = glds_xcd_remap((int)blockIdx.x, nwg);
+    int tm, tn;
+    {   // tile order: see the 16-wave kernel
+        const int GM = p.group_m;
+        const int per_group = GM * p.tiles_n;
+        const int grp = (int)uc_div((unsigned)t, p.dPerGroup), within = t - grp * per_group;
+        const int first_m = grp * GM;
+        const bool last = p.tiles_m - first_m < GM;
+        const int gsz = last ? p.tiles_m - first_m : GM;
+        tn = (int)uc_div((unsigned)within, last ? p.dGmLast : p.dGm);
+        tm = first_m + within - tn * gsz;
+    }
+    const int64_t m0 = (int64_t)tm * BM_;
+    const int64_t n0 = (int64_t)tn * BN_;
+    const int64_t wave_m = m0 + wr * 128;
+    const int64_t wave_n = n0 + wc * 128;
+    // (launcher: rope_cols and vt_col0 are multiples of 128, so a wave's two 64-column halves share a mode)
+    const bool is_vt = p.vt_col0 >= 0 && wave_n >= p.vt_col0;
+    const bool is_rope = !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
+    const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
+
+    // DMA slab of this wave: 128 rows of A (waves 0, 1) or of W (waves 2, 3), 16 pieces of 8 rows
+    const bool stages_a = wave < 2;
+    const bf16_t* mat = stages_a ? p.A : p.W;
+    const unsigned pitch = (unsigned)((stages_a ? p.lda : p.K) * 2);                       // bytes (launcher: < 2^31)
+    const unsigned row0 = (unsigned)((stages_a ? m0 : n0) + (wave & 1) * 128);
+    const unsigned lim = (unsigned)((stages_a ? p.M : p.N) - 8);
+    const unsigned long long mat_u = (unsigned long long)mat;
+    const unsigned base_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mat_u);
+    const unsigned base_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mat_u >> 32));
+    const unsigned voff_row = (unsigned)(lane >> 3) * pitch;
+    const unsigned voff0 = voff_row + (unsigned)(((lane & 7) ^ (lane >> 4)) << 4);
+    const unsigned voff1 = voff_row + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) << 4);
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    const unsigned lds_dma = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)wave * 16384u));
+    // fragment read addresses of stage 0 (K halves 0 / 1): row frow of the wave's block 0, chunk (4 ks + fk) ^ swizzle(frow)
+    const int frow = lane & 15, fk = lane >> 4, f_sw = glds_swz<64>(frow);
+    const unsigned ch0 = (unsigned)(((0 * 4 + fk) ^ f_sw) << 4), ch1 = (unsigned)(((1 * 4 + fk) ^ f_sw) << 4);
+    const unsigned a_row = lds_base + (unsigned)((wr * 128 + frow) * ROWB), w_row = lds_base + (unsigned)((BM_ + wc * 128 + frow) * ROWB);
+    const unsigned nk = (unsigned)(p.K / 64);
+    if (mode == 2) {
+        asm volatile(UC_GLDS4_LOOP_NOSWAP
+                     :
+                     : "v"(a_row + ch0), "v"(a_row + ch1), "v"(w_row + ch0), "v"(w_row + ch1), "v"(voff0), "v"(voff1), "s"(base_lo), "s"(base_hi),
+                       "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
+                     : UC_GLDS4_CLOBBERS);
+    } else {
+        asm volatile(UC_GLDS4_LOOP_SWAP
+                     :
+                     : "v"(a_row + ch0), "v"(a_row + ch1), "v"(w_row + ch0), "v"(w_row + ch1), "v"(voff0), "v"(voff1), "s"(base_lo), "s"(base_hi),
+                       "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
+                     : UC_GLDS4_CLOBBERS);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((opencl_constant)) GldsParams* kp =
+        (const __attribute__((opencl_constant)) GldsParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp)::"memory");
+    glds_pe_t pe = *kp;
+#else
+    glds_pe_t pe = p;
+#endif
+    __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the bounce space (8 KiB per wave)
+    asm volatile("" ::: "memory");
+    {
+        float4_t acc[8][4];
+        UC_GLDS4_READ_HALF0(acc)
+        glds_epilogue_dispatch<8, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n, tid, wave, 0, smem);
+    }
+    {
+        float4_t acc[8][4];
+        UC_GLDS4_READ_HALF1(acc)
+        glds_epilogue_dispatch<8, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n + 64, tid, wave, 0, smem);
+    }
+}
+
+template <int EPI>
+static void launch_glds4(GldsParams p, hipStream_t st) {
+    p.tiles_m = (int)ceil_div64(p.M, 256);
+    p.tiles_n = (int)ceil_div64(p.N, 256);
+    p.dNwg = uc_make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
+    p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
+    p.dGm = uc_make_fastdiv((unsigned)p.group_m);
+    p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
+    auto kfn = gemm_bf16_glds4_kernel<EPI>;
+    constexpr int smem = 2 * 512 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+}
+
+// what the four-wave kernel takes: whole 8-row groups, one mode per 128-column wave tile, no split-K, 32-bit row pitches
+static inline bool glds4_ok(const GldsParams& p) {
+    return p.a_mode == UC_A_DENSE && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && p.split_k <= 1 && p.K >= 64 &&
+           (p.vt_col0 < 0 || p.vt_col0 % 128 == 0) && (p.rope_cols <= 0 || p.rope_cols % 128 == 0) && p.lda * 2 < ((int64_t)1 << 31) &&
+           p.K * 2 < ((int64_t)1 << 31) && p.M < ((int64_t)1 << 31) && p.N < ((int64_t)1 << 31);
+}
+
 template <int EPI>
 static void launch_glds8(GldsParams p, hipStream_t st) {
     p.tiles_m = (int)ceil_div64(p.M, 256);
@@ -1520,6 +1644,11 @@ static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t s
             // (its DMA addresses row groups of 8 uniformly: matrices whose last group is partial stay on the 16-wave kernel)
             if (A_MODE == UC_A_DENSE && p.M % 8 == 0 && p.N % 8 == 0) {
                 if constexpr (A_MODE == UC_A_DENSE) launch_glds8<EPI>(p, st);
+            } else launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI>(p, st);
+            break;
+        case 7:   // 256x256x64 with four waves of 128x128, accumulators in AGPRs, hand-scheduled K-loop (dense only)
+            if (glds4_ok(p)) {
+                if constexpr (A_MODE == UC_A_DENSE) launch_glds4<EPI>(p, st);
             } else launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI>(p, st);
             break;
         default:

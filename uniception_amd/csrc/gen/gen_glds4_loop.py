@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled K-loop of the four-wave dense bf16 GEMM (gemm_bf16_glds4_kernel, gemm_glds4.hip).
+
+    python uniception_amd/csrc/gen/gen_glds4_loop.py > uniception_amd/csrc/gemm_glds4_loop.inc        (committed; build.py does not run this)
+
+256 x 256 x 64 workgroup tile, FOUR waves of 128 x 128 (one per SIMD), 256 fp32 accumulators per lane pinned in a0..a255 — the layout
+of the vendor's hand-written GEMM kernels.  hipcc cannot produce it (round 1 / round 2: 604 v_accvgpr moves and 1 KB of scratch in
+the loops from the intrinsic form), so the loop is emitted as ONE inline-asm statement whose registers are fixed here:
+
+    a[4 * (8 i + j) + r]   accumulator r of MFMA fragment (i, j): i = 16-row block of the wave's 128 rows, j = 16-column block
+    v[FR0 ...]             two fragment sets (current / next 32-deep K half): 8 A + 8 W fragments of 4 registers each
+    s[SB ...]              16 wave-uniform 64-bit source bases of the wave's DMA pieces, loop state
+
+Per K-step (64 deep): 128 v_mfma_f32_16x16x32_bf16, 32 ds_read_b128 (half of the 16-wave kernel's LDS read traffic per MFMA),
+16 LDS-DMA pieces of 1 KiB, ONE s_barrier in the middle of the step:
+
+    phase A   64 MFMAs on fragment set 0 (K half 0 of stage s)   | ds_read K half 1 of stage s   -> set 1
+    mid       s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier            (stage s + 1 has landed, everyone has read stage s)
+    phase B   64 MFMAs on set 1                                   | ds_read K half 0 of stage s + 1 -> set 0
+                                                                  | DMA of K-step kt + 2 -> the buffer of stage s
+
+The macros UC_GLDS4_LOOP_SWAP / _NOSWAP expand to the asm text; operands (see gemm_glds_kernel.h): %0..%3 LDS read addresses (A half
+0, A half 1, W half 0, W half 1 of stage 0), %4 / %5 per-lane source byte offsets of even / odd pieces, %6 / %7 source base (low, high
+dword), %8 first row of the wave's 128-row DMA slab, %9 last valid 8-row group start, %10 row pitch in bytes, %11 LDS byte address of
+the wave's DMA slab in stage 0, %12 number of K-steps (>= 1).
+"""
+import sys
+
+FR0 = 128              # first fragment VGPR: set s, operand o (0 = A, 1 = W), block b -> v[FR0 + 64 s + 32 o + 4 b .. + 3]
+SB = 36                # s[SB + 2 q : SB + 2 q + 1] = source base of piece q (16 pieces)
+S_DMA, S_DELTA, S_CNT, S_T0, S_T1, S_M0 = 68, 69, 70, 71, 72, 73
+V_OFF0, V_OFF1 = 120, 121      # running per-lane source offsets (even / odd pieces)
+V_A0, V_A1, V_W0, V_W1 = 122, 123, 124, 125   # running LDS read addresses of the current stage
+
+
+def frag(s, o, b):
+    r = FR0 + 64 * s + 32 * o + 4 * b
+    return f"v[{r}:{r + 3}]"
+
+
+def acc(i, j):
+    r = 4 * (8 * i + j)
+    return f"a[{r}:{r + 3}]"
+
+
+class Body:
+    def __init__(self):
+        self.lines = []
+
+    def emit(self, s):
+        self.lines.append(s)
+
+    def text(self):
+        return "\n".join(f'    "{ln}\\n\\t"' for ln in self.lines)
+
+
+def mfma(b, swap, s, i, j):
+    # SWAP: first operand = W rows -> C^T fragments (a lane owns 4 consecutive columns of one row); else first operand = A rows
+    a, w = frag(s, 0, i), frag(s, 1, j)
+    if swap:
+        b.emit(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {w}, {a}, {acc(i, j)}")
+    else:
+        b.emit(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {a}, {w}, {acc(i, j)}")
+
+
+def ds_read(b, s, o, blk, addr_reg):
+    b.emit(f"ds_read_b128 {frag(s, o, blk)}, v{addr_reg} offset:{blk * 2048}")
+
+
+def dma_piece(b, q):
+    # M0 = LDS byte address of the piece (wave-uniform); hazard M0 write -> LDS-DMA: s_nop 0
+    b.emit(f"s_add_u32 m0, s{S_DMA}, {q * 1024}")
+    b.emit("s_nop 0")
+    b.emit(f"global_load_lds_dwordx4 v{V_OFF1 if q & 1 else V_OFF0}, s[{SB + 2 * q}:{SB + 2 * q + 1}]")
+
+
+def phase(b, swap, cur_set, reads, dmas):
+    """64 MFMAs on fragment set `cur_set` with one filler behind every second MFMA: first the `reads` = (set, operand, block, address
+    register) of the NEXT phase's fragments (W first: its first MFMA group needs all eight W fragments; everything has returned long
+    before the phase ends), then the `dmas` (piece numbers, three instructions each)."""
+    fillers = [("r", x) for x in reads] + [("d", q) for q in dmas]
+    assert len(fillers) <= 32
+    n = 0
+    for i in range(8):
+        for j in range(8):
+            mfma(b, swap, cur_set, i, j)
+            n += 1
+            if n % 2 == 0 and fillers:
+                kind, x = fillers.pop(0)
+                if kind == "r":
+                    ds_read(b, *x)
+                else:
+                    dma_piece(b, x)
+    assert not fillers
+
+
+def step(b, swap, with_reads, with_dma, last):
+    # phase A: set 0, read K half 1 of the current stage into set 1
+    rd = [(1, 1, j, V_W1) for j in range(8)] + [(1, 0, i, V_A1) for i in range(8)]
+    b.emit("s_waitcnt lgkmcnt(0)")
+    phase(b, swap, 0, rd, [])
+    # mid-step synchronisation
+    if last:
+        b.emit("s_waitcnt lgkmcnt(0)")
+    else:
+        b.emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        b.emit("s_barrier")
+        for r in (V_A0, V_A1, V_W0, V_W1):          # read addresses move to the other stage
+            b.emit(f"v_add_u32 v{r}, s{S_DELTA}, v{r}")
+    rd = [(0, 1, j, V_W0) for j in range(8)] + [(0, 0, i, V_A0) for i in range(8)] if with_reads else []
+    phase(b, swap, 1, rd, list(range(16)) if with_dma else [])
+    if with_dma:
+        b.emit(f"v_add_u32 v{V_OFF0}, 128, v{V_OFF0}")
+        b.emit(f"v_add_u32 v{V_OFF1}, 128, v{V_OFF1}")
+    if not last:
+        b.emit(f"s_add_u32 s{S_DMA}, s{S_DMA}, s{S_DELTA}")
+        b.emit(f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}")
+
+
+def loop(swap):
+    b = Body()
+    e = b.emit
+    tag = "s" if swap else "u"
+    # ---- prologue: per-piece source bases ----
+    e(f"s_mov_b32 s{S_M0}, m0")                                # M0 is compiler-reserved: saved here, restored at the end
+    e(f"s_mov_b32 s{S_CNT}, %12")
+    e(f"v_mov_b32 v{V_OFF0}, %4")
+    e(f"v_mov_b32 v{V_OFF1}, %5")
+    e(f"v_mov_b32 v{V_A0}, %0")
+    e(f"v_mov_b32 v{V_A1}, %1")
+    e(f"v_mov_b32 v{V_W0}, %2")
+    e(f"v_mov_b32 v{V_W1}, %3")
+    e(f"s_mov_b32 s{S_DMA}, %11")
+    e(f"s_mov_b32 s{S_DELTA}, 0x10000")
+    for q in range(16):
+        e(f"s_add_u32 s{S_T0}, %8, {8 * q}")
+        e(f"s_min_u32 s{S_T0}, s{S_T0}, %9")                   # row groups past the matrix end: its last 8 rows (never stored)
+        e(f"s_mul_hi_u32 s{S_T1}, s{S_T0}, %10")
+        e(f"s_mul_i32 s{S_T0}, s{S_T0}, %10")
+        e(f"s_add_u32 s{SB + 2 * q}, %6, s{S_T0}")
+        e(f"s_addc_u32 s{SB + 2 * q + 1}, %7, s{S_T1}")
+    # ---- stage 0 (+ stage 1) in flight, accumulators cleared while they travel ----
+    for q in range(16):
+        dma_piece(b, q)
+    e(f"v_add_u32 v{V_OFF0}, 128, v{V_OFF0}")
+    e(f"v_add_u32 v{V_OFF1}, 128, v{V_OFF1}")
+    for r in range(256):
+        e(f"v_accvgpr_write_b32 a{r}, 0")
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    e(f"s_cmp_lt_u32 s{S_CNT}, 2")
+    e(f"s_cbranch_scc1 .Lg4{tag}_nos1_%=")
+    e(f"s_add_u32 s{S_DMA}, s{S_DMA}, 0x10000")
+    for q in range(16):
+        dma_piece(b, q)
+    e(f"s_sub_u32 s{S_DMA}, s{S_DMA}, 0x10000")
+    e(f"v_add_u32 v{V_OFF0}, 128, v{V_OFF0}")
+    e(f"v_add_u32 v{V_OFF1}, 128, v{V_OFF1}")
+    e(f".Lg4{tag}_nos1_%=:")
+    for j in range(8):
+        ds_read(b, 0, 1, j, V_W0)
+    for i in range(8):
+        ds_read(b, 0, 0, i, V_A0)
+    # ---- steps 0 .. nk-3: reads + DMA; step nk-2: reads only; step nk-1: nothing ----
+    e(f"s_cmp_lt_u32 s{S_CNT}, 3")
+    e(f"s_cbranch_scc1 .Lg4{tag}_tail_%=")
+    e(f".Lg4{tag}_loop_%=:")
+    step(b, swap, True, True, False)
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    e(f"s_cmp_gt_u32 s{S_CNT}, 2")
+    e(f"s_cbranch_scc1 .Lg4{tag}_loop_%=")
+    e(f".Lg4{tag}_tail_%=:")
+    e(f"s_cmp_lt_u32 s{S_CNT}, 2")
+    e(f"s_cbranch_scc1 .Lg4{tag}_last_%=")
+    step(b, swap, True, False, False)
+    e(f".Lg4{tag}_last_%=:")
+    step(b, swap, False, False, True)
+    e("s_nop 15")                                               # MFMA results -> v_accvgpr_read of the read-out macros
+    e("s_nop 15")
+    e(f"s_mov_b32 m0, s{S_M0}")
+    return b.text()
+
+
+def clobbers():
+    c = [f"a{r}" for r in range(256)] + [f"v{r}" for r in range(V_OFF0, 256)]
+    c += [f"s{r}" for r in range(SB, S_M0 + 1)] + ["scc", "memory"]
+    return ", ".join(f'"{x}"' for x in c)
+
+
+def main():
+    print("// GENERATED by csrc/gen/gen_glds4_loop.py — do not edit; regenerate and commit.")
+    print("// K-loop of gemm_bf16_glds4_kernel: see the generator's docstring for the register map and the schedule.")
+    print("#define UC_GLDS4_LOOP_SWAP \\")
+    print(loop(True).replace("\n", " \\\n"))
+    print("")
+    print("#define UC_GLDS4_LOOP_NOSWAP \\")
+    print(loop(False).replace("\n", " \\\n"))
+    print("")
+    print("#define UC_GLDS4_CLOBBERS " + clobbers())
+    print("")
+    # accumulator read-out: acc[i][jj][r] of column half hc <- a[4 * (8 i + 4 hc + jj) + r]
+    for hc in range(2):
+        print(f"#define UC_GLDS4_READ_HALF{hc}(ACC) \\")
+        rows = []
+        for i in range(8):
+            for jj in range(4):
+                for r in range(4):
+                    rows.append(f'    asm volatile("v_accvgpr_read_b32 %0, a{4 * (8 * i + 4 * hc + jj) + r}" : "=v"(ACC[{i}][{jj}][{r}]));')
+        print(" \\\n".join(rows))
+        print("")
+
+
+if __name__ == "__main__":
+    main()
