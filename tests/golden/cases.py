@@ -35,7 +35,7 @@ def sample_indices(numel: int, n: int = 4096) -> np.ndarray:
 
 
 # cases that also have a gradient fixture (<case>__grads.npz, written by make_golden_grads.py)
-GRAD_CASES = ("tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224")
+GRAD_CASES = ("tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224", "vitl_dpt_512")
 
 
 def grad_targets(c):

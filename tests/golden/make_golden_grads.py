@@ -35,11 +35,20 @@ def run(name):
     c = CASES[name]
     t0 = time.time()
     torch.manual_seed(0)
-    model = ComposedTwoView(c).train()
+    if c.get("factory"):     # the reference's own factory model (BASELINE configs[2]: the ViT-L two-view model at full size)
+        from uniception.models.factory import DUSt3R
+        model = DUSt3R(name="g", img_size=tuple(c["img"]), pred_head_type=c["head"]).train()
+    else:
+        model = ComposedTwoView(c).train()
     O.fill_state_dict_(model.state_dict(), gain=1.0, gains=GAINS)
     img1, img2 = O.make_images(c["seed"], c["B"], *c["img"])
     gt1, gt2 = grad_targets(c)
-    r1, r2 = model(img1, img2, {})
+    if c.get("factory"):
+        v1 = {"img": img1, "instance": [str(i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+        v2 = {"img": img2, "instance": [str(100 + i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+        r1, r2 = model(v1, v2)
+    else:
+        r1, r2 = model(img1, img2, {})
     loss = conf_loss(r1["pts3d"], r1["conf"], gt1) + conf_loss(r2["pts3d_in_other_view"], r2["conf"], gt2)
     loss.backward()
     ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}

@@ -26,7 +26,12 @@ def train_step(name, gpu, mode):
     img1, img2 = (t.to(gpu) for t in case_images(c))
     gt1, gt2 = (t.to(gpu) for t in grad_targets(c))
     with engine.precision(mode):
-        r1, r2 = model(img1, img2, {})
+        if c.get("factory"):     # the factory model at the size BASELINE configs[2] names (ViT-L + 12-block decoder + DPT, 512x512)
+            v1 = {"img": img1, "instance": [str(i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+            v2 = {"img": img2, "instance": [str(100 + i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+            r1, r2 = model(v1, v2)
+        else:
+            r1, r2 = model(img1, img2, {})
         loss = autograd.conf_loss(r1["pts3d"], r1["conf"], gt1, 0.2) + autograd.conf_loss(r2["pts3d_in_other_view"], r2["conf"], gt2, 0.2)
         loss.backward()
     torch.cuda.synchronize()
@@ -38,7 +43,7 @@ def load_grads(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + "__grads.npz")))
 
 
-@pytest.mark.parametrize("name", ["tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224"])
+@pytest.mark.parametrize("name", ["tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224", "vitl_dpt_512"])
 def test_fp32_gradients_match_reference_autograd(gpu, name):
     loss, grads = train_step(name, gpu, "fp32")
     gold = load_grads(name)
@@ -58,7 +63,7 @@ def test_fp32_gradients_match_reference_autograd(gpu, name):
     print(f"\n[fp32 grads] {name}: loss {loss:.6f}, worst {worst[0]} {worst[1]:.2e}")
 
 
-@pytest.mark.parametrize("name", ["tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224"])
+@pytest.mark.parametrize("name", ["tiny_linear", "tiny_dpt", "cfg1_vitb_linear_224", "vitl_dpt_512"])
 def test_bf16_gradients_track_reference_autograd(gpu, name):
     loss, grads = train_step(name, gpu, "bf16")
     gold = load_grads(name)
