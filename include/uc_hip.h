@@ -43,8 +43,8 @@ const char* uc_last_error(void);
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
  *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added.  4/5: see INTEGRATION.md.
  *   6: uc_adaptor_program_bwd added.  7: uc_build_flavor, uc_tuning_set / uc_tuning_get (environment knobs read once; no
- *      diagnostics in the release build), uc_attention_fwd_x3. */
-#define UC_ABI_VERSION 7
+ *      diagnostics in the release build), uc_attention_fwd_x3.  8: uc_gemm_desc gained ln_nblk / ln_eps. */
+#define UC_ABI_VERSION 8
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
 const char* uc_build_flavor(void);
@@ -167,6 +167,13 @@ typedef struct uc_gemm_desc {
     const float* tail_w;   /* [4][N] fp32 */
     const float* tail_b;   /* [4] fp32 or NULL */
     float* tail_out;       /* [M][4] fp32 */
+    /* Consumer side of the folded LayerNorm WITHOUT the uc_ln_stats_finalize launch (ABI 8): with ln_nblk > 0, ln_stats points at the
+       producer's per-block partials [M][ln_nblk][2] (its stats_out; K == 64 * ln_nblk) and every row's (mean, rstd) is merged in
+       the epilogue — the same arithmetic, bit for bit, as uc_ln_stats_finalize with ln_eps.  For small batches, where the ~120
+       merge launches of a forward are a tenth of its time; at large M the stand-alone merge is cheaper (every column tile of a
+       row panel repeats the in-epilogue merge).  ln_nblk == 0: ln_stats holds finalized (mean, rstd) rows. */
+    int ln_nblk;
+    float ln_eps;
 } uc_gemm_desc;
 
 int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);

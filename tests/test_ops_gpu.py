@@ -227,6 +227,9 @@ def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
         bias = (wq @ beta + bq)
         cs = wf.float().sum(1)
         y = ops.gemm(side.twin, wf.to(gpu), bias.to(gpu), act=act, ln=(side.stats(1e-6), cs.to(gpu)))
+        # the block partials merged inside the consumer's epilogue (uc_gemm_desc.ln_nblk: small batches, no finalize launch): same bits
+        y_m = ops.gemm(side.twin, wf.to(gpu), bias.to(gpu), act=act, ln=(ops.LnPartial(side.partial, 1e-6), cs.to(gpu)))
+        assert torch.equal(y, y_m)
         y_ref = h_ref @ wq.t() + bq
         y_ref = F.gelu(y_ref) if act else y_ref
         assert rel_l2(y.cpu().float(), y_ref) < 6e-3
@@ -240,6 +243,10 @@ def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     vt = ops.vt_buffer(B, H, N, gpu)
     qk = ops.gemm(side.twin, wf.to(gpu), bias.to(gpu), rope=(pos.to(gpu).view(-1, 2), table, 2 * C), vt=(2 * C, vt, N),
                   ln=(side.stats(1e-6), cs.to(gpu)))
+    vt_m = ops.vt_buffer(B, H, N, gpu)
+    qk_m = ops.gemm(side.twin, wf.to(gpu), bias.to(gpu), rope=(pos.to(gpu).view(-1, 2), table, 2 * C), vt=(2 * C, vt_m, N),
+                    ln=(ops.LnPartial(side.partial, 1e-6), cs.to(gpu)))
+    assert torch.equal(qk, qk_m) and torch.equal(vt, vt_m)
     full = (h_ref @ wq.t() + bq).view(B, N, 3, H, 64)
     got = qk.cpu().float().view(B, N, 2, H, 64)
     assert rel_l2(got[:, :, 0], rope_ref(full[:, :, 0], pos, 100.0, 1.0)) < 6e-3
@@ -611,7 +618,7 @@ def test_gemm_four_wave_kernel_is_bitwise_the_sixteen_wave_kernel(gpu, K):
     (the three loop forms: last / no-DMA / full) and many K-steps, several tiles, a ragged last row panel and a partial column tile."""
     from uniception_amd import ops
     g = torch.Generator().manual_seed(900 + K)
-    for (M, N) in [(512, 512), (776, 640), (256, 264)]:
+    for (M, N) in [(512, 512), (784, 640), (256, 272)]:
         a = torch.randn(M, K, generator=g).bfloat16().to(gpu)
         w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(gpu)
         bias = torch.randn(N, generator=g).to(gpu)

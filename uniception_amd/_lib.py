@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("C", vp), ("out_dtype", i32), ("ldc", i64),
         ("twin_out", vp), ("ldt", i64), ("stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
         ("tail_w", vp), ("tail_b", vp), ("tail_out", vp),
+        ("ln_nblk", i32), ("ln_eps", f32),
     ]
 
 
@@ -105,7 +106,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 7   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 8   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

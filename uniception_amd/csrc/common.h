@@ -107,3 +107,42 @@ static inline uc_fastdiv uc_make_fastdiv(unsigned d) {
     return f;
 }
 __device__ __forceinline__ unsigned uc_div(unsigned n, uc_fastdiv f) { return f.m ? (__umulhi(n, f.m) >> f.s) : n; }
+
+
+// ---------------------------------------------------------------------------------------
+// Row statistics of the folded LayerNorm from the producer GEMM's per-block partials: p[b] = (sum, squared deviations from the
+// block mean) of 64-column block b of one row; Chan et al.: with block means mu_b and the row mean mu, M2 = sum_b [M2_b + 64
+// (mu_b - mu)^2].  Returns (mean, 1 / sqrt(var_biased + eps)).  ONE definition for the stand-alone kernel
+// (uc_ln_stats_finalize, large batches) and the consumer GEMM's epilogue (small batches: no launch): the 16 slot sums are added up
+// in a fixed binary tree and nothing is contracted into FMAs, so both give the same bits — a pair's result does not depend on
+// which of the two its batch size selects.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float uc_ln_tree16(const float (&v)[16]) {
+#pragma clang fp contract(off)
+    float a[8], b[4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = v[q] + v[q + 8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = a[q] + a[q + 4];
+    return (b[0] + b[2]) + (b[1] + b[3]);
+}
+__device__ __forceinline__ float2 uc_ln_merge_row(const float2* __restrict__ p, int nblk, float eps) {
+#pragma clang fp contract(off)
+    float s[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        s[q] = 0.f;
+        for (int b = q; b < nblk; b += 16) s[q] += p[b].x;
+    }
+    const float cnt = 64.f * (float)nblk;
+    const float mu = uc_ln_tree16(s) / cnt;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        s[q] = 0.f;
+        for (int b = q; b < nblk; b += 16) {
+            const float d = p[b].x * (1.f / 64.f) - mu;
+            s[q] += p[b].y + (64.f * d) * d;
+        }
+    }
+    return make_float2(mu, 1.0f / sqrtf(uc_ln_tree16(s) / cnt + eps));
+}

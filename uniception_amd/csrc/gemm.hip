@@ -503,6 +503,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
         const bool glds_dense = d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a;
         if (d->ln_stats || d->ln_colsum) {
             UC_REQUIRE(d->ln_stats && d->ln_colsum, "uc_gemm: the folded LayerNorm needs both ln_stats and ln_colsum");
+            UC_REQUIRE(d->ln_nblk == 0 || (d->ln_nblk > 0 && d->K == (int64_t)64 * d->ln_nblk && d->ln_eps > 0.f),
+                       "uc_gemm: ln_nblk > 0 (block partials instead of finalized statistics) needs K == 64 * ln_nblk and ln_eps > 0");
             UC_REQUIRE(glds_dense && d->out_dtype == UC_BF16 && !d->residual && !d->preact_out && !d->dact_u && d->split_k <= 1 &&
                            d->N % 64 == 0 && (d->act == UC_ACT_NONE || d->act == UC_ACT_GELU_ERF),
                        "uc_gemm: ln_stats needs the dense direct-to-LDS kernel (K %% 64 == 0), bf16 output, N %% 64 == 0 and a plain epilogue");
@@ -555,7 +557,8 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const bool x_ok = (!d->preact_out || (uintptr_t)d->preact_out % 16 == 0) && (!d->dact_u || (uintptr_t)d->dact_u % 8 == 0);
             g.vec_ok = (c_ok && b_ok && r_ok && x_ok) ? 1 : 0;
             g.preact = d->preact_out; g.split_k = d->split_k > 1 ? d->split_k : 1;
-            g.ln_stats = (const float2*)d->ln_stats; g.ln_colsum = d->ln_colsum;
+            g.ln_stats = d->ln_nblk > 0 ? nullptr : (const float2*)d->ln_stats; g.ln_colsum = d->ln_colsum;
+            g.ln_partial = d->ln_nblk > 0 ? (const float2*)d->ln_stats : nullptr; g.ln_nblk = d->ln_nblk; g.ln_eps = d->ln_eps;
             g.twin = (bf16_t*)d->twin_out; g.ldt = d->ldt; g.stats_out = (float2*)d->stats_out;
             g.tail_w = d->tail_w; g.tail_b = d->tail_b; g.tail_out = d->tail_out;
             if (d->tail_out) g.vec_ok = 0;     // never one of the single-family kernels

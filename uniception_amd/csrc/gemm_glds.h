@@ -30,6 +30,11 @@ struct GldsParams {
     // compute rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]
     const float2* ln_stats;   // [M] (mean, rstd)
     const float* ln_colsum;   // [N] sum_k W'[n,k]
+    // ... or, instead of finalized ln_stats, the producer's per-block partials: merged per row in the epilogue (uc_ln_merge_row) —
+    // small batches, where a 4-us merge launch per LayerNorm is a tenth of the forward
+    const float2* ln_partial; // [M][ln_nblk] (sum, squared deviations from the block mean) per 64-column block of x
+    int ln_nblk;
+    float ln_eps;
     // producer side (fp32-output epilogue): bf16 twin of the stored rows and per-row statistics of every 64-column block
     bf16_t* twin;             // [M, ldt] bf16 copy of C, or NULL
     int64_t ldt;

@@ -18,7 +18,7 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool a
     // UC_GEMM_8WAVE: 0 off, 1 bf16-store family (default), 2 every family, 3 bf16-store family + bf16 residual stream.
     const int eight = uc_knobs().gemm_8wave;
     // bf16 residual stream (out bf16 + bf16 residual and / or row statistics): the residual family's drain, 2 + 2 bytes per element
-    const bool bf16_stream = plain && p.out_dtype == UC_BF16 && p.act == UC_ACT_NONE && p.vt_col0 < 0 && p.rope_cols <= 0 && !p.ln_stats &&
+    const bool bf16_stream = plain && p.out_dtype == UC_BF16 && p.act == UC_ACT_NONE && p.vt_col0 < 0 && p.rope_cols <= 0 && !p.ln_stats && !p.ln_partial &&
                              !p.residual2 && ((p.residual && p.res_dtype == UC_BF16) || p.stats_out);
     const bool bf16_fam = plain && p.out_dtype == UC_BF16 && !p.residual && !bf16_stream;
     if (auto_variant && variant == 2 && p.M % 8 == 0 && p.N % 8 == 0 &&

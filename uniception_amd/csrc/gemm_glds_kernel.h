@@ -145,6 +145,13 @@ __device__ __forceinline__ void dma16_buf_to_lds(unsigned voff, uint4_t srd, uns
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
+// (mean, rstd) of row m for the folded-LayerNorm epilogues: finalized by uc_ln_stats_finalize, or merged here from the producer's
+// block partials (small batches)
+__device__ __forceinline__ float2 glds_ln_row_stats(glds_pe_t p, int64_t m) {
+    if (p.ln_partial) return uc_ln_merge_row(p.ln_partial + m * p.ln_nblk, p.ln_nblk, p.ln_eps);
+    return p.ln_stats[m];
+}
+
 // Epilogue of V tiles that are written in the packed VT layout (un-swapped orientation).
 template <int FA, bool LN = false>
 __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane,
@@ -161,7 +168,7 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
     if constexpr (LN) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) csj[j] = p.ln_colsum[wave_n + 16 * j + frow];
-        mine = p.ln_stats[min(wave_m + lane, p.M - 1)];
+        mine = glds_ln_row_stats(p, min(wave_m + lane, p.M - 1));
     }
     float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
     auto row_stats = [&](int i) __attribute__((always_inline)) {
@@ -569,7 +576,7 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
         colbuf[lane] = p.ln_colsum[wave_n + lane];
         colbuf[64 + lane] = p.bias ? p.bias[wave_n + lane] : 0.f;
 #pragma unroll
-        for (int q = 0; q < FA / 4; ++q) mine[q] = p.ln_stats[min(wave_m + 64 * q + lane, p.M - 1)];
+        for (int q = 0; q < FA / 4; ++q) mine[q] = glds_ln_row_stats(p, min(wave_m + 64 * q + lane, p.M - 1));
     }
     float st_mu = 0.f, st_rs = 1.f;
     auto row_stats = [&](int i) __attribute__((always_inline)) {
@@ -870,7 +877,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
         const bool plain = pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && !pe.preact && !pe.dact_u && !UC_DBG(pe, 16);
         auto bf16_family = [&]() __attribute__((always_inline)) {
             const bool nt = pe.nt_out & (mode == 1 ? 4 : 2);
-            if (A_MODE == UC_A_DENSE && pe.ln_stats) {   // folded LayerNorm
+            if (A_MODE == UC_A_DENSE && (pe.ln_stats || pe.ln_partial)) {   // folded LayerNorm
                 if constexpr (A_MODE == UC_A_DENSE) {
                     if (nt) {
                         if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
@@ -898,7 +905,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
             if (mode == 2) {
                 // (a 128-row wave tile drains as two 64-row halves: the packed-VT fast path is one aligned 64-token group)
                 if constexpr (FA == 4) {
-                    if (A_MODE == UC_A_DENSE && pe.ln_stats) glds_epilogue_vt<4, A_MODE == UC_A_DENSE>(pe, acc, wave_m, wave_n, lane, wbuf);
+                    if (A_MODE == UC_A_DENSE && (pe.ln_stats || pe.ln_partial)) glds_epilogue_vt<4, A_MODE == UC_A_DENSE>(pe, acc, wave_m, wave_n, lane, wbuf);
                     else glds_epilogue_vt<4>(pe, acc, wave_m, wave_n, lane, wbuf);
                 } else {
 #pragma unroll
@@ -908,7 +915,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) half[i][j] = acc[4 * h + i][j];
-                        if (A_MODE == UC_A_DENSE && pe.ln_stats) glds_epilogue_vt<4, A_MODE == UC_A_DENSE>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
+                        if (A_MODE == UC_A_DENSE && (pe.ln_stats || pe.ln_partial)) glds_epilogue_vt<4, A_MODE == UC_A_DENSE>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
                         else glds_epilogue_vt<4>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
                     }
                 }
@@ -942,7 +949,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                 }
             } else if (plain && pe.out_dtype == UC_BF16 && !pe.residual) bf16_family();
             else if (mode == 0 && pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && pe.out_dtype == UC_BF16 && !pe.residual &&
-                     !UC_DBG(pe, 16) && !pe.ln_stats && (pe.preact != nullptr) != (pe.dact_u != nullptr)) {
+                     !UC_DBG(pe, 16) && !pe.ln_stats && !pe.ln_partial && (pe.preact != nullptr) != (pe.dact_u != nullptr)) {
                 // training: fc1 with its pre-activation copy / a data-gradient GEMM with the activation backward fused
                 if (pe.preact) {
                     if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16_train<FA, UC_ACT_GELU_ERF, true, false>(pe, acc, wave_m, wave_n, lane, wbuf);
@@ -1474,15 +1481,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
 // prologue (tile order, DMA source set-up) and the epilogues are the shared C++ ones: after the loop each wave drains its 128x128
 // tile as two 128x64 halves through glds_epilogue_dispatch<8, ...>.
 //
-// LDS image, stage ring, chunk swizzle and DMA piece addressing are those of the eight-wave kernel; waves 0-1 stage the A rows, waves
-// 2-3 the W rows (128 rows = 16 pieces of 1 KiB each per stage).  The accumulators cross from the asm statement to the epilogue in
+// K is consumed in half-stages of 32 (64-byte LDS rows with the 32-deep tile's chunk swizzle) through a ring of FOUR 32-KiB buffers: a
+// DMA piece is issued three phases before anyone waits for it, and the loop never drains its loads (counted s_waitcnt vmcnt).  Waves
+// 0-1 stage the A rows, waves 2-3 the W rows (128 rows = 8 pieces of 16 rows x 64 B per half-stage).  The accumulators cross from the asm statement to the epilogue in
 // the physical registers a0..a255 (read out by the v_accvgpr_read statements of UC_GLDS4_READ_HALF*): nothing between the loop and
 // the last read-out may allocate an AGPR — tools/check_glds4_agprs.py verifies that on the compiled code (build.py runs it).
 #include "gemm_glds4_loop.inc"
 
 template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GldsParams p) {
-    constexpr int BM_ = 256, BN_ = 256, ROWB = 128, A_MODE = UC_A_DENSE;
+    constexpr int BM_ = 256, BN_ = 256, A_MODE = UC_A_DENSE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1510,36 +1518,33 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GldsParams p) {
     const bool is_rope = !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
     const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
 
-    // DMA slab of this wave: 128 rows of A (waves 0, 1) or of W (waves 2, 3), 16 pieces of 8 rows
+    // DMA slab of this wave: 128 rows of A (waves 0, 1) or of W (waves 2, 3) = 8 pieces of 16 rows x 64 B per half-stage (32 of K)
     const bool stages_a = wave < 2;
     const bf16_t* mat = stages_a ? p.A : p.W;
     const unsigned pitch = (unsigned)((stages_a ? p.lda : p.K) * 2);                       // bytes (launcher: < 2^31)
     const unsigned row0 = (unsigned)((stages_a ? m0 : n0) + (wave & 1) * 128);
-    const unsigned lim = (unsigned)((stages_a ? p.M : p.N) - 8);
+    const unsigned lim = (unsigned)((stages_a ? p.M : p.N) - 16);
     const unsigned long long mat_u = (unsigned long long)mat;
     const unsigned base_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mat_u);
     const unsigned base_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mat_u >> 32));
-    const unsigned voff_row = (unsigned)(lane >> 3) * pitch;
-    const unsigned voff0 = voff_row + (unsigned)(((lane & 7) ^ (lane >> 4)) << 4);
-    const unsigned voff1 = voff_row + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) << 4);
+    // lane -> row lane >> 2 of the piece, physical 16-B chunk lane & 3 of its 64-B LDS row = logical chunk (lane & 3) ^ swizzle(row)
+    const unsigned voff = (unsigned)(lane >> 2) * pitch + (unsigned)(((lane & 3) ^ glds_swz<32>(lane >> 2)) << 4);
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
-    const unsigned lds_dma = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)wave * 16384u));
-    // fragment read addresses of stage 0 (K halves 0 / 1): row frow of the wave's block 0, chunk (4 ks + fk) ^ swizzle(frow)
-    const int frow = lane & 15, fk = lane >> 4, f_sw = glds_swz<64>(frow);
-    const unsigned ch0 = (unsigned)(((0 * 4 + fk) ^ f_sw) << 4), ch1 = (unsigned)(((1 * 4 + fk) ^ f_sw) << 4);
-    const unsigned a_row = lds_base + (unsigned)((wr * 128 + frow) * ROWB), w_row = lds_base + (unsigned)((BM_ + wc * 128 + frow) * ROWB);
+    const unsigned lds_dma = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)wave * 8192u));
+    // fragment read addresses in buffer 0: row frow of the wave's block 0, chunk fk ^ swizzle(frow) (64-B rows: one 32-deep K half)
+    const int frow = lane & 15, fk = lane >> 4;
+    const unsigned ch = (unsigned)((fk ^ glds_swz<32>(frow)) << 4);
+    const unsigned a_addr = lds_base + (unsigned)((wr * 128 + frow) * 64) + ch, w_addr = lds_base + (unsigned)((BM_ + wc * 128 + frow) * 64) + ch;
     const unsigned nk = (unsigned)(p.K / 64);
     if (mode == 2) {
         asm volatile(UC_GLDS4_LOOP_NOSWAP
                      :
-                     : "v"(a_row + ch0), "v"(a_row + ch1), "v"(w_row + ch0), "v"(w_row + ch1), "v"(voff0), "v"(voff1), "s"(base_lo), "s"(base_hi),
-                       "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
+                     : "v"(a_addr), "v"(w_addr), "v"(voff), "s"(base_lo), "s"(base_hi), "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
                      : UC_GLDS4_CLOBBERS);
     } else {
         asm volatile(UC_GLDS4_LOOP_SWAP
                      :
-                     : "v"(a_row + ch0), "v"(a_row + ch1), "v"(w_row + ch0), "v"(w_row + ch1), "v"(voff0), "v"(voff1), "s"(base_lo), "s"(base_hi),
-                       "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
+                     : "v"(a_addr), "v"(w_addr), "v"(voff), "s"(base_lo), "s"(base_hi), "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
                      : UC_GLDS4_CLOBBERS);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1582,9 +1587,9 @@ static void launch_glds4(GldsParams p, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
 }
 
-// what the four-wave kernel takes: whole 8-row groups, one mode per 128-column wave tile, no split-K, 32-bit row pitches
+// what the four-wave kernel takes: whole 16-row groups, one mode per 128-column wave tile, no split-K, 32-bit row pitches
 static inline bool glds4_ok(const GldsParams& p) {
-    return p.a_mode == UC_A_DENSE && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && p.split_k <= 1 && p.K >= 64 &&
+    return p.a_mode == UC_A_DENSE && p.M % 16 == 0 && p.N % 16 == 0 && p.M >= 16 && p.N >= 16 && p.split_k <= 1 && p.K >= 64 &&
            (p.vt_col0 < 0 || p.vt_col0 % 128 == 0) && (p.rope_cols <= 0 || p.rope_cols % 128 == 0) && p.lda * 2 < ((int64_t)1 << 31) &&
            p.K * 2 < ((int64_t)1 << 31) && p.M < ((int64_t)1 << 31) && p.N < ((int64_t)1 << 31);
 }

@@ -348,31 +348,17 @@ extern "C" int uc_layernorm(const void* x, int x_dtype, const float* gamma, cons
 // mu_b and the row mean mu,  M2 = sum_b [ M2_b + 64 (mu_b - mu)^2 ].  One thread per row (nblk <= 64 blocks of 8 bytes).
 // ---------------------------------------------------------------------------------------
 __global__ void ln_stats_finalize_kernel(const float2* __restrict__ partial, int64_t rows, int nblk, float eps, float2* __restrict__ out) {
-    // 16 lanes per row: lane q covers blocks q, q + 16, ... — a row's partials are one contiguous 8 * nblk-byte run
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int q = threadIdx.x & 15;
-    const bool live = r < rows;
-    const float2* p = partial + (live ? r : 0) * nblk;
-    float s = 0.f;
-    for (int b = q; b < nblk; b += 16) s += p[b].x;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-    const float mu = s / (64.f * nblk);
-    float m2 = 0.f;
-    for (int b = q; b < nblk; b += 16) {
-        const float d = p[b].x * (1.f / 64.f) - mu;
-        m2 += p[b].y + 64.f * d * d;
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 16);
-    if (live && q == 0) out[r] = make_float2(mu, 1.0f / sqrtf(m2 / (64.f * nblk) + eps));
+    // one thread per row (a row's partials are one contiguous 8 * nblk-byte run); the merge itself is uc_ln_merge_row (common.h),
+    // shared with the consumer GEMM's epilogue
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) out[r] = uc_ln_merge_row(partial + r * nblk, nblk, eps);
 }
 
 extern "C" int uc_ln_stats_finalize(const float* partial, int64_t rows, int nblk, float eps, float* out, uc_stream_t stream) {
     UC_REQUIRE(partial && out && rows >= 0 && nblk > 0, "uc_ln_stats_finalize: bad argument");
     UC_REQUIRE((uintptr_t)partial % 8 == 0 && (uintptr_t)out % 8 == 0, "uc_ln_stats_finalize: 8-byte alignment");
     if (rows == 0) return UC_OK;
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                        (const float2*)partial, rows, nblk, eps, (float2*)out);
     UC_CHECK_LAUNCH("uc_ln_stats_finalize");
     return UC_OK;

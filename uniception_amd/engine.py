@@ -193,7 +193,7 @@ def finalize_ln(x2d: torch.Tensor, ln: nn.Module) -> None:
     work that shares x2d across HIP streams: the lazily built statistics are cached on the tensor)."""
     side = getattr(x2d, "uc_ln", None)
     if side is not None and isinstance(ln, nn.LayerNorm):
-        side.stats(ln.eps)
+        side.stats_arg(ln.eps)       # (small batches: nothing to materialize, the consumers merge the block partials themselves)
 
 
 def ln_operand(x2d: torch.Tensor, ln: nn.Module, dt: torch.dtype):
@@ -202,7 +202,7 @@ def ln_operand(x2d: torch.Tensor, ln: nn.Module, dt: torch.dtype):
     side = getattr(x2d, "uc_ln", None)
     if (side is not None and isinstance(ln, nn.LayerNorm) and ln.elementwise_affine and fold_ok(dt, x2d.shape[-1])
             and side.twin.shape == x2d.shape):
-        return side.twin, (side.stats(ln.eps), ln)
+        return side.twin, (side.stats_arg(ln.eps), ln)
     return layernorm(x2d, ln, dt), None
 
 

@@ -238,9 +238,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         d.dact_u, d.dact_act = u.data_ptr(), ACT[act_name]
     if ln is not None:
         st, cs = ln
-        assert st.dtype == torch.float32 and st.is_contiguous() and st.shape == (M, 2)
         assert cs.dtype == torch.float32 and cs.is_contiguous() and cs.numel() == N
-        d.ln_stats, d.ln_colsum = st.data_ptr(), cs.data_ptr()
+        if isinstance(st, LnPartial):     # block partials merged in this GEMM's epilogue (small batches: no finalize launch)
+            pt = st.partial
+            assert pt.dtype == torch.float32 and pt.is_contiguous() and pt.shape == (M, K // 64, 2)
+            d.ln_stats, d.ln_nblk, d.ln_eps = pt.data_ptr(), K // 64, float(st.eps)
+        else:
+            assert st.dtype == torch.float32 and st.is_contiguous() and st.shape == (M, 2)
+            d.ln_stats = st.data_ptr()
+        d.ln_colsum = cs.data_ptr()
     side = None
     if emit_ln:
         assert out.dim() == 2 and N % 64 == 0 and vt is None
@@ -297,6 +303,19 @@ def split_weight_bf16x3(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
     return w3
 
 
+class LnPartial:
+    "ln= argument of gemm(): the producer's per-block row statistics, merged into (mean, rstd) inside the consumer's epilogue."
+    __slots__ = ("partial", "eps")
+
+    def __init__(self, partial, eps):
+        self.partial, self.eps = partial, eps
+
+
+# rows up to which the consumer GEMMs merge the LayerNorm block statistics themselves (uc_gemm_desc.ln_nblk) instead of reading
+# the output of a uc_ln_stats_finalize launch: 16384 rows = 8 pairs of 512x512 views per stream
+LN_MERGE_IN_EPILOGUE_MAX_ROWS = int(__import__("os").environ.get("UNICEPTION_AMD_LN_MERGE_ROWS", "16384"))
+
+
 class LnSide:
     """What a producer GEMM leaves next to its fp32 output rows for the folded LayerNorm of the consumer: a bf16 copy of the
     rows and their per-block statistics; (mean, rstd) per row are finalized on first use, per eps."""
@@ -304,6 +323,13 @@ class LnSide:
 
     def __init__(self, twin, partial):
         self.twin, self.partial, self._stats = twin, partial, {}
+
+    def stats_arg(self, eps: float):
+        """What the consumer GEMM gets as its LayerNorm statistics: the block partials themselves for small batches (merged in its
+        epilogue: same bits, no launch), the finalized (mean, rstd) rows otherwise."""
+        if self.partial.shape[0] <= LN_MERGE_IN_EPILOGUE_MAX_ROWS and eps not in self._stats:
+            return LnPartial(self.partial, eps)
+        return self.stats(eps)
 
     def stats(self, eps: float) -> torch.Tensor:
         st = self._stats.get(eps)
