@@ -1481,16 +1481,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
 // prologue (tile order, DMA source set-up) and the epilogues are the shared C++ ones: after the loop each wave drains its 128x128
 // tile as two 128x64 halves through glds_epilogue_dispatch<8, ...>.
 //
-// K is consumed in half-stages of 32 (64-byte LDS rows with the 32-deep tile's chunk swizzle) through a ring of FOUR 32-KiB buffers: a
-// DMA piece is issued three phases before anyone waits for it, and the loop never drains its loads (counted s_waitcnt vmcnt).  Waves
-// 0-1 stage the A rows, waves 2-3 the W rows (128 rows = 8 pieces of 16 rows x 64 B per half-stage).  The accumulators cross from the asm statement to the epilogue in
+// Measured (round 3): on par with the 16-wave kernel (8192^3: 1400 vs 1343-1412 TFLOP/s; encoder fc1 1132 vs 1142), not ahead — the
+// fragment-read + MFMA loop of this layout IS faster (1846 vs ~1700 without the DMA pieces), but one wave per SIMD has nobody to
+// cover the ~34 cycles each LDS-DMA piece costs its issuing wave (gen/gen_glds4_loop.py).  Opt-in: UC_GEMM_4WAVE / gemm_variant 7.
+//
+// LDS image, stage ring, chunk swizzle and DMA piece addressing are those of the eight-wave kernel; waves 0-1 stage the A rows, waves
+// 2-3 the W rows (128 rows = 16 pieces of 1 KiB each per stage).  The accumulators cross from the asm statement to the epilogue in
 // the physical registers a0..a255 (read out by the v_accvgpr_read statements of UC_GLDS4_READ_HALF*): nothing between the loop and
 // the last read-out may allocate an AGPR — tools/check_glds4_agprs.py verifies that on the compiled code (build.py runs it).
 #include "gemm_glds4_loop.inc"
 
 template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GldsParams p) {
-    constexpr int BM_ = 256, BN_ = 256, A_MODE = UC_A_DENSE;
+    constexpr int BM_ = 256, BN_ = 256, ROWB = 128, A_MODE = UC_A_DENSE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1518,33 +1521,36 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GldsParams p) {
     const bool is_rope = !is_vt && p.rope_cols > 0 && wave_n < p.rope_cols;
     const int mode = is_vt ? 2 : (is_rope ? 1 : 0);
 
-    // DMA slab of this wave: 128 rows of A (waves 0, 1) or of W (waves 2, 3) = 8 pieces of 16 rows x 64 B per half-stage (32 of K)
+    // DMA slab of this wave: 128 rows of A (waves 0, 1) or of W (waves 2, 3), 16 pieces of 8 rows
     const bool stages_a = wave < 2;
     const bf16_t* mat = stages_a ? p.A : p.W;
     const unsigned pitch = (unsigned)((stages_a ? p.lda : p.K) * 2);                       // bytes (launcher: < 2^31)
     const unsigned row0 = (unsigned)((stages_a ? m0 : n0) + (wave & 1) * 128);
-    const unsigned lim = (unsigned)((stages_a ? p.M : p.N) - 16);
+    const unsigned lim = (unsigned)((stages_a ? p.M : p.N) - 8);
     const unsigned long long mat_u = (unsigned long long)mat;
     const unsigned base_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mat_u);
     const unsigned base_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mat_u >> 32));
-    // lane -> row lane >> 2 of the piece, physical 16-B chunk lane & 3 of its 64-B LDS row = logical chunk (lane & 3) ^ swizzle(row)
-    const unsigned voff = (unsigned)(lane >> 2) * pitch + (unsigned)(((lane & 3) ^ glds_swz<32>(lane >> 2)) << 4);
+    const unsigned voff_row = (unsigned)(lane >> 3) * pitch;
+    const unsigned voff0 = voff_row + (unsigned)(((lane & 7) ^ (lane >> 4)) << 4);
+    const unsigned voff1 = voff_row + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) << 4);
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
-    const unsigned lds_dma = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)wave * 8192u));
-    // fragment read addresses in buffer 0: row frow of the wave's block 0, chunk fk ^ swizzle(frow) (64-B rows: one 32-deep K half)
-    const int frow = lane & 15, fk = lane >> 4;
-    const unsigned ch = (unsigned)((fk ^ glds_swz<32>(frow)) << 4);
-    const unsigned a_addr = lds_base + (unsigned)((wr * 128 + frow) * 64) + ch, w_addr = lds_base + (unsigned)((BM_ + wc * 128 + frow) * 64) + ch;
+    const unsigned lds_dma = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)wave * 16384u));
+    // fragment read addresses of stage 0 (K halves 0 / 1): row frow of the wave's block 0, chunk (4 ks + fk) ^ swizzle(frow)
+    const int frow = lane & 15, fk = lane >> 4, f_sw = glds_swz<64>(frow);
+    const unsigned ch0 = (unsigned)(((0 * 4 + fk) ^ f_sw) << 4), ch1 = (unsigned)(((1 * 4 + fk) ^ f_sw) << 4);
+    const unsigned a_row = lds_base + (unsigned)((wr * 128 + frow) * ROWB), w_row = lds_base + (unsigned)((BM_ + wc * 128 + frow) * ROWB);
     const unsigned nk = (unsigned)(p.K / 64);
     if (mode == 2) {
         asm volatile(UC_GLDS4_LOOP_NOSWAP
                      :
-                     : "v"(a_addr), "v"(w_addr), "v"(voff), "s"(base_lo), "s"(base_hi), "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
+                     : "v"(a_row + ch0), "v"(a_row + ch1), "v"(w_row + ch0), "v"(w_row + ch1), "v"(voff0), "v"(voff1), "s"(base_lo), "s"(base_hi),
+                       "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
                      : UC_GLDS4_CLOBBERS);
     } else {
         asm volatile(UC_GLDS4_LOOP_SWAP
                      :
-                     : "v"(a_addr), "v"(w_addr), "v"(voff), "s"(base_lo), "s"(base_hi), "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
+                     : "v"(a_row + ch0), "v"(a_row + ch1), "v"(w_row + ch0), "v"(w_row + ch1), "v"(voff0), "v"(voff1), "s"(base_lo), "s"(base_hi),
+                       "s"(row0), "s"(lim), "s"(pitch), "s"(lds_dma), "s"(nk)
                      : UC_GLDS4_CLOBBERS);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1587,9 +1593,9 @@ static void launch_glds4(GldsParams p, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
 }
 
-// what the four-wave kernel takes: whole 16-row groups, one mode per 128-column wave tile, no split-K, 32-bit row pitches
+// what the four-wave kernel takes: whole 8-row groups, one mode per 128-column wave tile, no split-K, 32-bit row pitches
 static inline bool glds4_ok(const GldsParams& p) {
-    return p.a_mode == UC_A_DENSE && p.M % 16 == 0 && p.N % 16 == 0 && p.M >= 16 && p.N >= 16 && p.split_k <= 1 && p.K >= 64 &&
+    return p.a_mode == UC_A_DENSE && p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8 && p.split_k <= 1 && p.K >= 64 &&
            (p.vt_col0 < 0 || p.vt_col0 % 128 == 0) && (p.rope_cols <= 0 || p.rope_cols % 128 == 0) && p.lda * 2 < ((int64_t)1 << 31) &&
            p.K * 2 < ((int64_t)1 << 31) && p.M < ((int64_t)1 << 31) && p.N < ((int64_t)1 << 31);
 }

@@ -1,48 +1,37 @@
 #!/usr/bin/env python3
-"""Generator of the hand-scheduled K-loop of the four-wave dense bf16 GEMM (gemm_bf16_glds4_kernel, gemm_glds_kernel.h).
+"""Generator of the hand-scheduled K-loop of the four-wave dense bf16 GEMM (gemm_bf16_glds4_kernel, gemm_glds4.hip).
 
     python uniception_amd/csrc/gen/gen_glds4_loop.py > uniception_amd/csrc/gemm_glds4_loop.inc        (committed; build.py does not run this)
 
-256 x 256 workgroup tile, FOUR waves of 128 x 128 (one per SIMD), 256 fp32 accumulators per lane pinned in a0..a255 — the layout of
-the vendor's hand-written GEMM kernels.  hipcc cannot produce it (round 1 / round 2: 604 v_accvgpr moves and 1 KB of scratch in the
-loops from the intrinsic form), so the loop is emitted as ONE inline-asm statement whose registers are fixed here:
+256 x 256 x 64 workgroup tile, FOUR waves of 128 x 128 (one per SIMD), 256 fp32 accumulators per lane pinned in a0..a255 — the layout
+of the vendor's hand-written GEMM kernels.  hipcc cannot produce it (round 1 / round 2: 604 v_accvgpr moves and 1 KB of scratch in
+the loops from the intrinsic form), so the loop is emitted as ONE inline-asm statement whose registers are fixed here:
 
     a[4 * (8 i + j) + r]   accumulator r of MFMA fragment (i, j): i = 16-row block of the wave's 128 rows, j = 16-column block
     v[FR0 ...]             two fragment sets (current / next 32-deep K half): 8 A + 8 W fragments of 4 registers each
-    s[SB ...]              8 wave-uniform 64-bit source bases of the wave's DMA pieces, loop state
+    s[SB ...]              16 wave-uniform 64-bit source bases of the wave's DMA pieces, loop state
 
-K is consumed in HALF-STAGES of 32 (64-byte LDS rows, 512 rows = 32 KiB per half-stage) through a ring of FOUR buffers; one phase =
-one half-stage = 64 v_mfma_f32_16x16x32_bf16 per wave:
+Per K-step (64 deep): 128 v_mfma_f32_16x16x32_bf16, 32 ds_read_b128 (half of the 16-wave kernel's LDS read traffic per MFMA),
+16 LDS-DMA pieces of 1 KiB, ONE s_barrier in the middle of the step:
 
-    phase p   s_waitcnt vmcnt(16) lgkmcnt(0); s_barrier      half-stage p + 1 has landed for everyone (p + 2 and p + 3 stay in flight:
-                                                             the loads are never drained inside the loop), buffer p % 4 is free
-              64 MFMAs on fragment set p & 1                 | 16 ds_read_b128: fragments of half-stage p + 1 -> set (p + 1) & 1
-                                                             | 8 LDS-DMA pieces of 1 KiB: half-stage p + 4 -> buffer p % 4
+    phase A   64 MFMAs on fragment set 0 (K half 0 of stage s)   | ds_read K half 1 of stage s   -> set 1
+    mid       s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier            (stage s + 1 has landed, everyone has read stage s)
+    phase B   64 MFMAs on set 1                                   | ds_read K half 0 of stage s + 1 -> set 0
+                                                                  | DMA of K-step kt + 2 -> the buffer of stage s
 
-so a DMA piece has three phases (~1.5 us) to land before anyone waits for it.  What the two-stage form of this kernel taught (round 3,
-tools/_libs experiments at 8192^3: 1254 TFLOP/s as first written, 1584 without its barrier, 1846 without its DMA): one wave per SIMD
-has nobody to cover a wait, so every cycle a wave spends in `s_waitcnt vmcnt(0)` + `s_barrier` behind loads issued half a step
-earlier is an idle matrix pipe; issue order and per-wave staggering of the pieces change little.
-
-The macros UC_GLDS4_LOOP_SWAP / _NOSWAP expand to the asm text; operands (see gemm_glds_kernel.h): %0 / %1 LDS read addresses of the
-wave's A / W fragment rows in buffer 0, %2 per-lane source byte offset, %3 / %4 source base (low, high dword), %5 first row of the
-wave's 128-row DMA slab, %6 last valid 16-row group start, %7 row pitch in bytes, %8 LDS byte address of the wave's DMA slab in
-buffer 0, %9 number of 64-deep K-steps (>= 1).
+The macros UC_GLDS4_LOOP_SWAP / _NOSWAP expand to the asm text; operands (see gemm_glds_kernel.h): %0..%3 LDS read addresses (A half
+0, A half 1, W half 0, W half 1 of stage 0), %4 / %5 per-lane source byte offsets of even / odd pieces, %6 / %7 source base (low, high
+dword), %8 first row of the wave's 128-row DMA slab, %9 last valid 8-row group start, %10 row pitch in bytes, %11 LDS byte address of
+the wave's DMA slab in stage 0, %12 number of K-steps (>= 1).
 """
 import os
 import sys
 
 FR0 = 128              # first fragment VGPR: set s, operand o (0 = A, 1 = W), block b -> v[FR0 + 64 s + 32 o + 4 b .. + 3]
-SB = 36                # s[SB + 2 q : SB + 2 q + 1] = source base of piece q (8 pieces)
-S_LDS, S_CNT, S_T0, S_T1, S_M0 = 52, 53, 54, 55, 56
-V_OFF = 120                        # running per-lane source offset
-V_A, V_A2, V_W, V_W2 = 121, 122, 123, 124   # LDS read addresses: buffers 0-1 / 2-3 (+ 65536), A and W
-BUF = 32768
-# experiment switches (environment; the committed .inc is generated with none of them set)
-NODMA = os.environ.get("G4_NODMA") == "1"          # no DMA pieces inside the loop (WRONG results)
-NOBAR = os.environ.get("G4_NOBAR") == "1"          # no per-phase barrier (wrong)
-DMA_AT = [int(x) for x in os.environ.get("G4_DMA_AT", "6,14,22,30,38,46,54,62").split(",")]    # piece q behind MFMA DMA_AT[q]
-READ_STEP = int(os.environ.get("G4_READ_STEP", "2"))     # a fragment read behind every READ_STEP-th MFMA, from the first
+SB = 36                # s[SB + 2 q : SB + 2 q + 1] = source base of piece q (16 pieces)
+S_DMA, S_DELTA, S_CNT, S_T0, S_T1, S_M0 = 68, 69, 70, 71, 72, 73
+V_OFF0, V_OFF1 = 120, 121      # running per-lane source offsets (even / odd pieces)
+V_A0, V_A1, V_W0, V_W1 = 122, 123, 124, 125   # running LDS read addresses of the current stage
 
 
 def frag(s, o, b):
@@ -75,128 +64,127 @@ def mfma(b, swap, s, i, j):
         b.emit(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {a}, {w}, {acc(i, j)}")
 
 
-def ds_read(b, s, o, blk, buf):
-    reg = (V_A, V_A2)[buf >> 1] if o == 0 else (V_W, V_W2)[buf >> 1]
-    b.emit(f"ds_read_b128 {frag(s, o, blk)}, v{reg} offset:{(buf & 1) * BUF + blk * 1024}")
+def ds_read(b, s, o, blk, addr_reg):
+    b.emit(f"ds_read_b128 {frag(s, o, blk)}, v{addr_reg} offset:{blk * 2048}")
 
 
-def dma_piece(b, q, buf):
+def dma_piece(b, q):
     # M0 = LDS byte address of the piece (wave-uniform); hazard M0 write -> LDS-DMA: s_nop 0
-    b.emit(f"s_add_u32 m0, s{S_LDS}, {buf * BUF + q * 1024}")
+    b.emit(f"s_add_u32 m0, s{S_DMA}, {q * 1024}")
     b.emit("s_nop 0")
-    b.emit(f"global_load_lds_dwordx4 v{V_OFF}, s[{SB + 2 * q}:{SB + 2 * q + 1}]")
+    b.emit(f"global_load_lds_dwordx4 v{V_OFF1 if q & 1 else V_OFF0}, s[{SB + 2 * q}:{SB + 2 * q + 1}]")
 
 
-def issue_half_stage(b, buf):
-    for q in range(8):
-        dma_piece(b, q, buf)
-    b.emit(f"v_add_u32 v{V_OFF}, 64, v{V_OFF}")
+# experiment switches (environment; the committed .inc is generated with none of them set)
+NODMA = os.environ.get("G4_NODMA") == "1"          # no DMA pieces inside the loop (WRONG results: what the loop costs without them)
+NOBAR = os.environ.get("G4_NOBAR") == "1"          # no mid-step barrier (wrong)
 
 
-def read_frags(b, s, buf):
-    for j in range(8):
-        ds_read(b, s, 1, j, buf)
-    for i in range(8):
-        ds_read(b, s, 0, i, buf)
-
-
-def phase(b, swap, buf, vm, reads, dma, last=False):
-    """Phase p with p % 4 == buf: synchronise, then 64 MFMAs on set buf & 1 with the fillers in between."""
-    if last:
-        b.emit("s_waitcnt lgkmcnt(0)")
-    else:
-        b.emit(f"s_waitcnt vmcnt({vm}) lgkmcnt(0)")
-        if not NOBAR:
-            b.emit("s_barrier")
-    cur, nxt = buf & 1, (buf + 1) & 1
-    nbuf = (buf + 1) & 3
-    rl = ([(nxt, 1, j, nbuf) for j in range(8)] + [(nxt, 0, i, nbuf) for i in range(8)]) if reads else []
+def phase(b, swap, cur_set, reads, dmas):
+    """64 MFMAs on fragment set `cur_set`.  Fillers: the `reads` = (set, operand, block, address register) of the NEXT phase's
+    fragments behind the odd MFMAs of the first half (W first: the next phase's first MFMA group needs all eight W fragments; all of
+    them have returned long before the phase ends), one of the `dmas` (piece numbers, three instructions each) behind every fourth
+    MFMA of the whole phase — evenly spread pieces measured best (clustered at either end: -3 %)."""
     slots = {}
-    for k, x in enumerate(rl):
-        slots.setdefault(READ_STEP * k + 1, []).append(("r", x))
-    if dma and not NODMA:
-        for q in range(8):
-            slots.setdefault(DMA_AT[q], []).append(("d", q))
+    for k, x in enumerate(reads):
+        slots[2 * k + 1] = ("r", x)
+    for k, q in enumerate([] if NODMA else dmas):
+        slots[4 * k + 2] = ("d", q)
     n = 0
     for i in range(8):
         for j in range(8):
-            mfma(b, swap, cur, i, j)
+            mfma(b, swap, cur_set, i, j)
             n += 1
-            for kind, x in slots.get(n, []):
+            if n in slots:
+                kind, x = slots[n]
                 if kind == "r":
                     ds_read(b, *x)
                 else:
-                    dma_piece(b, x, buf)
-    if dma:
-        b.emit(f"v_add_u32 v{V_OFF}, 64, v{V_OFF}")
+                    dma_piece(b, x)
 
 
-def tail(b, swap, start):
-    "the last four phases: no more DMA; buffers start, start + 1, ... (mod 4)"
-    phase(b, swap, start, 16, True, False)
-    phase(b, swap, (start + 1) & 3, 8, True, False)
-    phase(b, swap, (start + 2) & 3, 0, True, False)
-    phase(b, swap, (start + 3) & 3, 0, False, False, last=True)
+def step(b, swap, with_reads, with_dma, last):
+    # phase A: set 0, read K half 1 of the current stage into set 1
+    rd = [(1, 1, j, V_W1) for j in range(8)] + [(1, 0, i, V_A1) for i in range(8)]
+    b.emit("s_waitcnt lgkmcnt(0)")
+    phase(b, swap, 0, rd, [])
+    # mid-step synchronisation
+    if last:
+        b.emit("s_waitcnt lgkmcnt(0)")
+    else:
+        b.emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        if not NOBAR:
+            b.emit("s_barrier")
+        for r in (V_A0, V_A1, V_W0, V_W1):          # read addresses move to the other stage
+            b.emit(f"v_add_u32 v{r}, s{S_DELTA}, v{r}")
+    rd = [(0, 1, j, V_W0) for j in range(8)] + [(0, 0, i, V_A0) for i in range(8)] if with_reads else []
+    phase(b, swap, 1, rd, list(range(16)) if with_dma else [])
+    if with_dma:
+        b.emit(f"v_add_u32 v{V_OFF0}, 128, v{V_OFF0}")
+        b.emit(f"v_add_u32 v{V_OFF1}, 128, v{V_OFF1}")
+    if not last:
+        b.emit(f"s_add_u32 s{S_DMA}, s{S_DMA}, s{S_DELTA}")
+        b.emit(f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}")
 
 
 def loop(swap):
     b = Body()
     e = b.emit
     tag = "s" if swap else "u"
+    # ---- prologue: per-piece source bases ----
     e(f"s_mov_b32 s{S_M0}, m0")                                # M0 is compiler-reserved: saved here, restored at the end
-    e(f"v_mov_b32 v{V_OFF}, %2")
-    e(f"v_mov_b32 v{V_A}, %0")
-    e(f"v_add_u32 v{V_A2}, 0x10000, v{V_A}")
-    e(f"v_mov_b32 v{V_W}, %1")
-    e(f"v_add_u32 v{V_W2}, 0x10000, v{V_W}")
-    e(f"s_mov_b32 s{S_LDS}, %8")
-    for q in range(8):
-        e(f"s_add_u32 s{S_T0}, %5, {16 * q}")
-        e(f"s_min_u32 s{S_T0}, s{S_T0}, %6")                   # row groups past the matrix end: its last 16 rows (never stored)
-        e(f"s_mul_hi_u32 s{S_T1}, s{S_T0}, %7")
-        e(f"s_mul_i32 s{S_T0}, s{S_T0}, %7")
-        e(f"s_add_u32 s{SB + 2 * q}, %3, s{S_T0}")
-        e(f"s_addc_u32 s{SB + 2 * q + 1}, %4, s{S_T1}")
-    issue_half_stage(b, 0)
-    issue_half_stage(b, 1)
-    e(f"s_cmp_lt_u32 %9, 2")
-    e(f"s_cbranch_scc1 .Lg4{tag}_small_%=")
-    issue_half_stage(b, 2)
-    issue_half_stage(b, 3)
+    e(f"s_mov_b32 s{S_CNT}, %12")
+    e(f"v_mov_b32 v{V_OFF0}, %4")
+    e(f"v_mov_b32 v{V_OFF1}, %5")
+    e(f"v_mov_b32 v{V_A0}, %0")
+    e(f"v_mov_b32 v{V_A1}, %1")
+    e(f"v_mov_b32 v{V_W0}, %2")
+    e(f"v_mov_b32 v{V_W1}, %3")
+    e(f"s_mov_b32 s{S_DMA}, %11")
+    e(f"s_mov_b32 s{S_DELTA}, 0x10000")
+    for q in range(16):
+        e(f"s_add_u32 s{S_T0}, %8, {8 * q}")
+        e(f"s_min_u32 s{S_T0}, s{S_T0}, %9")                   # row groups past the matrix end: its last 8 rows (never stored)
+        e(f"s_mul_hi_u32 s{S_T1}, s{S_T0}, %10")
+        e(f"s_mul_i32 s{S_T0}, s{S_T0}, %10")
+        e(f"s_add_u32 s{SB + 2 * q}, %6, s{S_T0}")
+        e(f"s_addc_u32 s{SB + 2 * q + 1}, %7, s{S_T1}")
+    # ---- stage 0 (+ stage 1) in flight, accumulators cleared while they travel ----
+    for q in range(16):
+        dma_piece(b, q)
+    e(f"v_add_u32 v{V_OFF0}, 128, v{V_OFF0}")
+    e(f"v_add_u32 v{V_OFF1}, 128, v{V_OFF1}")
     for r in range(256):
         e(f"v_accvgpr_write_b32 a{r}, 0")
-    e("s_waitcnt vmcnt(24)")
+    e("s_waitcnt vmcnt(0)")
     e("s_barrier")
-    read_frags(b, 0, 0)
-    e(f"s_lshl_b32 s{S_CNT}, %9, 1")
-    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 4")                      # phases that still issue a half-stage: 2 nk - 4
-    e(f"s_cmp_lt_u32 s{S_CNT}, 4")
-    e(f"s_cbranch_scc1 .Lg4{tag}_rest_%=")
+    e(f"s_cmp_lt_u32 s{S_CNT}, 2")
+    e(f"s_cbranch_scc1 .Lg4{tag}_nos1_%=")
+    e(f"s_add_u32 s{S_DMA}, s{S_DMA}, 0x10000")
+    for q in range(16):
+        dma_piece(b, q)
+    e(f"s_sub_u32 s{S_DMA}, s{S_DMA}, 0x10000")
+    e(f"v_add_u32 v{V_OFF0}, 128, v{V_OFF0}")
+    e(f"v_add_u32 v{V_OFF1}, 128, v{V_OFF1}")
+    e(f".Lg4{tag}_nos1_%=:")
+    for j in range(8):
+        ds_read(b, 0, 1, j, V_W0)
+    for i in range(8):
+        ds_read(b, 0, 0, i, V_A0)
+    # ---- steps 0 .. nk-3: reads + DMA; step nk-2: reads only; step nk-1: nothing ----
+    e(f"s_cmp_lt_u32 s{S_CNT}, 3")
+    e(f"s_cbranch_scc1 .Lg4{tag}_tail_%=")
     e(f".Lg4{tag}_loop_%=:")
-    for buf in range(4):
-        phase(b, swap, buf, 16, True, True)
-    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 4")
-    e(f"s_cmp_ge_u32 s{S_CNT}, 4")
+    step(b, swap, True, True, False)
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    e(f"s_cmp_gt_u32 s{S_CNT}, 2")
     e(f"s_cbranch_scc1 .Lg4{tag}_loop_%=")
-    e(f".Lg4{tag}_rest_%=:")
-    e(f"s_cmp_eq_u32 s{S_CNT}, 0")
-    e(f"s_cbranch_scc1 .Lg4{tag}_tail0_%=")
-    phase(b, swap, 0, 16, True, True)
-    phase(b, swap, 1, 16, True, True)
-    tail(b, swap, 2)
-    e(f"s_branch .Lg4{tag}_end_%=")
-    e(f".Lg4{tag}_tail0_%=:")
-    tail(b, swap, 0)
-    e(f"s_branch .Lg4{tag}_end_%=")
-    e(f".Lg4{tag}_small_%=:")                                  # K = 64: two phases
-    for r in range(256):
-        e(f"v_accvgpr_write_b32 a{r}, 0")
-    e("s_waitcnt vmcnt(8)")
-    e("s_barrier")
-    read_frags(b, 0, 0)
-    phase(b, swap, 0, 0, True, False)
-    phase(b, swap, 1, 0, False, False, last=True)
-    e(f".Lg4{tag}_end_%=:")
+    e(f".Lg4{tag}_tail_%=:")
+    e(f"s_cmp_lt_u32 s{S_CNT}, 2")
+    e(f"s_cbranch_scc1 .Lg4{tag}_last_%=")
+    step(b, swap, True, False, False)
+    e(f".Lg4{tag}_last_%=:")
+    step(b, swap, False, False, True)
     e("s_nop 15")                                               # MFMA results -> v_accvgpr_read of the read-out macros
     e("s_nop 15")
     e(f"s_mov_b32 m0, s{S_M0}")
@@ -204,7 +192,7 @@ def loop(swap):
 
 
 def clobbers():
-    c = [f"a{r}" for r in range(256)] + [f"v{r}" for r in range(V_OFF, 256)]
+    c = [f"a{r}" for r in range(256)] + [f"v{r}" for r in range(V_OFF0, 256)]
     c += [f"s{r}" for r in range(SB, S_M0 + 1)] + ["scc", "memory"]
     return ", ".join(f'"{x}"' for x in c)
 
