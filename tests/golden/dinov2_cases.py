@@ -10,6 +10,9 @@ DINOV2_HF_CASES = {
     "small_noreg": dict(size="small", regs=False, layers=2, hw=(518, 518), B=1, seed=11),
     "small_reg": dict(size="small", regs=True, layers=3, hw=(518, 518), B=1, seed=12),
     "base_reg": dict(size="base", regs=True, layers=1, hw=(518, 518), B=1, seed=13),
+    # the size BASELINE configs[3] names: ViT-L/14, all 24 blocks, 518 x 518 (the reference's defaults: size="large", with_registers=False,
+    # encoders/dinov2.py:18-24)
+    "large_full": dict(size="large", regs=False, layers=24, hw=(518, 518), B=1, seed=14),
 }
 
 

@@ -141,7 +141,7 @@ def test_config4_pipeline_matches_oracle_composition_and_trains_with_frozen_enco
     assert gnorm > 0 and torch.isfinite(torch.tensor(gnorm))
 
 
-@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg"])
+@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg", "large_full"])     # large_full: ViT-L/14 x 24 at 518^2, the size configs[3] names
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2)])
 def test_matches_huggingface_transformers_golden(gpu, name, mode, tol):
     """The HIP DINOv2 encoder against goldens of an INDEPENDENT implementation of the published network (transformers'
@@ -227,3 +227,45 @@ def test_gradients_match_huggingface_transformers_autograd(gpu, name, mode):
         assert worst[1] < 1e-3, worst
     else:
         assert cos > 0.999, cos
+
+
+def test_config3_full_size_pipeline_matches_oracle(gpu):
+    """BASELINE configs[3] at the size it names — DINOv2 ViT-L/14 (24 blocks, 518 x 518, 37 x 37 tokens) + the factory's 12-block CroCo
+    decoder + DPT heads + adaptor, the model `bench.py --encoder dinov2` measures — against the oracle's composition (its DINOv2 part
+    pinned to transformers' implementation at this very size: `large_full`; decoder / DPT / adaptor pinned to the reference), fp32
+    gate 1e-3 / 1e-2 on the four outputs, bf16 <= 3e-2."""
+    from tests.golden.cases import GAINS as G2, sample_indices
+    from uniception_amd import engine
+    from uniception_amd.models.encoders import encoder_factory
+    from uniception_amd.models.factory import DUSt3R
+    torch.manual_seed(0)
+    model = DUSt3R(name="c3", img_size=(518, 518), pred_head_type="dpt")
+    model.encoder = encoder_factory("dinov2", name="c3_dinov2", size="large")
+    model = model.eval()
+    O.fill_state_dict_(model.state_dict(), gains=dict(GAINS, **G2))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(33)
+    img1, img2 = torch.randn(1, 3, 518, 518, generator=g), torch.randn(1, 3, 518, 518, generator=g)
+    with torch.no_grad():
+        enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+        feats, _ = O.dinov2_encoder(torch.cat([img1, img2], 0), enc_sd, "model.", num_heads=16)
+        final, taken = O.cross_attention_transformer([feats[:1], feats[1:]], sd, "info_sharing.", depth=12, num_heads=12, indices=(5, 8),
+                                                     norm_intermediate=False)
+        ref = []
+        for v in range(2):
+            up8 = O.dpt_feature([feats[v:v + 1], taken[0][v], taken[1][v], final[v]], sd, f"dpt_feature_head{v + 1}.")
+            pts, conf = O.pointmap_adaptor(O.dpt_regressor(up8, (518, 518), sd, f"dpt_regressor_head{v + 1}."))
+            ref += [pts.permute(0, 2, 3, 1), conf.permute(0, 2, 3, 1)]
+    model = model.to(gpu)
+    v1 = {"img": img1.to(gpu), "instance": ["0"], "data_norm_type": "dinov2"}
+    v2 = {"img": img2.to(gpu), "instance": ["1"], "data_norm_type": "dinov2"}
+    for mode, tol, atol in (("fp32", 1e-3, 1e-2), ("bf16", 3e-2, None)):
+        with torch.no_grad(), engine.precision(mode):
+            r1, r2 = model(v1, v2)
+        got = [r1["pts3d"], r1["conf"], r2["pts3d_in_other_view"], r2["conf"]]
+        errs = [rel_l2(a.float().cpu(), b) for a, b in zip(got, ref)]
+        aerr = [float((a.float().cpu() - b).abs().max()) for a, b in zip(got, ref)]
+        print(f"\n[config 3 full size, {mode}] rel-L2 pts1 {errs[0]:.2e} conf1 {errs[1]:.2e} pts2 {errs[2]:.2e} conf2 {errs[3]:.2e}; max-abs {max(aerr):.2e}")
+        assert got[0].shape == (1, 518, 518, 3) and max(errs) < tol
+        if atol is not None:
+            assert max(aerr) < atol

@@ -311,9 +311,13 @@ class LnPartial:
         self.partial, self.eps = partial, eps
 
 
-# rows up to which the consumer GEMMs merge the LayerNorm block statistics themselves (uc_gemm_desc.ln_nblk) instead of reading
-# the output of a uc_ln_stats_finalize launch: 16384 rows = 8 pairs of 512x512 views per stream
-LN_MERGE_IN_EPILOGUE_MAX_ROWS = int(__import__("os").environ.get("UNICEPTION_AMD_LN_MERGE_ROWS", "16384"))
+# rows up to which the consumer GEMMs merge the LayerNorm block statistics themselves (uc_gemm_desc.ln_nblk) instead of reading the
+# output of a uc_ln_stats_finalize launch.  Measured (512x512 pairs, ms per batch at 1 / 2 / 4 / 8 pairs): eager 12.8 / 13.7 / 15.0 /
+# 25.1 -> 11.6 / 10.8 / 16.5 / 27.0 — the eager forward of 1-2 pairs is HOST-bound (~640 launches through ctypes), so 120 fewer
+# launches are worth 1-3 ms there; replayed from a hipGraph (GPU-bound) 8.2 / 9.8 / 14.8 / 24.5 -> 8.4 / 10.3 / 16.3 / 26.9: every
+# column tile of a row panel repeats the merge at the head of its epilogue, which costs more than the 4-us launches it saves.  Hence:
+# up to 2048 rows (two pairs per stream), and never while a graph is being captured.
+LN_MERGE_IN_EPILOGUE_MAX_ROWS = int(__import__("os").environ.get("UNICEPTION_AMD_LN_MERGE_ROWS", "2048"))
 
 
 class LnSide:
@@ -327,7 +331,8 @@ class LnSide:
     def stats_arg(self, eps: float):
         """What the consumer GEMM gets as its LayerNorm statistics: the block partials themselves for small batches (merged in its
         epilogue: same bits, no launch), the finalized (mean, rstd) rows otherwise."""
-        if self.partial.shape[0] <= LN_MERGE_IN_EPILOGUE_MAX_ROWS and eps not in self._stats:
+        if (self.partial.shape[0] <= LN_MERGE_IN_EPILOGUE_MAX_ROWS and eps not in self._stats
+                and not torch.cuda.is_current_stream_capturing()):
             return LnPartial(self.partial, eps)
         return self.stats(eps)
 
