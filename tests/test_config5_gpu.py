@@ -9,10 +9,9 @@ from tests.helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-ENC, DEC = 4, 4
-
-
-def test_1024_fp8_attention_inside_the_model(gpu, monkeypatch):
+# (4, 4): the quick form; (24, 12): the depth BASELINE configs[4] names (ViT-L encoder + 12-block decoder), oracle on the host cores
+@pytest.mark.parametrize("ENC,DEC,bar8", [(4, 4, 4e-2), (24, 12, 4e-2)])
+def test_1024_fp8_attention_inside_the_model(gpu, monkeypatch, ENC, DEC, bar8):
     from uniception_amd import engine, ops
     from uniception_amd.models.factory import DUSt3R
 
@@ -57,8 +56,8 @@ def test_1024_fp8_attention_inside_the_model(gpu, monkeypatch):
                                    ("pts3d_2", f2["pts3d_in_other_view"], b2["pts3d_in_other_view"], o2["pts3d_in_other_view"]),
                                    ("conf_2", f2["conf"], b2["conf"], o2["conf"])):
         errs[name] = (rel_l2(got8.cpu(), ref), rel_l2(got16.cpu(), ref), rel_l2(got8.cpu(), got16.cpu()))
-    print("\n[config 5, 1024x1024, 4+4 blocks] rel-L2 (fp8 vs oracle, bf16 vs oracle, fp8 vs bf16): " +
+    print(f"\n[config 5, 1024x1024, {ENC}+{DEC} blocks] rel-L2 (fp8 vs oracle, bf16 vs oracle, fp8 vs bf16): " +
           ", ".join(f"{k}={a:.1e}/{b:.1e}/{c:.1e}" for k, (a, b, c) in errs.items()))
     for k, (e8, e16, d) in errs.items():
         assert e16 < 3e-2, (k, e16)
-        assert e8 < 8e-2 and d < 8e-2, (k, e8, d)
+        assert e8 < bar8 and d < bar8, (k, e8, d)

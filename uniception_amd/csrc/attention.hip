@@ -30,6 +30,7 @@ struct AttnParams {
     float scale;
     float* lse;   // optional [B,H,Nq]: log-sum-exp of the scaled scores (saved for the backward)
     uc_fastdiv dGroup, dNq, dH;   // exact fast division by 8*nq, nq, H (workgroup -> (query tile, batch, head) in the DMA kernel)
+    int prio_young;               // eight-wave workgroups: s_setprio 1 for waves 4-7 (the younger half loses every VALU arbitration to the older one)
 };
 
 #define KV_TILE 64
@@ -376,6 +377,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bf16_dma_kernel(AttnParams p)
     float m_run = -1e30f;
     float l_run = 0.f;
     const float c = p.scale * 1.44269504088896340736f;  // scale * log2(e)
+    if constexpr (NW == 8) {
+        // static priority for the second-dispatched half (MI355X_MICROARCH.md "Two waves per SIMD", item 4): one s_setprio before the
+        // loop, no per-segment flips (`wave` is a readfirstlane value: the branch is scalar, s_setprio ignores EXEC)
+        if (p.prio_young && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
 
     const int nt = (p.Nk + KV_TILE - 1) / KV_TILE;
     for (int t = 0; t < nt; ++t) {
@@ -632,6 +638,7 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
     p.npad = (Nk + 63) / 64 * 64;
     p.scale = scale;
     p.lse = lse;
+    p.prio_young = uc_knobs().attn_prio;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UC_BF16) {
         UC_REQUIRE(D == 64, "uc_attention_fwd(bf16): head_dim must be 64 (got %d)", D);

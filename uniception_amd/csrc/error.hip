@@ -45,6 +45,7 @@ const UcKnobs& uc_knobs() {
         g_knobs.gemm_4wave = env_int("UC_GEMM_4WAVE", 0);
         g_knobs.attn_nw = env_int("UC_ATTN_NW", 0);
         g_knobs.attn_dma = env_int("UC_ATTN_DMA", 1);
+        g_knobs.attn_prio = env_int("UC_ATTN_PRIO", 0);
         g_knobs.bilinear_rows2 = env_int("UC_BILINEAR_ROWS2", 4);
         g_knobs.ln_nt = env_int("UC_LN_NT", -1);
         g_knobs.gemm_splitk_small = env_int("UC_GEMM_SMALLM", 1);

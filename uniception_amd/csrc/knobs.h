@@ -21,6 +21,7 @@ struct UcKnobs {
     int gemm_small_stages;   // UC_GEMM_SMALL_STAGES 3-stage ring for launches with fewer workgroups than CUs (default 3)
     int attn_nw;             // UC_ATTN_NW           waves per attention workgroup: 0 policy, 4, 8
     int attn_dma;            // UC_ATTN_DMA          LDS-DMA attention kernel (default 1)
+    int attn_prio;           // UC_ATTN_PRIO         eight-wave attention: static s_setprio 1 for waves 4-7 (default 0)
     int bilinear_rows2;      // UC_BILINEAR_ROWS2    output rows per work item of the upsampling form (default 4)
     int ln_nt;               // UC_LN_NT             non-temporal LayerNorm loads override (-1: policy)
     int gemm_splitk_small;   // UC_GEMM_SMALLM       small-M policy of the dense GEMM (default 1: fill the CUs with split-K slices / smaller tiles)
