@@ -206,6 +206,17 @@ def reference_policy_legs(model, v1, v2, args, dev):
                                                    "pairs_per_gpu": args.pairs, "heads": "bf16x3 split-operand MFMA, fp32 tensors"}
     finally:
         engine.set_head_precision("follow")
+    engine.set_head_precision("fp16")
+    try:   # the same policy on TF32-class arithmetic: fp16 MFMA operands (10-bit mantissa = TF32's, what the reference's fp32 heads run
+        # on in its own environment: allow_tf32, libs/croco/blocks.py:15), fp32 accumulate
+        f = fwd(v1, v2, "bf16")
+        f(); f()
+        dt, _ = timed(f, steps, 1)
+        out["bf16_transformer_tf32class_heads"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
+                                                   "pairs_per_gpu": args.pairs, "heads": "fp16 MFMA operands, fp32 accumulate, fp16 maps, fp32 final layer",
+                                                   "heads_only_rel_l2_vs_exact_fp32_heads": "~1e-3 (tests/test_precision_modes_gpu.py), bf16 heads ~1e-2"}
+    finally:
+        engine.set_head_precision("follow")
     if engine.bf16_stream_enabled() and args.encoder == "croco":
         # the same bf16 forward with the residual stream kept in fp32 (round 1's policy: more accurate than the reference's own bf16
         # stream under autocast, 10 instead of 4 bytes per element in the residual epilogues)

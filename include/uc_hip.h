@@ -97,7 +97,10 @@ enum uc_a_mode { UC_A_DENSE = 0, UC_A_CONV3X3 = 1 };
 enum uc_act { UC_ACT_NONE = 0, UC_ACT_GELU_ERF = 1, UC_ACT_RELU = 2 };
 
 typedef struct uc_gemm_desc {
-    int compute_dtype;   /* UC_F32: A,W fp32, exact-fp32 FMA chain; UC_BF16: A,W bf16, MFMA, fp32 accumulate */
+    int compute_dtype;   /* UC_F32: A,W fp32, exact-fp32 FMA chain; UC_BF16: A,W bf16, MFMA, fp32 accumulate; UC_F16 (round 3): A,W fp16
+                            on the f16 MFMA (10-bit mantissa = TF32's: what the reference's fp32 heads run on under allow_tf32,
+                            libs/croco/blocks.py:15, factory/dust3r.py:288-309) at the bf16 rate; 16-bit outputs / residuals are
+                            then fp16; bias / activation / residual(s) / fused tail only (no RoPE, VT, LayerNorm fold, split-K) */
     int a_mode;          /* uc_a_mode */
     int relu_a;          /* apply ReLU to A elements while loading (DPT ResidualConvUnit pre-activation) */
     const void* A;       /* dense: [M,K] row-major, leading dim lda.  conv: NHWC [B,H,W,Cin] */

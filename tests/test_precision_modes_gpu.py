@@ -71,6 +71,78 @@ def test_split_operand_attention_matches_fp64(gpu, shape):
         assert float((o - ref.float()).abs().max()) < 2e-4 * float(ref.abs().max())
 
 
+def test_fp16_operand_gemm_and_conv_are_tf32_class(gpu):
+    """uc_gemm with compute_dtype UC_F16 (the heads' TF32-class mode): fp16 MFMA operands, fp32 accumulate.  Against the fp64 product
+    of the SAME fp16-rounded operands the kernel is exact to fp32 accumulation (<= 2e-6); against the fp32 operands it carries the
+    operand rounding 2^-11 (TF32's) — 8x below bf16's 2^-8.  Dense (bias + GELU, fp32 out, fp16 residual), 3x3 convolution with
+    ReLU-on-load / residual / stride 2, and the fused 128 -> 4 tail."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(31)
+    a = torch.randn(520, 256, generator=g)
+    w = torch.randn(328, 256, generator=g) / 16
+    b = torch.randn(328, generator=g)
+    res = torch.randn(520, 328, generator=g)
+    a16, w16, r16 = a.half(), w.half(), res.half()
+    exact = a16.double() @ w16.double().t() + b.double()
+    y = ops.gemm(a16.to(gpu), w16.to(gpu), b.to(gpu), out_dtype=torch.float32)
+    assert y.dtype == torch.float32 and rel_l2(y.cpu(), exact) < 2e-6
+    y16 = ops.gemm(a16.to(gpu), w16.to(gpu), b.to(gpu), act="gelu")
+    assert y16.dtype == torch.float16 and rel_l2(y16.float().cpu(), F.gelu(exact)) < 4e-4            # + one fp16 rounding of the output
+    yr = ops.gemm(a16.to(gpu), w16.to(gpu), b.to(gpu), residual=r16.to(gpu), out_dtype=torch.float16)
+    assert rel_l2(yr.float().cpu(), exact + r16.double()) < 4e-4
+    true = a.double() @ w.double().t() + b.double()
+    e16 = rel_l2(y.cpu(), true)
+    ebf = rel_l2(ops.gemm(a.bfloat16().to(gpu), w.bfloat16().to(gpu), b.to(gpu), out_dtype=torch.float32).cpu(), true)
+    print(f"\n[fp16 operands] dense: {e16:.2e} against the fp32 operands (bf16 operands: {ebf:.2e})")
+    assert e16 < 5e-4 and e16 < ebf / 5
+    for (B, H, W, Cin, Cout, s_) in [(2, 9, 11, 32, 40, 1), (1, 12, 8, 64, 24, 2), (1, 16, 16, 96, 64, 1)]:
+        x = torch.randn(B, H, W, Cin, generator=g)
+        wc = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+        bc = torch.randn(Cout, generator=g)
+        x16, wc16 = x.half(), wc.half()
+        refc = F.conv2d(F.relu(x16.permute(0, 3, 1, 2)).double(), wc16.double(), bc.double(), stride=s_, padding=1).permute(0, 2, 3, 1)
+        wg = wc16.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+        yc = ops.gemm(x16.to(gpu), wg.to(gpu), bc.to(gpu), relu_a=True, conv=(B, H, W, Cin, s_), out_dtype=torch.float32)
+        assert rel_l2(yc.view(refc.shape).cpu(), refc) < 2e-6
+    # fused tail: conv3x3(Cin -> 128) -> ReLU -> 1x1(128 -> 4)
+    B, H, W, Cin = 2, 16, 24, 128
+    x = torch.randn(B, H, W, Cin, generator=g).half()
+    wc = (torch.randn(128, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half()
+    bc = torch.randn(128, generator=g) * 0.3
+    w4, b4 = torch.randn(4, 128, generator=g) / math.sqrt(128), torch.randn(4, generator=g)
+    yt = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), wc.double(), bc.double(), padding=1))
+    reft = torch.einsum("bchw,oc->bhwo", yt, w4.double()) + b4.double()
+    out = ops.gemm(x.to(gpu), wc.permute(0, 2, 3, 1).reshape(128, -1).contiguous().to(gpu), bc.to(gpu), act="relu", conv=(B, H, W, Cin, 1),
+                   tail=(w4.to(gpu), b4.to(gpu)))
+    assert out.dtype == torch.float32 and rel_l2(out.view(B, H, W, 4).cpu(), reft) < 1e-5
+
+
+def test_fp16_heads_are_tf32_class_against_exact_fp32_heads(gpu):
+    """engine.set_head_precision("fp16") — the reference's fp32 heads on TF32-class arithmetic (fp16 MFMA operands, fp32 accumulate;
+    TF32 is what "fp32" convolutions / linears run on in the reference's own environment, libs/croco/blocks.py:15) — on the SAME bf16
+    transformer features as the exact-fp32 heads: the four outputs of the full-size ViT-L + DPT 512x512 model agree to ~1e-3 where
+    the bf16 heads are at ~1e-2 (VERDICT r2 next #3b: reported and gated)."""
+    exact, c = _run("vitl_dpt_512", gpu, "bf16", "fp32_exact")
+    h16, _ = _run("vitl_dpt_512", gpu, "bf16", "fp16")
+    hbf, _ = _run("vitl_dpt_512", gpu, "bf16", "follow")
+    x3, _ = _run("vitl_dpt_512", gpu, "bf16", "fp32")
+    e16 = {k: rel_l2(h16[k].cpu(), exact[k].cpu()) for k in HEAD_OUTPUTS}
+    ebf = {k: rel_l2(hbf[k].cpu(), exact[k].cpu()) for k in HEAD_OUTPUTS}
+    ex3 = {k: rel_l2(x3[k].cpu(), exact[k].cpu()) for k in HEAD_OUTPUTS}
+    print("\n[heads only, same bf16 features, vs exact fp32 heads] fp16 heads " + ", ".join(f"{k}={v:.1e}" for k, v in e16.items()) +
+          " | bf16 heads " + ", ".join(f"{k}={v:.1e}" for k, v in ebf.items()) + " | bf16x3 heads " + ", ".join(f"{k}={v:.1e}" for k, v in ex3.items()))
+    for k in HEAD_OUTPUTS:
+        assert e16[k] < 3e-3 and e16[k] < ebf[k] / 3, (k, e16[k], ebf[k])
+    # end to end against the reference golden: the bf16 transformer's error class
+    rep = {}
+    compare_to_golden(load_golden("vitl_dpt_512"), h16, c, tol=3e-2, report=rep)
+    print("[bf16 transformer + fp16 heads vs reference golden] " + ", ".join(f"{k}={rep[k]:.1e}" for k in HEAD_OUTPUTS))
+    # and the small models incl. the linear head
+    for name in ("tiny_dpt", "tiny_linear", "tiny_dpt_odd"):
+        t, cc = _run(name, gpu, "bf16", "fp16")
+        compare_to_golden(load_golden(name), t, cc, tol=3e-2)
+
+
 def _run(name, gpu, mode, head_mode):
     from uniception_amd import engine
     model, c = build_case_model(name)

@@ -30,8 +30,33 @@ __device__ __forceinline__ V8 load8<BF16Tag>(const bf16_t* p) {
     r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
     return r;
 }
+typedef _Float16 uc_half2_t __attribute__((ext_vector_type(2)));
+typedef float uc_float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {       // round-to-nearest-even, like torch's Half
+    const uc_float2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, uc_half2_t));
+}
+__device__ __forceinline__ void unpack_f16x2(unsigned u, float& lo, float& hi) {
+    const uc_float2_t v = __builtin_convertvector(__builtin_bit_cast(uc_half2_t, u), uc_float2_t);
+    lo = v.x; hi = v.y;
+}
+template <>
+__device__ __forceinline__ V8 load8<F16Tag>(const unsigned short* p) {
+    V8 r;
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    unpack_f16x2(u.x, r.v[0], r.v[1]); unpack_f16x2(u.y, r.v[2], r.v[3]);
+    unpack_f16x2(u.z, r.v[4], r.v[5]); unpack_f16x2(u.w, r.v[6], r.v[7]);
+    return r;
+}
 template <typename Tag>
 __device__ __forceinline__ void store8(typename Tag::storage* p, const V8& r);
+template <>
+__device__ __forceinline__ void store8<F16Tag>(unsigned short* p, const V8& r) {
+    uint4 u;
+    u.x = pack_f16x2(r.v[0], r.v[1]); u.y = pack_f16x2(r.v[2], r.v[3]);
+    u.z = pack_f16x2(r.v[4], r.v[5]); u.w = pack_f16x2(r.v[6], r.v[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+}
 template <>
 __device__ __forceinline__ void store8<F32Tag>(float* p, const V8& r) {
     *reinterpret_cast<float4_t*>(p) = (float4_t){r.v[0], r.v[1], r.v[2], r.v[3]};
@@ -180,6 +205,9 @@ extern "C" int uc_convert(const void* src, int sd, void* dst, int dd, int64_t n,
     else if (sd == UC_BF16 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<BF16Tag, F32Tag>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
     else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<F32Tag, F32Tag>), g, b, 0, st, (const float*)src, (float*)dst, n);
     else if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((convert_kernel<BF16Tag, BF16Tag>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else if (sd == UC_F32 && dd == UC_F16) hipLaunchKernelGGL((convert_kernel<F32Tag, F16Tag>), g, b, 0, st, (const float*)src, (unsigned short*)dst, n);
+    else if (sd == UC_F16 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<F16Tag, F32Tag>), g, b, 0, st, (const unsigned short*)src, (float*)dst, n);
+    else if (sd == UC_BF16 && dd == UC_F16) hipLaunchKernelGGL((convert_kernel<BF16Tag, F16Tag>), g, b, 0, st, (const bf16_t*)src, (unsigned short*)dst, n);
     else { uc_set_error("uc_convert: unsupported dtypes %d -> %d", sd, dd); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_convert");
     return UC_OK;
@@ -346,6 +374,12 @@ extern "C" int uc_bilinear_nhwc(const void* src, void* dst, int dtype, int B, in
     const int rows2 = uc_knobs().bilinear_rows2;   // rows per work item of the upsampling form: 4 (default), 2, 0 = one-row kernel
     // (bf16 only: the fp32 kernels are the verification path — its gradient fixtures sit on ReLU boundaries of the tiny test models,
     // where a 1e-7 change of the forward's rounding flips a mask and moves a small gradient tensor by 1e-3)
+    if (rows2 && dtype == UC_F16 && sy <= 0.5f) {
+        const dim3 gr(grid.x, (unsigned)((crop_h + 3) / 4), (unsigned)B);
+        hipLaunchKernelGGL((bilinear_rows_kernel<F16Tag, 4>), gr, dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx);
+        UC_CHECK_LAUNCH("uc_bilinear_nhwc");
+        return UC_OK;
+    }
     if (rows2 && dtype == UC_BF16 && sy <= 0.5f) {
         const int R = rows2 == 4 ? 4 : 2;
         const dim3 gr(grid.x, (unsigned)((crop_h + R - 1) / R), (unsigned)B);
@@ -358,6 +392,8 @@ extern "C" int uc_bilinear_nhwc(const void* src, void* dst, int dtype, int B, in
         hipLaunchKernelGGL((bilinear_kernel<F32Tag>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx);
     else if (dtype == UC_BF16)
         hipLaunchKernelGGL((bilinear_kernel<BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx);
+    else if (dtype == UC_F16)
+        hipLaunchKernelGGL((bilinear_kernel<F16Tag>), grid, dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, B, Hi, Wi, C, Ho, Wo, crop_h, crop_w, sy, sx);
     else { uc_set_error("uc_bilinear_nhwc: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_bilinear_nhwc");
     return UC_OK;
@@ -394,6 +430,8 @@ extern "C" int uc_convt_scatter(const void* src, void* dst, int dtype, int B, in
         hipLaunchKernelGGL((convt_scatter_kernel<F32Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const float*)src, (float*)dst, B, h, w, k, Cout, items);
     else if (dtype == UC_BF16)
         hipLaunchKernelGGL((convt_scatter_kernel<BF16Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, B, h, w, k, Cout, items);
+    else if (dtype == UC_F16)
+        hipLaunchKernelGGL((convt_scatter_kernel<F16Tag>), dim3(EW_GRID(items)), dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, B, h, w, k, Cout, items);
     else { uc_set_error("uc_convt_scatter: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_convt_scatter");
     return UC_OK;
@@ -427,6 +465,8 @@ extern "C" int uc_pixel_shuffle(const void* src, int src_dtype, float* dst, int 
         hipLaunchKernelGGL((pixel_shuffle_kernel<F32Tag>), dim3(EW_GRID(n)), dim3(256), 0, st, (const float*)src, dst, B, h, w, P, Cout, n);
     else if (src_dtype == UC_BF16)
         hipLaunchKernelGGL((pixel_shuffle_kernel<BF16Tag>), dim3(EW_GRID(n)), dim3(256), 0, st, (const bf16_t*)src, dst, B, h, w, P, Cout, n);
+    else if (src_dtype == UC_F16)
+        hipLaunchKernelGGL((pixel_shuffle_kernel<F16Tag>), dim3(EW_GRID(n)), dim3(256), 0, st, (const unsigned short*)src, dst, B, h, w, P, Cout, n);
     else { uc_set_error("uc_pixel_shuffle: bad dtype %d", src_dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_pixel_shuffle");
     return UC_OK;
@@ -548,7 +588,8 @@ extern "C" int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const
     UC_REQUIRE(Cin > 0 && Cin <= 256 && Cin % 8 == 0, "uc_conv1x1_to4: Cin must be a multiple of 8 and <= 256 (got %d)", Cin);
     hipStream_t st = (hipStream_t)stream;
     if (((uintptr_t)b % 16 == 0) && ((dtype == UC_F32 && launch_conv1x1_to4_coop<F32Tag>(feat, w, b, out, npix, Cin, st)) ||
-                                      (dtype == UC_BF16 && launch_conv1x1_to4_coop<BF16Tag>(feat, w, b, out, npix, Cin, st)))) {
+                                      (dtype == UC_BF16 && launch_conv1x1_to4_coop<BF16Tag>(feat, w, b, out, npix, Cin, st)) ||
+                                      (dtype == UC_F16 && launch_conv1x1_to4_coop<F16Tag>(feat, w, b, out, npix, Cin, st)))) {
         UC_CHECK_LAUNCH("uc_conv1x1_to4");
         return UC_OK;
     }
@@ -556,6 +597,8 @@ extern "C" int uc_conv1x1_to4(const void* feat, int dtype, const float* w, const
         hipLaunchKernelGGL((conv1x1_to4_kernel<F32Tag>), dim3(EW_GRID(npix)), dim3(256), 0, st, (const float*)feat, w, b, out, npix, Cin);
     else if (dtype == UC_BF16)
         hipLaunchKernelGGL((conv1x1_to4_kernel<BF16Tag>), dim3(EW_GRID(npix)), dim3(256), 0, st, (const bf16_t*)feat, w, b, out, npix, Cin);
+    else if (dtype == UC_F16)
+        hipLaunchKernelGGL((conv1x1_to4_kernel<F16Tag>), dim3(EW_GRID(npix)), dim3(256), 0, st, (const unsigned short*)feat, w, b, out, npix, Cin);
     else { uc_set_error("uc_conv1x1_to4: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_conv1x1_to4");
     return UC_OK;

@@ -431,11 +431,13 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     UC_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0, "uc_gemm: bad shape M=%lld N=%lld K=%lld", (long long)d->M,
                (long long)d->N, (long long)d->K);
     UC_REQUIRE(d->a_mode == UC_A_DENSE || d->a_mode == UC_A_CONV3X3, "uc_gemm: bad a_mode %d", d->a_mode);
-    UC_REQUIRE(d->out_dtype == UC_F32 || d->out_dtype == UC_BF16, "uc_gemm: bad out_dtype %d", d->out_dtype);
+    const bool f16 = d->compute_dtype == UC_F16;   // fp16 operands (TF32-class heads): the bf16 MFMA path with the f16 instruction
+    const int lo16 = f16 ? UC_F16 : UC_BF16;        // the 16-bit storage dtype that goes with the operands
+    UC_REQUIRE(d->out_dtype == UC_F32 || d->out_dtype == lo16, "uc_gemm: bad out_dtype %d for compute dtype %d", d->out_dtype, d->compute_dtype);
     UC_REQUIRE(d->act >= UC_ACT_NONE && d->act <= UC_ACT_RELU, "uc_gemm: bad act %d", d->act);
     UC_REQUIRE(d->residual || !d->residual2, "uc_gemm: residual2 without residual");
     if (d->residual)
-        UC_REQUIRE(d->res_dtype == UC_F32 || d->res_dtype == UC_BF16, "uc_gemm: bad res_dtype %d", d->res_dtype);
+        UC_REQUIRE(d->res_dtype == UC_F32 || d->res_dtype == lo16, "uc_gemm: bad res_dtype %d for compute dtype %d", d->res_dtype, d->compute_dtype);
     if (d->M == 0) return UC_OK;
 
     GemmParams p;
@@ -461,7 +463,11 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     if (d->residual) UC_REQUIRE(d->ldr >= d->N, "uc_gemm: ldr < N");
 
     hipStream_t st = (hipStream_t)stream;
-    if (d->compute_dtype == UC_BF16) {
+    if (d->compute_dtype == UC_BF16 || f16) {
+        if (f16)
+            UC_REQUIRE(d->rope_cols <= 0 && d->vt_col0 < 0 && !d->ln_stats && !d->ln_colsum && !d->twin_out && !d->stats_out && d->split_k <= 1 &&
+                           !d->preact_out && !d->dact_u,
+                       "uc_gemm(f16): the fp16 operand form takes bias / activation / residual(s) / the fused tail only (prediction heads)");
         UC_REQUIRE(d->K % 8 == 0, "uc_gemm(bf16): K must be a multiple of 8 (got %lld)", (long long)d->K);
         UC_REQUIRE(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->W % 16 == 0), "uc_gemm(bf16): A/W must be 16-byte aligned");
         if (d->a_mode == UC_A_DENSE) UC_REQUIRE(d->lda % 8 == 0, "uc_gemm(bf16): lda must be a multiple of 8");
@@ -569,6 +575,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
 #else
             g.dbg = 0;
 #endif
+            g.f16 = f16 ? 1 : 0;
             g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
             g.cStride = d->conv_stride; g.cHo = d->conv_Ho; g.cWo = d->conv_Wo;
             if (d->a_mode == UC_A_CONV3X3) {
@@ -649,6 +656,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
 #endif
             return UC_OK;
         }
+        UC_REQUIRE(!f16, "uc_gemm(f16): only the direct-to-LDS kernels take fp16 operands (dense K %% 64 == 0, conv Cin %% 32 == 0)");
         UC_REQUIRE(!d->ln_stats && !d->twin_out && !d->stats_out, "uc_gemm: the LayerNorm fusion options need the direct-to-LDS kernel (forced off?)");
         UC_REQUIRE(!d->tail_out, "uc_gemm: the fused tail needs the direct-to-LDS kernel (dense K %% 64 == 0 / conv Cin %% 32 == 0)");
         p.tiles_m = (int)ceil_div64(d->M, BM);

@@ -9,8 +9,15 @@ void glds_launch_dense_f32(const GldsParams& p, int variant, hipStream_t st);
 void glds_launch_dense_bs(const GldsParams& p, int variant, hipStream_t st);
 void glds_launch_dense_all(const GldsParams& p, int variant, hipStream_t st);
 void glds_launch_conv(const GldsParams& p, int variant, hipStream_t st);
+void glds_launch_conv_f16(const GldsParams& p, int variant, hipStream_t st);
+void glds_launch_dense_all_f16(const GldsParams& p, int variant, hipStream_t st);
 
 int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool auto_variant) {
+    if (p.f16) {      // fp16 operands: one family (EPI_ALL), 16-wave / co-resident tiles only
+        if (variant == 6 || variant == 7) variant = 2;
+        if (p.a_mode == UC_A_CONV3X3) glds_launch_conv_f16(p, variant, st); else glds_launch_dense_all_f16(p, variant, st);
+        return 0;
+    }
     if (p.a_mode == UC_A_CONV3X3) { glds_launch_conv(p, variant, st); return 0; }
     // a descriptor goes to a single-family kernel only when EVERY wave of the launch takes that family's epilogue
     const bool plain = p.vec_ok && p.N % 64 == 0 && p.split_k <= 1 && !p.preact && !p.dact_u && !UC_DBG(p, 16);

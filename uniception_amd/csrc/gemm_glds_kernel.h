@@ -34,6 +34,31 @@ typedef const GldsParams& glds_pe_t;
 #include <algorithm>
 #include <type_traits>
 
+// fp16 operand form (F16 = true): the same kernels with v_mfma_f32_16x16x32_f16 and fp16 stores — the prediction heads'
+// "TF32-class" mode (10-bit mantissa like TF32, which is what the reference's fp32 heads run on under allow_tf32,
+// libs/croco/blocks.py:15 / factory/dust3r.py:288-309), at the bf16 rate.  Only the EPI_ALL family is instantiated for it (3x3
+// convolutions, 1x1 convolutions / ConvTranspose GEMMs: bias, ReLU / GELU, residuals, fused tail); RoPE / VT / LayerNorm options
+// are rejected by the launcher.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 glds_half2_t __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ float4_t glds_mfma(bf16x8_t a, bf16x8_t b, float4_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned glds_pack2(float lo, float hi) {
+    if constexpr (F16) {
+        const float2v_t v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, glds_half2_t));
+    } else return pack_bf16x2(lo, hi);
+}
+__device__ __forceinline__ float4_t glds_unpack_f16x4(uint2 q) {
+    const float2v_t a = __builtin_convertvector(__builtin_bit_cast(glds_half2_t, q.x), float2v_t);
+    const float2v_t b = __builtin_convertvector(__builtin_bit_cast(glds_half2_t, q.y), float2v_t);
+    return (float4_t){a.x, a.y, b.x, b.y};
+}
+
 // erf-GELU of the bf16 MFMA path.  libm's erff is a branchy two-range evaluation (~50 VALU ops per element once both
 // sides of the branch run in a wave); with only 16 K-steps per fc1 tile that epilogue cost as much as the MFMA loop.
 // Abramowitz-Stegun 7.1.26: erf(z) = 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1/(1 + p z), |error| <= 1.5e-7 — at fp32
@@ -560,7 +585,7 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
 
 // LN: the folded-LayerNorm form — the accumulator holds x . W'^T of the RAW rows; row statistics and the column sums of W'
 // turn it into LN(x) . W^T:  rstd[m] * (acc - mean[m] * colsum[n]) + bias[n].
-template <int FA, int ACT, bool NT = false, bool LN = false>
+template <int FA, int ACT, bool NT = false, bool LN = false, bool F16 = false>
 __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
                                                    int64_t wave_n, int lane, char* wbuf) {
     const int frow = lane & 15, g = lane >> 4;
@@ -631,14 +656,14 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
                     ou[r] = __builtin_fmaf(u, cs, -(w * sn));
                     ow[r] = __builtin_fmaf(w, cs, u * sn);
                 }
-                *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ou[0], ou[1]), pack_bf16x2(ou[2], ou[3])};
-                *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + 2 + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(ow[0], ow[1]), pack_bf16x2(ow[2], ow[3])};
+                *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){glds_pack2<F16>(ou[0], ou[1]), glds_pack2<F16>(ou[2], ou[3])};
+                *reinterpret_cast<uint2*>(buf + wr_off + (((4 * h + 2 + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){glds_pack2<F16>(ow[0], ow[1]), glds_pack2<F16>(ow[2], ow[3])};
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4_t v = glds_act4<ACT>(val4(i, j));
-                *reinterpret_cast<uint2*>(buf + wr_off + (((2 * j + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+                *reinterpret_cast<uint2*>(buf + wr_off + (((2 * j + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){glds_pack2<F16>(v.x, v.y), glds_pack2<F16>(v.z, v.w)};
             }
         }
     };
@@ -750,24 +775,28 @@ __device__ __forceinline__ float4_t glds_load4(const void* base, int dt, int64_t
     float4_t v = (float4_t){0.f, 0.f, 0.f, 0.f};
     if (full) {
         if (dt == UC_F32) v = *reinterpret_cast<const float4_t*>((const float*)base + idx);
+        else if (dt == UC_F16) v = glds_unpack_f16x4(*reinterpret_cast<const uint2*>((const bf16_t*)base + idx));
         else {
             const uint2 q = *reinterpret_cast<const uint2*>((const bf16_t*)base + idx);
             v = (float4_t){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
         }
     } else {
         for (int r = 0; r < 4; ++r)
-            if (nb + r < N) v[r] = dt == UC_F32 ? ((const float*)base)[idx + r] : bf16_to_f32(((const bf16_t*)base)[idx + r]);
+            if (nb + r < N) v[r] = dt == UC_F32 ? ((const float*)base)[idx + r] : (dt == UC_F16 ? f16_to_f32(((const bf16_t*)base)[idx + r]) : bf16_to_f32(((const bf16_t*)base)[idx + r]));
     }
     return v;
 }
 __device__ __forceinline__ void glds_store4(void* base, int dt, int64_t idx, bool full, int64_t nb, int64_t N, float4_t v) {
     if (full) {
         if (dt == UC_F32) *reinterpret_cast<float4_t*>((float*)base + idx) = v;
+        else if (dt == UC_F16) *reinterpret_cast<uint2*>((bf16_t*)base + idx) = (uint2){glds_pack2<true>(v.x, v.y), glds_pack2<true>(v.z, v.w)};
         else *reinterpret_cast<uint2*>((bf16_t*)base + idx) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
     } else {
         for (int r = 0; r < 4; ++r) {
             if (nb + r >= N) continue;
-            if (dt == UC_F32) ((float*)base)[idx + r] = v[r]; else ((bf16_t*)base)[idx + r] = f32_to_bf16(v[r]);
+            if (dt == UC_F32) ((float*)base)[idx + r] = v[r];
+            else if (dt == UC_F16) ((bf16_t*)base)[idx + r] = f32_to_f16(v[r]);
+            else ((bf16_t*)base)[idx + r] = f32_to_bf16(v[r]);
         }
     }
 }
@@ -863,9 +892,11 @@ __device__ __forceinline__ void glds_epilogue_tail4(glds_pe_t p, float4_t (&acc)
 
 // Epilogue dispatch shared by the 16-wave and the 8-wave kernels: picks the drain of this wave's 64-column block from the family
 // compiled into the instantiation (EPI) and the wave's mode (0 plain, 1 RoPE, 2 packed-VT).
-template <int FA, int A_MODE, int EPI>
+template <int FA, int A_MODE, int EPI, bool F16 = false>
 __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&acc)[FA][4], int mode, int64_t wave_m, int64_t wave_n,
                                                        int tid, int wave, int ksplit, char* smem) {
+    static_assert(!F16 || EPI == GLDS_EPI_ALL, "the fp16 operand form exists in the EPI_ALL family only");
+    constexpr int OUT16 = F16 ? UC_F16 : UC_BF16;        // the 16-bit storage dtype of this instantiation
     if (wave_n >= pe.N) return;
     {
         // a fresh definition of the lane id: keeps the compiler from hoisting the epilogue's per-lane address math above
@@ -877,8 +908,8 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
         const bool plain = pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && !pe.preact && !pe.dact_u && !UC_DBG(pe, 16);
         auto bf16_family = [&]() __attribute__((always_inline)) {
             const bool nt = pe.nt_out & (mode == 1 ? 4 : 2);
-            if (A_MODE == UC_A_DENSE && (pe.ln_stats || pe.ln_partial)) {   // folded LayerNorm
-                if constexpr (A_MODE == UC_A_DENSE) {
+            if (!F16 && A_MODE == UC_A_DENSE && (pe.ln_stats || pe.ln_partial)) {   // folded LayerNorm
+                if constexpr (A_MODE == UC_A_DENSE && !F16) {
                     if (nt) {
                         if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
                         else glds_epilogue_bf16<FA, UC_ACT_NONE, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
@@ -888,13 +919,13 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                     }
                 }
             } else if (nt) {
-                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                else glds_epilogue_bf16<FA, UC_ACT_NONE, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true, false, F16>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU, true, false, F16>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_bf16<FA, UC_ACT_NONE, true, false, F16>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
             } else {
-                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                else glds_epilogue_bf16<FA, UC_ACT_NONE>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, false, false, F16>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else if (pe.act == UC_ACT_RELU) glds_epilogue_bf16<FA, UC_ACT_RELU, false, false, F16>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                else glds_epilogue_bf16<FA, UC_ACT_NONE, false, false, F16>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
             }
         };
         auto f32_family = [&]() __attribute__((always_inline)) {
@@ -934,8 +965,9 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                     return;
                 }
             }
-            if (mode == 2) {
-                if constexpr (FA == 4) glds_epilogue_vt<4>(pe, acc, wave_m, wave_n, lane, wbuf);
+            if (!F16 && mode == 2) {
+                if constexpr (F16) { }
+                else if constexpr (FA == 4) glds_epilogue_vt<4>(pe, acc, wave_m, wave_n, lane, wbuf);
                 else {
 #pragma unroll
                     for (int h = 0; h < FA / 4; ++h) {
@@ -947,8 +979,8 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                         glds_epilogue_vt<4>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
                     }
                 }
-            } else if (plain && pe.out_dtype == UC_BF16 && !pe.residual) bf16_family();
-            else if (mode == 0 && pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && pe.out_dtype == UC_BF16 && !pe.residual &&
+            } else if (plain && pe.out_dtype == OUT16 && !pe.residual) bf16_family();
+            else if (!F16 && mode == 0 && pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && pe.out_dtype == UC_BF16 && !pe.residual &&
                      !UC_DBG(pe, 16) && !pe.ln_stats && !pe.ln_partial && (pe.preact != nullptr) != (pe.dact_u != nullptr)) {
                 // training: fc1 with its pre-activation copy / a data-gradient GEMM with the activation backward fused
                 if (pe.preact) {
@@ -974,7 +1006,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
 // One family per kernel keeps the register allocation of the 128-VGPR K-loop out of reach of epilogue code it never runs:
 // with all of them inlined into one function, every option added to one epilogue spilled DMA pointers inside the K-loop.
 
-template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1, int EPI = GLDS_EPI_ALL>
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1, int EPI = GLDS_EPI_ALL, bool F16 = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES_N / 4) void gemm_bf16_glds_kernel(GldsParams p) {
     static_assert(BN_ / WAVES_N == 64, "a wave owns 64 output columns (one 64-wide head)");
     constexpr int WTM = BM_ / WAVES_M;
@@ -1155,8 +1187,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
                 for (int i = 0; i < FA; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                        if constexpr (SWAP) acc[i][j] = glds_mfma<F16>(wf[j], af[i], acc[i][j]);
+                        else acc[i][j] = glds_mfma<F16>(af[i], wf[j], acc[i][j]);
                     }
             } else {
                 // conv tiles carry more loop state (offsets, tap masks, two descriptors): W fragments are read one at a time
@@ -1165,7 +1197,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
                 for (int j = 0; j < 4; ++j) {
                     const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(st + w_base + ch_off[ks] + j * 16 * ROWB);
 #pragma unroll
-                    for (int i = 0; i < FA; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < FA; ++i) acc[i][j] = glds_mfma<F16>(wf, af[i], acc[i][j]);
                 }
             }
             if (ks == 0) mid();
@@ -1241,7 +1273,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (UC_TRACE(pe)) tr2 = __builtin_amdgcn_s_memrealtime();
-    glds_epilogue_dispatch<FA, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n, tid, wave, ksplit, smem);
+    glds_epilogue_dispatch<FA, A_MODE, EPI, F16>(pe, acc, mode, wave_m, wave_n, tid, wave, ksplit, smem);
     if (UC_TRACE(pe)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1618,7 +1650,7 @@ static void launch_glds8(GldsParams p, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n * (unsigned)p.split_k), dim3(512), smem, st, p);
 }
 
-template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1, int EPI = GLDS_EPI_ALL>
+template <int BM_, int BN_, int WM_, int WN_, int STAGES, int A_MODE, int BK_ = 64, int WGS_PER_CU = 1, int EPI = GLDS_EPI_ALL, bool F16 = false>
 static void launch_variant_mode(GldsParams p, hipStream_t st) {
     p.tiles_m = (int)ceil_div64(p.M, BM_);
     p.tiles_n = (int)ceil_div64(p.N, BN_);
@@ -1626,7 +1658,7 @@ static void launch_variant_mode(GldsParams p, hipStream_t st) {
     p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
     p.dGm = uc_make_fastdiv((unsigned)p.group_m);
     p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
-    auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES, A_MODE, BK_, WGS_PER_CU, EPI>;
+    auto kfn = gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, STAGES, A_MODE, BK_, WGS_PER_CU, EPI, F16>;
     constexpr int smem = STAGES * (BM_ + BN_) * BK_ * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1639,32 +1671,32 @@ static void launch_variant_mode(GldsParams p, hipStream_t st) {
 
 // Tile variants of one (A_MODE, EPI) pair: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2), 2 = 256x256 (4x4), 3 = 256x128x32 with
 // two co-resident workgroups per CU.
-template <int A_MODE, int EPI>
+template <int A_MODE, int EPI, bool F16 = false>
 static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t st) {
     const int deep = uc_knobs().gemm_small_stages;
     const int64_t sk = p.split_k > 1 ? p.split_k : 1;
     switch (variant) {
         case 1:
             // latency regime (fewer workgroups than CUs: every K-step waits for its own DMA): a 3-stage ring keeps two stages in flight
-            if (deep == 3 && ceil_div64(p.M, 256) * ceil_div64(p.N, 128) * sk <= 256) launch_variant_mode<256, 128, 4, 2, 3, A_MODE, 64, 1, EPI>(p, st);
-            else launch_variant_mode<256, 128, 4, 2, 2, A_MODE, 64, 1, EPI>(p, st);
+            if (deep == 3 && ceil_div64(p.M, 256) * ceil_div64(p.N, 128) * sk <= 256) launch_variant_mode<256, 128, 4, 2, 3, A_MODE, 64, 1, EPI, F16>(p, st);
+            else launch_variant_mode<256, 128, 4, 2, 2, A_MODE, 64, 1, EPI, F16>(p, st);
             break;
-        case 2: launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI>(p, st); break;
-        case 3: launch_variant_mode<256, 128, 4, 2, 3, A_MODE, 32, 2, EPI>(p, st); break;
+        case 2: launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI, F16>(p, st); break;
+        case 3: launch_variant_mode<256, 128, 4, 2, 3, A_MODE, 32, 2, EPI, F16>(p, st); break;
         case 6:   // 256x256x64 with eight waves of 128x64 and register-resident next-chunk fragments (dense only)
             // (its DMA addresses row groups of 8 uniformly: matrices whose last group is partial stay on the 16-wave kernel)
-            if (A_MODE == UC_A_DENSE && p.M % 8 == 0 && p.N % 8 == 0) {
-                if constexpr (A_MODE == UC_A_DENSE) launch_glds8<EPI>(p, st);
-            } else launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI>(p, st);
+            if (!F16 && A_MODE == UC_A_DENSE && p.M % 8 == 0 && p.N % 8 == 0) {
+                if constexpr (A_MODE == UC_A_DENSE && !F16) launch_glds8<EPI>(p, st);
+            } else launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI, F16>(p, st);
             break;
         case 7:   // 256x256x64 with four waves of 128x128, accumulators in AGPRs, hand-scheduled K-loop (dense only)
-            if (glds4_ok(p)) {
-                if constexpr (A_MODE == UC_A_DENSE) launch_glds4<EPI>(p, st);
-            } else launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI>(p, st);
+            if (!F16 && glds4_ok(p)) {
+                if constexpr (A_MODE == UC_A_DENSE && !F16) launch_glds4<EPI>(p, st);
+            } else launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI, F16>(p, st);
             break;
         default:
-            if (deep == 3 && ceil_div64(p.M, 128) * ceil_div64(p.N, 128) * sk <= 512) launch_variant_mode<128, 128, 2, 2, 3, A_MODE, 64, 1, EPI>(p, st);
-            else launch_variant_mode<128, 128, 2, 2, 2, A_MODE, 64, 1, EPI>(p, st);
+            if (deep == 3 && ceil_div64(p.M, 128) * ceil_div64(p.N, 128) * sk <= 512) launch_variant_mode<128, 128, 2, 2, 3, A_MODE, 64, 1, EPI, F16>(p, st);
+            else launch_variant_mode<128, 128, 2, 2, 2, A_MODE, 64, 1, EPI, F16>(p, st);
             break;
     }
 }

@@ -27,7 +27,7 @@ from ._lib import UcHipError
 
 _forced_dtype: Optional[torch.dtype] = None
 _forced_x3: bool = False       # precision("bf16x3"): fp32 tensors, every GEMM / conv on split bf16 operands
-_head_mode: str = os.environ.get("UNICEPTION_AMD_HEAD_PRECISION", "follow")  # "follow" | "fp32" | "fp32_exact"
+_head_mode: str = os.environ.get("UNICEPTION_AMD_HEAD_PRECISION", "follow")  # "follow" | "fp16" | "fp32" | "fp32_exact"
 ROPE_TABLE_NPOS = 1024  # positions covered by the fused-epilogue cos/sin table (16k px at patch 16)
 
 
@@ -52,12 +52,15 @@ def precision(name: Optional[str]):
 
 def set_head_precision(mode: str) -> None:
     """"follow": prediction heads use the compute dtype;
+    "fp16": TF32-class heads — fp16 MFMA operands (10-bit mantissa, exactly TF32's: what the reference's "fp32" heads multiply with on
+            its own GPUs, allow_tf32 = True in libs/croco/blocks.py:15 and cuDNN's default for convolutions), fp32 accumulate, fp16
+            maps between the layers, fp32 final layer + adaptor: the reference's head policy at the cost of the bf16 heads;
     "fp32": the reference's policy (it disables autocast around the heads, factory/dust3r.py:288-309): fp32 tensors, GEMMs and
             convolutions on split bf16 operands (bf16x3, ~1e-6 relative) when the transformer runs bf16, exact kernels in
             verification mode;
     "fp32_exact": heads always on the exact fp32 kernels (slow)."""
     global _head_mode
-    assert mode in ("follow", "fp32", "fp32_exact")
+    assert mode in ("follow", "fp16", "fp32", "fp32_exact")
     _head_mode = mode
 
 
@@ -124,6 +127,8 @@ def compute_dtype() -> torch.dtype:
 
 
 def head_dtype() -> torch.dtype:
+    if _head_mode == "fp16":
+        return torch.float16
     return torch.float32 if _head_mode in ("fp32", "fp32_exact") else compute_dtype()
 
 
@@ -628,7 +633,7 @@ def conv3x3_tail4(x: torch.Tensor, conv: nn.Conv2d, act, last: nn.Conv2d) -> Opt
     B, H, W, Cin = x.shape
     if conv.stride[0] != 1 or Cin % 32 != 0 or os.environ.get("UNICEPTION_AMD_FUSED_TAIL", "1") == "0":
         return None
-    if not (x.dtype == torch.bfloat16 or (x.dtype == torch.float32 and ops.fp32_matmul_hook() == "bf16x3")):
+    if not (x.dtype in (torch.bfloat16, torch.float16) or (x.dtype == torch.float32 and ops.fp32_matmul_hook() == "bf16x3")):
         return None
     w, b = conv3x3_weights(conv, x.dtype)
     w4, b4 = prepared(last, "c1x4", (last.weight, last.bias),

@@ -156,7 +156,7 @@ class DUSt3R(nn.Module):
         info_in = MultiViewTransformerInput(features=[feat1, feat2])
 
         def f32(t):      # the reference hands fp32 features to its heads (dust3r.py:288-309); rows of a bf16 residual stream that a bf16
-            return t if (t.dtype == torch.bfloat16 and engine.head_dtype() == torch.bfloat16) else t.float()   # head reads as they are
+            return t if (t.dtype == torch.bfloat16 and engine.head_dtype() in (torch.bfloat16, torch.float16)) else t.float()   # 16-bit head reads as they are
         if self.pred_head_type == "linear":
             final = self.info_sharing(info_in)
             outs = {"1": f32(final.features[0]), "2": f32(final.features[1])}
