@@ -181,8 +181,10 @@ def timed(step, steps, world):
 
 
 def reference_policy_legs(model, v1, v2, args, dev):
-    """Beside the bf16 headline: the reference keeps its heads in fp32 (factory/dust3r.py:288-309).  (a) bf16 transformer +
-    fp32-class heads (split bf16 operands on the matrix pipe) at the headline batch; (b) EVERYTHING fp32-class
+    """Beside the headline (bf16 transformer + TF32-class heads: fp16 MFMA operands carry TF32's 10-bit mantissa, which is what the
+    reference's fp32 heads — factory/dust3r.py:288-309 — multiply with in its own environment, allow_tf32 in libs/croco/blocks.py:15).
+    (a) bf16 transformer + fp32-class heads (split bf16 operands on the matrix pipe: ~1e-5 from exact fp32) and + bf16 heads (round
+    1-2's headline policy) at the headline batch; (b) EVERYTHING fp32-class
     (engine.precision("bf16x3"): split-operand GEMMs / convolutions / attention products on the matrix pipe) — the mode that meets
     the 1e-3 / 1e-2 gate (tests/test_precision_modes_gpu.py) — at the headline batch; (c) the encoder + decoder alone (linear
     head, 0.15 % of the FLOPs), the quantity the 40 % MFMA target is defined on; (d) the headline forward with an fp32 residual
@@ -197,26 +199,18 @@ def reference_policy_legs(model, v1, v2, args, dev):
             with torch.no_grad(), engine.precision(mode), engine.attention_precision(args.attention):
                 return m(vv1, vv2)
         return f
-    engine.set_head_precision("fp32")
-    try:
+    with engine.head_precision("fp32"):
         f = fwd(v1, v2, "bf16")
         f(); f()          # (the first call of a shape runs its fork points one after the other)
         dt, _ = timed(f, steps, 1)
         out["bf16_transformer_fp32class_heads"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
-                                                   "pairs_per_gpu": args.pairs, "heads": "bf16x3 split-operand MFMA, fp32 tensors"}
-    finally:
-        engine.set_head_precision("follow")
-    engine.set_head_precision("fp16")
-    try:   # the same policy on TF32-class arithmetic: fp16 MFMA operands (10-bit mantissa = TF32's, what the reference's fp32 heads run
-        # on in its own environment: allow_tf32, libs/croco/blocks.py:15), fp32 accumulate
+                                                   "pairs_per_gpu": args.pairs, "heads": "bf16x3 split-operand MFMA, fp32 tensors (~1e-5 from exact fp32 heads)"}
+    with engine.head_precision("follow"):     # round 1-2's headline policy: heads in the transformer's bf16
         f = fwd(v1, v2, "bf16")
         f(); f()
         dt, _ = timed(f, steps, 1)
-        out["bf16_transformer_tf32class_heads"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
-                                                   "pairs_per_gpu": args.pairs, "heads": "fp16 MFMA operands, fp32 accumulate, fp16 maps, fp32 final layer",
-                                                   "heads_only_rel_l2_vs_exact_fp32_heads": "~1e-3 (tests/test_precision_modes_gpu.py), bf16 heads ~1e-2"}
-    finally:
-        engine.set_head_precision("follow")
+        out["bf16_transformer_bf16_heads"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
+                                              "pairs_per_gpu": args.pairs, "heads": "bf16 operands and maps (1.7e-2 from exact fp32 heads)"}
     if engine.bf16_stream_enabled() and args.encoder == "croco":
         # the same bf16 forward with the residual stream kept in fp32 (round 1's policy: more accurate than the reference's own bf16
         # stream under autocast, 10 instead of 4 bytes per element in the residual epilogues)
@@ -420,6 +414,9 @@ def main():
                    "head": args.head, "encoder": args.encoder, "attention": args.attention, "hipgraph": bool(args.graph),
                    "streams": ("1" if (not engine.CONCURRENT or not fwd) else
                                "2 (the two views through the encoder, the two decoder branches and the two heads run as concurrent HIP streams)"),
+                   "heads": (("TF32-class: fp16 MFMA operands (10-bit mantissa), fp32 accumulate, fp32 final layer + adaptor — the reference's "
+                              "fp32 heads under allow_tf32 (2e-3 from exact-fp32 heads; bf16 heads: 1.7e-2)") if (fwd and args.precision == "bf16" and engine.head_dtype_name() == "fp16")
+                             else engine.head_dtype_name()),
                    "residual_stream": ("bf16 (the reference's stream under autocast: bf16 sub-layer outputs added to a bf16 x)"
                                        if (fwd and args.precision == "bf16" and args.encoder == "croco" and engine.bf16_stream_enabled())
                                        else "fp32"),

@@ -148,8 +148,7 @@ def _run(name, gpu, mode, head_mode):
     model, c = build_case_model(name)
     model = model.to(gpu)
     img1, img2 = (t.to(gpu) for t in case_images(c))
-    engine.set_head_precision(head_mode)
-    try:
+    with engine.head_precision(head_mode):
         with torch.no_grad(), engine.precision(mode):
             if c.get("factory"):
                 v1 = {"img": img1, "instance": [str(i) for i in range(c["B"])], "data_norm_type": "dust3r"}
@@ -157,8 +156,6 @@ def _run(name, gpu, mode, head_mode):
                 r1, r2 = model(v1, v2)
             else:
                 r1, r2 = model(img1, img2, {})
-    finally:
-        engine.set_head_precision("follow")
     torch.cuda.synchronize()
     return dict(pts3d_1=r1["pts3d"], conf_1=r1["conf"], pts3d_2=r2["pts3d_in_other_view"], conf_2=r2["conf"]), c
 

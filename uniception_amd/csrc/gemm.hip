@@ -60,11 +60,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 __device__ __forceinline__ float load_res(const void* r, int dtype, int64_t idx) {
-    return dtype == UC_F32 ? ((const float*)r)[idx] : bf16_to_f32(((const bf16_t*)r)[idx]);
+    return dtype == UC_F32 ? ((const float*)r)[idx] : (dtype == UC_F16 ? f16_to_f32(((const bf16_t*)r)[idx]) : bf16_to_f32(((const bf16_t*)r)[idx]));
 }
 
 __device__ __forceinline__ void store_out(void* c, int dtype, int64_t idx, float v) {
     if (dtype == UC_F32) ((float*)c)[idx] = v;
+    else if (dtype == UC_F16) ((bf16_t*)c)[idx] = f32_to_f16(v);
     else ((bf16_t*)c)[idx] = f32_to_bf16(v);
 }
 
@@ -100,7 +101,10 @@ __device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
     return v;
 }
 
-template <int A_MODE>
+// F16: fp16 operands (v_mfma_f32_16x16x32_f16) and fp16 outputs / residuals — the fallback of the heads' TF32-class mode for channel
+// counts the direct-to-LDS kernels do not take (small test models); bias / activation / residuals only.
+typedef _Float16 gemm_f16x8_t __attribute__((ext_vector_type(8)));
+template <int A_MODE, bool F16 = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                    if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(gemm_f16x8_t, af[i]), __builtin_bit_cast(gemm_f16x8_t, wf[j]), acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) stage_write(buf ^ 1);
         __syncthreads();
@@ -506,7 +511,10 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                            ((d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a) || (d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 32 == 0)),
                        "uc_gemm: dact_u needs the bf16 direct-to-LDS kernels, bf16 output and a plain epilogue");
         }
-        const bool glds_dense = d->a_mode == UC_A_DENSE && d->K % 64 == 0 && !d->relu_a;
+        // (fp16 operands have no register-staged fallback kernel: K % 32 == 0 — the DPT's 96-channel ConvTranspose GEMM — takes the
+        // 32-deep tile of the direct-to-LDS kernel instead)
+        const bool dense32 = f16 && d->a_mode == UC_A_DENSE && d->K % 64 != 0 && d->K % 32 == 0 && !d->relu_a;
+        const bool glds_dense = d->a_mode == UC_A_DENSE && (d->K % 64 == 0 || dense32) && !d->relu_a;
         if (d->ln_stats || d->ln_colsum) {
             UC_REQUIRE(d->ln_stats && d->ln_colsum, "uc_gemm: the folded LayerNorm needs both ln_stats and ln_colsum");
             UC_REQUIRE(d->ln_nblk == 0 || (d->ln_nblk > 0 && d->K == (int64_t)64 * d->ln_nblk && d->ln_eps > 0.f),
@@ -583,7 +591,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 g.dHWo = uc_make_fastdiv((unsigned)d->conv_Ho * (unsigned)d->conv_Wo); g.dCin = uc_make_fastdiv((unsigned)d->conv_Cin);
             }
             int variant = forced_variant;
-            if (d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 != 0) variant = 3;
+            if ((d->a_mode == UC_A_CONV3X3 && d->conv_Cin % 64 != 0) || dense32) variant = 3;
             else if (variant < 0) {
                 // tile choice: the 256x256 tile (16 waves) has the best steady state (least LDS fill per flop) but needs
                 // enough tiles to cover the 256 CUs; smaller problems fall back to 256x128 / 128x128 tiles.
@@ -656,14 +664,17 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
 #endif
             return UC_OK;
         }
-        UC_REQUIRE(!f16, "uc_gemm(f16): only the direct-to-LDS kernels take fp16 operands (dense K %% 64 == 0, conv Cin %% 32 == 0)");
         UC_REQUIRE(!d->ln_stats && !d->twin_out && !d->stats_out, "uc_gemm: the LayerNorm fusion options need the direct-to-LDS kernel (forced off?)");
         UC_REQUIRE(!d->tail_out, "uc_gemm: the fused tail needs the direct-to-LDS kernel (dense K %% 64 == 0 / conv Cin %% 32 == 0)");
         p.tiles_m = (int)ceil_div64(d->M, BM);
         p.tiles_n = (int)ceil_div64(d->N, BN);
         const unsigned grid = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
         const size_t smem = 4 * TILE_BYTES;
-        if (d->a_mode == UC_A_DENSE)
+        if (f16 && d->a_mode == UC_A_DENSE)
+            hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_DENSE, true>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);
+        else if (f16)
+            hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_CONV3X3, true>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);
+        else if (d->a_mode == UC_A_DENSE)
             hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_DENSE>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);
         else
             hipLaunchKernelGGL((gemm_bf16_kernel<UC_A_CONV3X3>), dim3(grid), dim3(GEMM_THREADS), smem, st, p);

@@ -27,7 +27,11 @@ from ._lib import UcHipError
 
 _forced_dtype: Optional[torch.dtype] = None
 _forced_x3: bool = False       # precision("bf16x3"): fp32 tensors, every GEMM / conv on split bf16 operands
-_head_mode: str = os.environ.get("UNICEPTION_AMD_HEAD_PRECISION", "follow")  # "follow" | "fp16" | "fp32" | "fp32_exact"
+# Default "fp16": the reference keeps its prediction heads in fp32 under autocast (factory/dust3r.py:288-309) — which its own
+# environment multiplies in TF32 (allow_tf32, libs/croco/blocks.py:15; cuDNN's convolution default).  fp16 MFMA operands carry TF32's
+# 10-bit mantissa at the bf16 rate: 2e-3 from the exact-fp32 heads on the full-size model where bf16 heads are at 1.7e-2, for 1 % of
+# the forward (372 -> 368 pairs/s).  "follow" = round 1-2's bf16 heads.
+_head_mode: str = os.environ.get("UNICEPTION_AMD_HEAD_PRECISION", "fp16")  # "fp16" | "follow" | "fp32" | "fp32_exact"
 ROPE_TABLE_NPOS = 1024  # positions covered by the fused-epilogue cos/sin table (16k px at patch 16)
 
 
@@ -52,7 +56,7 @@ def precision(name: Optional[str]):
 
 def set_head_precision(mode: str) -> None:
     """"follow": prediction heads use the compute dtype;
-    "fp16": TF32-class heads — fp16 MFMA operands (10-bit mantissa, exactly TF32's: what the reference's "fp32" heads multiply with on
+    "fp16" (default): TF32-class heads next to a bf16 transformer — fp16 MFMA operands (10-bit mantissa, exactly TF32's: what the reference's "fp32" heads multiply with on
             its own GPUs, allow_tf32 = True in libs/croco/blocks.py:15 and cuDNN's default for convolutions), fp32 accumulate, fp16
             maps between the layers, fp32 final layer + adaptor: the reference's head policy at the cost of the bf16 heads;
     "fp32": the reference's policy (it disables autocast around the heads, factory/dust3r.py:288-309): fp32 tensors, GEMMs and
@@ -62,6 +66,22 @@ def set_head_precision(mode: str) -> None:
     global _head_mode
     assert mode in ("follow", "fp16", "fp32", "fp32_exact")
     _head_mode = mode
+
+
+def head_dtype_name() -> str:
+    "The head policy in force (for reports)."
+    return _head_mode
+
+
+@contextlib.contextmanager
+def head_precision(mode: str):
+    "Scoped set_head_precision."
+    prev = _head_mode
+    set_head_precision(mode)
+    try:
+        yield
+    finally:
+        set_head_precision(prev)
 
 
 def _fp32_matmul() -> str:
@@ -128,7 +148,9 @@ def compute_dtype() -> torch.dtype:
 
 def head_dtype() -> torch.dtype:
     if _head_mode == "fp16":
-        return torch.float16
+        # next to a bf16 transformer in inference; the verification modes (fp32, bf16x3) and training (bf16 backward kernels) follow
+        cd = compute_dtype()
+        return torch.float16 if (cd == torch.bfloat16 and not torch.is_grad_enabled()) else cd
     return torch.float32 if _head_mode in ("fp32", "fp32_exact") else compute_dtype()
 
 

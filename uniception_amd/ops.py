@@ -213,7 +213,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         assert b4 is None or (b4.dtype == torch.float32 and b4.is_contiguous() and b4.numel() == 4)
         out4 = torch.empty((M, 4), dtype=torch.float32, device=a.device)
         d.tail_w, d.tail_b, d.tail_out = w4.data_ptr(), _p(b4), out4.data_ptr()
-        d.C, d.out_dtype, d.ldc = None, UC_BF16, N
+        d.C, d.out_dtype, d.ldc = None, (UC_F16 if cd == UC_F16 else UC_BF16), N      # (nothing is stored: the storage dtype of the operands)
         _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
         return out4
     if out is None and split_k > 1:
