@@ -78,7 +78,7 @@ def roofline_pass(step_fn, v1, precision, steps):
     orig = ops.gemm
 
     def timed_gemm(a, w, *args, **kw):
-        if kw.get("conv") is not None or a.dtype != torch.bfloat16:
+        if kw.get("conv") is not None or a.dtype not in (torch.bfloat16, torch.float16):     # (fp16: the heads' 1x1 / ConvTranspose GEMMs, same kernels)
             return orig(a, w, *args, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -51,7 +51,8 @@ const char* uc_build_flavor(void);
 /* Tuning knobs switchable at run time (process-wide atomics; every value selects a correct kernel):
  *   "gemm_variant": -3 automatic (default), -1 register-staged kernel, 0 128x128, 1 256x128, 2 256x256, 3 256x128x32 co-resident,
  *                   6 eight-wave / 7 four-wave (128x128 wave tiles, hand-scheduled K-loop) 256x256 tile of the direct-to-LDS bf16 GEMM;  "gemm_stagger": -1 launcher policy, >= 0 ticks.
- * Their initial values come from UC_GEMM_VARIANT / UC_GEMM_STAGGER; every other UC_* environment knob (csrc/knobs.h) is read
+ *   "attn_role_split": 0 / 1 — the eight-wave bf16 attention forward as role-split segments (bitwise the same results).
+ * Their initial values come from UC_GEMM_VARIANT / UC_GEMM_STAGGER / UC_ATTN_RS; every other UC_* environment knob (csrc/knobs.h) is read
  * once, on first use. */
 int uc_tuning_set(const char* name, int value);
 int uc_tuning_get(const char* name, int* value);

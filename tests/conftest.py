@@ -21,6 +21,9 @@ def gpu():
     return torch.device("cuda:0")
 
 
+ATTN_RS_DEFAULT = int(os.environ.get("UC_ATTN_RS", "0"))
+
+
 @pytest.fixture(autouse=True)
 def _automatic_gemm_variant():
     """Tests that force a tile variant of the bf16 GEMM (ops.tuning_set) leave the library on its automatic choice."""
@@ -30,3 +33,4 @@ def _automatic_gemm_variant():
         from uniception_amd import ops
         ops.tuning_set("gemm_variant", -3)
         ops.tuning_set("gemm_stagger", -1)
+        ops.tuning_set("attn_role_split", ATTN_RS_DEFAULT)

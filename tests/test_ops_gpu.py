@@ -637,3 +637,27 @@ def test_gemm_four_wave_kernel_is_bitwise_the_sixteen_wave_kernel(gpu, K):
         if N % 64 == 0:
             s2, s7 = outs[2][4].uc_ln, outs[7][4].uc_ln
             assert torch.equal(s2.stats(1e-6), s7.stats(1e-6))
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 1024, 1024), (1, 2, 1369, 1369), (2, 1, 300, 37), (1, 2, 256, 64), (3, 2, 512, 700), (1, 1, 260, 4096)])
+def test_attention_role_split_kernel_is_bitwise_the_dma_kernel(gpu, B, H, Nq, Nk):
+    """attn_bf16_rs_kernel (tuning knob attn_role_split): the eight-wave forward cut into matrix / vector segments that the two halves
+    of a workgroup run one segment apart.  Same MFMAs on the same operands in the same order, same softmax arithmetic: the outputs
+    and the log-sum-exp must equal the one-barrier-per-tile kernel's to the bit — one and many key tiles, ragged key / query counts,
+    and a spiked key that takes the rescale branch in a late tile."""
+    from uniception_amd import ops
+    D = 64
+    g = torch.Generator().manual_seed(1000 + Nq + Nk)
+    q = (torch.randn(B, Nq, H, D, generator=g) * 1.5).bfloat16()
+    k = (torch.randn(B, Nk, H, D, generator=g) * 1.5).bfloat16()
+    v = torch.randn(B, Nk, H, D, generator=g).bfloat16()
+    if Nk > 200:
+        k[0, Nk - 7, 0] = q[0, 17, 0] * 6
+    vt = ops.vt_pack(v.to(gpu))
+    outs = {}
+    for rs in (0, 1):
+        with ops.tuning("attn_role_split", rs):
+            lse = torch.empty(B, H, Nq, device=gpu)
+            outs[rs] = (ops.attention(q.to(gpu), k.to(gpu), vt, D ** -0.5, v_packed=True, lse=lse), lse)
+    assert rel_l2(outs[1][0].cpu().float(), sdpa_ref(q, k, v, D ** -0.5)) < 8e-3
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -484,6 +484,232 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bf16_dma_kernel(AttnParams p)
 }
 
 // ---------------------------------------------------------------------------------------
+// attn_bf16_rs_kernel — the same arithmetic as attn_bf16_dma_kernel<8>, ROLE-SPLIT (round 3): the loop is cut into segments that
+// are either matrix work (PV of the previous key tile + QK^T of the next one: 16 MFMAs and their fragment reads) or vector work
+// (the softmax of one tile: max, exp2, sums, conversions), every segment ends in a workgroup barrier, and the two halves of the
+// workgroup run the SAME segment sequence one segment apart — while waves 0-3 are in a matrix segment, waves 4-7 (their partners
+// on the four SIMDs: a workgroup's waves go to the SIMDs cyclically) are in a vector segment, and vice versa.
+//
+// Why: with every wave of a workgroup in the same phase (one barrier per tile), the matrix pipe of a SIMD sees both of its waves'
+// MFMAs together and then neither — round 2 measured the exp2 work (-18 %) and the PV products (-20 %) as ADDITIVE costs and the
+// pipe 41-48 % busy.  Here a SIMD's two waves of a workgroup alternate by construction (MI355X_MICROARCH.md "Two waves per SIMD":
+// the pairing that nets is matrix beside vector); per tile and wave the matrix segment is 512 cycles and the vector segment ~350.
+//
+// Segment s = 0 .. 2 nt + 1 (nt key tiles); half h (0: waves 0-3, 1: waves 4-7) executes local segment ls = s - h:
+//     ls = 2 t      matrix:  O += V(t-1) P(t-1)   (t >= 1),   S = K(t) Q^T   (t < nt)
+//     ls = 2 t + 1  vector:  softmax of tile t: running max (deferred rescale), P(t) = exp2(..) as bf16 fragments, row sums
+// LDS ring as before (two K buffers, two VT buffers): K(t) is read in segments 2t, 2t+1 and VT(t) in 2t+2, 2t+3; K(t+1) and VT(t)
+// are issued at the start of segment 2t (their buffers were last read in segment 2t-1) and waited for before the barrier that
+// ends segment 2t+1.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void attn_bf16_rs_kernel(AttnParams p) {
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) char smem[6 * ATT_TILE_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2;
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    constexpr int QT = 32 * NW;
+    const int nq = (p.Nq + QT - 1) / QT;
+    const int nbh = p.B * p.H;
+    int qt, bh;
+    {
+        const int w = blockIdx.x;
+        const int per_group = 8 * nq;
+        const int grp = (int)uc_div((unsigned)w, p.dGroup), within = w - grp * per_group;
+        if ((grp + 1) * 8 <= nbh) { bh = grp * 8 + (within & 7); qt = within >> 3; }
+        else {
+            const int rem = w - (nbh >> 3) * 8 * nq, rb = (int)uc_div((unsigned)rem, p.dNq);
+            bh = (nbh >> 3) * 8 + rb; qt = rem - rb * nq;
+        }
+    }
+    const int b = (int)uc_div((unsigned)bh, p.dH), h = bh - b * p.H;
+    const int q0 = qt * QT + wave * 32;
+
+    const bf16_t* Qb = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const bf16_t* Kb = (const bf16_t*)p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+    const bf16_t* VTb = (const bf16_t*)p.V + ((int64_t)b * p.H + h) * 64 * (int64_t)p.npad;
+
+    // DMA: a tile is 8 instructions of 8 rows x 128 B; wave w issues instruction w of the K tile and of the VT tile
+    att_uint4_t srd_k = att_make_srd(Kb);
+    srd_k.z = (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)p.Nk - 1) * p.k_sn + 64) * 2));   // key rows >= Nk read as zeros
+    const att_uint4_t srd_v = att_make_srd(VTb);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    unsigned voff_k, voff_v;
+    {
+        const int rr = wave * 8 + (lane >> 3);
+        const int cch = (lane & 7) ^ ((rr >> 1) & 7);
+        voff_k = (unsigned)(((int64_t)rr * p.k_sn + cch * 8) * 2);
+        voff_v = (unsigned)(((int64_t)rr * p.npad + cch * 8) * 2);
+    }
+    const unsigned kstep = (unsigned)(KV_TILE * p.k_sn * 2);
+    auto issue_k = [&](int t) {
+        att_dma16(voff_k, srd_k, (unsigned)t * kstep, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((t & 1) * 2 * ATT_TILE_BYTES + wave * 1024)));
+    };
+    auto issue_v = [&](int t) {
+        att_dma16(voff_v, srd_v, (unsigned)t * (KV_TILE * 2),
+                  __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((t & 1) * 2 * ATT_TILE_BYTES + ATT_TILE_BYTES + wave * 1024)));
+    };
+    {   // Q rows of this wave into the second stage (waves 0-3) / the third region (waves 4-7)
+        const unsigned long long qa = (unsigned long long)(Qb + (int64_t)q0 * p.q_sn);
+        const int64_t q_rows = min((int64_t)32, (int64_t)p.Nq - q0);
+        att_uint4_t srd_q = att_make_srd((const void*)qa);
+        srd_q.z = (unsigned)__builtin_amdgcn_readfirstlane((int)(q_rows > 0 ? ((q_rows - 1) * p.q_sn + 64) * 2 : 0));
+        const unsigned dstq = lds0 + (unsigned)(2 * ATT_TILE_BYTES + wave * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = i * 8 + (lane >> 3);
+            const int cch = (lane & 7) ^ ((rr >> 1) & 7);
+            att_dma16((unsigned)(((int64_t)rr * p.q_sn + cch * 8) * 2), srd_q, 0u, __builtin_amdgcn_readfirstlane(dstq + i * 1024));
+        }
+    }
+    int r_off[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) r_off[st] = att_swz(l31, 2 * st + hi);
+
+    issue_k(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(smem + 2 * ATT_TILE_BYTES + wave * 4096 + r_off[s]);
+    __syncthreads();     // every wave holds its Q fragments before K(1) / VT(1) overwrite the buffer
+
+    float16_t o[2], sc[2];
+    o[0] = (float16_t)(0.f);
+    o[1] = (float16_t)(0.f);
+    sc[0] = (float16_t)(0.f);
+    sc[1] = (float16_t)(0.f);
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pf[g] = (bf16x8_t)(0.f);
+    float m_run = -1e30f;
+    float l_run = 0.f;
+    const float c = p.scale * 1.44269504088896340736f;
+    const int nt = (p.Nk + KV_TILE - 1) / KV_TILE;
+    auto issue = [&](int t) __attribute__((always_inline)) {       // start of even segment 2t: VT(t) and K(t+1) set out
+        if (t < nt) issue_v(t);
+        if (t + 1 < nt) issue_k(t + 1);
+    };
+    auto matrix = [&](int t) __attribute__((always_inline)) {      // O += VT(t-1) P(t-1); S = K(t) Q^T
+        if (t >= 1) {
+            const char* sv = smem + ((t - 1) & 1) * 2 * ATT_TILE_BYTES + ATT_TILE_BYTES;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sv + r_off[g] + db * (32 * 128));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o[db], 0, 0, 0);
+                }
+        }
+        if (t < nt) {
+            const char* sk = smem + (t & 1) * 2 * ATT_TILE_BYTES;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                sc[kb] = (float16_t)(0.f);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + r_off[st] + kb * (32 * 128));
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], sc[kb], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto vector = [&](int t) __attribute__((always_inline)) {      // softmax of tile t: sc -> pf
+        if (t == nt - 1 && (p.Nk & (KV_TILE - 1))) {
+            const int k0 = t * KV_TILE;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Nk) sc[kb][r] = -1e30f;
+        }
+        float mt = sc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const bool grow = (mt - m_run) * c > 8.0f;     // deferred rescale, see attn_bf16_kernel (PV of tile t-1 is complete)
+        if (__any(grow)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float mc = m_run * c;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    e[j] = __builtin_amdgcn_exp2f(fmaf(sc[kb][hf * 8 + j], c, -mc));
+                    psum += e[j];
+                }
+                union { bf16x8_t v; unsigned u[4]; } pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk.u[j] = pack_bf16x2(e[2 * j], e[2 * j + 1]);
+                pf[kb * 2 + hf] = pk.v;
+            }
+        }
+        l_run += psum;
+    };
+    // two loops with the same barrier sequence (2 nt + 2 segments), one segment apart: a single loop with a role switch keeps the
+    // union of both roles' registers alive across its back edge (468 bytes of scratch at the 128-register budget)
+    if (half == 0) {
+        for (int t = 0; t <= nt; ++t) {
+            issue(t);
+            matrix(t);                                            // segment 2t
+            __syncthreads();
+            if (t < nt) vector(t);                                // segment 2t + 1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // what was issued at the start of segment 2t has landed
+            __syncthreads();
+        }
+    } else {
+        for (int t = 0; t <= nt; ++t) {
+            issue(t);
+            if (t >= 1) vector(t - 1);                            // segment 2t
+            __syncthreads();
+            matrix(t);                                            // segment 2t + 1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(l_tot);
+    const int q = q0 + l31;
+    if (p.lse && q < p.Nq && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + q] = m_run * p.scale + logf(l_tot);
+    char* ob = smem + wave * 4096;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv);
+            pk.y = pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv);
+            *reinterpret_cast<uint2*>(ob + l31 * 128 + (((4 * db + g4) ^ (l31 & 7)) << 4) + hi * 8) = pk;
+        }
+    bf16_t* obase = (bf16_t*)p.O + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int R = 8 * ps + (lane >> 3);
+        const int chunk = (lane & 7) ^ (R & 7);
+        const uint4 v = *reinterpret_cast<const uint4*>(ob + R * 128 + ((lane & 7) << 4));
+        if (q0 + R < p.Nq) *reinterpret_cast<uint4*>(obase + (int64_t)(q0 + R) * p.o_sn + chunk * 8) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // row-major V -> VT packing (for callers that did not get VT from the GEMM epilogue)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__ V, bf16_t* __restrict__ VT, int H,
@@ -671,7 +897,8 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
             else hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 24>), g, dim3(256), 0, st, p);
         } else
 #endif
-        if (dma_ok && nw == 8) hipLaunchKernelGGL(attn_bf16_dma_kernel<8>, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
+        if (dma_ok && nw == 8 && g_uc_attn_rs.load(std::memory_order_relaxed)) hipLaunchKernelGGL(attn_bf16_rs_kernel, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
+        else if (dma_ok && nw == 8) hipLaunchKernelGGL(attn_bf16_dma_kernel<8>, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
         else if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel<4>, dim3((unsigned)(nqt * H * B)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_bf16_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
     } else if (dtype == UC_F32) {

@@ -176,6 +176,9 @@ static int dispatch_transpose(const char* name, const void* src, int sd, void* d
     else if (sd == UC_F32 && dd == UC_BF16) launch_transpose<F32Tag, BF16Tag>(src, dst, Bn, R, S, st);
     else if (sd == UC_BF16 && dd == UC_F32) launch_transpose<BF16Tag, F32Tag>(src, dst, Bn, R, S, st);
     else if (sd == UC_BF16 && dd == UC_BF16) launch_transpose<BF16Tag, BF16Tag>(src, dst, Bn, R, S, st);
+    else if (sd == UC_F32 && dd == UC_F16) launch_transpose<F32Tag, F16Tag>(src, dst, Bn, R, S, st);
+    else if (sd == UC_F16 && dd == UC_F32) launch_transpose<F16Tag, F32Tag>(src, dst, Bn, R, S, st);
+    else if (sd == UC_BF16 && dd == UC_F16) launch_transpose<BF16Tag, F16Tag>(src, dst, Bn, R, S, st);
     else { uc_set_error("%s: unsupported dtypes %d -> %d", name, sd, dd); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH(name);
     return UC_OK;

@@ -24,10 +24,12 @@ extern "C" const char* uc_build_flavor(void) { return "diag"; }
 extern "C" const char* uc_build_flavor(void) { return "release"; }
 #endif
 
+#define UC_ATTN_RS_DEFAULT 0
 static UcKnobs g_knobs;
 static std::once_flag g_knobs_once;
 std::atomic<int> g_uc_gemm_variant{-3};
 std::atomic<int> g_uc_gemm_stagger{-1};
+std::atomic<int> g_uc_attn_rs{UC_ATTN_RS_DEFAULT};
 
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -56,6 +58,7 @@ const UcKnobs& uc_knobs() {
 #endif
         g_uc_gemm_variant.store(env_int("UC_GEMM_VARIANT", -3));
         g_uc_gemm_stagger.store(env_int("UC_GEMM_STAGGER", -1));
+        g_uc_attn_rs.store(env_int("UC_ATTN_RS", UC_ATTN_RS_DEFAULT));
     });
     return g_knobs;
 }
@@ -69,8 +72,11 @@ extern "C" int uc_tuning_set(const char* name, int value) {
     } else if (!strcmp(name, "gemm_stagger")) {
         UC_REQUIRE(value >= -1 && value <= 100000, "uc_tuning_set: gemm_stagger out of range (%d)", value);
         g_uc_gemm_stagger.store(value);
+    } else if (!strcmp(name, "attn_role_split")) {
+        UC_REQUIRE(value == 0 || value == 1, "uc_tuning_set: attn_role_split must be 0 or 1 (got %d)", value);
+        g_uc_attn_rs.store(value);
     } else {
-        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger; everything else is read from the environment once, see csrc/knobs.h)", name);
+        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split; everything else is read from the environment once, see csrc/knobs.h)", name);
         return UC_ERR_BAD_ARG;
     }
     return UC_OK;
@@ -81,6 +87,7 @@ extern "C" int uc_tuning_get(const char* name, int* value) {
     (void)uc_knobs();
     if (!strcmp(name, "gemm_variant")) *value = g_uc_gemm_variant.load();
     else if (!strcmp(name, "gemm_stagger")) *value = g_uc_gemm_stagger.load();
+    else if (!strcmp(name, "attn_role_split")) *value = g_uc_attn_rs.load();
     else { uc_set_error("uc_tuning_get: unknown knob '%s'", name); return UC_ERR_BAD_ARG; }
     return UC_OK;
 }
