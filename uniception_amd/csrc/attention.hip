@@ -665,10 +665,13 @@ __global__ __launch_bounds__(512, 4) void attn_bf16_rs_kernel(AttnParams p) {
     };
     // two loops with the same barrier sequence (2 nt + 2 segments), one segment apart: a single loop with a role switch keeps the
     // union of both roles' registers alive across its back edge (468 bytes of scratch at the 128-register budget)
+    const bool seg_prio = p.prio_young == 2;     // experiment: priority 1 while in a matrix segment (cdna guide T5)
     if (half == 0) {
         for (int t = 0; t <= nt; ++t) {
             issue(t);
+            if (seg_prio) __builtin_amdgcn_s_setprio(1);
             matrix(t);                                            // segment 2t
+            if (seg_prio) __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             if (t < nt) vector(t);                                // segment 2t + 1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // what was issued at the start of segment 2t has landed
@@ -679,7 +682,9 @@ __global__ __launch_bounds__(512, 4) void attn_bf16_rs_kernel(AttnParams p) {
             issue(t);
             if (t >= 1) vector(t - 1);                            // segment 2t
             __syncthreads();
+            if (seg_prio) __builtin_amdgcn_s_setprio(1);
             matrix(t);                                            // segment 2t + 1
+            if (seg_prio) __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
