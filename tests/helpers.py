@@ -78,16 +78,24 @@ class ComposedTwoView(nn.Module):
         return ({"pts3d": res[0][0], "conf": res[0][1]}, {"pts3d_in_other_view": res[1][0], "conf": res[1][1]})
 
 
+_CASE_MODELS = {}
+
+
 def build_case_model(name):
-    """uniception_amd model of golden case `name`, weights from the name-keyed filler (CPU tensors)."""
+    """uniception_amd model of golden case `name`, weights from the name-keyed filler (CPU tensors).  Built once per session and
+    handed out as deep copies: constructing + filling the 570 M-parameter factory model takes ~10 s, a copy ~1 s, and two dozen
+    tests ask for it."""
+    import copy
     c = CASES[name]
-    if c.get("factory"):
-        from uniception_amd.models.factory import DUSt3R
-        model = DUSt3R(name="g", img_size=tuple(c["img"]), pred_head_type=c["head"]).eval()
-    else:
-        model = ComposedTwoView(c).eval()
-    O.fill_state_dict_(model.state_dict(), gain=1.0, gains=GAINS)
-    return model, c
+    if name not in _CASE_MODELS:
+        if c.get("factory"):
+            from uniception_amd.models.factory import DUSt3R
+            model = DUSt3R(name="g", img_size=tuple(c["img"]), pred_head_type=c["head"]).eval()
+        else:
+            model = ComposedTwoView(c).eval()
+        O.fill_state_dict_(model.state_dict(), gain=1.0, gains=GAINS)
+        _CASE_MODELS[name] = model
+    return copy.deepcopy(_CASE_MODELS[name]), c
 
 
 def case_images(c):

@@ -9,8 +9,9 @@ from tests.helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-# (4, 4): the quick form; (24, 12): the depth BASELINE configs[4] names (ViT-L encoder + 12-block decoder), oracle on the host cores
-@pytest.mark.parametrize("ENC,DEC,bar8", [(4, 4, 4e-2), (24, 12, 4e-2)])
+# (24, 12): the depth BASELINE configs[4] names (ViT-L encoder + 12-block decoder), the oracle on the host cores (~80 s of the test);
+# observed 1.1e-2 for the e4m3 attention against the oracle, the same as bf16 attention: the bar is 2e-2
+@pytest.mark.parametrize("ENC,DEC,bar8", [(24, 12, 2e-2)])
 def test_1024_fp8_attention_inside_the_model(gpu, monkeypatch, ENC, DEC, bar8):
     from uniception_amd import engine, ops
     from uniception_amd.models.factory import DUSt3R

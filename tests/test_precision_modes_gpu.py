@@ -133,6 +133,7 @@ def test_fp16_heads_are_tf32_class_against_exact_fp32_heads(gpu):
           " | bf16 heads " + ", ".join(f"{k}={v:.1e}" for k, v in ebf.items()) + " | bf16x3 heads " + ", ".join(f"{k}={v:.1e}" for k, v in ex3.items()))
     for k in HEAD_OUTPUTS:
         assert e16[k] < 3e-3 and e16[k] < ebf[k] / 3, (k, e16[k], ebf[k])
+        assert ex3[k] < 1e-4, (k, ex3[k])          # split-operand heads == exact fp32 heads to fp32-class accuracy
     # end to end against the reference golden: the bf16 transformer's error class
     rep = {}
     compare_to_golden(load_golden("vitl_dpt_512"), h16, c, tol=3e-2, report=rep)
@@ -169,7 +170,7 @@ def test_bf16x3_everything_meets_the_reference_gate(gpu, name):
           "; max-abs " + ", ".join(f"{k}={abs_report[k]:.1e}" for k in HEAD_OUTPUTS))
 
 
-@pytest.mark.parametrize("name", ["tiny_dpt", "vitl_dpt_512"])
+@pytest.mark.parametrize("name", ["tiny_dpt"])     # (the full-size model: test_fp16_heads_are_tf32_class_against_exact_fp32_heads compares all head policies on it)
 def test_reference_policy_bf16_transformer_fp32_class_heads(gpu, name):
     ref_pol, c = _run(name, gpu, "bf16", "fp32")
     follow, _ = _run(name, gpu, "bf16", "follow")
