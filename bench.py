@@ -24,7 +24,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md §Chip-level parameters)
 # forward GFLOP per 512x512 pair, encoder+decoder and the two DPT heads
 GFLOP_ENC_DEC_512, GFLOP_DPT_512 = 2068.0, 497.9
-PMC_TRAFFIC_FILE = "r2_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r3_pmc_traffic.json"
 
 
 def parse():

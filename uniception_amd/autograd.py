@@ -75,6 +75,16 @@ def _sinkable(param, rows: int, cols: int) -> bool:
             and g.numel() == rows * cols and param.requires_grad)
 
 
+def _ln_grad_targets(ln, g):
+    """(dgamma buffer, dbeta buffer, sunk): with the gradient sink on, uc_layernorm_bwd adds (atomically, per block) STRAIGHT INTO the
+    LayerNorm parameters' own gradient buffers — views of the trainer's flat buffer — and the Function returns None for them: no zero
+    fill, no autograd add kernel per LayerNorm (240 of each per training step of the ViT-L model); otherwise fresh zeroed buffers."""
+    w, b = getattr(ln, "weight", None), getattr(ln, "bias", None)
+    if w is not None and b is not None and _sinkable(w, w.numel(), 1) and _sinkable(b, b.numel(), 1):
+        return w.grad.view(-1), b.grad.view(-1), True
+    return torch.zeros_like(g), torch.zeros_like(g), False
+
+
 def _bias_target(bias_sink, N: int):
     """One contiguous fp32 [N] view covering the gradient buffers of the bias parameter(s) of a linear (two adjacent ones
     for the fused K|V projection), or None when they cannot take direct accumulation."""
@@ -369,8 +379,10 @@ class SelfAttnSubLayerFn(Function):
         _rope_inverse_(d5[:, :, 1], pos, rope)
         dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * C)], bias_sink=[qkv.bias])
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
-        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        dg, db, sunk = _ln_grad_targets(ln, g)
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
+        if sunk:
+            dg = db = None
         return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10 + (dgamma,)
 
 
@@ -442,15 +454,19 @@ class CrossAttnSubLayerFn(Function):
         # query side
         dWq, dbq = _wgrad(dq, hq, dt, has_bq, sink=[(projq.weight, 0, C)], bias_sink=[projq.bias])
         dhq = ops.gemm(dq, lin_weight_t(projq, dt))
-        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        dg, db, sunk = _ln_grad_targets(ln, g)
         dx = _ln_bwd_residual(x2d, g, dhq, ln.eps, dg, db, dxo, dt)
+        if sunk:
+            dg = db = None
         # key/value side (the other view's tokens)
         dWkv, dbkv = _wgrad(dkv, hy, dt, has_bk or has_bv, sink=[(projk.weight, 0, C), (projv.weight, C, 2 * C)],
                             bias_sink=[projk.bias, projv.bias] if (has_bk and has_bv) else None)
         dhy = ops.gemm(dkv, kv_weight_t(projk, projv, dt), out_dtype=dt if lny is not None else torch.float32)
         if lny is not None:
-            dgy, dby = torch.zeros_like(gy), torch.zeros_like(gy)
+            dgy, dby, sunk_y = _ln_grad_targets(lny, gy)
             dy = ops.layernorm_bwd(y2d, gy, dhy, lny.eps, dgy, dby)
+            if sunk_y:
+                dgy = dby = None
         else:
             dgy = dby = None
             dy = dhy
@@ -506,8 +522,10 @@ class MlpSubLayerFn(Function):
             du = ops.act_bwd(da, u, act) if act != "none" else da
         dW1, db1 = _wgrad(du, h, dt, has_b1, sink=[(fc1.weight, 0, fc1.weight.shape[0])], bias_sink=[fc1.bias])
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
-        dg, db = torch.zeros_like(g), torch.zeros_like(g)
+        dg, db, sunk = _ln_grad_targets(ln, g)
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
+        if sunk:
+            dg = db = None
         return (dx, dg, db, dW1, db1, dW2, db2) + (None,) * 5 + (dgamma,)
 
 

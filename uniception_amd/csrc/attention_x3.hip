@@ -235,8 +235,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(X3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        // exact running max (no deferred rescale: P <= 1 keeps the hi / lo split of P at full relative accuracy)
-        if (__any(mt > m_run)) {
+        // deferred rescale as in the bf16 kernel: the old running max is kept while no query of the wave grew by more than 2^8 (P <= 256;
+        // the hi / lo split of P is floating point, so its RELATIVE accuracy does not depend on the scale), the O / l rescale then
+        // runs on a wave-uniform branch
+        if (__any(mt - m_run > 8.0f)) {
             const float m_new = fmaxf(m_run, mt);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
