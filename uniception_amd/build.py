@@ -27,7 +27,7 @@ def _read(path):
 def _headers_digest():
     h = hashlib.sha256()
     for n in sorted(os.listdir(CSRC)):
-        if n.endswith(".h"):
+        if n.endswith((".h", ".inc")):
             h.update(n.encode())
             h.update(_read(os.path.join(CSRC, n)))
     h.update(_read(os.path.join(HERE, "..", "include", "uc_hip.h")))

@@ -146,3 +146,14 @@ __device__ __forceinline__ float2 uc_ln_merge_row(const float2* __restrict__ p, 
     }
     return make_float2(mu, 1.0f / sqrtf(uc_ln_tree16(s) / cnt + eps));
 }
+
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+static inline int uc_num_cus() {
+    static int n = [] {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+        return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }();
+    return n;
+}

@@ -34,7 +34,7 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool a
     // UC_GEMM_4WAVE: 0 off, 1 bf16-store family, 2 + bf16 residual stream, 3 every family.
     const int four = uc_knobs().gemm_4wave;
     const bool f32_fam = plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0;
-    if (auto_variant && (variant == 2 || variant == 6) && four > 0 &&
+    if (auto_variant && (variant == 2 || variant == 6) && four > 0 && p.K >= uc_knobs().gemm_4wave_min_k &&
         (four >= 3 || (bf16_fam && four >= 1) || (bf16_stream && four >= 2) || (f32_fam && four >= 3))) variant = 7;
     if (bf16_fam) glds_launch_dense_bf16(p, variant, st);
     else if (bf16_stream || (plain && p.out_dtype == UC_F32 && (!p.residual || p.res_dtype == UC_F32) && p.act == UC_ACT_NONE && p.vt_col0 < 0)) {
@@ -43,7 +43,7 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool a
         // start their first round of workgroups in 8 phase groups 1.5 us apart (by row panel, see the kernel):
         // encoder proj 480 -> 432 us, fc2 1095 -> 1043 us; neutral-to-worse for shorter launches, hence the threshold.
         GldsParams q = p;
-        if (q.stagger < 0) q.stagger = ((variant == 2 || variant == 6) && (int64_t)ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 6 * 256) ? 150 : 0;
+        if (q.stagger < 0) q.stagger = ((variant == 2 || variant == 6 || variant == 7) && (int64_t)ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 6 * 256) ? 150 : 0;
         if (bf16_stream) glds_launch_dense_bs(q, variant, st);
         else glds_launch_dense_f32(q, variant, st);
         return 0;

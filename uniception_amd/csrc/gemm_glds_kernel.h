@@ -1544,6 +1544,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GldsParams p) {
         tn = (int)uc_div((unsigned)within, last ? p.dGmLast : p.dGm);
         tm = first_m + within - tn * gsz;
     }
+    if (p.stagger > 0 && blockIdx.x < 256u) {
+        // de-phase the CUs by row panel (see the 16-wave kernel): the epilogues' store / residual traffic as a stream, not a burst per round
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)((unsigned)tm & 7u) * (unsigned)p.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     const int64_t m0 = (int64_t)tm * BM_;
     const int64_t n0 = (int64_t)tn * BN_;
     const int64_t wave_m = m0 + wr * 128;

@@ -77,7 +77,12 @@ def dma_piece(b, q):
 
 # experiment switches (environment; the committed .inc is generated with none of them set)
 NODMA = os.environ.get("G4_NODMA") == "1"          # no DMA pieces inside the loop (WRONG results: what the loop costs without them)
-NOBAR = os.environ.get("G4_NOBAR") == "1"          # no mid-step barrier (wrong)
+NOBAR = os.environ.get("G4_NOBAR") == "1"          # no barriers (wrong)
+SCHED = int(os.environ.get("G4_SCHED", "2"))       # 1 = the first form (one mid-step barrier, vmcnt(0)); 2 = two barriers, counted vmcnt
+B1 = int(os.environ.get("G4_B1", "18"))            # MFMA behind which the first barrier of a step sits
+DSTEP = int(os.environ.get("G4_DSTEP", "5"))       # one DMA piece behind every DSTEP-th MFMA
+R1 = int(os.environ.get("G4_R1", "1"))             # a K-half-1 fragment read behind every R1-th MFMA from the first
+R0 = int(os.environ.get("G4_R0", "1"))             # a K-half-0 fragment read (next stage) behind every R0-th MFMA after the second barrier
 
 
 def phase(b, swap, cur_set, reads, dmas):
@@ -103,7 +108,7 @@ def phase(b, swap, cur_set, reads, dmas):
                     dma_piece(b, x)
 
 
-def step(b, swap, with_reads, with_dma, last):
+def step_one_barrier(b, swap, with_reads, with_dma, last):
     # phase A: set 0, read K half 1 of the current stage into set 1
     rd = [(1, 1, j, V_W1) for j in range(8)] + [(1, 0, i, V_A1) for i in range(8)]
     b.emit("s_waitcnt lgkmcnt(0)")
@@ -119,6 +124,68 @@ def step(b, swap, with_reads, with_dma, last):
             b.emit(f"v_add_u32 v{r}, s{S_DELTA}, v{r}")
     rd = [(0, 1, j, V_W0) for j in range(8)] + [(0, 0, i, V_A0) for i in range(8)] if with_reads else []
     phase(b, swap, 1, rd, list(range(16)) if with_dma else [])
+    if with_dma:
+        b.emit(f"v_add_u32 v{V_OFF0}, 128, v{V_OFF0}")
+        b.emit(f"v_add_u32 v{V_OFF1}, 128, v{V_OFF1}")
+    if not last:
+        b.emit(f"s_add_u32 s{S_DMA}, s{S_DMA}, s{S_DELTA}")
+        b.emit(f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}")
+
+
+def step(b, swap, with_reads, with_dma, last):
+    """One 64-deep K-step = 128 MFMAs (set 0 then set 1, fixed order: the results do not depend on the schedule).
+
+    MFMA   1..31   ds_read K half 1 of the current stage -> set 1 (behind the odd MFMAs, W first)
+           36      s_waitcnt lgkmcnt(0); s_barrier      every wave has read ALL of the current stage's buffer (its K half 0 was read
+                                                        in the previous step) -> the buffer is free
+           38..83  the 16 DMA pieces of K-step kt + 2 into that buffer, one behind every third MFMA
+           86      s_waitcnt vmcnt(16); s_barrier       all but this step's 16 pieces have landed = stage kt + 1 is complete, for
+                                                        every wave
+           88..118 ds_read K half 0 of stage kt + 1 -> set 0 (free since MFMA 64), behind every second MFMA
+
+    A piece issued in step kt is not waited for before MFMA 86 of step kt + 1: 130-176 MFMAs (2100-2800 cycles) of flight, where the
+    first form of this loop (everything behind ONE mid-step barrier with vmcnt(0)) left 66-126."""
+    if SCHED == 1:
+        return step_one_barrier(b, swap, with_reads, with_dma, last)
+    slots = {}
+    rd1 = [(1, 1, j, V_W1) for j in range(8)] + [(1, 0, i, V_A1) for i in range(8)]
+    for k, x in enumerate(rd1):
+        slots.setdefault(R1 * k + 1, []).append(("r", x))
+    if with_dma and not NODMA:
+        slots.setdefault(B1, []).append(("bar1", None))
+        for q in range(16):
+            slots.setdefault(B1 + 2 + DSTEP * q, []).append(("d", q))
+    b2 = B1 + 2 + DSTEP * 15 + 3 if with_dma else 66
+    if not last:
+        slots.setdefault(b2, []).append(("bar2", 16 if (with_dma and not NODMA) else 0))
+        if with_reads:
+            rd0 = [(0, 1, j, V_W0) for j in range(8)] + [(0, 0, i, V_A0) for i in range(8)]
+            for k, x in enumerate(rd0):
+                slots.setdefault(min(b2 + 1 + R0 * k, 127), []).append(("r", x))
+    b.emit("s_waitcnt lgkmcnt(0)")
+    n = 0
+    for s_ in (0, 1):
+        if s_ == 1 and not (with_dma and not NODMA and B1 < 64):
+            b.emit("s_waitcnt lgkmcnt(0)")             # set 1 complete (no first barrier in this step, or it comes later)
+        for i in range(8):
+            for j in range(8):
+                mfma(b, swap, s_, i, j)
+                n += 1
+                for kind, x in slots.get(n, []):
+                    if kind == "r":
+                        ds_read(b, *x)
+                    elif kind == "d":
+                        dma_piece(b, x)
+                    elif kind == "bar1":
+                        b.emit("s_waitcnt lgkmcnt(0)")
+                        if not NOBAR:
+                            b.emit("s_barrier")
+                    else:
+                        b.emit(f"s_waitcnt vmcnt({x})")
+                        if not NOBAR:
+                            b.emit("s_barrier")
+                        for r in (V_A0, V_A1, V_W0, V_W1):          # read addresses move to the other stage
+                            b.emit(f"v_add_u32 v{r}, s{S_DELTA}, v{r}")
     if with_dma:
         b.emit(f"v_add_u32 v{V_OFF0}, 128, v{V_OFF0}")
         b.emit(f"v_add_u32 v{V_OFF1}, 128, v{V_OFF1}")
@@ -189,6 +256,7 @@ def loop(swap):
     e("s_nop 15")
     e(f"s_mov_b32 m0, s{S_M0}")
     return b.text()
+
 
 
 def clobbers():
