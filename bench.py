@@ -128,7 +128,7 @@ def roofline_pass(step_fn, v1, precision, steps):
     n = len(records)
     return {"bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-            "kernel": "gemm_bf16_glds_kernel<.., dense, ..> + gemm_bf16_glds8_kernel (dense bf16 MFMA GEMM, all tile variants and epilogue families)",
+            "kernel": "gemm_bf16_glds_kernel<.., dense, ..> + gemm_bf16_glds8_kernel + gemm_bf16_glds4_kernel (dense bf16 MFMA GEMM, all tile variants and epilogue families)",
             "launches_per_step": n // steps, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2), "algorithmic_bytes_per_launch": int(alg_bytes / n)}
 

@@ -16,7 +16,7 @@ def table(counter):
             continue
         m = re.search(r"total=\s*([0-9.]+)\s+per-dispatch=\s*([0-9.]+)\s+\(n=(\d+)\)", line)
         # dense kernels: A_MODE (6th template argument) == 0
-        dense = re.match(r"gemm_bf16_glds_kernel<\d+, \d+, \d+, \d+, \d+, 0,", cur) or cur.startswith("gemm_bf16_glds8_kernel<")   # the eight-wave kernel is dense only
+        dense = re.match(r"gemm_bf16_glds_kernel<\d+, \d+, \d+, \d+, \d+, 0,", cur) or cur.startswith(("gemm_bf16_glds8_kernel<", "gemm_bf16_glds4_kernel<"))   # the eight- and four-wave kernels are dense only
         if m and dense and counter in line:
             tot += float(m.group(1)); n += int(m.group(3))
     return tot, n
@@ -26,7 +26,7 @@ f, nf = table("FETCH_SIZE")
 w, nw = table("WRITE_SIZE")
 assert nf == nw and nf > 0, (nf, nw)
 rec = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 (64 pairs/GPU, 512x512, DPT); tables profiles/{tag}_pmc_*_bench_pairs64.txt",
-       "kernel": "gemm_bf16_glds_kernel<*, A_MODE dense, *> + gemm_bf16_glds8_kernel<*> (all dense tile variants and epilogue families)",
+       "kernel": "gemm_bf16_glds_kernel<*, A_MODE dense, *> + gemm_bf16_glds8_kernel<*> + gemm_bf16_glds4_kernel<*> (all dense tile variants and epilogue families)",
        "kernel_fingerprint": build.loaded_fingerprint(),
        "config": {"pairs_per_gpu": 64, "img": 512, "head": "dpt", "precision": "bf16"},
        "dispatches": nf, "FETCH_SIZE_KB_per_launch": round(f / nf, 1), "WRITE_SIZE_KB_per_launch": round(w / nw, 1),

@@ -33,7 +33,7 @@ def main(path):
         print(f"| {k} | {a[0]} | {a[1]/1e3:.3f} | {a[1]/a[0]:.2f} | {a[2]:.2f} | {a[3]:.2f} | {100*a[1]/total:.1f} |")
     # the dominant kernel of bench.py's roofline object is the dense bf16 GEMM across its instantiations (16-wave kernels with
     # A_MODE = 0, every epilogue family, and the eight-wave kernel): one aggregate line to compare with roofline.avg_launch_us
-    dense = [a for k, a in agg.items() if re.match(r"gemm_bf16_glds_kernel<\d+, \d+, \d+, \d+, \d+, 0,", k) or k.startswith("gemm_bf16_glds8_kernel<")]
+    dense = [a for k, a in agg.items() if re.match(r"gemm_bf16_glds_kernel<\d+, \d+, \d+, \d+, \d+, 0,", k) or k.startswith(("gemm_bf16_glds8_kernel<", "gemm_bf16_glds4_kernel<"))]
     if dense:
         n = sum(a[0] for a in dense); t = sum(a[1] for a in dense)
         print(f"\ndense bf16 GEMM (all dense instantiations): {n} calls, {t/1e3:.3f} ms, avg {t/n:.2f} us, {100*t/total:.1f} % of kernel time")

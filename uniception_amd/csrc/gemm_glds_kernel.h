@@ -1227,6 +1227,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
             }
         } else {
             // 3-stage ring, DMA two K-steps ahead: the loads of step kt+1 stay in flight across the barrier of step kt.
+            // (A 4-stage ring of the 128x128 tile — three steps ahead — was measured at 1 pair per batch, where every K-step is a wait
+            // for its own DMA: 8.49 vs 8.57 ms per forward, within noise; not kept.)
             if (nk > 0) issue_stage(0, kbase);
             if (nk > 1) issue_stage(1, kbase + BK_);
             int cur = 0;
@@ -1513,9 +1515,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
 // prologue (tile order, DMA source set-up) and the epilogues are the shared C++ ones: after the loop each wave drains its 128x128
 // tile as two 128x64 halves through glds_epilogue_dispatch<8, ...>.
 //
-// Measured (round 3): on par with the 16-wave kernel (8192^3: 1400 vs 1343-1412 TFLOP/s; encoder fc1 1132 vs 1142), not ahead — the
-// fragment-read + MFMA loop of this layout IS faster (1846 vs ~1700 without the DMA pieces), but one wave per SIMD has nobody to
-// cover the ~34 cycles each LDS-DMA piece costs its issuing wave (gen/gen_glds4_loop.py).  Opt-in: UC_GEMM_4WAVE / gemm_variant 7.
+// Measured (round 3).  First schedule (all 16 pieces behind ONE mid-step barrier with vmcnt(0)): on par with the
+// 16-wave kernel (8192^3: 1384-1400 vs 1343-1412 TFLOP/s) — a piece had 1000-2000 cycles to land, less than the loaded latency.  Second
+// schedule (two barriers per step, counted vmcnt(16), a piece behind every fifth MFMA: gen/gen_glds4_loop.py `step`): 8192^3 1535
+// (the vendor's hand-written kernel of the same design: 1543), K = 4096 shapes +5.6 % over the 16-wave kernel, K = 1024 shapes +-1 %
+// (bound by the ~5.6 us a tile costs outside its K-loop).  Routed for K >= 2048 (UC_GEMM_4WAVE, UC_GEMM_4WAVE_MIN_K); gemm_variant 7.
 //
 // LDS image, stage ring, chunk swizzle and DMA piece addressing are those of the eight-wave kernel; waves 0-1 stage the A rows, waves
 // 2-3 the W rows (128 rows = 16 pieces of 1 KiB each per stage).  The accumulators cross from the asm statement to the epilogue in

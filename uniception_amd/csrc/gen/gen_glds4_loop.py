@@ -12,12 +12,10 @@ the loops from the intrinsic form), so the loop is emitted as ONE inline-asm sta
     s[SB ...]              16 wave-uniform 64-bit source bases of the wave's DMA pieces, loop state
 
 Per K-step (64 deep): 128 v_mfma_f32_16x16x32_bf16, 32 ds_read_b128 (half of the 16-wave kernel's LDS read traffic per MFMA),
-16 LDS-DMA pieces of 1 KiB, ONE s_barrier in the middle of the step:
-
-    phase A   64 MFMAs on fragment set 0 (K half 0 of stage s)   | ds_read K half 1 of stage s   -> set 1
-    mid       s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier            (stage s + 1 has landed, everyone has read stage s)
-    phase B   64 MFMAs on set 1                                   | ds_read K half 0 of stage s + 1 -> set 0
-                                                                  | DMA of K-step kt + 2 -> the buffer of stage s
+16 LDS-DMA pieces of 1 KiB, TWO s_barriers (see `step`): fragment reads of K half 1 behind MFMAs 1-16, barrier (the stage's buffer is
+free), the pieces of K-step kt + 2 behind every fifth MFMA 20..95, s_waitcnt vmcnt(16) + barrier (stage kt + 1 complete), fragment
+reads of its K half 0 behind MFMAs 99-114.  The first form (G4_SCHED=1: one mid-step barrier behind vmcnt(0), all pieces in the second
+half of the step) is kept for the record: 10 % slower at 8192^3.
 
 The macros UC_GLDS4_LOOP_SWAP / _NOSWAP expand to the asm text; operands (see gemm_glds_kernel.h): %0..%3 LDS read addresses (A half
 0, A half 1, W half 0, W half 1 of stage 0), %4 / %5 per-lane source byte offsets of even / odd pieces, %6 / %7 source base (low, high
