@@ -43,8 +43,8 @@ const char* uc_last_error(void);
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
  *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added.  4/5: see INTEGRATION.md.
  *   6: uc_adaptor_program_bwd added.  7: uc_build_flavor, uc_tuning_set / uc_tuning_get (environment knobs read once; no
- *      diagnostics in the release build), uc_attention_fwd_x3.  8: uc_gemm_desc gained ln_nblk / ln_eps. */
-#define UC_ABI_VERSION 8
+ *      diagnostics in the release build), uc_attention_fwd_x3.  8: uc_gemm_desc gained ln_nblk / ln_eps.  9: uc_gemm_tn_conv_tiles added. */
+#define UC_ABI_VERSION 9
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
 const char* uc_build_flavor(void);
@@ -388,6 +388,11 @@ int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_
 int uc_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t T, int64_t I, int64_t J, int conv_B, int conv_H,
                int conv_W, int conv_Cin, int conv_stride, int relu_b, float* C, float* colsum_a, int colsum_atomic,
                int split_k, uc_stream_t stream);
+/* Output tiles one K-slice of the conv form of uc_gemm_tn occupies (workgroups per slice) — what a caller sizes split_k with so that
+ * tiles * split_k fills the CUs.  Stride-1 convs on maps a multiple of 64 wide with Cin and Cout multiples of 128 take the
+ * row-walking kernel (one kernel row ky per workgroup, the three taps kx as row shifts of the staged pixels: no im2col decode, every
+ * input pixel fetched three times instead of nine): 3 * (Cout/128) * (Cin/128) tiles; every other shape the implicit-im2col kernel. */
+int uc_gemm_tn_conv_tiles(int64_t Cout, int conv_H, int conv_W, int conv_Cin, int conv_stride);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_s ws[s*slab_stride + i], i < n (n, slab_stride multiples of 4): reduction of the
  * split_k slabs of uc_gemm / uc_gemm_tn (a row range of every slab when slab_stride > n); with accumulate it adds the result

@@ -353,6 +353,30 @@ def test_gemm_tn_conv_weight_gradient(gpu, stride, relu, B, H, W, Cin, Cout, sk)
     assert rel_l2(cs.sum(0).cpu(), dy.float().sum((0, 1, 2))) < 2e-5
 
 
+@pytest.mark.parametrize("relu,B,H,W,Cin,Cout,sk", [(False, 1, 5, 64, 128, 128, 1), (True, 2, 7, 128, 128, 256, 3), (False, 1, 3, 192, 256, 128, 5),
+                                                    (True, 3, 64, 64, 256, 256, 21), (False, 1, 1, 64, 128, 128, 2)])
+def test_gemm_tn_conv_rows_kernel(gpu, relu, B, H, W, Cin, Cout, sk):
+    """Stride-1 convs on maps a multiple of 64 wide with 128-channel tiles take conv_dw_rows_kernel (one kernel row per workgroup, the
+    taps kx as row shifts of the staged pixels): the same contract as the implicit-im2col kernel — weight gradient and bias gradient
+    against torch's conv backward on the same bf16 inputs, image borders (first / last row and column segments, a one-row image),
+    several images, ReLU on load, K slices that do not divide the segment count, more slices than segments."""
+    from uniception_amd import ops
+    assert ops.gemm_tn_conv_tiles(Cout, H, W, Cin, 1) == 3 * (Cout // 128) * (Cin // 128)
+    g = torch.Generator().manual_seed(H * W + Cin + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).bfloat16()
+    dy = torch.randn(B, H, W, Cout, generator=g).bfloat16()
+    wref = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    xa = x.float().relu() if relu else x.float()
+    F.conv2d(xa.permute(0, 3, 1, 2), wref, stride=1, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    ws, cs = ops.gemm_tn(dy.view(-1, Cout).to(gpu), x.to(gpu), split_k=sk, conv=(1, relu), colsum=True)
+    dW = ops.splitk_reduce(ws).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    assert rel_l2(dW.cpu(), wref.grad) < 2e-5
+    assert rel_l2(cs.sum(0).cpu(), dy.float().sum((0, 1, 2))) < 2e-5
+    into = torch.full((Cout,), 2.0, device=gpu)
+    ws2 = ops.gemm_tn(dy.view(-1, Cout).to(gpu), x.to(gpu), split_k=sk, conv=(1, relu), colsum_into=into)
+    assert torch.equal(ws2, ws) and rel_l2((into - 2.0).cpu(), dy.float().sum((0, 1, 2))) < 2e-5
+
+
 @pytest.mark.parametrize("act", ["gelu", "relu"])
 def test_gemm_fused_activation_backward(gpu, act):
     """du = (dy W) * act'(u) in the data-gradient GEMM's epilogue == act_bwd(gemm(dy, W), u)."""

@@ -84,6 +84,7 @@ SIGNATURES = {
     "uc_token_slice": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "uc_layernorm_bwd": [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "uc_gemm_tn": [vp, i64, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp],
+    "uc_gemm_tn_conv_tiles": [i64, i32, i32, i32, i32],
     "uc_splitk_reduce": [vp, i32, i64, i64, vp, i32, vp],
     "uc_colsum": [vp, i32, i64, i64, i64, vp, vp],
     "uc_act_bwd": [vp, vp, vp, i32, i32, i64, vp],
@@ -106,7 +107,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 8   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 9   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

@@ -136,7 +136,8 @@ def _wgrad_conv(dz: torch.Tensor, x: torch.Tensor, stride: int, relu_in: bool, b
     Cout = dz.shape[-1]
     dz2 = dz.view(-1, Cout)
     if x.dtype == torch.bfloat16 and _tn_ok(dz2, x):
-        sk = _split_k(Cout, 9 * x.shape[-1], dz2.shape[0])
+        # (split so that tiles * sk fills the 256 CUs once; the tile count depends on which kernel the shape takes)
+        sk = max(1, min(dz2.shape[0] // 512, 256 // ops.gemm_tn_conv_tiles(Cout, x.shape[1], x.shape[2], x.shape[3], stride)))
         if bias:
             ws, cs = ops.gemm_tn(dz2, x, split_k=sk, conv=(stride, relu_in), colsum=True)
             return _reduce_slabs(ws), _reduce_slabs(cs.unsqueeze(1)).reshape(-1)

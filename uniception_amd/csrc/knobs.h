@@ -17,6 +17,7 @@ struct UcKnobs {
     int gemm_coresident;     // UC_GEMM_CORESIDENT   256x128x32 tiles with two workgroups per CU for narrow outputs (default 1)
     int gemm_nt;             // UC_GEMM_NT           non-temporal epilogue mask override (-1: policy)
     int gemm_8wave;          // UC_GEMM_8WAVE        eight-wave 256x256 kernel: 0 off, 1 bf16-store family (default), 2 all, 3 + bf16 stream
+    int conv_dw_rows;        // UC_CONV_DW_ROWS      row-walking conv weight-gradient kernel where the shape allows (default 1; 0: implicit im2col everywhere)
     int gemm_4wave_min_k;    // UC_GEMM_4WAVE_MIN_K  ... for launches at least this deep (2048: where it beats the 16-wave kernel)
     int gemm_4wave;          // UC_GEMM_4WAVE        four-wave 256x256 kernel (128x128 wave tiles, asm K-loop): 0 off, 1 bf16-store family, 2 + bf16 stream, 3 all (default)
     int gemm_small_stages;   // UC_GEMM_SMALL_STAGES 3-stage ring for launches with fewer workgroups than CUs (default 3)

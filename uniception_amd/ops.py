@@ -675,6 +675,11 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, split_k: int = 1, conv: Optional[T
     return (out, cs) if colsum else out
 
 
+def gemm_tn_conv_tiles(Cout: int, H: int, W: int, Cin: int, stride: int) -> int:
+    "Workgroups one K-slice of gemm_tn(conv=...) occupies (uc_gemm_tn_conv_tiles): sizes split_k."
+    return int(_lib.load().uc_gemm_tn_conv_tiles(int(Cout), int(H), int(W), int(Cin), int(stride)))
+
+
 def splitk_reduce(ws: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """ws [sk, M, N] fp32 slabs (uc_gemm split_k / uc_gemm_tn output, or a row range ws_full[:, r0:r1] of them) ->
     out [M,N] (= or += the sum over slabs)."""
