@@ -282,8 +282,10 @@ def pointmap_adaptor(x: Tensor, conf_vmin: float = 1.0, conf_vmax: float = float
 # NestedTensorBlock without drop-path / forward_features), anchored on the reference's call sites
 # (encoders/dinov2.py:140-163 SDPA attention, :188-216 output split) and PINNED at the native 37x37 grid to an independent
 # implementation of the same network: HuggingFace transformers 5.15.0's Dinov2Model / Dinov2WithRegistersModel
-# (tests/golden/make_golden_dinov2_hf.py -> dinov2_hf.npz; agreement ~1e-7).  PARITY UNPINNED for other grids: the hub's
-# position-embedding resize (dinov2_pos_embed below) is restated from the published code only — transformers resizes differently.
+# (tests/golden/make_golden_dinov2_hf.py -> dinov2_hf.npz; agreement ~1e-7).  Other grids: the *_reg models' position-embedding
+# resize (bicubic, antialias, explicit size) is pinned to transformers' Dinov2WithRegistersEmbeddings too (16x16, 32x24 and 50x40
+# cases).  PARITY UNPINNED only for the NON-register models on other grids: the hub's resize there (a 0.1 offset folded into a scale
+# factor, no antialias — dinov2_pos_embed below) is restated from the published code; transformers' Dinov2Model resizes to an explicit size.
 # ---------------------------------------------------------------------------------------------
 def dinov2_pos_embed(sd: SD, prefix: str, h0: int, w0: int, num_registers: int) -> Tensor:
     pe = sd[prefix + "pos_embed"].float()

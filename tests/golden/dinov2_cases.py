@@ -13,6 +13,13 @@ DINOV2_HF_CASES = {
     # the size BASELINE configs[3] names: ViT-L/14, all 24 blocks, 518 x 518 (the reference's defaults: size="large", with_registers=False,
     # encoders/dinov2.py:18-24)
     "large_full": dict(size="large", regs=False, layers=24, hw=(518, 518), B=1, seed=14),
+    # other grids than the checkpoint's 37 x 37: the position table goes through the resize of the *_reg hub models (bicubic, antialias,
+    # explicit size), which transformers' Dinov2WithRegistersEmbeddings.interpolate_pos_encoding implements independently — down, up,
+    # non-square.  (The non-register models' resize — a 0.1 offset folded into a scale factor, no antialias — has no second
+    # implementation here: transformers' Dinov2Model resizes to an explicit size instead.)
+    "small_reg_224": dict(size="small", regs=True, layers=2, hw=(224, 224), B=2, seed=15),
+    "base_reg_448x336": dict(size="base", regs=True, layers=1, hw=(448, 336), B=1, seed=16),
+    "small_reg_700x560": dict(size="small", regs=True, layers=1, hw=(700, 560), B=1, seed=17),
 }
 
 

@@ -141,7 +141,7 @@ def test_config4_pipeline_matches_oracle_composition_and_trains_with_frozen_enco
     assert gnorm > 0 and torch.isfinite(torch.tensor(gnorm))
 
 
-@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg", "large_full"])     # large_full: ViT-L/14 x 24 at 518^2, the size configs[3] names
+@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg", "large_full", "small_reg_224", "base_reg_448x336", "small_reg_700x560"])     # large_full: ViT-L/14 x 24 at 518^2, the size configs[3] names
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2)])
 def test_matches_huggingface_transformers_golden(gpu, name, mode, tol):
     """The HIP DINOv2 encoder against goldens of an INDEPENDENT implementation of the published network (transformers'
