@@ -30,6 +30,7 @@ static std::once_flag g_knobs_once;
 std::atomic<int> g_uc_gemm_variant{-3};
 std::atomic<int> g_uc_gemm_stagger{-1};
 std::atomic<int> g_uc_attn_rs{UC_ATTN_RS_DEFAULT};
+std::atomic<int> g_uc_conv_rows{1};
 
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -61,6 +62,7 @@ const UcKnobs& uc_knobs() {
         g_uc_gemm_variant.store(env_int("UC_GEMM_VARIANT", -3));
         g_uc_gemm_stagger.store(env_int("UC_GEMM_STAGGER", -1));
         g_uc_attn_rs.store(env_int("UC_ATTN_RS", UC_ATTN_RS_DEFAULT));
+        g_uc_conv_rows.store(env_int("UC_CONV_ROWS", 1));
     });
     return g_knobs;
 }
@@ -77,8 +79,11 @@ extern "C" int uc_tuning_set(const char* name, int value) {
     } else if (!strcmp(name, "attn_role_split")) {
         UC_REQUIRE(value == 0 || value == 1, "uc_tuning_set: attn_role_split must be 0 or 1 (got %d)", value);
         g_uc_attn_rs.store(value);
+    } else if (!strcmp(name, "conv_rows")) {
+        UC_REQUIRE(value >= 0 && value <= 2, "uc_tuning_set: conv_rows must be 0 (implicit GEMM everywhere), 1 (row-walking kernel where it wins) or 2 (wherever the shape allows) (got %d)", value);
+        g_uc_conv_rows.store(value);
     } else {
-        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split; everything else is read from the environment once, see csrc/knobs.h)", name);
+        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split, conv_rows; everything else is read from the environment once, see csrc/knobs.h)", name);
         return UC_ERR_BAD_ARG;
     }
     return UC_OK;
@@ -90,6 +95,7 @@ extern "C" int uc_tuning_get(const char* name, int* value) {
     if (!strcmp(name, "gemm_variant")) *value = g_uc_gemm_variant.load();
     else if (!strcmp(name, "gemm_stagger")) *value = g_uc_gemm_stagger.load();
     else if (!strcmp(name, "attn_role_split")) *value = g_uc_attn_rs.load();
+    else if (!strcmp(name, "conv_rows")) *value = g_uc_conv_rows.load();
     else { uc_set_error("uc_tuning_get: unknown knob '%s'", name); return UC_ERR_BAD_ARG; }
     return UC_OK;
 }

@@ -1679,12 +1679,219 @@ static void launch_variant_mode(GldsParams p, hipStream_t st) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3x3 / pad 1 / stride 1 convolution on maps at least 64 wide, ROW-WALKING form (round 3).  The implicit-GEMM kernel above stages
+// a 256-pixel x 64-channel A tile per (tap, channel chunk): every input pixel crosses the LDS-DMA path nine times.  In the NT
+// layout an LDS row IS a pixel, so the horizontal taps kx are ROW OFFSETS of the fragment reads: here a stage of A is the slab
+// of input pixels a tile needs for ONE kernel row ky and 64 channels — for each of the tile's R = 256 / seg image-row segments the
+// seg + 2 pixels ox0 - 1 .. ox0 + seg of input row oy + ky - 1 (zeros outside the image, through the descriptor's range check) — and
+// the three taps (ky, 0..2) are three MFMA passes over it, each with its own 128 x 64 weight tile.  A crosses the DMA path three
+// times instead of nine, with no per-tap masks; the weight tiles are what they were.
+//   tile 256 pixels x 128 output channels, 8 waves of 64 x 64 (the accumulator layout of the <256, 128, 4, 2, ..> variants: the
+//   shared epilogues apply unchanged); K order (ky, channel chunk, kx).
+//   LDS: two slabs of 320 rows x 128 B (5 pieces per wave, the last ones may lie outside the slab: zeros) + a ring of three
+//   weight tiles of 16 KiB = 128 KiB.  Unit = one (ky, chunk, kx): its weight tile, and with kx == 0 the slab; DMA two units ahead;
+//   a wave waits for its own pieces of the NEXT unit only: vmcnt(2), vmcnt(2), vmcnt(7) round the three taps.
+template <int EPI, bool F16>
+__global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(GldsParams p) {
+    constexpr int BM_ = 256, BN_ = 128, ROWB = 128, SLAB_ROWS = 320, SLAB_BYTES = SLAB_ROWS * ROWB, WT_BYTES = BN_ * ROWB;
+    constexpr int A_MODE = UC_A_CONV3X3, FA = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int t = glds_xcd_remap((int)blockIdx.x, nwg);
+    int tm, tn;
+    {   // tile order: see the 16-wave kernel
+        const int GM = p.group_m;
+        const int per_group = GM * p.tiles_n;
+        const int grp = (int)uc_div((unsigned)t, p.dPerGroup), within = t - grp * per_group;
+        const int first_m = grp * GM;
+        const bool last = p.tiles_m - first_m < GM;
+        const int gsz = last ? p.tiles_m - first_m : GM;
+        tn = (int)uc_div((unsigned)within, last ? p.dGmLast : p.dGm);
+        tm = first_m + within - tn * gsz;
+    }
+    const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
+    const int64_t wave_m = m0 + wr * 64, wave_n = n0 + wc * 64;
+
+    // ---- tile geometry (wave-uniform): R row segments of seg pixels, first at (image row id rowid0 = b * H + oy0, ox0) ----
+    const int W_ = p.cW, H_ = p.cH, Cin = p.cCin;
+    const int seg = min(BM_, W_), R = BM_ / seg, segp = seg + 2;
+    const unsigned rowid0 = uc_div((unsigned)m0, p.dWo);
+    const int ox0 = (int)((unsigned)m0 - rowid0 * (unsigned)W_);
+    const unsigned b0 = uc_div(rowid0, p.dHo);
+    const int oy0 = (int)(rowid0 - b0 * (unsigned)H_);
+    // descriptors: the slab's source window shifted back by one image row + one pixel (tap row ky and the chunk are a uniform
+    // non-negative soffset), and the tile's weight rows
+    const unsigned long long pa = (unsigned long long)(p.A + (((int64_t)rowid0 - 1) * W_ + (ox0 - 1)) * Cin);
+    const unsigned long long pw = (unsigned long long)(p.W + n0 * p.K);
+    const uint4_t srd_a = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
+    const uint4_t srd_w = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pw), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pw >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
+    // slab pieces of this wave: piece n = wave + 8 q covers slab rows 8 n .. 8 n + 7; lane -> row 8 n + lane / 8, physical chunk lane % 8
+    unsigned sl_off[5], sl_mask[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int row = (wave + 8 * q) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ glds_swz<64>(row);
+        const int rr = row / segp, xs = row - rr * segp;             // (division by a wave-uniform value, once per tile)
+        const int ix = ox0 - 1 + xs;
+        sl_off[q] = (unsigned)((((int64_t)rr * W_ + xs) * Cin + c * 8) * 2);
+        unsigned mask = 0;
+        if (rr < R && ix >= 0 && ix < W_) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) mask |= ((unsigned)(oy0 + rr + ky - 1) < (unsigned)H_ ? 1u : 0u) << ky;
+        }
+        sl_mask[q] = mask;
+    }
+    unsigned w_off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ glds_swz<64>(row);
+        w_off[q] = (unsigned)(((int64_t)row * p.K + c * 8) * 2);
+    }
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    const unsigned lds_w = lds_base + 2u * SLAB_BYTES;
+    const int nch = Cin / 64;
+    const int nunit = 9 * nch;
+    auto issue_unit = [&](int u) {                     // u = (ky * nch + chunk) * 3 + kx, wave-uniform
+        const int sstep = u / 3, kx = u - 3 * sstep;
+        const int ky = sstep / nch, ch = sstep - ky * nch;
+        if (kx == 0) {
+            const unsigned soff = (unsigned)((((int64_t)ky * W_) * Cin + ch * 64) * 2);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const unsigned vo = ((sl_mask[q] >> ky) & 1u) ? sl_off[q] : 0xffffffffu;
+                dma16_buf_to_lds(vo, srd_a, soff, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((sstep & 1) * SLAB_BYTES + (wave + 8 * q) * 1024)));
+            }
+        }
+        const unsigned soff_w = (unsigned)((((ky * 3 + kx) * Cin) + ch * 64) * 2);
+        const int slot = u % 3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            dma16_buf_to_lds(w_off[q], srd_w, soff_w, __builtin_amdgcn_readfirstlane(lds_w + (unsigned)(slot * WT_BYTES + (wave * 2 + q) * 1024)));
+    };
+
+    // ---- fragment addressing: A fragment i of this wave = tile pixels wr * 64 + 16 i + frow = slab row base_i + frow, base_i =
+    //      m_i + 2 (m_i / seg) (two halo pixels per row segment before it), + kx for the tap; W fragments as in the main kernel ----
+    const int frow = lane & 15, fk = lane >> 4;
+    int a_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mi = wr * 64 + 16 * i;
+        a_row[i] = mi + 2 * (mi / seg) + frow;
+    }
+    const int w_sw = glds_swz<64>(frow);
+    const int w_base = (wc * 64 + frow) * ROWB;
+    const int w_ch[2] = {((0 * 4 + fk) ^ w_sw) << 4, ((1 * 4 + fk) ^ w_sw) << 4};
+
+    float4_t acc[FA][4];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    auto compute_unit = [&](const char* slab, const char* wt, int kx) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[FA], wf[4];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+                const int row = a_row[i] + kx;
+                uint4 raw = *reinterpret_cast<const uint4*>(slab + row * ROWB + (((ks * 4 + fk) ^ glds_swz<64>(row)) << 4));
+                if (p.relu_a) raw = glds_relu_bf16x8(raw);
+                af[i] = __builtin_bit_cast(bf16x8_t, raw);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(wt + w_base + w_ch[ks] + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = glds_mfma<F16>(wf[j], af[i], acc[i][j]);
+        }
+    };
+
+    issue_unit(0);
+    if (nunit > 1) issue_unit(1);
+    for (int sstep = 0; sstep < 3 * nch; ++sstep) {
+        const char* slab = smem + (sstep & 1) * SLAB_BYTES;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int u = sstep * 3 + kx;
+            // this wave's pieces of unit u have landed when only unit u + 1's are outstanding: 2 weight pieces (+ 5 slab pieces if
+            // it opens a new slab)
+            if (u + 1 >= nunit) wait_vmcnt<0>();
+            else if (kx == 2) wait_vmcnt<7>();
+            else wait_vmcnt<2>();
+            __builtin_amdgcn_s_barrier();          // ... everyone's have; and every wave is done with unit u - 1 (its ring slot is unit u + 2's)
+            asm volatile("" ::: "memory");
+            if (u + 2 < nunit) issue_unit(u + 2);
+            compute_unit(slab, smem + 2 * SLAB_BYTES + (u % 3) * WT_BYTES, kx);
+        }
+    }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((opencl_constant)) GldsParams* kp =
+        (const __attribute__((opencl_constant)) GldsParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp)::"memory");
+    glds_pe_t pe = *kp;
+#else
+    glds_pe_t pe = p;
+#endif
+    __syncthreads();     // every wave is done with the slabs and the ring: they become the epilogue's bounce space (8 KiB per wave)
+    glds_epilogue_dispatch<FA, A_MODE, EPI, F16>(pe, acc, 0, wave_m, wave_n, tid, wave, 0, smem);
+}
+
+// shapes the row-walking conv kernel takes: stride 1, whole 64-channel chunks, 128-column tiles, maps 64 .. wide whose rows tile 256
+// pixels exactly (a tile = whole row segments of one image), 32-bit source windows
+static inline bool conv_rows_ok(const GldsParams& p) {
+    if (p.a_mode != UC_A_CONV3X3 || p.cStride != 1 || p.cCin % 64 != 0 || p.N % 128 != 0 || p.split_k > 1) return false;
+    const int W = p.cW, H = p.cH;
+    if (W < 64 || !(W % 256 == 0 || 256 % W == 0)) return false;
+    const int R = W >= 256 ? 1 : 256 / W;
+    if (H % R != 0 || p.M % 256 != 0) return false;
+    return ((int64_t)(R + 3) * W + 4) * p.cCin * 2 < ((int64_t)1 << 31) && p.N * p.K * 2 < ((int64_t)1 << 31) && p.M < ((int64_t)1 << 30);
+}
+
+template <int EPI, bool F16>
+static void launch_conv_rows(GldsParams p, hipStream_t st) {
+    p.tiles_m = (int)(p.M / 256);
+    p.tiles_n = (int)(p.N / 128);
+    p.dNwg = uc_make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
+    p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
+    p.dGm = uc_make_fastdiv((unsigned)p.group_m);
+    p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
+    auto kfn = conv3x3_rows_kernel<EPI, F16>;
+    constexpr int smem = 2 * 320 * 128 + 3 * 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+}
+
 // Tile variants of one (A_MODE, EPI) pair: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2), 2 = 256x256 (4x4), 3 = 256x128x32 with
 // two co-resident workgroups per CU.
 template <int A_MODE, int EPI, bool F16 = false>
 static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t st) {
     const int deep = uc_knobs().gemm_small_stages;
     const int64_t sk = p.split_k > 1 ? p.split_k : 1;
+    if constexpr (A_MODE == UC_A_CONV3X3) {
+        // Where it wins (conv_rows 1): 128 output channels and >= 256 input channels — 256^2 256 -> 128: 850 -> 959 TFLOP/s (fp16 834 -> 926).
+        // With 128 input channels it is level (873 -> 891, fp16 875 -> 864), with 256 output channels the 256x256 tile of the
+        // implicit-GEMM kernel streams half the weights per MFMA and stays ahead (1016 / 1106 vs 1000 / 1003 at 128^2 / 64^2): the weight
+        // tiles, which this form does not reduce, are what a conv tile's LDS-DMA traffic mostly is.  Fewer tiles than CUs: the
+        // latency-regime variants below.
+        const int rows_mode = g_uc_conv_rows.load(std::memory_order_relaxed);
+        if (rows_mode > 0 && conv_rows_ok(p) && (rows_mode >= 2 || (p.N == 128 && p.cCin >= 256)) && (p.M / 256) * (p.N / 128) >= 256) {
+            launch_conv_rows<EPI, F16>(p, st);
+            return;
+        }
+    }
     switch (variant) {
         case 1:
             // latency regime (fewer workgroups than CUs: every K-step waits for its own DMA): a 3-stage ring keeps two stages in flight

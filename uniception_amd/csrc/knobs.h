@@ -38,6 +38,7 @@ const UcKnobs& uc_knobs();
 // run-time switchable (uc_tuning_set): -3 / -1 mean "automatic / launcher policy"
 extern std::atomic<int> g_uc_gemm_variant;   // UC_GEMM_VARIANT: -3 automatic, -1 register-staged kernel, 0..3, 6, 7 direct-to-LDS tile variants
 extern std::atomic<int> g_uc_gemm_stagger;   // UC_GEMM_STAGGER: -1 launcher policy, >= 0 ticks per phase group
+extern std::atomic<int> g_uc_conv_rows;      // UC_CONV_ROWS: row-walking 3x3 conv kernel: 0 never, 1 where it wins (128 output channels, >= 256 input channels), 2 wherever the shape allows
 extern std::atomic<int> g_uc_attn_rs;        // UC_ATTN_RS: eight-wave bf16 attention as role-split segments (matrix beside vector on every SIMD): 0 / 1
 
 #ifdef UC_DIAG
