@@ -199,6 +199,19 @@ def reference_policy_legs(model, v1, v2, args, dev):
             with torch.no_grad(), engine.precision(mode), engine.attention_precision(args.attention):
                 return m(vv1, vv2)
         return f
+    # (first: on some boxes of the pool whatever follows the split-operand legs below runs 25 % slow for a while — 345-351 instead of
+    #  465-476 pairs/s for this leg when it came last, on two boxes out of five)
+    if args.head == "dpt" and args.encoder == "croco":
+        torch.manual_seed(0)
+        lin = DUSt3R(name="bench_linear", img_size=(args.img, args.img), pred_head_type="linear").to(dev).eval()
+        f = fwd(v1, v2, "bf16", lin)
+        f(); f()
+        dt, _ = timed(f, steps, 1)
+        pps = args.pairs * steps / dt
+        out["enc_dec_linear_head"] = {"pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": args.pairs,
+                                      "enc_dec_mfma_frac": round(pps * GFLOP_ENC_DEC_512 * (args.img / 512) ** 2 / 1e3 / PEAK_BF16_TFLOPS, 4)}
+        del lin
+        torch.cuda.empty_cache()
     with engine.head_precision("fp32"):
         f = fwd(v1, v2, "bf16")
         f(); f()          # (the first call of a shape runs its fork points one after the other)
@@ -227,17 +240,6 @@ def reference_policy_legs(model, v1, v2, args, dev):
                                    "mode": "bf16x3: every GEMM / convolution and both products of the attention as three bf16 MFMA products of "
                                            "split operands, fp32 accumulate, fp32 softmax, fp32 tensors",
                                    "meets": "rel-L2 < 1e-3 and max-abs < 1e-2 vs reference (tests/test_precision_modes_gpu.py)"}
-    torch.cuda.empty_cache()
-    if args.head == "dpt" and args.encoder == "croco":
-        torch.manual_seed(0)
-        lin = DUSt3R(name="bench_linear", img_size=(args.img, args.img), pred_head_type="linear").to(dev).eval()
-        f = fwd(v1, v2, "bf16", lin)
-        f(); f()
-        dt, _ = timed(f, steps, 1)
-        pps = args.pairs * steps / dt
-        out["enc_dec_linear_head"] = {"pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": args.pairs,
-                                      "enc_dec_mfma_frac": round(pps * GFLOP_ENC_DEC_512 * (args.img / 512) ** 2 / 1e3 / PEAK_BF16_TFLOPS, 4)}
-        del lin
     return out
 
 
