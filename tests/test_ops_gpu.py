@@ -189,7 +189,7 @@ def test_gemm_bf16_rope_and_vt_epilogue(gpu):
         assert torch.equal(packed.cpu()[:, :, :, posn], v_ref.bfloat16().permute(0, 2, 3, 1))
 
 
-@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6", "7"])
+@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "4", "6", "7"])
 def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     """LayerNorm fused into the GEMMs around it (blocks.py:158-161, transformer_blocks.py:643-646): the producer's fp32 epilogue
     emits a bf16 twin + per-row block statistics, the consumer GEMM on the RAW twin with gamma folded into W reproduces
@@ -257,7 +257,7 @@ def test_gemm_folded_layernorm(gpu, variant, monkeypatch):
     assert rel_l2(vt.cpu().float()[:, :, :, posn].permute(0, 3, 1, 2), full[:, :, 2]) < 6e-3
 
 
-@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "6", "7"])
+@pytest.mark.parametrize("variant", ["auto", "0", "1", "2", "3", "4", "6", "7"])
 def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
     """The producer GEMM of a bf16 residual stream (the reference's stream under autocast): bf16 output = round(acc + bias + bf16
     residual) in ONE rounding, row statistics of the STORED (rounded) rows, the output its own twin; ragged M;
@@ -298,7 +298,7 @@ def test_gemm_bf16_residual_stream_producer(gpu, variant, monkeypatch):
         assert rel_l2(y.cpu().float(), y_ref) < 6e-3
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "6", "7"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "6", "7"])
 def test_gemm_bf16_tile_variants(gpu, variant, monkeypatch):
     """Every tile variant of the direct-to-LDS kernel (uc_tuning_set "gemm_variant") against the fp32 product, through
     each specialised epilogue: bf16 store (+GELU), fp32 residual add, RoPE + VT, the generic drain (ragged N, bf16 residual)."""
@@ -394,6 +394,59 @@ def test_conv3x3_implicit_gemm(gpu, dtype, geom):
         Ho, Wo = ref.shape[2:]
         got = out.cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
         assert rel_l2(got, ref) < (3e-6 if dtype == torch.float32 else 2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 4096), (1024, 768, 3072), (2048, 1024, 1024), (1000, 1024, 1152)])
+def test_gemm_small_m_fused_k_split(gpu, M, N, K):
+    """Small-M path: a dense launch whose 128x128 tiles cover at most half the CUs splits K in two across twice the workgroups and hands
+    the first half's accumulators over inside the kernel (uc_gemm_desc unchanged; csrc/gemm_glds.h fuse_split2).  Against the unsplit
+    kernel (gemm_variant 0 forced) and fp64: every epilogue family (bf16 store + GELU, bf16 residual stream with row statistics, fp32
+    residual), a ragged M, two streams at once (each has its own hand-over workspace) and a hipGraph replay (the flags must be back
+    at zero after every launch)."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(gpu)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(gpu)
+    b = torch.randn(N, generator=g).to(gpu)
+    res16 = torch.randn(M, N, generator=g).bfloat16().to(gpu)
+    res32 = torch.randn(M, N, generator=g).to(gpu)
+    ref = a.double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    cases = {"gelu": (lambda: ops.gemm(a, w, b, act="gelu"), F.gelu(ref), 6e-3),
+             "bf16 stream": (lambda: ops.gemm(a, w, b, residual=res16, emit_ln=True), ref + res16.double().cpu(), 6e-3),
+             "f32 residual": (lambda: ops.gemm(a, w, b, residual=res32, out_dtype=torch.float32), ref + res32.double().cpu(), 2e-5)}
+    for name, (fn, want, tol) in cases.items():
+        y = fn()
+        with ops.tuning("gemm_variant", 0):
+            y0 = fn()
+        assert rel_l2(y.float().cpu(), want) < tol, name
+        assert rel_l2(y.float(), y0.float()) < (2e-6 if y.dtype == torch.float32 else 2e-3), name     # two partial sums instead of one chain
+        if name == "bf16 stream":
+            assert torch.allclose(y.uc_ln.stats(1e-6), y0.uc_ln.stats(1e-6), rtol=2e-2, atol=2e-2)
+    # two streams at once, many launches back to back
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    torch.cuda.synchronize()
+    for _ in range(8):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(ops.gemm(a, w, b, residual=res32, out_dtype=torch.float32))
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    # graph replay
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        out = torch.empty(M, N, device=gpu, dtype=torch.float32)
+        ops.gemm(a, w, b, residual=res32, out=out)          # (the stream's workspace is created outside the capture)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            ops.gemm(a, w, b, residual=res32, out=out)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, outs[0])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -31,6 +31,7 @@ std::atomic<int> g_uc_gemm_variant{-3};
 std::atomic<int> g_uc_gemm_stagger{-1};
 std::atomic<int> g_uc_attn_rs{UC_ATTN_RS_DEFAULT};
 std::atomic<int> g_uc_conv_rows{1};
+std::atomic<int> g_uc_small_m_split{2048};
 
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -53,7 +54,6 @@ const UcKnobs& uc_knobs() {
         g_knobs.attn_prio = env_int("UC_ATTN_PRIO", 0);
         g_knobs.bilinear_rows2 = env_int("UC_BILINEAR_ROWS2", 4);
         g_knobs.ln_nt = env_int("UC_LN_NT", -1);
-        g_knobs.gemm_splitk_small = env_int("UC_GEMM_SMALLM", 1);
 #ifdef UC_DIAG
         g_knobs.gemm_dbg = env_int("UC_GEMM_DBG", 0);
         g_knobs.attn_dbg = env_int("UC_ATTN_DBG", 0);
@@ -63,6 +63,7 @@ const UcKnobs& uc_knobs() {
         g_uc_gemm_stagger.store(env_int("UC_GEMM_STAGGER", -1));
         g_uc_attn_rs.store(env_int("UC_ATTN_RS", UC_ATTN_RS_DEFAULT));
         g_uc_conv_rows.store(env_int("UC_CONV_ROWS", 1));
+        g_uc_small_m_split.store(env_int("UC_GEMM_SMALLM", 2048));
     });
     return g_knobs;
 }
@@ -71,7 +72,7 @@ extern "C" int uc_tuning_set(const char* name, int value) {
     UC_REQUIRE(name, "uc_tuning_set: null name");
     (void)uc_knobs();   // the environment's initial values first, so that a later first use does not overwrite this call
     if (!strcmp(name, "gemm_variant")) {
-        UC_REQUIRE(value == -3 || value == -1 || (value >= 0 && value <= 3) || value == 6 || value == 7, "uc_tuning_set: gemm_variant must be -3 (automatic), -1, 0..3, 6 or 7 (got %d)", value);
+        UC_REQUIRE(value == -3 || value == -1 || (value >= 0 && value <= 4) || value == 6 || value == 7, "uc_tuning_set: gemm_variant must be -3 (automatic), -1, 0..4, 6 or 7 (got %d)", value);
         g_uc_gemm_variant.store(value);
     } else if (!strcmp(name, "gemm_stagger")) {
         UC_REQUIRE(value >= -1 && value <= 100000, "uc_tuning_set: gemm_stagger out of range (%d)", value);
@@ -79,11 +80,14 @@ extern "C" int uc_tuning_set(const char* name, int value) {
     } else if (!strcmp(name, "attn_role_split")) {
         UC_REQUIRE(value == 0 || value == 1, "uc_tuning_set: attn_role_split must be 0 or 1 (got %d)", value);
         g_uc_attn_rs.store(value);
+    } else if (!strcmp(name, "small_m_split")) {
+        UC_REQUIRE(value >= 0, "uc_tuning_set: small_m_split is the smallest K a small-M launch splits in two for (0: never) (got %d)", value);
+        g_uc_small_m_split.store(value);
     } else if (!strcmp(name, "conv_rows")) {
         UC_REQUIRE(value >= 0 && value <= 2, "uc_tuning_set: conv_rows must be 0 (implicit GEMM everywhere), 1 (row-walking kernel where it wins) or 2 (wherever the shape allows) (got %d)", value);
         g_uc_conv_rows.store(value);
     } else {
-        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split, conv_rows; everything else is read from the environment once, see csrc/knobs.h)", name);
+        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split, conv_rows, small_m_split; everything else is read from the environment once, see csrc/knobs.h)", name);
         return UC_ERR_BAD_ARG;
     }
     return UC_OK;
@@ -96,6 +100,7 @@ extern "C" int uc_tuning_get(const char* name, int* value) {
     else if (!strcmp(name, "gemm_stagger")) *value = g_uc_gemm_stagger.load();
     else if (!strcmp(name, "attn_role_split")) *value = g_uc_attn_rs.load();
     else if (!strcmp(name, "conv_rows")) *value = g_uc_conv_rows.load();
+    else if (!strcmp(name, "small_m_split")) *value = g_uc_small_m_split.load();
     else { uc_set_error("uc_tuning_get: unknown knob '%s'", name); return UC_ERR_BAD_ARG; }
     return UC_OK;
 }

@@ -17,6 +17,10 @@
 // aligned to a 64-wide head, the RoPE partner of channel d (< 16) is channel d+16 of the same
 // row: fragment ni and ni+1 of the SAME lane and register, so the rotation needs no cross-lane traffic.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "gemm_glds.h"
 #include "knobs.h"
 #include <stdlib.h>
@@ -430,6 +434,48 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 }
 
 // =======================================================================================
+// hand-over workspaces of the fused two-way K split (gemm_glds.h: fuse_split2): 128 tiles x 64 KiB + one flag per tile each.  Launches of
+// a stream are ordered, launches of different streams (the two views' branches) must not share one: a stream keeps the set it was
+// given first.  The sets come from a pool created at the first eligible launch OUTSIDE a stream capture (allocation is not allowed
+// inside one); handing a pooled set to a new stream is bookkeeping only, so streams first seen while capturing get one too — a graph
+// then holds the same kernels as the eager run it was warmed up with.  Pool exhausted or not created yet: the launch runs unsplit.
+struct UcFuseWs { float* ws; unsigned* flags; };
+static UcFuseWs uc_fuse_ws(hipStream_t st) {
+    constexpr int POOL = 16;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, UcFuseWs> sets;
+    static std::map<int, std::vector<UcFuseWs>> pool;       // per device: sets not handed out yet
+    static std::map<int, bool> pool_made;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(dev, st);
+    auto it = sets.find(key);
+    if (it != sets.end()) return it->second;
+    if (!pool_made[dev]) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return UcFuseWs{nullptr, nullptr}; }
+        pool_made[dev] = true;
+        // uncached: the partners may run on different XCDs (separate, non-coherent L2s) — see the kernel
+        float* ws = nullptr;
+        unsigned* flags = nullptr;
+        const size_t per = (size_t)128 * 128 * 128;
+        if (hipExtMallocWithFlags((void**)&ws, POOL * per * sizeof(float), hipDeviceMallocUncached) != hipSuccess ||
+            hipExtMallocWithFlags((void**)&flags, POOL * 128 * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess ||
+            hipMemset(flags, 0, POOL * 128 * sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            return UcFuseWs{nullptr, nullptr};
+        }
+        for (int i = 0; i < POOL; ++i) pool[dev].push_back(UcFuseWs{ws + i * per, flags + i * 128});
+    }
+    auto& free_sets = pool[dev];
+    if (free_sets.empty()) return UcFuseWs{nullptr, nullptr};
+    const UcFuseWs w = free_sets.back();
+    free_sets.pop_back();
+    sets[key] = w;
+    return w;
+}
+
 extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     UC_REQUIRE(d, "uc_gemm: null descriptor");
     UC_REQUIRE(d->A && d->W && (d->C || d->tail_out), "uc_gemm: null operand pointer");
@@ -599,6 +645,18 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 const int64_t t256x128 = ceil_div64(d->M, 256) * ceil_div64(d->N, 128);
                 const int64_t sk = d->split_k > 1 ? d->split_k : 1;
                 variant = t256 * sk >= 192 ? 2 : (t256x128 * sk >= 160 ? 1 : 0);
+                if (d->a_mode == UC_A_DENSE) {
+                    // Dense launches of a few rounds of tiles (the batch sweep's 2 - 16 pairs): what matters is how many ROUNDS of
+                    // workgroups a tile size needs on the 256 CUs, times what a round of that tile costs — measured per round at
+                    // K = 768 / 1024 (tools/bench_midsize_variants.py): 128x128 ~13 / 19 us, 256x128 ~16 / 23 us, 256x256 ~22 / 29 us,
+                    // i.e. 1 : 1.25 : 1.7.  The thresholds above missed the quantisation: 144 tiles of 256x256 beat 288 of 256x128 by
+                    // 38 % (decoder qkv at 4 pairs), 144 of 256x128 beat 288 of 128x128 by 47 % (at 2 pairs).
+                    const int64_t cus = uc_num_cus();
+                    const int64_t t128 = ceil_div64(d->M, 128) * ceil_div64(d->N, 128);
+                    const double c0 = (double)ceil_div64(t128 * sk, cus), c1 = 1.25 * (double)ceil_div64(t256x128 * sk, cus),
+                                 c2 = 1.7 * (double)ceil_div64(t256 * sk, cus);
+                    variant = (c2 <= c1 && c2 <= c0) ? 2 : (c1 <= c0 ? 1 : 0);
+                }
                 // a 256-wide tile whose last column block is at most half full wastes a 128-column slab of MFMA work per row
                 // panel (N = 128: half of every tile): take the 256x128 tile there
                 const int64_t waste256 = ceil_div64(d->N, 256) * 256 - d->N, waste128 = ceil_div64(d->N, 128) * 128 - d->N;
@@ -608,6 +666,18 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 if (variant == 1 && t256x128 * sk >= 512 && knobs.gemm_coresident) variant = 3;
             }
             if (d->tail_out && (variant == 2 || variant == 6)) variant = 1;    // the tail needs a tile that spans all 128 columns with two wave columns
+            // Small-M path: a dense launch whose 128x128 tiles cover at most half the CUs is a chain of K / 64 dependent steps of
+            // ~0.7 us on each of them (neither a smaller tile nor a deeper ring shortens it: measured) — split K in two across twice
+            // the workgroups, hand-over inside the kernel (fuse_split2).  UC_GEMM_SMALLM / tuning knob small_m_split = smallest K it is taken for
+            // (0: never — the sum over K is then one chain whatever the batch size, and a pair's bits do not depend on its batch).
+            g.fuse_split2 = 0; g.fs_ws = nullptr; g.fs_flags = nullptr;
+            const int small_m_k = g_uc_small_m_split.load(std::memory_order_relaxed);
+            if (forced_variant < 0 && variant == 0 && d->a_mode == UC_A_DENSE && !f16 && d->split_k <= 1 && small_m_k > 0 &&
+                d->K >= small_m_k && d->K % 128 == 0 &&
+                2 * ceil_div64(d->M, 128) * ceil_div64(d->N, 128) <= uc_num_cus()) {
+                const UcFuseWs w = uc_fuse_ws(st);
+                if (w.ws) { g.fuse_split2 = 1; g.fs_ws = w.ws; g.fs_flags = w.flags; }
+            }
             { const int nt = knobs.gemm_nt;
               const int64_t out_bytes = d->M * d->N * (d->out_dtype == UC_F32 ? 4 : 2);
               g.nt_out = out_bytes > ((int64_t)128 << 20) ? (nt >= 0 ? nt : 7) : 0; }   // bit 0: fp32 residual stream, 1: bf16 outputs, 2: bf16 RoPE (q, k) tiles

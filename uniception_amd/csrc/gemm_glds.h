@@ -47,6 +47,12 @@ struct GldsParams {
     const bf16_t* dact_u;   // optional: multiply the result by act'(u), u bf16 [M, ldc]
     int dact_act;
     int split_k;    // >1: K split over blockIdx groups, slice s writes its fp32 partial product to C + s*M*ldc
+    // fused two-way split of K (the latency regime's small dense launches, 128x128 tiles on at most half the CUs): workgroups [0, nwg)
+    // compute the first half of K and hand their accumulators over through fs_ws; workgroups [nwg, 2 nwg) compute the second half, wait
+    // for their partner's flag, add, and run the normal epilogue
+    int fuse_split2;
+    float* fs_ws;           // [tiles][128 * 128] fp32
+    unsigned* fs_flags;     // [tiles], 0 between launches
     int tiles_m, tiles_n;
     int group_m;  // row panels per L2-sharing tile group (tile traversal order)
     uc_fastdiv dNwg, dPerGroup, dGm, dGmLast;   // exact fast division by tiles_m*tiles_n, group_m*tiles_n, group_m, tiles_m % group_m

@@ -1030,7 +1030,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int ksplit = p.split_k > 1 ? (int)uc_div(blockIdx.x, p.dNwg) : 0;   // split-K slice
+    constexpr bool FUSE2_OK = BM_ == 128 && BN_ == 128 && A_MODE == UC_A_DENSE && !F16;   // fused two-way K split (fuse_split2): this tile only
+    const bool fuse2 = FUSE2_OK && p.fuse_split2;
+    const int ksplit = fuse2 ? ((int)blockIdx.x >= nwg ? 1 : 0)
+                             : (p.split_k > 1 ? (int)uc_div(blockIdx.x, p.dNwg) : 0);   // split-K slice
     const int t = glds_xcd_remap((int)blockIdx.x - ksplit * nwg, nwg);
     // Tile order inside an XCD's run: groups of GM row panels swept column by column, so the ~32 tiles an XCD runs
     // concurrently form a GM x (32/GM) block that shares GM A-panels and 32/GM W-panels in its L2 (a plain row-major
@@ -1159,7 +1162,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
 
     // K range of this workgroup (whole K unless split_k > 1)
     const int nk_total = (int)(p.K / BK_);
-    const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
+    const int nsplit = fuse2 ? 2 : p.split_k;
+    const int nk_per = (nk_total + nsplit - 1) / nsplit;
     const int kt0 = ksplit * nk_per;
     int nk = max(0, min(nk_per, nk_total - kt0));
     if UC_DBG(p, 8) nk = min(nk, 1);                      // diagnostics: one K-step only (launch + prologue + epilogue cost)
@@ -1248,6 +1252,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
         if (mode == 2) main_loop(std::false_type{}); else main_loop(std::true_type{});
     } else {
         main_loop(std::true_type{});
+    }
+
+    if constexpr (FUSE2_OK) {
+        if (fuse2) {
+            // Fused two-way K split.  The producers are the LOW block ids: the dispatcher starts them first and they never wait, so a
+            // consumer that spins always has a partner that is running or has finished — also when two such launches share the CUs
+            // (the decoder's two view streams).  The hand-over buffer is UNCACHED device memory (hipDeviceMallocUncached: no L2 on
+            // either side, so partners on different XCDs — whose L2s are not coherent — need no buffer_wbl2 / buffer_inv, which
+            // write back / invalidate a whole L2 and cost more than the split saves: measured); the flag is polled with volatile
+            // (L1-bypassing) loads; ordering by s_waitcnt + barrier.
+            float* ws = p.fs_ws + (size_t)t * (128 * 128) + (size_t)tid * 4;
+            volatile unsigned* flag = p.fs_flags + t;
+            if (ksplit == 0) {
+#pragma unroll
+                for (int i = 0; i < FA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4_t*>(ws + (size_t)(i * 4 + j) * (NW * 64 * 4)) = acc[i][j];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's partial sums are in memory
+                __syncthreads();                                        // ... everyone's
+                if (tid == 0) *flag = 1u;
+                return;
+            }
+            if (tid == 0) {
+                while (*flag != 1u) __builtin_amdgcn_s_sleep(4);
+            }
+            __syncthreads();
+            asm volatile("" ::: "memory");
+            {   // (plain loads, all 16 in flight: the buffer is uncached memory, and no line of it can sit in this CU's L1 — a volatile
+                //  access would be waited for one by one, 16 round trips)
+                float4_t part[FA][4];
+#pragma unroll
+                for (int i = 0; i < FA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) part[i][j] = *reinterpret_cast<const float4_t*>(ws + (size_t)(i * 4 + j) * (NW * 64 * 4));
+#pragma unroll
+                for (int i = 0; i < FA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += part[i][j];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) *flag = 0u;            // for the next launch on this stream / the next graph replay
+        }
     }
 
     // The epilogue's parameters are re-read from the kernarg segment HERE.  Carried through the K-loop in SGPRs (some 60 of
@@ -1675,7 +1722,8 @@ static void launch_variant_mode(GldsParams p, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n * (unsigned)p.split_k), dim3(WM_ * WN_ * 64), smem, st, p);
+    const unsigned slices = (BM_ == 128 && BN_ == 128 && A_MODE == UC_A_DENSE && !F16 && p.fuse_split2) ? 2u : (unsigned)p.split_k;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n * slices), dim3(WM_ * WN_ * 64), smem, st, p);
 }
 
 
@@ -1911,6 +1959,9 @@ static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t s
                 if constexpr (A_MODE == UC_A_DENSE && !F16) launch_glds4<EPI>(p, st);
             } else launch_variant_mode<256, 256, 4, 4, 2, A_MODE, 64, 1, EPI, F16>(p, st);
             break;
+        case 4:   // 128x64 (two waves): the latency regime's small tile — launches whose 128x128 tiles cover at most half the CUs
+            if constexpr (A_MODE == UC_A_DENSE && !F16) { launch_variant_mode<128, 64, 2, 1, 3, A_MODE, 64, 1, EPI, F16>(p, st); break; }
+            [[fallthrough]];
         default:
             if (deep == 3 && ceil_div64(p.M, 128) * ceil_div64(p.N, 128) * sk <= 512) launch_variant_mode<128, 128, 2, 2, 3, A_MODE, 64, 1, EPI, F16>(p, st);
             else launch_variant_mode<128, 128, 2, 2, 2, A_MODE, 64, 1, EPI, F16>(p, st);

@@ -26,7 +26,6 @@ struct UcKnobs {
     int attn_prio;           // UC_ATTN_PRIO         eight-wave attention: static s_setprio 1 for waves 4-7 (default 0)
     int bilinear_rows2;      // UC_BILINEAR_ROWS2    output rows per work item of the upsampling form (default 4)
     int ln_nt;               // UC_LN_NT             non-temporal LayerNorm loads override (-1: policy)
-    int gemm_splitk_small;   // UC_GEMM_SMALLM       small-M policy of the dense GEMM (default 1: fill the CUs with split-K slices / smaller tiles)
 #ifdef UC_DIAG
     int gemm_dbg;            // UC_GEMM_DBG          (diag build only) wrong-result anatomy switches of the GEMM kernels
     int attn_dbg;            // UC_ATTN_DBG          (diag build only) wrong-result anatomy switches of the attention kernel
@@ -38,6 +37,7 @@ const UcKnobs& uc_knobs();
 // run-time switchable (uc_tuning_set): -3 / -1 mean "automatic / launcher policy"
 extern std::atomic<int> g_uc_gemm_variant;   // UC_GEMM_VARIANT: -3 automatic, -1 register-staged kernel, 0..3, 6, 7 direct-to-LDS tile variants
 extern std::atomic<int> g_uc_gemm_stagger;   // UC_GEMM_STAGGER: -1 launcher policy, >= 0 ticks per phase group
+extern std::atomic<int> g_uc_small_m_split;  // UC_GEMM_SMALLM: small-M path of the dense GEMM — smallest K for which a launch on <= half the CUs splits K in two inside the kernel (default 2048: K = 1024 is level, 3072 / 4096 gain 26-28 %; 0: never, and a pair's bits then do not depend on its batch size)
 extern std::atomic<int> g_uc_conv_rows;      // UC_CONV_ROWS: row-walking 3x3 conv kernel: 0 never, 1 where it wins (128 output channels, >= 256 input channels), 2 wherever the shape allows
 extern std::atomic<int> g_uc_attn_rs;        // UC_ATTN_RS: eight-wave bf16 attention as role-split segments (matrix beside vector on every SIMD): 0 / 1
 
