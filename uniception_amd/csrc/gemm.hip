@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 // then holds the same kernels as the eager run it was warmed up with.  Pool exhausted or not created yet: the launch runs unsplit.
 struct UcFuseWs { float* ws; unsigned* flags; };
 static UcFuseWs uc_fuse_ws(hipStream_t st) {
-    constexpr int POOL = 16;
+    constexpr int POOL = 8;
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, UcFuseWs> sets;
     static std::map<int, std::vector<UcFuseWs>> pool;       // per device: sets not handed out yet
