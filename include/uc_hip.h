@@ -183,9 +183,10 @@ typedef struct uc_gemm_desc {
 /* Notes on uc_gemm's behaviour outside the descriptor:
  *   small-M path — a dense bf16 launch whose 128 x 128 tiles cover at most half the CUs, with K >= the tuning knob small_m_split
  *   (UC_GEMM_SMALLM, default 2048; 0 = never), splits K in two across twice the workgroups and hands the first half's accumulators
- *   over inside the kernel.  The hand-over buffers come from a pool of 8 x 8 MiB of uncached device memory that the library
- *   allocates ONCE, at the first such launch outside a stream capture (a stream keeps the buffer it was given; launches on a
- *   stream that meets an empty pool, or a pool not created yet while capturing, run unsplit).  The result is the same sum taken in
+ *   over inside the kernel.  The hand-over buffers (8 MiB of uncached device memory per stream that makes such launches) come from
+ *   a pool the library grows in chunks of 64 MiB, at such launches outside a stream capture (at most 512 MiB; a stream keeps the
+ *   buffer it was given; launches on a
+ *   stream that meets an empty pool — e.g. a capture before any eager launch — run unsplit).  The result is the same sum taken in
  *   two halves: not bit-identical to the unsplit kernel (and therefore to the same rows inside a larger batch); small_m_split = 0
  *   restores one chain per accumulator for every batch size. */
 int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);

@@ -278,8 +278,9 @@ def test_bench_sized_batch_reproduces_the_golden_pair_to_the_bit(gpu):
     diffs = {k: rel_l2(alone_split[k].float().cpu(), v.float().cpu()) for k, v in alone.items()}
     print("\n[bf16] one pair, K >= 2048 summed in two halves vs in one chain: " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(diffs.items())))
     assert max(diffs.values()) < BF16_TOL["default"]        # two bf16 roundings of the same forward: apart by what each is from fp32
-    batch = run(img1, img2)
-    again = run(img1, img2)            # second call: every fork point past its warm-up call
+    with ops.tuning("small_m_split", 0):      # (at 20 pairs the heads' smallest maps still make small-M launches)
+        batch = run(img1, img2)
+        again = run(img1, img2)            # second call: every fork point past its warm-up call
     for k, v in alone.items():
         for pos in (0, 13):
             assert torch.equal(batch[k][pos], v[0]), f"{k}: the golden pair at position {pos} of a {B}-pair batch differs from the pair alone"

@@ -422,6 +422,23 @@ def test_gemm_small_m_fused_k_split(gpu, M, N, K):
         assert rel_l2(y.float(), y0.float()) < (2e-6 if y.dtype == torch.float32 else 2e-3), name     # two partial sums instead of one chain
         if name == "bf16 stream":
             assert torch.allclose(y.uc_ln.stats(1e-6), y0.uc_ln.stats(1e-6), rtol=2e-2, atol=2e-2)
+    if K == 4096:
+        # the 3x3 conv form (K = 9 Cin = 2304, 64 tiles) and fp16 operands (the prediction heads' mode) take the same path
+        for dt in (torch.bfloat16, torch.float16):
+            x = torch.randn(1, 64, 64, 256, generator=g).to(dt).to(gpu)
+            wc = (torch.randn(256, 9 * 256, generator=g) / 48).to(dt).to(gpu)
+            r = torch.randn(4096, 256, generator=g).to(dt).to(gpu)
+            fn = lambda: ops.gemm(x, wc, b[:256].contiguous(), conv=(1, 64, 64, 256, 1), relu_a=True, residual=r, out_dtype=torch.float32)
+            y = fn()
+            with ops.tuning("small_m_split", 0):
+                y0 = fn()
+            assert rel_l2(y, y0) < 2e-6 and not torch.equal(y, y0), dt
+            a16 = a.to(dt)
+            w16 = w.to(dt)
+            y = ops.gemm(a16, w16, b, out_dtype=torch.float32)
+            with ops.tuning("small_m_split", 0):
+                y0 = ops.gemm(a16, w16, b, out_dtype=torch.float32)
+            assert rel_l2(y, y0) < 2e-6 and not torch.equal(y, y0), dt
     # two streams at once, many launches back to back
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     outs = []

@@ -436,39 +436,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 // =======================================================================================
 // hand-over workspaces of the fused two-way K split (gemm_glds.h: fuse_split2): 128 tiles x 64 KiB + one flag per tile each.  Launches of
 // a stream are ordered, launches of different streams (the two views' branches) must not share one: a stream keeps the set it was
-// given first.  The sets come from a pool created at the first eligible launch OUTSIDE a stream capture (allocation is not allowed
-// inside one); handing a pooled set to a new stream is bookkeeping only, so streams first seen while capturing get one too — a graph
-// then holds the same kernels as the eager run it was warmed up with.  Pool exhausted or not created yet: the launch runs unsplit.
+// given.  The sets come from a pool that grows in chunks of 8 (64 MiB of uncached device memory) at eligible launches OUTSIDE a stream
+// capture, whenever fewer than 4 are free (allocation is not allowed inside a capture; neither is asking another stream whether it
+// is idle, so sets are not taken back): handing a pooled set to a new stream is bookkeeping only, and the streams a capture brings
+// along (torch's capture stream, the branch streams) find one — a graph then holds the same kernels as the eager run it was warmed
+// up with.  At most 64 sets (a PyTorch process has ~36 stream handles per device); nothing free: the launch runs unsplit.
 struct UcFuseWs { float* ws; unsigned* flags; };
 static UcFuseWs uc_fuse_ws(hipStream_t st) {
-    constexpr int POOL = 8;
+    constexpr int CHUNK = 8, RESERVE = 4, MAX_SETS = 64;
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, UcFuseWs> sets;
     static std::map<int, std::vector<UcFuseWs>> pool;       // per device: sets not handed out yet
-    static std::map<int, bool> pool_made;
+    static std::map<int, int> made;                         // per device: sets created so far
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
-    const auto key = std::make_pair(dev, st);
-    auto it = sets.find(key);
-    if (it != sets.end()) return it->second;
-    if (!pool_made[dev]) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return UcFuseWs{nullptr, nullptr}; }
-        pool_made[dev] = true;
+    auto& free_sets = pool[dev];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (!capturing && (int)free_sets.size() < RESERVE && made[dev] + CHUNK <= MAX_SETS) {
         // uncached: the partners may run on different XCDs (separate, non-coherent L2s) — see the kernel
         float* ws = nullptr;
         unsigned* flags = nullptr;
         const size_t per = (size_t)128 * 128 * 128;
-        if (hipExtMallocWithFlags((void**)&ws, POOL * per * sizeof(float), hipDeviceMallocUncached) != hipSuccess ||
-            hipExtMallocWithFlags((void**)&flags, POOL * 128 * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess ||
-            hipMemset(flags, 0, POOL * 128 * sizeof(unsigned)) != hipSuccess) {
-            (void)hipGetLastError();
-            return UcFuseWs{nullptr, nullptr};
+        if (hipExtMallocWithFlags((void**)&ws, CHUNK * per * sizeof(float), hipDeviceMallocUncached) == hipSuccess &&
+            hipExtMallocWithFlags((void**)&flags, CHUNK * 128 * sizeof(unsigned), hipDeviceMallocUncached) == hipSuccess &&
+            hipMemset(flags, 0, CHUNK * 128 * sizeof(unsigned)) == hipSuccess) {
+            for (int i = 0; i < CHUNK; ++i) free_sets.push_back(UcFuseWs{ws + i * per, flags + i * 128});
+            made[dev] += CHUNK;
+        } else {
+            made[dev] = MAX_SETS;      // no memory for it: stop trying
         }
-        for (int i = 0; i < POOL; ++i) pool[dev].push_back(UcFuseWs{ws + i * per, flags + i * 128});
     }
-    auto& free_sets = pool[dev];
+    (void)hipGetLastError();
+    const auto key = std::make_pair(dev, st);
+    auto it = sets.find(key);
+    if (it != sets.end()) return it->second;
     if (free_sets.empty()) return UcFuseWs{nullptr, nullptr};
     const UcFuseWs w = free_sets.back();
     free_sets.pop_back();
@@ -666,13 +669,13 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 if (variant == 1 && t256x128 * sk >= 512 && knobs.gemm_coresident) variant = 3;
             }
             if (d->tail_out && (variant == 2 || variant == 6)) variant = 1;    // the tail needs a tile that spans all 128 columns with two wave columns
-            // Small-M path: a dense launch whose 128x128 tiles cover at most half the CUs is a chain of K / 64 dependent steps of
+            // Small-M path: a launch (dense or 3x3 conv) whose 128x128 tiles cover at most half the CUs is a chain of K / 64 dependent steps of
             // ~0.7 us on each of them (neither a smaller tile nor a deeper ring shortens it: measured) — split K in two across twice
             // the workgroups, hand-over inside the kernel (fuse_split2).  UC_GEMM_SMALLM / tuning knob small_m_split = smallest K it is taken for
             // (0: never — the sum over K is then one chain whatever the batch size, and a pair's bits do not depend on its batch).
             g.fuse_split2 = 0; g.fs_ws = nullptr; g.fs_flags = nullptr;
             const int small_m_k = g_uc_small_m_split.load(std::memory_order_relaxed);
-            if (forced_variant < 0 && variant == 0 && d->a_mode == UC_A_DENSE && !f16 && d->split_k <= 1 && small_m_k > 0 &&
+            if (forced_variant < 0 && variant == 0 && d->split_k <= 1 && !d->tail_out && small_m_k > 0 &&
                 d->K >= small_m_k && d->K % 128 == 0 &&
                 2 * ceil_div64(d->M, 128) * ceil_div64(d->N, 128) <= uc_num_cus()) {
                 const UcFuseWs w = uc_fuse_ws(st);

@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, WGS_PER_CU * WAVES_M * WAVES
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int nwg = p.tiles_m * p.tiles_n;
-    constexpr bool FUSE2_OK = BM_ == 128 && BN_ == 128 && A_MODE == UC_A_DENSE && !F16;   // fused two-way K split (fuse_split2): this tile only
+    constexpr bool FUSE2_OK = BM_ == 128 && BN_ == 128;   // fused two-way K split (fuse_split2): this tile only (dense and conv, bf16 and fp16)
     const bool fuse2 = FUSE2_OK && p.fuse_split2;
     const int ksplit = fuse2 ? ((int)blockIdx.x >= nwg ? 1 : 0)
                              : (p.split_k > 1 ? (int)uc_div(blockIdx.x, p.dNwg) : 0);   // split-K slice
@@ -1722,7 +1722,7 @@ static void launch_variant_mode(GldsParams p, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    const unsigned slices = (BM_ == 128 && BN_ == 128 && A_MODE == UC_A_DENSE && !F16 && p.fuse_split2) ? 2u : (unsigned)p.split_k;
+    const unsigned slices = (BM_ == 128 && BN_ == 128 && p.fuse_split2) ? 2u : (unsigned)p.split_k;
     hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n * slices), dim3(WM_ * WN_ * 64), smem, st, p);
 }
 
