@@ -199,19 +199,23 @@ def reference_policy_legs(model, v1, v2, args, dev):
             with torch.no_grad(), engine.precision(mode), engine.attention_precision(args.attention):
                 return m(vv1, vv2)
         return f
-    # (first: on some boxes of the pool whatever follows the split-operand legs below runs 25 % slow for a while — 345-351 instead of
-    #  465-476 pairs/s for this leg when it came last, on two boxes out of five)
     if args.head == "dpt" and args.encoder == "croco":
         torch.manual_seed(0)
         lin = DUSt3R(name="bench_linear", img_size=(args.img, args.img), pred_head_type="linear").to(dev).eval()
         f = fwd(v1, v2, "bf16", lin)
         f(); f()
         dt, _ = timed(f, steps, 1)
+        per_step = []
+        for _ in range(steps):          # the same forward once more, step by step: a leg that reads low shows here whether every step was slow
+            d1, _ = timed(f, 1, 1)
+            per_step.append(round(d1 * 1e3, 1))
         pps = args.pairs * steps / dt
         out["enc_dec_linear_head"] = {"pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": args.pairs,
-                                      "enc_dec_mfma_frac": round(pps * GFLOP_ENC_DEC_512 * (args.img / 512) ** 2 / 1e3 / PEAK_BF16_TFLOPS, 4)}
-        del lin
-        torch.cuda.empty_cache()
+                                      "enc_dec_mfma_frac": round(pps * GFLOP_ENC_DEC_512 * (args.img / 512) ** 2 / 1e3 / PEAK_BF16_TFLOPS, 4),
+                                      "ms_per_step_one_by_one": per_step}
+        del lin          # (no torch.cuda.empty_cache() here or anywhere between legs: on some boxes of the pool the leg that runs on freshly
+                         #  hipMalloc'ed blocks reads 15-25 % low — 345 instead of 470 pairs/s for this one, 213 instead of 248 for the next —
+                         #  while legs that reuse the caching allocator's blocks do not)
     with engine.head_precision("fp32"):
         f = fwd(v1, v2, "bf16")
         f(); f()          # (the first call of a shape runs its fork points one after the other)
@@ -303,8 +307,7 @@ def batch_sweep(model, sizes, args, dev):
             e["hipgraph_pairs_per_s"] = round(b / mg.mean, 2)
             del g
         out.append(e)
-        del v1, v2
-        torch.cuda.empty_cache()
+        del v1, v2          # (no empty_cache(): see reference_policy_legs)
     return out
 
 
