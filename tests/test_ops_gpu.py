@@ -464,6 +464,24 @@ def test_gemm_small_m_fused_k_split(gpu, M, N, K):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, outs[0])
+    # a second graph, recorded on the same capture stream, replayed at the same time on another stream: each graph owns its hand-over buffers
+    with torch.cuda.stream(st):
+        out2 = torch.empty(M, N, device=gpu, dtype=torch.float32)
+        graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph2, stream=st):
+            for _ in range(4):
+                ops.gemm(a, w, b, residual=res32, out=out2)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        out.zero_(); out2.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            for _ in range(4):
+                graph.replay()
+        with torch.cuda.stream(s2):
+            graph2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, outs[0]) and torch.equal(out2, outs[0])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

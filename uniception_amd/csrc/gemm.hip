@@ -19,6 +19,7 @@
 #include "common.h"
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 #include <vector>
 #include "gemm_glds.h"
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 // =======================================================================================
 // hand-over workspaces of the fused two-way K split (gemm_glds.h: fuse_split2): 128 tiles x 64 KiB + one flag per tile each.  Launches of
 // a stream are ordered, launches of different streams (the two views' branches) must not share one: a stream keeps the set it was
-// given.  The sets come from a pool that grows in chunks of 8 (64 MiB of uncached device memory) at eligible launches OUTSIDE a stream
+// given, and so does every (capture, stream) pair — a graph owns the sets of the launches recorded into it.  The sets come from a pool that grows in chunks of 8 (64 MiB of uncached device memory) at eligible launches OUTSIDE a stream
 // capture, whenever fewer than 4 are free (allocation is not allowed inside a capture; neither is asking another stream whether it
 // is idle, so sets are not taken back): handing a pooled set to a new stream is bookkeeping only, and the streams a capture brings
 // along (torch's capture stream, the branch streams) find one — a graph then holds the same kernels as the eager run it was warmed
@@ -445,15 +446,20 @@ struct UcFuseWs { float* ws; unsigned* flags; };
 static UcFuseWs uc_fuse_ws(hipStream_t st) {
     constexpr int CHUNK = 8, RESERVE = 4, MAX_SETS = 64;
     static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, UcFuseWs> sets;
+    static std::map<std::tuple<int, hipStream_t, unsigned long long>, UcFuseWs> sets;   // (device, stream, capture id | 0)
     static std::map<int, std::vector<UcFuseWs>> pool;       // per device: sets not handed out yet
     static std::map<int, int> made;                         // per device: sets created so far
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     auto& free_sets = pool[dev];
+    // a captured launch belongs to its GRAPH, not to the stream it was recorded on (PyTorch records every graph on one capture stream,
+    // and two graphs may be replayed at the same time on different streams): sets of captured launches are keyed by the capture's id
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    unsigned long long cap_id = 0;
+    const bool capturing = hipStreamGetCaptureInfo(st, &cs, &cap_id) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (!capturing) cap_id = 0;
+    else if (cap_id == 0) cap_id = ~0ull;
     if (!capturing && (int)free_sets.size() < RESERVE && made[dev] + CHUNK <= MAX_SETS) {
         // uncached: the partners may run on different XCDs (separate, non-coherent L2s) — see the kernel
         float* ws = nullptr;
@@ -469,7 +475,7 @@ static UcFuseWs uc_fuse_ws(hipStream_t st) {
         }
     }
     (void)hipGetLastError();
-    const auto key = std::make_pair(dev, st);
+    const auto key = std::make_tuple(dev, st, cap_id);
     auto it = sets.find(key);
     if (it != sets.end()) return it->second;
     if (free_sets.empty()) return UcFuseWs{nullptr, nullptr};
