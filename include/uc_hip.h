@@ -43,8 +43,9 @@ const char* uc_last_error(void);
  *   1: forward path.  2: training entry points, uc_gemm_desc gained preact_out / split_k / dact_u, uc_attention_fwd gained lse,
  *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added.  4/5: see INTEGRATION.md.
  *   6: uc_adaptor_program_bwd added.  7: uc_build_flavor, uc_tuning_set / uc_tuning_get (environment knobs read once; no
- *      diagnostics in the release build), uc_attention_fwd_x3.  8: uc_gemm_desc gained ln_nblk / ln_eps.  9: uc_gemm_tn_conv_tiles added. */
-#define UC_ABI_VERSION 9
+ *      diagnostics in the release build), uc_attention_fwd_x3.  8: uc_gemm_desc gained ln_nblk / ln_eps.  9: uc_gemm_tn_conv_tiles added.
+ *   10: uc_attention_fwd_x3 takes RoPE-2D positions (rotation fused into its operand split). */
+#define UC_ABI_VERSION 10
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
 const char* uc_build_flavor(void);
@@ -218,7 +219,10 @@ int64_t uc_attention_x3_workspace_bytes(int B, int H, int Nq, int Nk);
 int uc_attention_fwd_x3(const float* Q, const float* K, const float* V, float* O, void* workspace, int B, int H, int Nq, int Nk,
                         int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
                         int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale, float* lse,
-                        uc_stream_t stream);
+                        const int64_t* q_pos, const int64_t* k_pos, const float* rope_table, int rope_npos, uc_stream_t stream);
+/* (q_pos [B, Nq, 2] / k_pos [B, Nk, 2] int64 + rope_table [rope_npos][16] (cos, sin) from uc_rope_table: Q and K are rotated by RoPE-2D — the
+ *  arithmetic of uc_rope2d, libs/croco/pos_embed.py:113-155 — inside the operand split, so the rotated rows never make a pass of their
+ *  own; all NULL / 0: Q and K are taken as they are.) */
 
 /* ------------------------------------------------------------------------------------
  * Scaled-dot-product attention, no mask, no dropout:  O = softmax(Q K^T * scale) V

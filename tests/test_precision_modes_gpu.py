@@ -69,6 +69,19 @@ def test_split_operand_attention_matches_fp64(gpu, shape):
         print(f"[x3 attention] {shape} scale {scale}: rel-L2 {err:.2e} (exact fp32 kernel {rel_l2(exact.cpu(), ref.cpu()):.2e})")
         assert err < 3e-5
         assert float((o - ref.float()).abs().max()) < 2e-4 * float(ref.abs().max())
+    # RoPE-2D fused into the operand split (ABI 10): the same bits as rotating q and k in place first (rope_2d_, the same cos / sin table)
+    pq = torch.stack([torch.randint(0, 40, (B, Nq), generator=g), torch.randint(0, 50, (B, Nq), generator=g)], -1).to(gpu)
+    pk = torch.stack([torch.randint(0, 40, (B, Nk), generator=g), torch.randint(0, 50, (B, Nk), generator=g)], -1).to(gpu)
+    table = ops.rope_table(gpu, 64, 100.0, 1.0)
+    fused = ops.attention_x3(q, k, v, 0.125, rope=(pq.reshape(-1, 2).contiguous(), pk.reshape(-1, 2).contiguous(), table))
+    qr, kr = q.contiguous().clone(), k.contiguous().clone()
+    ops.rope_2d_(qr, pq, 100.0, 1.0)
+    ops.rope_2d_(kr, pk, 100.0, 1.0)
+    two_pass = ops.attention_x3(qr, kr, v, 0.125)
+    assert rel_l2(fused, two_pass) < 1e-6 and float((fused - two_pass).abs().max()) < 1e-5
+    qd, kd, vd = (t.double().permute(0, 2, 1, 3) for t in (qr, kr, v))
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) * 0.125, -1) @ vd).permute(0, 2, 1, 3)
+    assert rel_l2(fused.cpu(), ref.cpu()) < 3e-5
 
 
 def test_fp16_operand_gemm_and_conv_are_tf32_class(gpu):

@@ -64,7 +64,7 @@ SIGNATURES = {
     "uc_add_view_pe": [vp, vp, i64, i32, i32, i32, i32, vp],
     "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
     "uc_attention_x3_workspace_bytes": [i32, i32, i32, i32],
-    "uc_attention_fwd_x3": [vp, vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
+    "uc_attention_fwd_x3": [vp, vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp, vp, vp, i32, vp],
     "uc_attention_fwd_fp8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [f32, vp],
     "uc_vt_pack_fp8": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
     "uc_attention_fwd_fp8_k8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 6 + [f32, vp],
@@ -107,7 +107,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 9   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 10   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

@@ -43,8 +43,12 @@ __device__ __forceinline__ x3_uint4_t x3_make_srd(const void* base, unsigned byt
 // ---------------------------------------------------------------------------------------------------------------------------
 // split passes.  rows: fp32 [B, N, H, 64] strided (unit channel stride) -> hi, lo bf16 [B, N, H, 64] contiguous, x * mul first.
 // ---------------------------------------------------------------------------------------------------------------------------
+// With pos != nullptr the rows are rotated by RoPE-2D on the way (pos [B, N, 2] int64, table [npos][16] (cos, sin) of uc_rope_table: the
+// arithmetic of uc_rope2d, channels [0,16) = u_y, [16,32) = v_y, [32,48) = u_x, [48,64) = v_x, u' = u cos - v sin, v' = v cos + u sin):
+// the rotated q / k never make a pass through memory of their own.
 __global__ __launch_bounds__(256) void x3_split_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int N, int H,
-                                                            int64_t sb, int64_t sn, int64_t sh, float mul, int64_t n_items) {
+                                                            int64_t sb, int64_t sn, int64_t sh, float mul, int64_t n_items,
+                                                            const int64_t* __restrict__ pos, const float2* __restrict__ table, int npos) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         const int c8 = (int)(i & 7);
         const int64_t row = i >> 3;                 // (b * N + n) * H + h
@@ -52,9 +56,26 @@ __global__ __launch_bounds__(256) void x3_split_rows_kernel(const float* __restr
         const int64_t bn = row / H;
         const int n = (int)(bn % N);
         const int64_t b = bn / N;
-        const float4_t* src = reinterpret_cast<const float4_t*>(x + b * sb + (int64_t)n * sn + (int64_t)h * sh + c8 * 8);
+        const float* base = x + b * sb + (int64_t)n * sn + (int64_t)h * sh;
+        const float4_t* src = reinterpret_cast<const float4_t*>(base + c8 * 8);
         const float4_t u = src[0], w = src[1];
-        const float v[8] = {u.x * mul, u.y * mul, u.z * mul, u.w * mul, w.x * mul, w.y * mul, w.z * mul, w.w * mul};
+        float v[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+        if (pos) {
+            const int axis = c8 >> 2, is_v = (c8 >> 1) & 1, i0 = (c8 & 1) * 8;
+            const float4_t* psrc = reinterpret_cast<const float4_t*>(base + (is_v ? c8 - 2 : c8 + 2) * 8);     // the pair's other half
+            const float4_t pu = psrc[0], pw = psrc[1];
+            const float o[8] = {pu.x, pu.y, pu.z, pu.w, pw.x, pw.y, pw.z, pw.w};
+            int64_t p = pos[bn * 2 + axis];
+            p = p < 0 ? 0 : (p >= npos ? npos - 1 : p);          // (the launcher's caller guarantees the range; no wild reads if it does not)
+            const float2* cs = table + p * 16 + i0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 c = cs[k];
+                v[k] = is_v ? v[k] * c.x + o[k] * c.y : v[k] * c.x - o[k] * c.y;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= mul;
         unsigned hh[4], ll[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -317,9 +338,10 @@ extern "C" int64_t uc_attention_x3_workspace_bytes(int B, int H, int Nq, int Nk)
 extern "C" int uc_attention_fwd_x3(const float* Q, const float* K, const float* V, float* O, void* workspace, int B, int H, int Nq, int Nk,
                                    int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
                                    int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale, float* lse,
-                                   uc_stream_t stream) {
+                                   const int64_t* q_pos, const int64_t* k_pos, const float* rope_table, int rope_npos, uc_stream_t stream) {
     UC_REQUIRE(Q && K && V && O && workspace, "uc_attention_fwd_x3: null pointer");
     UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "uc_attention_fwd_x3: bad shape");
+    UC_REQUIRE((!q_pos && !k_pos) || (q_pos && k_pos && rope_table && rope_npos > 0), "uc_attention_fwd_x3: RoPE needs both position arrays and the table");
     UC_REQUIRE(q_sb % 4 == 0 && q_sn % 4 == 0 && q_sh % 4 == 0 && k_sb % 4 == 0 && k_sn % 4 == 0 && k_sh % 4 == 0 && v_sb % 4 == 0 && v_sn % 4 == 0 &&
                    v_sh % 4 == 0 && o_sb % 4 == 0 && o_sn % 4 == 0 && o_sh % 4 == 0,
                "uc_attention_fwd_x3: strides must be multiples of 4 elements");
@@ -337,8 +359,9 @@ extern "C" int uc_attention_fwd_x3(const float* Q, const float* K, const float* 
     bf16_t *Qh = w, *Ql = Qh + nQ, *Kh = Ql + nQ, *Kl = Kh + nK, *VTh = Kl + nK, *VTl = VTh + nV;
     const int64_t iq = nQ / 8, ik = nK / 8;
     const unsigned gq = (unsigned)std::min<int64_t>((iq + 255) / 256, 65535 * 16), gk = (unsigned)std::min<int64_t>((ik + 255) / 256, 65535 * 16);
-    hipLaunchKernelGGL(x3_split_rows_kernel, dim3(gq), dim3(256), 0, st, Q, Qh, Ql, Nq, H, q_sb, q_sn, q_sh, scale * 1.44269504088896340736f, iq);
-    hipLaunchKernelGGL(x3_split_rows_kernel, dim3(gk), dim3(256), 0, st, K, Kh, Kl, Nk, H, k_sb, k_sn, k_sh, 1.0f, ik);
+    hipLaunchKernelGGL(x3_split_rows_kernel, dim3(gq), dim3(256), 0, st, Q, Qh, Ql, Nq, H, q_sb, q_sn, q_sh, scale * 1.44269504088896340736f, iq,
+                       q_pos, (const float2*)rope_table, rope_npos);
+    hipLaunchKernelGGL(x3_split_rows_kernel, dim3(gk), dim3(256), 0, st, K, Kh, Kl, Nk, H, k_sb, k_sn, k_sh, 1.0f, ik, k_pos, (const float2*)rope_table, rope_npos);
     UC_REQUIRE(H <= 65535 && B <= 65535, "uc_attention_fwd_x3: B and H must fit a grid dimension");
     hipLaunchKernelGGL(x3_vt_pack_kernel, dim3(npad / 64, H, B), dim3(256), 0, st, V, VTh, VTl, H, Nk, npad, v_sb, v_sn, v_sh);
     X3Params p;

@@ -513,8 +513,10 @@ def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.L
             raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh}); use fp32 precision for this model")
         t = ops.gemm(h2d, wq, bq, ln=lnq).view(B, N, 3, num_heads, Dh)
         q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
-        q, k = _apply_rope(rope, q, k, pos, pos)
-        o = _attention_generic(q, k, v, scale)
+        o = _x3_rope_attention(rope, q, k, v, pos, pos, scale)
+        if o is None:
+            q, k = _apply_rope(rope, q, k, pos, pos)
+            o = _attention_generic(q, k, v, scale)
     emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cd)
     return ops.gemm(o.view(M, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
@@ -528,6 +530,16 @@ def _apply_rope(rope, q, k, qpos, kpos):
         ops.rope_2d_(k, kpos.contiguous(), rope.base, rope.F0)
         return q, k
     return rope(q.transpose(1, 2), qpos).transpose(1, 2), rope(k.transpose(1, 2), kpos).transpose(1, 2)
+
+
+def _x3_rope_attention(rope, q, k, v, qpos, kpos, scale):
+    """precision("bf16x3") with the native RoPE-2D: the rotation of q and k rides in the operand split of the split-operand attention
+    (uc_attention_fwd_x3) instead of making two passes of its own over q and k.  Returns None when that path does not apply."""
+    if not (_forced_x3 and _x3_attention and rope is not None and is_native_rope(rope) and q.dtype == torch.float32 and q.shape[-1] == 64
+            and not torch.is_grad_enabled() and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1):
+        return None
+    table = ops.rope_table(q.device, ROPE_TABLE_NPOS, rope.base, rope.F0)
+    return ops.attention_x3(q, k, v, scale, rope=(_pos2d(qpos), _pos2d(kpos), table))
 
 
 def _attention_generic(q, k, v, scale):
@@ -580,8 +592,10 @@ def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk
         q = ops.gemm(hq2d, wq, bq, ln=lnq).view(B, Nq, num_heads, Dh)
         kv = ops.gemm(hkv2d, wkv, bkv, ln=lnkv).view(B, Nk, 2, num_heads, Dh)
         k, v = kv[:, :, 0], kv[:, :, 1]
-        q, k = _apply_rope(rope, q, k, qpos, kpos)
-        o = _attention_generic(q, k, v, scale)
+        o = _x3_rope_attention(rope, q, k, v, qpos, kpos, scale)
+        if o is None:
+            q, k = _apply_rope(rope, q, k, qpos, kpos)
+            o = _attention_generic(q, k, v, scale)
     emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cd)
     return ops.gemm(o.reshape(B * Nq, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 

@@ -444,9 +444,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, v
 
 
 def attention_x3(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None,
-                 lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 lse: Optional[torch.Tensor] = None, rope: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """fp32-class attention on the matrix pipe (uc_attention_fwd_x3: split bf16 operands, three MFMA products per product, fp32
-    softmax).  q [B,Nq,H,64], k / v [B,Nk,H,64]: fp32 strided views with stride(3) == 1.  Returns fp32 O [B,Nq,H,64] contiguous."""
+    softmax).  q [B,Nq,H,64], k / v [B,Nk,H,64]: fp32 strided views with stride(3) == 1.  Returns fp32 O [B,Nq,H,64] contiguous.
+    rope = (q positions [B*Nq, 2] int64, k positions [B*Nk, 2] int64, table from rope_table): q and k are rotated by RoPE-2D inside the
+    operand split (the arithmetic of rope_2d_), instead of in a pass of their own."""
     _need_gpu(q, k, v)
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
@@ -454,12 +456,19 @@ def attention_x3(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float
     assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and k.shape == v.shape
     if out is None:
         out = torch.empty((B, Nq, H, D), dtype=torch.float32, device=q.device)
+    qp = kp = tab = None
+    npos = 0
+    if rope is not None:
+        qp, kp, tab = rope
+        assert qp.dtype == kp.dtype == torch.int64 and qp.is_contiguous() and kp.is_contiguous() and qp.numel() == B * Nq * 2 and kp.numel() == B * Nk * 2
+        assert tab.dtype == torch.float32 and tab.is_contiguous() and tab.numel() % 32 == 0
+        npos = tab.numel() // 32
     lib = _lib.load()
     ws = torch.empty(int(lib.uc_attention_x3_workspace_bytes(B, H, Nq, Nk)), dtype=torch.uint8, device=q.device)
     _lib.check(lib.uc_attention_fwd_x3(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), ws.data_ptr(), B, H, Nq, Nk,
                                        q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                                        v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2), float(scale),
-                                       _p(lse), _stream()), "uc_attention_fwd_x3")
+                                       _p(lse), _p(qp), _p(kp), _p(tab), npos, _stream()), "uc_attention_fwd_x3")
     return out
 
 
