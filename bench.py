@@ -22,9 +22,19 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md §Chip-level parameters)
-# forward GFLOP per 512x512 pair, encoder+decoder and the two DPT heads
-GFLOP_ENC_DEC_512, GFLOP_DPT_512 = 2068.0, 497.9
-PMC_TRAFFIC_FILE = "r3_pmc_traffic.json"
+PEAK_HBM_GBS = 8000.0      # HBM3E peak (same guide)
+PMC_TRAFFIC_FILE = "r4_pmc_traffic.json"
+
+
+def gflop_enc_dec(img, patch=16, enc_dim=1024, enc_depth=24, dec_dim=768, dec_depth=12, n_extra=0):
+    """Forward GFLOP of encoder + decoder per image PAIR (both views), SURVEY.md §8d:
+    enc = depth.N.(24 D^2 + 4 N D) + 2.3.P^2.D.N per view; dec = depth.(N.28 D^2 + Nk.4 D^2 + 4 N^2 D + 4 N Nk D) + 2.Din.D.N per view.
+    512^2 -> 2068.0, 224^2 -> 340.0, 1024^2 -> 12601.4, DINOv2 ViT-L/14 518^2 (n_extra = 1 cls token in the encoder) -> 2926.3."""
+    n = (img // patch) ** 2
+    ne = n + n_extra
+    enc = enc_depth * ne * (24 * enc_dim ** 2 + 4 * ne * enc_dim) + 2 * 3 * patch ** 2 * enc_dim * n
+    dec = dec_depth * (n * 28 * dec_dim ** 2 + n * 4 * dec_dim ** 2 + 4 * n * n * dec_dim + 4 * n * n * dec_dim) + 2 * enc_dim * dec_dim * n
+    return 2.0 * (enc + dec) / 1e9
 
 
 def parse():
@@ -49,10 +59,12 @@ def parse():
     ap.add_argument("--no-reference-policy", action="store_true",
                     help="skip the extra legs: fp32-class heads beside the bf16 transformer, everything fp32-class, linear-head (enc+dec) run")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the `fwd_224` (224x224 pairs) and `train_step` (BASELINE configs[2], 32 pairs, 3 fenced steps) legs of the default line")
     ap.add_argument("--single-stream", action="store_true",
                     help="no two-stream execution of independent sub-graphs at large batch (engine.concurrent(False)): what the "
                          "roofline pass and the committed kernel profiles use — per-kernel durations are only defined without overlap")
-    ap.add_argument("--cpu-baseline-max-s", type=float, default=30.0)
+    ap.add_argument("--cpu-baseline-max-s", type=float, default=45.0)
     ap.add_argument("--sweep", default=None,
                     help="comma-separated batch sizes (pairs), e.g. 1,2,4,8,16,64: adds `batch_sweep` to the JSON line — the forward at each "
                          "size, timed like the reference's own harness (examples/models/dust3r/profile_dust3r.py:31-46: randn images, "
@@ -70,43 +82,75 @@ def make_views(B, H, W, rank, dev):
 
 
 def roofline_pass(step_fn, v1, precision, steps):
-    """Bracket every dense bf16 GEMM launch (the dominant kernel: gemm_bf16_kernel<dense>) with HIP events on the
-    launch stream and relate its algorithmic FLOPs to the measured launch time."""
-    from uniception_amd import engine, ops
+    """One instrumented single-stream pass: every launch of the path's kernel families is bracketed with HIP events on the launch
+    stream (PyTorch's current stream — the one every uc_hip call is handed) and its ALGORITHMIC work related to the measured time.
+    Returns (roofline of the dominant family: the dense bf16 MFMA GEMM, roofline_families: attention / 3x3 convolutions against the
+    bf16 MFMA peak, the bandwidth-bound kernels against the HBM peak)."""
+    from uniception_amd import ops
 
-    records = []
-    orig = ops.gemm
+    rec = {}          # family -> list of (e0, e1, flops, bytes)
+    saved = {}
 
-    def timed_gemm(a, w, *args, **kw):
-        if kw.get("conv") is not None or a.dtype not in (torch.bfloat16, torch.float16):     # (fp16: the heads' 1x1 / ConvTranspose GEMMs, same kernels)
-            return orig(a, w, *args, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig(a, w, *args, **kw)
-        e1.record()
-        M_, N_, K_ = a.shape[0], w.shape[0], w.shape[1]
-        nbytes = 2.0 * (M_ * K_ + N_ * K_) + out.numel() * out.element_size()          # A + W + C ...
+    def bracket(family, fn, work):
+        def wrapped(*args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*args, **kw)
+            e1.record()
+            fam, fl, by = work(out, *args, **kw)
+            rec.setdefault(fam or family, []).append((e0, e1, fl, by))
+            return out
+        return wrapped
+
+    def nbytes(*ts):
+        return float(sum(t.numel() * t.element_size() for t in ts if isinstance(t, torch.Tensor)))
+
+    def gemm_work(out, a, w, *args, **kw):
+        N_, K_ = w.shape
+        if kw.get("conv") is not None:
+            M_ = out.numel() // (4 if kw.get("tail") is not None else N_)
+            return "conv3x3", 2.0 * M_ * N_ * K_, nbytes(a, w, out)
+        if a.dtype not in (torch.bfloat16, torch.float16):     # (fp16: the heads' 1x1 / ConvTranspose GEMMs, same kernels)
+            return "gemm_other", 2.0 * a.shape[0] * N_ * K_, nbytes(a, w, out)
+        M_ = a.shape[0]
+        by = 2.0 * (M_ * K_ + N_ * K_) + nbytes(out)                     # A + W + C ...
         if kw.get("residual") is not None:
-            nbytes += kw["residual"].numel() * kw["residual"].element_size()            # ... + the residual read by the epilogue
+            by += nbytes(kw["residual"])                                 # ... + the residual read by the epilogue
         if kw.get("vt") is not None:
-            nbytes += 2.0 * M_ * (N_ - out.shape[1])                                     # ... + the V columns stored as packed VT
+            by += 2.0 * M_ * (N_ - out.shape[1])                         # ... + the V columns stored as packed VT
         side = getattr(out, "uc_ln", None)
         if side is not None:
-            nbytes += 8.0 * M_ * (N_ // 64)                                              # ... + the row statistics of the LayerNorm fold (producer)
+            by += 8.0 * M_ * (N_ // 64)                                  # ... + the row statistics of the LayerNorm fold (producer)
             if side.twin is not out:
-                nbytes += 2.0 * M_ * N_                                                  # ... + the bf16 twin of an fp32 stream (a bf16 stream is its own twin)
+                by += 2.0 * M_ * N_                                      # ... + the bf16 twin of an fp32 stream (a bf16 stream is its own twin)
         if kw.get("ln") is not None:
-            nbytes += 8.0 * M_ + 4.0 * N_                                                # ... + (mean, rstd) per row and the column sums (consumer)
-        records.append((e0, e1, 2.0 * M_ * N_ * K_, nbytes))
-        return out
+            by += 8.0 * M_ + 4.0 * N_                                    # ... + (mean, rstd) per row and the column sums (consumer)
+        return "dense_gemm", 2.0 * M_ * N_ * K_, by
 
-    ops.gemm = timed_gemm
+    def attn_work(out, q, k, v, *args, **kw):
+        B_, Nq, H_, D_ = q.shape
+        Nk = k.shape[1]
+        return None, 4.0 * B_ * H_ * Nq * Nk * D_, nbytes(out) + 2.0 * q.element_size() * B_ * H_ * D_ * (Nq / 2 + Nk)   # Q + K + V read, O written
+
+    def io_work(out, x, *args, **kw):
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        return None, 0.0, nbytes(x, *outs)
+
+    plan = {"gemm": ("dense_gemm", gemm_work), "attention": ("attention_fwd", attn_work), "attention_fp8": ("attention_fwd_fp8", attn_work),
+            "bilinear_nhwc": ("bilinear", io_work), "pointmap_adaptor": ("adaptor", io_work), "adaptor_program": ("adaptor", io_work),
+            "patch_gather": ("patch_gather", io_work), "convert": ("convert", io_work), "convt_scatter": ("convt_scatter", io_work),
+            "pixel_shuffle": ("pixel_shuffle", io_work), "conv1x1_to4": ("conv1x1_to4", io_work), "layernorm": ("layernorm", io_work),
+            "nchw_to_nhwc": ("layout", io_work), "nhwc_to_nchw": ("layout", io_work)}
+    for name, (fam, work) in plan.items():
+        saved[name] = getattr(ops, name)
+        setattr(ops, name, bracket(fam, saved[name], work))
     try:
         for _ in range(steps):
             step_fn()
         torch.cuda.synchronize()
     finally:
-        ops.gemm = orig
+        for name, fn in saved.items():
+            setattr(ops, name, fn)
     traffic, traffic_note = None, "no PMC record for this build"
     try:  # HBM bytes per launch from the committed PMC passes (profiles/): only when they were taken on this workload AND on
         # this very build of the kernels (fingerprint of csrc/ + flags recorded next to the counters)
@@ -122,15 +166,30 @@ def roofline_pass(step_fn, v1, precision, steps):
             traffic, traffic_note = pmc["traffic_bytes_per_launch"], f"profiles/{PMC_TRAFFIC_FILE}"
     except (OSError, KeyError, ValueError):
         pass
-    t = sum(r[0].elapsed_time(r[1]) for r in records) * 1e-3
-    fl = sum(r[2] for r in records)
-    alg_bytes = sum(r[3] for r in records)
-    n = len(records)
-    return {"bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+
+    def summarize(records):
+        t = sum(r[0].elapsed_time(r[1]) for r in records) * 1e-3
+        return t, sum(r[2] for r in records), sum(r[3] for r in records), len(records)
+
+    t, fl, alg_bytes, n = summarize(rec["dense_gemm"]) if rec.get("dense_gemm") else (1.0, 0.0, 0.0, 1)
+    roof = {"bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-            "kernel": "gemm_bf16_glds_kernel<.., dense, ..> + gemm_bf16_glds8_kernel + gemm_bf16_glds4_kernel (dense bf16 MFMA GEMM, all tile variants and epilogue families)",
+            "kernel": "gemm_bf16_glds_kernel<.., dense, ..> + gemm_bf16_glds8_kernel + gemm_bf16_glds4_kernel + gemm_bf16_co_kernel (dense bf16 MFMA GEMM, all tile variants and epilogue families)",
             "launches_per_step": n // steps, "avg_launch_us": round(t / n * 1e6, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2), "algorithmic_bytes_per_launch": int(alg_bytes / n)}
+    fams = {}
+    total_t = sum(summarize(r)[0] for r in rec.values())
+    for fam, records in sorted(rec.items()):
+        ft, ffl, fby, fn_ = summarize(records)
+        e = {"launches_per_step": fn_ // steps, "ms_per_step": round(ft / steps * 1e3, 3), "share_of_bracketed_time": round(ft / total_t, 4)}
+        if ffl > 0:   # matrix-pipe families: algorithmic flops against the dense bf16 MFMA peak
+            e.update({"bound": "mfma", "achieved": round(ffl / ft / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(ffl / ft / 1e12 / PEAK_BF16_TFLOPS, 4)})
+        else:         # data movement: algorithmic bytes (tensors read + written once) against the HBM peak
+            e.update({"bound": "hbm", "achieved": round(fby / ft / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": round(fby / ft / 1e9 / PEAK_HBM_GBS, 4)})
+        fams[fam] = e
+    return roof, fams
 
 
 def cpu_model_name():
@@ -144,25 +203,67 @@ def cpu_model_name():
     return "unknown CPU"
 
 
+def cpu_topology():
+    """(sockets, physical cores, logical cpus) from /proc/cpuinfo (falls back to os.cpu_count())."""
+    phys, sockets, logical = set(), set(), 0
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("processor"):
+                    logical += 1
+                elif line.startswith("physical id"):
+                    pid = line.split(":")[1].strip(); sockets.add(pid)
+                elif line.startswith("core id"):
+                    cid = line.split(":")[1].strip(); phys.add((pid, cid))
+    except OSError:
+        pass
+    n = os.cpu_count() or 1
+    return max(1, len(sockets)), (len(phys) or n), (logical or n)
+
+
 def cpu_baseline(model, H, W, head, max_s):
-    """The oracle (CPU restatement of the reference path, validated against the real reference in tests/golden) timed on
-    the host cores the way the reference times itself (utils/profile.py:4-6: torch.utils.benchmark Timer.blocked_autorange)
-    on ONE pair — a bounded sample of the same workload."""
-    import torch.utils.benchmark as tbench
+    """The oracle (CPU restatement of the reference path, validated against the real reference in tests/golden) timed on the host
+    cores on ONE pair — a bounded sample of the same workload.  torch's default thread count (= logical CPUs) oversubscribes
+    a multi-socket SMT host (round 3: 128 threads of an EPYC 9575F ran 4x slower than 8 Xeon vCPUs), so the thread count is SWEPT
+    ({8, 12, 16, 24, 32, 64, physical cores, physical cores of one socket}, one forward each after a warm-up at the first count), and the best count
+    is then sampled n >= 3 times (median reported, the reference's own method — utils/profile.py:4-6 — is a Timer over the forward)."""
     from oracle import dust3r_oracle as O
 
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     img1, img2 = O.make_images(7, 1, H, W)
-    cores = torch.get_num_threads()
-    with torch.no_grad():
-        timer = tbench.Timer(stmt="f(sd, a, b, head=head)", globals={"f": O.dust3r_forward, "sd": sd, "a": img1, "b": img2, "head": head},
-                             num_threads=cores)
-        m = timer.blocked_autorange(min_run_time=min(max_s, 20.0))
-    t = m.median
-    return {"value": round(1.0 / t, 4), "unit": "image-pairs/s", "cores": cores, "cpu": cpu_model_name(), "kind": "port",
-            "n_samples": len(m.times),
-            "sample": f"1 pair (2x{H}x{W}) fp32 forward incl. heads, Timer.blocked_autorange, n={len(m.times)} run(s) (median), "
-                      f"{t:.2f}s each, torch CPU {cores} threads"}
+    sockets, phys, logical = cpu_topology()
+    default_threads = torch.get_num_threads()
+    cands = sorted({c for c in (8, 12, 16, 24, 32, 64, phys, max(1, phys // sockets)) if 1 <= c <= logical})
+    t_begin = time.perf_counter()
+
+    def one(nthreads):
+        torch.set_num_threads(nthreads)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.dust3r_forward(sd, img1, img2, head=head)
+            return time.perf_counter() - t0
+
+    sweep = {}
+    try:
+        one(cands[len(cands) // 2])       # warm-up (allocator, oneDNN primitive caches)
+        for c in cands:
+            if time.perf_counter() - t_begin > 0.6 * max_s and sweep:
+                break
+            sweep[c] = one(c)
+        best = min(sweep, key=sweep.get)
+        times = [sweep[best]]
+        while len(times) < 3 or (len(times) < 5 and time.perf_counter() - t_begin < max_s):
+            times.append(one(best))
+    finally:
+        torch.set_num_threads(default_threads)
+    times.sort()
+    t = times[len(times) // 2]
+    return {"value": round(1.0 / t, 4), "unit": "image-pairs/s", "cores": best, "cpu": cpu_model_name(), "kind": "port",
+            "n_samples": len(times), "host": {"sockets": sockets, "physical_cores": phys, "logical_cpus": logical},
+            "thread_sweep_s_per_pair": {str(k): round(v, 2) for k, v in sorted(sweep.items())},
+            "sample": f"1 pair (2x{H}x{W}) fp32 forward incl. heads: thread sweep {sorted(sweep)} (one forward each), then n={len(times)} forwards at the "
+                      f"best count ({best} threads, median {t:.2f}s each), torch CPU"}
 
 
 def timed(step, steps, world):
@@ -181,16 +282,19 @@ def timed(step, steps, world):
 
 
 def timed_each(step, steps):
-    """The legs beside the headline: every step fenced and timed on its own, the MEDIAN reported.  (A block of K steps right after a
-    model switch now and then contains one ~250-ms host-side stall — the first K-step block of the encoder + decoder leg read 345
-    instead of 471 pairs/s on several boxes while each of its steps, timed one by one right after, took 136.5 ms; the headline keeps
-    the driver's contract: K steps between two fences.)"""
+    """The legs beside the headline: every step fenced and timed on its own.  Returns (median * steps, stats) where stats carries the
+    sorted step times, their MEDIAN (what the legs' pairs/s and enc_dec_mfma_frac are computed from: a block of K steps right after a
+    model switch now and then contains one ~250-ms host-side stall — DESIGN.md section 7) AND the block mean over the same steps
+    (what the headline's contract — K steps between two fences — would have read), so the two are comparable."""
     ts = []
     for _ in range(steps):
         d1, _ = timed(step, 1, 1)
         ts.append(d1)
+    mean = sum(ts) / len(ts)
     ts.sort()
-    return ts[len(ts) // 2] * steps, [round(t * 1e3, 1) for t in ts]
+    med = ts[len(ts) // 2]
+    return med * steps, {"n": steps, "ms_per_step_median": round(med * 1e3, 2), "ms_per_step_block_mean": round(mean * 1e3, 2),
+                         "ms_per_step_sorted": [round(t * 1e3, 1) for t in ts], "reported": "median"}
 
 
 def reference_policy_legs(model, v1, v2, args, dev):
@@ -201,7 +305,7 @@ def reference_policy_legs(model, v1, v2, args, dev):
     (engine.precision("bf16x3"): split-operand GEMMs / convolutions / attention products on the matrix pipe) — the mode that meets
     the 1e-3 / 1e-2 gate (tests/test_precision_modes_gpu.py) — at the headline batch; (c) the encoder + decoder alone (linear
     head, 0.15 % of the FLOPs), the quantity the 40 % MFMA target is defined on; (d) the headline forward with an fp32 residual
-    stream instead of the reference's bf16 one."""
+    stream instead of the reference's bf16 one.  Every leg: steps fenced one by one, median AND block mean reported (timed_each)."""
     from uniception_amd import engine
     from uniception_amd.models.factory import DUSt3R
     out = {}
@@ -212,47 +316,107 @@ def reference_policy_legs(model, v1, v2, args, dev):
             with torch.no_grad(), engine.precision(mode), engine.attention_precision(args.attention):
                 return m(vv1, vv2)
         return f
+
+    def leg(f, n, extra):
+        f(); f()          # (the first call of a shape runs its fork points one after the other)
+        dt, st = timed_each(f, n)
+        e = {"pairs_per_s": round(args.pairs * n / dt, 2), "ms_per_step": round(dt / n * 1e3, 2), "pairs_per_gpu": args.pairs, "timing": st}
+        e.update(extra)
+        return e, args.pairs * n / dt
     if args.head == "dpt" and args.encoder == "croco":
         torch.manual_seed(0)
         lin = DUSt3R(name="bench_linear", img_size=(args.img, args.img), pred_head_type="linear").to(dev).eval()
-        f = fwd(v1, v2, "bf16", lin)
-        f(); f()
-        dt, per_step = timed_each(f, steps)
-        pps = args.pairs * steps / dt
-        out["enc_dec_linear_head"] = {"pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": args.pairs,
-                                      "enc_dec_mfma_frac": round(pps * GFLOP_ENC_DEC_512 * (args.img / 512) ** 2 / 1e3 / PEAK_BF16_TFLOPS, 4),
-                                      "ms_per_step_sorted": per_step}
+        e, pps = leg(fwd(v1, v2, "bf16", lin), steps, {})
+        e["enc_dec_mfma_frac"] = round(pps * gflop_enc_dec(args.img) / 1e3 / PEAK_BF16_TFLOPS, 4)
+        e["enc_dec_mfma_frac_from"] = "median step time x SURVEY section 8d flops per pair"
+        out["enc_dec_linear_head"] = e
         del lin          # (no torch.cuda.empty_cache() here or anywhere between legs: on some boxes of the pool the leg that runs on freshly
                          #  hipMalloc'ed blocks reads 15-25 % low — 345 instead of 470 pairs/s for this one, 213 instead of 248 for the next —
                          #  while legs that reuse the caching allocator's blocks do not)
     with engine.head_precision("fp32"):
-        f = fwd(v1, v2, "bf16")
-        f(); f()          # (the first call of a shape runs its fork points one after the other)
-        dt, _ = timed_each(f, steps)
-        out["bf16_transformer_fp32class_heads"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
-                                                   "pairs_per_gpu": args.pairs, "heads": "bf16x3 split-operand MFMA, fp32 tensors (~1e-5 from exact fp32 heads)"}
+        out["bf16_transformer_fp32class_heads"], _ = leg(fwd(v1, v2, "bf16"), steps, {"heads": "bf16x3 split-operand MFMA, fp32 tensors (~1e-5 from exact fp32 heads)"})
     with engine.head_precision("follow"):     # round 1-2's headline policy: heads in the transformer's bf16
-        f = fwd(v1, v2, "bf16")
-        f(); f()
-        dt, _ = timed_each(f, steps)
-        out["bf16_transformer_bf16_heads"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
-                                              "pairs_per_gpu": args.pairs, "heads": "bf16 operands and maps (1.7e-2 from exact fp32 heads)"}
+        out["bf16_transformer_bf16_heads"], _ = leg(fwd(v1, v2, "bf16"), steps, {"heads": "bf16 operands and maps (1.7e-2 from exact fp32 heads)"})
     if engine.bf16_stream_enabled() and args.encoder == "croco":
         # the same bf16 forward with the residual stream kept in fp32 (round 1's policy: more accurate than the reference's own bf16
         # stream under autocast, 10 instead of 4 bytes per element in the residual epilogues)
         with engine.bf16_stream(False):
-            f = fwd(v1, v2, "bf16")
-            f(); f()
-            dt, _ = timed_each(f, steps)
-        out["bf16_operands_fp32_residual_stream"] = {"pairs_per_s": round(args.pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
-                                                     "pairs_per_gpu": args.pairs}
-    f = fwd(v1, v2, "bf16x3")
-    f(); f()
-    dt, _ = timed_each(f, 3)
-    out["everything_fp32class"] = {"pairs_per_s": round(args.pairs * 3 / dt, 2), "ms_per_step": round(dt / 3 * 1e3, 2), "pairs_per_gpu": args.pairs,
-                                   "mode": "bf16x3: every GEMM / convolution and both products of the attention as three bf16 MFMA products of "
-                                           "split operands, fp32 accumulate, fp32 softmax, fp32 tensors",
-                                   "meets": "rel-L2 < 1e-3 and max-abs < 1e-2 vs reference (tests/test_precision_modes_gpu.py)"}
+            out["bf16_operands_fp32_residual_stream"], _ = leg(fwd(v1, v2, "bf16"), steps, {})
+    out["everything_fp32class"], _ = leg(fwd(v1, v2, "bf16x3"), 3, {
+        "mode": "bf16x3: every GEMM / convolution and both products of the attention as three bf16 MFMA products of "
+                "split operands, fp32 accumulate, fp32 softmax, fp32 tensors",
+        "meets": "rel-L2 < 1e-3 and max-abs < 1e-2 vs reference (tests/test_precision_modes_gpu.py)"})
+    return out
+
+
+def fwd_224_leg(args, dev, pairs_list=(64, 256)):
+    """north_star's second workload: 224x224 pairs through the same ViT-L/16 + 12-block decoder + DPT model (the reference's own
+    small-image case, encoders/utils.py:57-59), forward, bf16, the headline's policy.  Timed by the same fences as the headline."""
+    from uniception_amd import engine
+    from uniception_amd.models.factory import DUSt3R
+    torch.manual_seed(0)
+    m = DUSt3R(name="bench_224", img_size=(224, 224), pred_head_type=args.head).to(dev).eval()
+    out = {"workload": f"ViT-L/16 CroCo encoder + 12-block decoder + {args.head} head, 224x224 pairs, forward, bf16", "by_pairs_per_gpu": []}
+    gf = gflop_enc_dec(224)
+    for b in pairs_list:
+        a1, a2 = make_views(b, 224, 224, 0, dev)
+
+        def f():
+            with torch.no_grad(), engine.precision("bf16"), engine.attention_precision(args.attention):
+                return m(a1, a2)
+        f(); f(); f()
+        n = 5
+        dt, st = timed_each(f, n)     # (median of fenced steps, like every leg beside the headline: a new model's first steps carry a one-time host stall)
+        pps = b * n / dt
+        out["by_pairs_per_gpu"].append({"pairs_per_gpu": b, "pairs_per_s": round(pps, 1), "ms_per_step": round(dt / n * 1e3, 3), "timing": st,
+                                        "enc_dec_gflop_per_pair": round(gf, 1),
+                                        "enc_dec_mfma_frac_lower_bound": round(pps * gf / 1e3 / PEAK_BF16_TFLOPS, 4)})
+        del a1, a2
+    del m
+    return out
+
+
+def train_step_leg(args, dev, pairs=32, steps=3):
+    """BASELINE configs[2] inside the default line: forward + backward + (1-rank) gradient exchange + AdamW of the same ViT-L + DPT model
+    at 512x512, `pairs` pairs, `steps` individually fenced steps (median AND block mean reported), with its own dense-GEMM roofline."""
+    from uniception_amd import autograd, engine
+    from uniception_amd.models.factory import DUSt3R
+    from uniception_amd.training import Trainer
+    torch.manual_seed(0)
+    m = DUSt3R(name="bench_train", img_size=(args.img, args.img), pred_head_type=args.head).to(dev).train()
+    trainer = Trainer(m, lr=1e-5, weight_decay=0.05)
+    a1, a2 = make_views(pairs, args.img, args.img, 0, dev)
+    g = torch.Generator().manual_seed(2000)
+    gt1 = torch.randn(pairs, args.img, args.img, 3, generator=g).to(dev)
+    gt2 = torch.randn(pairs, args.img, args.img, 3, generator=g).to(dev)
+
+    def step():
+        trainer.zero_grad()
+        with engine.precision("bf16"):
+            r1, r2 = m(a1, a2)
+            loss = autograd.conf_loss(r1["pts3d"], r1["conf"], gt1) + autograd.conf_loss(r2["pts3d_in_other_view"], r2["conf"], gt2)
+        loss.backward()
+        trainer.step()
+        return loss.detach()
+    step(); step()
+    dt, st = timed_each(step, steps)
+    loss = step()
+    assert torch.isfinite(loss).all()
+    pps = pairs * steps / dt
+    gf = gflop_enc_dec(args.img)
+    out = {"workload": f"BASELINE configs[2]: ViT-L/16 + 12-block decoder + {args.head} head, {args.img}x{args.img} pairs, forward + backward + AdamW, "
+                       "synthetic pointmap targets, 1 rank (the gradient exchange is a no-op at world 1)",
+           "pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": pairs, "timing": st,
+           "heads": engine.train_head_dtype_name() if hasattr(engine, "train_head_dtype_name") else "bf16 kernels (forward and backward)",
+           "enc_dec_mfma_frac_lower_bound": round(pps * gf * 3 / 1e3 / PEAK_BF16_TFLOPS, 4),
+           "note": "fraction = pairs/s x 3 x forward enc+dec flops / peak: charges heads, optimizer and the whole step to the enc+dec flops"}
+    if not args.no_roofline:
+        with engine.concurrent(False):
+            roof, fams = roofline_pass(step, a1, "bf16", 1)
+        roof["traffic"], roof["traffic_source"] = None, "not collected for the training step"
+        out["roofline"] = roof
+        out["roofline_families"] = fams
+    del trainer, m, a1, a2, gt1, gt2
     return out
 
 
@@ -411,7 +575,8 @@ def main():
 
     pairs_total = world * args.pairs * args.steps
     value = pairs_total / dt
-    gflop_pair = GFLOP_ENC_DEC_512 * (args.img / 512) ** 2  # informational (exact only at 512)
+    # encoder + decoder flops per pair from the SURVEY section 8d formulas (exact at every image size: attention's N^2 term included)
+    gflop_pair = gflop_enc_dec(args.img) if args.encoder == "croco" else gflop_enc_dec(args.img, patch=14, n_extra=1)
     fwd = args.mode == "fwd"
     enc_name = "ViT-L/16" if args.encoder == "croco" else "DINOv2 ViT-L/14"
     line = {
@@ -430,13 +595,15 @@ def main():
                                "2 (the two views through the encoder, the two decoder branches and the two heads run as concurrent HIP streams)"),
                    "heads": (("TF32-class: fp16 MFMA operands (10-bit mantissa), fp32 accumulate, fp32 final layer + adaptor — the reference's "
                               "fp32 heads under allow_tf32 (2e-3 from exact-fp32 heads; bf16 heads: 1.7e-2)") if (fwd and args.precision == "bf16" and engine.head_dtype_name() == "fp16")
-                             else engine.head_dtype_name()),
+                             else (engine.head_dtype_name() if fwd else
+                                   (engine.train_head_dtype_name() if hasattr(engine, "train_head_dtype_name") else "bf16 kernels (forward and backward)"))),
                    "residual_stream": ("bf16 (the reference's stream under autocast: bf16 sub-layer outputs added to a bf16 x)"
                                        if (fwd and args.precision == "bf16" and args.encoder == "croco" and engine.bf16_stream_enabled())
                                        else "fp32"),
                    "parallelism": (f"dp{world} (independent pairs per rank, no data-path collective)" if fwd else
                                    f"dp{world} (replicated model, bucketed in-place gradient all-reduce over RCCL)")},
         "enc_dec_mfma_frac": round(value / world * gflop_pair * (1 if fwd else 3) / 1e3 / PEAK_BF16_TFLOPS, 4),
+        "enc_dec_gflop_per_pair": round(gflop_pair, 1),
     }
     if share:
         line["config"]["shared_gpu_dry_run"] = "ranks share devices, gloo process group: control-flow check only, not a measurement"
@@ -444,15 +611,19 @@ def main():
         # training: the same kernel family carries the forward and the data-gradient GEMMs (the TN weight-gradient kernel is
         # a separate, smaller share): all dense bf16 uc_gemm launches of a step, forward and backward
         with engine.concurrent(False):
-            line["roofline"] = roofline_pass(step, v1, args.precision, min(args.steps, 2))
+            line["roofline"], line["roofline_families"] = roofline_pass(step, v1, args.precision, min(args.steps, 2))
     if rank == 0 and world == 1 and fwd:
         if not args.no_roofline and args.precision == "bf16":
             with engine.concurrent(False):   # per-launch durations are only defined when kernels do not overlap
-                line["roofline"] = roofline_pass(step, v1, args.precision, min(args.steps, 3))
+                line["roofline"], line["roofline_families"] = roofline_pass(step, v1, args.precision, min(args.steps, 3))
             line["roofline"]["schedule"] = ("single-stream pass (engine.concurrent(False), = bench.py --single-stream, the command of the "
                                             "committed profiles); the timed region runs two kernel streams")
         if not args.no_reference_policy and args.precision == "bf16" and not args.graph:
             line["reference_policy"] = reference_policy_legs(model, v1, v2, args, dev)
+        if (not args.no_extra_legs and args.precision == "bf16" and not args.graph and args.encoder == "croco" and args.img == 512
+                and args.attention == "bf16"):
+            line["fwd_224"] = fwd_224_leg(args, dev)
+            line["train_step"] = train_step_leg(args, dev)
         if args.sweep:
             line["batch_sweep"] = batch_sweep(model, [int(x) for x in args.sweep.split(",")], args, dev)
         if not args.no_cpu_baseline:

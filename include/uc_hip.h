@@ -44,8 +44,10 @@ const char* uc_last_error(void);
  *      fp8 attention, DINOv2 token ops.  3: uc_attention_fwd_fp8_k8, uc_k_pack_fp8 added.  4/5: see INTEGRATION.md.
  *   6: uc_adaptor_program_bwd added.  7: uc_build_flavor, uc_tuning_set / uc_tuning_get (environment knobs read once; no
  *      diagnostics in the release build), uc_attention_fwd_x3.  8: uc_gemm_desc gained ln_nblk / ln_eps.  9: uc_gemm_tn_conv_tiles added.
- *   10: uc_attention_fwd_x3 takes RoPE-2D positions (rotation fused into its operand split). */
-#define UC_ABI_VERSION 10
+ *   10: uc_attention_fwd_x3 takes RoPE-2D positions (rotation fused into its operand split).
+ *   11: the folded LayerNorm's block statistics (uc_gemm_desc.stats_out, ln_stats with ln_nblk > 0, uc_ln_stats_finalize) are
+ *       block-major [N/64][M][2] instead of [M][N/64][2]. */
+#define UC_ABI_VERSION 11
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
 const char* uc_build_flavor(void);
@@ -153,8 +155,9 @@ typedef struct uc_gemm_desc {
        the pre-LN sub-layers (libs/croco/blocks.py:158-161, utils/transformer_blocks.py:643-646):
        producer (the GEMM that writes the fp32 residual stream: proj, fc2, patch / input embedding; out_dtype UC_F32):
          twin_out : if non-NULL, the stored rows are also written as bf16 to twin_out [M, ldt] — the A operand of the consumer;
-         stats_out: if non-NULL, [M][N/64][2] fp32: per row and 64-column block (sum, sum of squared deviations from the block
-                    mean) of the stored values; uc_ln_stats_finalize merges the blocks into (mean, rstd) per row;
+         stats_out: if non-NULL, [N/64][M][2] fp32, BLOCK-major (ABI 11; [M][N/64][2] before): per 64-column block and row (sum, sum
+                    of squared deviations from the block mean) of the stored values — a wave's 64 rows of one block are 512
+                    contiguous bytes, written by one store; uc_ln_stats_finalize merges the blocks into (mean, rstd) per row;
        consumer (qkv, q / kv projections, fc1; out_dtype UC_BF16, no residual):
          A = the bf16 twin (RAW rows x), W = W * gamma[k] (bf16), bias = b + W beta,
          ln_stats : [M][2] fp32 (mean, rstd) of the rows of x, ln_colsum: [N] fp32 = sum_k W'[n,k] of the bf16 W';
@@ -173,7 +176,7 @@ typedef struct uc_gemm_desc {
     const float* tail_b;   /* [4] fp32 or NULL */
     float* tail_out;       /* [M][4] fp32 */
     /* Consumer side of the folded LayerNorm WITHOUT the uc_ln_stats_finalize launch (ABI 8): with ln_nblk > 0, ln_stats points at the
-       producer's per-block partials [M][ln_nblk][2] (its stats_out; K == 64 * ln_nblk) and every row's (mean, rstd) is merged in
+       producer's per-block partials [ln_nblk][M][2] (its stats_out, block-major; K == 64 * ln_nblk) and every row's (mean, rstd) is merged in
        the epilogue — the same arithmetic, bit for bit, as uc_ln_stats_finalize with ln_eps.  For small batches, where the ~120
        merge launches of a forward are a tenth of its time; at large M the stand-alone merge is cheaper (every column tile of a
        row panel repeats the in-epilogue merge).  ln_nblk == 0: ln_stats holds finalized (mean, rstd) rows. */
@@ -203,7 +206,7 @@ int uc_add_view_pe(float* x, const float* pe, int64_t B, int L, int T, int V, in
  * factory/dust3r.py:288-309, to ~2^-16 per product).  C % 8 == 0. */
 int uc_split_bf16x3(const float* x, void* out, int64_t rows, int C, int relu, uc_stream_t stream);
 
-/* Merge the per-block row statistics a producer GEMM wrote (stats_out: [rows][nblk][2] = (sum, squared deviations from the
+/* Merge the per-block row statistics a producer GEMM wrote (stats_out: [nblk][rows][2], block-major = (sum, squared deviations from the
  * block mean) over 64-column blocks, C = 64 * nblk columns) into LayerNorm statistics: out[row] = (mean, 1/sqrt(var_biased + eps)). */
 int uc_ln_stats_finalize(const float* partial, int64_t rows, int nblk, float eps, float* out, uc_stream_t stream);
 

@@ -107,7 +107,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 10   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 11   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

@@ -126,13 +126,15 @@ __device__ __forceinline__ float uc_ln_tree16(const float (&v)[16]) {
     for (int q = 0; q < 4; ++q) b[q] = a[q] + a[q + 4];
     return (b[0] + b[2]) + (b[1] + b[3]);
 }
-__device__ __forceinline__ float2 uc_ln_merge_row(const float2* __restrict__ p, int nblk, float eps) {
+// p[b * stride] = block b of the row: stride 1 for a row-major [rows][nblk] array, `rows` for the block-major [nblk][rows] array the
+// producer GEMMs write since ABI 11 (one coalesced statistics store per 64 rows instead of a scattered 8-byte store per row)
+__device__ __forceinline__ float2 uc_ln_merge_row(const float2* __restrict__ p, int64_t stride, int nblk, float eps) {
 #pragma clang fp contract(off)
     float s[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         s[q] = 0.f;
-        for (int b = q; b < nblk; b += 16) s[q] += p[b].x;
+        for (int b = q; b < nblk; b += 16) s[q] += p[b * stride].x;
     }
     const float cnt = 64.f * (float)nblk;
     const float mu = uc_ln_tree16(s) / cnt;
@@ -140,8 +142,9 @@ __device__ __forceinline__ float2 uc_ln_merge_row(const float2* __restrict__ p, 
     for (int q = 0; q < 16; ++q) {
         s[q] = 0.f;
         for (int b = q; b < nblk; b += 16) {
-            const float d = p[b].x * (1.f / 64.f) - mu;
-            s[q] += p[b].y + (64.f * d) * d;
+            const float2 pb = p[b * stride];
+            const float d = pb.x * (1.f / 64.f) - mu;
+            s[q] += pb.y + (64.f * d) * d;
         }
     }
     return make_float2(mu, 1.0f / sqrtf(uc_ln_tree16(s) / cnt + eps));

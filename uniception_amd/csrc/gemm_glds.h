@@ -32,13 +32,13 @@ struct GldsParams {
     const float* ln_colsum;   // [N] sum_k W'[n,k]
     // ... or, instead of finalized ln_stats, the producer's per-block partials: merged per row in the epilogue (uc_ln_merge_row) —
     // small batches, where a 4-us merge launch per LayerNorm is a tenth of the forward
-    const float2* ln_partial; // [M][ln_nblk] (sum, squared deviations from the block mean) per 64-column block of x
+    const float2* ln_partial; // [ln_nblk][M] (block-major) (sum, squared deviations from the block mean) per 64-column block of x
     int ln_nblk;
     float ln_eps;
     // producer side (fp32-output epilogue): bf16 twin of the stored rows and per-row statistics of every 64-column block
     bf16_t* twin;             // [M, ldt] bf16 copy of C, or NULL
     int64_t ldt;
-    float2* stats_out;        // [M][N/64] (sum, sum of squared deviations from the block mean), or NULL
+    float2* stats_out;        // [N/64][M] (block-major) (sum, sum of squared deviations from the block mean), or NULL
     // fused narrow tail (N == 128): out4[m][o] = tail_b[o] + sum_n act(acc + bias)[m][n] * tail_w[o][n]; C is not stored
     const float* tail_w;      // [4][N]
     const float* tail_b;      // [4] or NULL

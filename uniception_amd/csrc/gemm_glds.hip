@@ -43,7 +43,9 @@ int uc_launch_gemm_glds(const GldsParams& p, int variant, hipStream_t st, bool a
         // start their first round of workgroups in 8 phase groups 1.5 us apart (by row panel, see the kernel):
         // encoder proj 480 -> 432 us, fc2 1095 -> 1043 us; neutral-to-worse for shorter launches, hence the threshold.
         GldsParams q = p;
-        if (q.stagger < 0) q.stagger = ((variant == 2 || variant == 6 || variant == 7) && (int64_t)ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 6 * 256) ? 150 : 0;
+        // (bf16 residual stream, round 4: 4 bytes per element in the epilogue — the stagger measures 316 vs 322 us AGAINST it on the encoder's
+        //  proj GEMM: off for that family)
+        if (q.stagger < 0) q.stagger = (!bf16_stream && (variant == 2 || variant == 6 || variant == 7) && (int64_t)ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 6 * 256) ? 150 : 0;
         if (bf16_stream) glds_launch_dense_bs(q, variant, st);
         else glds_launch_dense_f32(q, variant, st);
         return 0;

@@ -173,7 +173,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // (mean, rstd) of row m for the folded-LayerNorm epilogues: finalized by uc_ln_stats_finalize, or merged here from the producer's
 // block partials (small batches)
 __device__ __forceinline__ float2 glds_ln_row_stats(glds_pe_t p, int64_t m) {
-    if (p.ln_partial) return uc_ln_merge_row(p.ln_partial + m * p.ln_nblk, p.ln_nblk, p.ln_eps);
+    if (p.ln_partial) return uc_ln_merge_row(p.ln_partial + m, p.M, p.ln_nblk, p.ln_eps);      // partials are [nblk][M]
     return p.ln_stats[m];
 }
 
@@ -509,7 +509,8 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
     const unsigned toff = (unsigned)(crow * (int)p.ldt + 4 * cc) * 2u;
     const int64_t tstep = 4 * p.ldt * 2;
     const int nblk = (int)(p.N >> 6);
-    float2* sbase = p.stats_out ? p.stats_out + wave_m * nblk + (wave_n >> 6) : nullptr;
+    float2* sbase = p.stats_out ? p.stats_out + (wave_n >> 6) * p.M + wave_m : nullptr;      // [N/64][M]: block-major (ABI 11)
+    (void)nblk;
     // ONE register set for the residual: pass ps of row block i + 1 is requested as soon as pass ps of block i has used
     // its value (each element is still read before the in-place store of its own row), so 4 loads per lane stay in flight.
     // (BS: the four bf16 values stay packed — 2 registers — until they are used; one residual only, see the launcher)
@@ -569,7 +570,7 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
                 if constexpr (NT) __builtin_nontemporal_store(v, cq); else *cq = v;
                 if (tbase) *reinterpret_cast<uint2*>(tbase + (4 * i + ps) * tstep + toff) = (uint2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
             }
-            if (sbase) {   // all 64 lanes take part in the row reductions (rows past M carry finite garbage and are not stored)
+            if (sbase && !UC_DBG(p, 512)) {   // all 64 lanes take part in the row reductions (rows past M carry finite garbage and are not stored)
                 // (no FMA contraction here: hipcc contracts each unrolled copy of this block differently, and a row's statistics —
                 // hence the bf16 roundings of everything downstream — must not depend on where in a tile the row sits)
 #pragma clang fp contract(off)
@@ -577,8 +578,111 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
                 const float mu = s * (1.f / 64.f);
                 const float4_t dv = v - mu;
                 const float q = glds_row16_sum((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w));
-                if (row_ok && cc == 0) sbase[(int64_t)(16 * i + 4 * ps + crow) * nblk] = make_float2(s, q);
+                if (row_ok && cc == 0 && !UC_DBG(p, 1024)) sbase[16 * i + 4 * ps + crow] = make_float2(s, q);
             }
+        }
+    }
+}
+
+#ifndef GLDS_BS_RES_AHEAD
+#define GLDS_BS_RES_AHEAD 2     // row blocks of residual in flight ahead of the one being drained (bf16-stream epilogue)
+#endif
+// sum over the 8 lanes 8k .. 8k+7 (one row of the bf16-stream drain), result in every lane: xor 1, xor 2 inside the quad, then the
+// mirrored lane of the 8-lane half row (which lies in the other quad)
+__device__ __forceinline__ float glds_row8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    return v;
+}
+
+// bf16 residual stream (round 4 form): bf16 output = one rounding of acc + bias + bf16 residual, row statistics of the STORED rows.
+// Round 3 ran this through the fp32 residual drain (4 columns per lane: 8-byte loads / stores, one scattered 8-byte statistics store
+// per row and wave): measured on the encoder's proj GEMM (316 us; 236 with a plain bf16 store) 20 us were the statistics stores
+// (1024 eight-byte stores to 1024 different lines per tile), 6 us the reductions, 36 us the residual read (at the HBM burst rate: all
+// CUs reach their epilogues together) and 18 us the drain's own instructions.  Here: the bf16-store drain layout — 8 columns per lane,
+// 8 lanes per row, 8 rows x 128 B per instruction: 16-byte residual loads and stores, half the instructions; the row sums over 8
+// lanes (3 DPP steps instead of 4) of 8 in-lane values; and the statistics leave as ONE coalesced store per 64 rows: after each pass
+// every lane of a row holds that row's pair, lane (crow, cc) keeps the pair of pass cc, so at the end lane (crow, cc) owns row
+// 8 cc + crow and the 64 lanes write 512 contiguous bytes of the block-major statistics array [N/64][M] (ABI 11).
+template <int FA, bool NT>
+__device__ __forceinline__ void glds_epilogue_bs(glds_pe_t p, float4_t (&acc)[FA][4], int /*mode*/, int64_t wave_m, int64_t wave_n, int lane,
+                                                 char* wbuf) {
+    constexpr int mode = 0;      // (the launcher routes no RoPE / VT tile to this family: keeps the RoPE branch of glds_stage_rows out of the kernel)
+    const int frow = lane & 15, g = lane >> 4;
+    const int crow = lane >> 3, cc = lane & 7;
+    const int64_t nb = wave_n + 8 * cc;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f}, bias4b = bias4;
+    if (mode != 1 && p.bias) {
+        bias4 = *reinterpret_cast<const float4_t*>(p.bias + nb);
+        bias4b = *reinterpret_cast<const float4_t*>(p.bias + nb + 4);
+    }
+    const int rows_total = (int)min((int64_t)(16 * FA), p.M - wave_m);
+    const int rows_left = rows_total - crow;              // row 16i + 8ps + crow exists iff 16i + 8ps < rows_left
+    // wave-uniform 64-bit bases + one 32-bit lane offset per matrix (see glds_epilogue_resid)
+    char* cbase = (char*)p.C + (wave_m * p.ldc + wave_n) * 2;
+    const unsigned coff = (unsigned)(crow * (int)p.ldc + 8 * cc) * 2u;
+    const int64_t cstep = 8 * p.ldc * 2;
+    const char* rbase = (p.residual && !UC_DBG(p, 128)) ? (const char*)p.residual + (wave_m * p.ldr + wave_n) * 2 : nullptr;
+    const unsigned roff = (unsigned)(crow * (int)p.ldr + 8 * cc) * 2u;
+    const int64_t rstep = 8 * p.ldr * 2;
+    float2* sbase = (p.stats_out && !UC_DBG(p, 512)) ? p.stats_out + (wave_n >> 6) * p.M + wave_m : nullptr;
+    // the residual of the next AHEAD row blocks (2 x 16 bytes per lane each) is in flight while block i drains
+    constexpr int AHEAD = GLDS_BS_RES_AHEAD;
+    uint4_t res[AHEAD][2];
+    auto load_res = [&](int i, int ps) __attribute__((always_inline)) {
+        res[i % AHEAD][ps] = (uint4_t){0u, 0u, 0u, 0u};
+        if (rbase && 16 * i + 8 * ps < rows_left) {
+            const uint4_t* q = reinterpret_cast<const uint4_t*>(rbase + (2 * i + ps) * rstep + roff);
+            if constexpr (NT) res[i % AHEAD][ps] = __builtin_nontemporal_load(q); else res[i % AHEAD][ps] = *q;
+        }
+    };
+    auto lo = [](unsigned u) __attribute__((always_inline)) { return __uint_as_float(u << 16); };
+    auto hi = [](unsigned u) __attribute__((always_inline)) { return __uint_as_float(u & 0xffff0000u); };
+    float keep_s[FA / 4], keep_q[FA / 4];
+#pragma unroll
+    for (int h = 0; h < FA / 4; ++h) keep_s[h] = keep_q[h] = 0.f;
+#pragma unroll
+    for (int i = 0; i < AHEAD && i < FA; ++i) { load_res(i, 0); load_res(i, 1); }
+    glds_stage_rows<FA>(p, acc, 0, mode, wave_m, wave_n, frow, g, wbuf);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const char* buf = wbuf + (i & 1) * 4096;
+        if (i + 1 < FA) glds_stage_rows<FA>(p, acc, i + 1, mode, wave_m, wave_n, frow, g, wbuf + ((i + 1) & 1) * 4096);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int R = 8 * ps + crow;
+            float4_t v = glds_bounce_read(buf, R, 2 * cc), w = glds_bounce_read(buf, R, 2 * cc + 1);
+            if (mode != 1) { v += bias4; w += bias4b; }
+            const uint4_t rr = res[i % AHEAD][ps];
+            v += (float4_t){lo(rr.x), hi(rr.x), lo(rr.y), hi(rr.y)};
+            w += (float4_t){lo(rr.z), hi(rr.z), lo(rr.w), hi(rr.w)};
+            if (i + AHEAD < FA) load_res(i + AHEAD, ps);
+            const bool row_ok = 16 * i + 8 * ps < rows_left;
+            const uint4_t pk = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w), pack_bf16x2(w.x, w.y), pack_bf16x2(w.z, w.w)};
+            if (row_ok) {
+                uint4_t* cq = reinterpret_cast<uint4_t*>(cbase + (2 * i + ps) * cstep + coff);
+                if constexpr (NT) __builtin_nontemporal_store(pk, cq); else *cq = pk;
+            }
+            if (sbase) {   // statistics of the stored (rounded) row; all 64 lanes take part (rows past M carry finite garbage, not stored)
+                // (no FMA contraction: a row's statistics must not depend on where in a tile the row sits — see glds_epilogue_resid)
+#pragma clang fp contract(off)
+                const float x0 = lo(pk.x), x1 = hi(pk.x), x2 = lo(pk.y), x3 = hi(pk.y), x4 = lo(pk.z), x5 = hi(pk.z), x6 = lo(pk.w), x7 = hi(pk.w);
+                const float s = glds_row8_sum(((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7)));
+                const float mu = s * (1.f / 64.f);
+                const float d0 = x0 - mu, d1 = x1 - mu, d2 = x2 - mu, d3 = x3 - mu, d4 = x4 - mu, d5 = x5 - mu, d6 = x6 - mu, d7 = x7 - mu;
+                const float q = glds_row8_sum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7)));
+                const bool mine = cc == ((2 * i + ps) & 7);
+                keep_s[(2 * i + ps) >> 3] = mine ? s : keep_s[(2 * i + ps) >> 3];
+                keep_q[(2 * i + ps) >> 3] = mine ? q : keep_q[(2 * i + ps) >> 3];
+            }
+        }
+    }
+    if (sbase && !UC_DBG(p, 1024)) {
+#pragma unroll
+        for (int h = 0; h < FA / 4; ++h) {
+            const int row = 64 * h + 8 * cc + crow;      // pass 8 h + cc covered rows 64 h + 8 cc + (0..7)
+            if (row < rows_total) sbase[row] = make_float2(keep_s[h], keep_q[h]);
         }
     }
 }
@@ -954,8 +1058,8 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
         } else if constexpr (EPI == GLDS_EPI_F32) {
             f32_family();
         } else if constexpr (EPI == GLDS_EPI_BS) {          // bf16 residual stream: bf16 output + bf16 residual(s) + row statistics
-            if (pe.nt_out & 1) glds_epilogue_resid<FA, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-            else glds_epilogue_resid<FA, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            if (pe.nt_out & 1) glds_epilogue_bs<FA, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_bs<FA, false>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
         } else {
             if constexpr (A_MODE != UC_A_DENSE && FA == 4) {
                 if (pe.tail_out) {      // (launcher: N == 128 on a 128-wide tile, every wave of the workgroup arrives here)

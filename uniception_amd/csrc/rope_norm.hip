@@ -348,17 +348,17 @@ extern "C" int uc_layernorm(const void* x, int x_dtype, const float* gamma, cons
 // mu_b and the row mean mu,  M2 = sum_b [ M2_b + 64 (mu_b - mu)^2 ].  One thread per row (nblk <= 64 blocks of 8 bytes).
 // ---------------------------------------------------------------------------------------
 __global__ void ln_stats_finalize_kernel(const float2* __restrict__ partial, int64_t rows, int nblk, float eps, float2* __restrict__ out) {
-    // one thread per row (a row's partials are one contiguous 8 * nblk-byte run); the merge itself is uc_ln_merge_row (common.h),
+    // one thread per row; the merge itself is uc_ln_merge_row (common.h),
     // shared with the consumer GEMM's epilogue
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < rows) out[r] = uc_ln_merge_row(partial + r * nblk, nblk, eps);
+    if (r < rows) out[r] = uc_ln_merge_row(partial + r, rows, nblk, eps);     // block-major partials [nblk][rows]: coalesced across the rows of a wave
 }
 
 extern "C" int uc_ln_stats_finalize(const float* partial, int64_t rows, int nblk, float eps, float* out, uc_stream_t stream) {
     UC_REQUIRE(partial && out && rows >= 0 && nblk > 0, "uc_ln_stats_finalize: bad argument");
     UC_REQUIRE((uintptr_t)partial % 8 == 0 && (uintptr_t)out % 8 == 0, "uc_ln_stats_finalize: 8-byte alignment");
     if (rows == 0) return UC_OK;
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float2*)partial, rows, nblk, eps, (float2*)out);
     UC_CHECK_LAUNCH("uc_ln_stats_finalize");
     return UC_OK;

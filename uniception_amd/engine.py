@@ -73,6 +73,13 @@ def head_dtype_name() -> str:
     return _head_mode
 
 
+def train_head_dtype_name() -> str:
+    "What the prediction heads compute in while autograd records (for reports): see head_dtype()."
+    if _head_mode in ("fp32", "fp32_exact"):
+        return "fp32-class heads in training (policy %s): fp32 tensors, split bf16 operands forward and backward" % _head_mode
+    return "bf16 kernels, forward and backward (policy %s applies to inference; the reference trains its heads in fp32 / TF32)" % _head_mode
+
+
 @contextlib.contextmanager
 def head_precision(mode: str):
     "Scoped set_head_precision."

@@ -243,7 +243,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         assert cs.dtype == torch.float32 and cs.is_contiguous() and cs.numel() == N
         if isinstance(st, LnPartial):     # block partials merged in this GEMM's epilogue (small batches: no finalize launch)
             pt = st.partial
-            assert pt.dtype == torch.float32 and pt.is_contiguous() and pt.shape == (M, K // 64, 2)
+            assert pt.dtype == torch.float32 and pt.is_contiguous() and pt.shape == (K // 64, M, 2)     # block-major
             d.ln_stats, d.ln_nblk, d.ln_eps = pt.data_ptr(), K // 64, float(st.eps)
         else:
             assert st.dtype == torch.float32 and st.is_contiguous() and st.shape == (M, 2)
@@ -252,7 +252,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     side = None
     if emit_ln:
         assert out.dim() == 2 and N % 64 == 0 and vt is None
-        partial = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
+        partial = torch.empty((N // 64, M, 2), dtype=torch.float32, device=a.device)     # block-major: [N/64][M] (sum, M2) pairs
         if out.dtype == torch.bfloat16:      # bf16 residual stream: the stored rows are their own twin
             assert out.is_contiguous() and (residual is None or residual.dtype == torch.bfloat16)
             side = LnSide(out, partial)
@@ -333,7 +333,7 @@ class LnSide:
     def stats_arg(self, eps: float):
         """What the consumer GEMM gets as its LayerNorm statistics: the block partials themselves for small batches (merged in its
         epilogue: same bits, no launch), the finalized (mean, rstd) rows otherwise."""
-        if (self.partial.shape[0] <= LN_MERGE_IN_EPILOGUE_MAX_ROWS and eps not in self._stats
+        if (self.partial.shape[1] <= LN_MERGE_IN_EPILOGUE_MAX_ROWS and eps not in self._stats
                 and not torch.cuda.is_current_stream_capturing()):
             return LnPartial(self.partial, eps)
         return self.stats(eps)
@@ -341,7 +341,7 @@ class LnSide:
     def stats(self, eps: float) -> torch.Tensor:
         st = self._stats.get(eps)
         if st is None:
-            M, nblk, _ = self.partial.shape
+            nblk, M, _ = self.partial.shape
             st = torch.empty((M, 2), dtype=torch.float32, device=self.partial.device)
             _lib.check(_lib.load().uc_ln_stats_finalize(self.partial.data_ptr(), M, nblk, float(eps), st.data_ptr(), _stream()),
                        "uc_ln_stats_finalize")
