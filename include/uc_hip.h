@@ -5,10 +5,12 @@
  * Boundary rules:
  *   - extern "C", plain pointers + explicit sizes/strides, no torch types.
  *   - every entry point is asynchronous on the hipStream_t it is given, allocates
- *     nothing, keeps no mutable global state (except the thread-local last-error text and
- *     the tuning knobs below: environment read ONCE under std::call_once, two run-time
- *     switchable atomics — all of them choose between correct code paths)
- *     and returns 0 on success or a negative uc_status.
+ *     nothing (no hipMalloc* is reachable from the release library: tests/test_abi.py reads
+ *     its import table), takes every workspace from the caller (uc_attention_x3_workspace_bytes,
+ *     uc_gemm_fuse_ws_bytes) and keeps no mutable global state except the thread-local
+ *     last-error text and the tuning knobs below (environment read ONCE under
+ *     std::call_once, a few run-time switchable atomics — all of them choose between
+ *     correct code paths); returns 0 on success or a negative uc_status.
  *   - the shipped (release) build contains no diagnostics: the wrong-result anatomy
  *     switches and the allocating / synchronising timeline trace of the kernel work exist
  *     only in a -DUC_DIAG build (libuc_hip_diag.so, uc_build_flavor() == "diag").
@@ -46,7 +48,8 @@ const char* uc_last_error(void);
  *      diagnostics in the release build), uc_attention_fwd_x3.  8: uc_gemm_desc gained ln_nblk / ln_eps.  9: uc_gemm_tn_conv_tiles added.
  *   10: uc_attention_fwd_x3 takes RoPE-2D positions (rotation fused into its operand split).
  *   11: the folded LayerNorm's block statistics (uc_gemm_desc.stats_out, ln_stats with ln_nblk > 0, uc_ln_stats_finalize) are
- *       block-major [N/64][M][2] instead of [M][N/64][2]. */
+ *       block-major [N/64][M][2] instead of [M][N/64][2]; uc_gemm_desc gained fuse_ws (caller-provided hand-over buffer of the
+ *       small-M path, uc_gemm_fuse_ws_bytes): the library no longer allocates. */
 #define UC_ABI_VERSION 11
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
@@ -182,17 +185,24 @@ typedef struct uc_gemm_desc {
        row panel repeats the in-epilogue merge).  ln_nblk == 0: ln_stats holds finalized (mean, rstd) rows. */
     int ln_nblk;
     float ln_eps;
+    /* Hand-over buffer of the small-M path (ABI 11; see the notes below), or NULL: CALLER-provided — uc_gemm allocates nothing.
+       uc_gemm_fuse_ws_bytes() bytes of UNCACHED device memory (hipExtMallocWithFlags(.., hipDeviceMallocUncached): the two halves of
+       a split tile may run on different XCDs, whose L2s are not coherent), zero-filled once by the caller, 256-byte aligned, used
+       by ONE launch at a time — one buffer per stream that issues such launches, and one per stream of a captured graph for as
+       long as the graph lives.  The library leaves its flag words zero after every launch. */
+    void* fuse_ws;
 } uc_gemm_desc;
 
 /* Notes on uc_gemm's behaviour outside the descriptor:
- *   small-M path — a dense bf16 launch whose 128 x 128 tiles cover at most half the CUs, with K >= the tuning knob small_m_split
- *   (UC_GEMM_SMALLM, default 2048; 0 = never), splits K in two across twice the workgroups and hands the first half's accumulators
- *   over inside the kernel.  The hand-over buffers (8 MiB of uncached device memory per stream that makes such launches) come from
- *   a pool the library grows in chunks of 64 MiB, at such launches outside a stream capture (at most 512 MiB; a stream keeps the
- *   buffer it was given; launches on a
- *   stream that meets an empty pool — e.g. a capture before any eager launch — run unsplit).  The result is the same sum taken in
- *   two halves: not bit-identical to the unsplit kernel (and therefore to the same rows inside a larger batch); small_m_split = 0
- *   restores one chain per accumulator for every batch size. */
+ *   small-M path — a dense bf16 launch whose 128 x 128 tiles cover at most half the CUs (and at most 128 tiles), with K >= the
+ *   tuning knob small_m_split (UC_GEMM_SMALLM, default 2048; 0 = never) AND a caller-provided hand-over buffer (desc->fuse_ws),
+ *   splits K in two across twice the workgroups and hands the first half's accumulators over inside the kernel.  Without a buffer
+ *   the launch runs unsplit.  The result is the same sum taken in two halves: not bit-identical to the unsplit kernel (and therefore
+ *   to the same rows inside a larger batch); small_m_split = 0, or fuse_ws = NULL, keeps one chain per accumulator for every batch
+ *   size.  Nothing in libuc_hip.so allocates device memory or keeps per-stream state (round 3 kept a lazily grown pool inside
+ *   uc_gemm: removed). */
+/* Size in bytes of a hand-over buffer for desc->fuse_ws: 128 tiles x 128 x 128 fp32 partial sums + 128 flag words. */
+int64_t uc_gemm_fuse_ws_bytes(void);
 int uc_gemm(const uc_gemm_desc* desc, uc_stream_t stream);
 
 /* View positional encoding of the global / alternating multi-view transformers

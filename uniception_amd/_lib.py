@@ -45,7 +45,7 @@ class GemmDesc(C.Structure):
         ("C", vp), ("out_dtype", i32), ("ldc", i64),
         ("twin_out", vp), ("ldt", i64), ("stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
         ("tail_w", vp), ("tail_b", vp), ("tail_out", vp),
-        ("ln_nblk", i32), ("ln_eps", f32),
+        ("ln_nblk", i32), ("ln_eps", f32), ("fuse_ws", vp),
     ]
 
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     "uc_add_view_pe": [vp, vp, i64, i32, i32, i32, i32, vp],
     "uc_attention_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp],
     "uc_attention_x3_workspace_bytes": [i32, i32, i32, i32],
+    "uc_gemm_fuse_ws_bytes": [],
     "uc_attention_fwd_x3": [vp, vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, vp, vp, vp, i32, vp],
     "uc_attention_fwd_fp8": [vp, vp, vp, vp, i32, i32, i32, i32] + [i64] * 9 + [f32, vp],
     "uc_vt_pack_fp8": [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],

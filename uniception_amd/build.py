@@ -92,9 +92,42 @@ def build(force=False, verbose=True):
     if verbose:
         print("[uniception_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    check_glds4_agprs(fp, verbose)
     with open(stamp, "w") as f:
         f.write(fp)
     return LIB
+
+
+def check_glds4_agprs(fp=None, verbose=True):
+    """gemm_bf16_glds4_kernel hands 256 accumulators from its asm K-loop to the C++ epilogues in the PHYSICAL registers a0..a255
+    (not declarable as asm outputs): sound only while the compiler itself touches no AGPR in that kernel.  Proven here on the code
+    THIS compiler generates for all four translation units that instantiate it (tools/check_glds4_agprs.py), once per build
+    fingerprint; a violation fails the build — the library is not stamped and never loads silently wrong."""
+    fp = fp or _fingerprint()
+    mark = LIB + ".agpr"
+    try:
+        with open(mark) as f:
+            if f.read().strip() == fp:
+                return
+    except OSError:
+        pass
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import check_glds4_agprs as chk
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        reports = list(ex.map(chk.check, chk.TUS))
+    n = 0
+    for tu, rep in zip(chk.TUS, reports):
+        for name, (blocks, bad) in rep.items():
+            n += 1
+            if bad or blocks < 257:
+                raise RuntimeError(f"[uniception_amd.build] {tu}: {name}: the compiler uses AGPRs outside the asm K-loop ({bad[:3]}, {blocks} asm "
+                                   "statements): the four-wave GEMM would be silently wrong with this compiler — set UC_GEMM_4WAVE=0 and report")
+    if n < 4:
+        raise RuntimeError(f"[uniception_amd.build] AGPR check found only {n} gemm_bf16_glds4_kernel instantiations (expected 4)")
+    if verbose:
+        print(f"[uniception_amd.build] AGPR hand-over check: {n} gemm_bf16_glds4_kernel instantiations clean", flush=True)
+    with open(mark, "w") as f:
+        f.write(fp)
 
 
 def build_diag(verbose=True):

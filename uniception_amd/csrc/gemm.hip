@@ -434,56 +434,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-// =======================================================================================
-// hand-over workspaces of the fused two-way K split (gemm_glds.h: fuse_split2): 128 tiles x 64 KiB + one flag per tile each.  Launches of
-// a stream are ordered, launches of different streams (the two views' branches) must not share one: a stream keeps the set it was
-// given, and so does every (capture, stream) pair — a graph owns the sets of the launches recorded into it.  The sets come from a pool that grows in chunks of 8 (64 MiB of uncached device memory) at eligible launches OUTSIDE a stream
-// capture, whenever fewer than 4 are free (allocation is not allowed inside a capture; neither is asking another stream whether it
-// is idle, so sets are not taken back): handing a pooled set to a new stream is bookkeeping only, and the streams a capture brings
-// along (torch's capture stream, the branch streams) find one — a graph then holds the same kernels as the eager run it was warmed
-// up with.  At most 64 sets (a PyTorch process has ~36 stream handles per device); nothing free: the launch runs unsplit.
-struct UcFuseWs { float* ws; unsigned* flags; };
-static UcFuseWs uc_fuse_ws(hipStream_t st) {
-    constexpr int CHUNK = 8, RESERVE = 4, MAX_SETS = 64;
-    static std::mutex mu;
-    static std::map<std::tuple<int, hipStream_t, unsigned long long>, UcFuseWs> sets;   // (device, stream, capture id | 0)
-    static std::map<int, std::vector<UcFuseWs>> pool;       // per device: sets not handed out yet
-    static std::map<int, int> made;                         // per device: sets created so far
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
-    auto& free_sets = pool[dev];
-    // a captured launch belongs to its GRAPH, not to the stream it was recorded on (PyTorch records every graph on one capture stream,
-    // and two graphs may be replayed at the same time on different streams): sets of captured launches are keyed by the capture's id
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    unsigned long long cap_id = 0;
-    const bool capturing = hipStreamGetCaptureInfo(st, &cs, &cap_id) != hipSuccess || cs != hipStreamCaptureStatusNone;
-    if (!capturing) cap_id = 0;
-    else if (cap_id == 0) cap_id = ~0ull;
-    if (!capturing && (int)free_sets.size() < RESERVE && made[dev] + CHUNK <= MAX_SETS) {
-        // uncached: the partners may run on different XCDs (separate, non-coherent L2s) — see the kernel
-        float* ws = nullptr;
-        unsigned* flags = nullptr;
-        const size_t per = (size_t)128 * 128 * 128;
-        if (hipExtMallocWithFlags((void**)&ws, CHUNK * per * sizeof(float), hipDeviceMallocUncached) == hipSuccess &&
-            hipExtMallocWithFlags((void**)&flags, CHUNK * 128 * sizeof(unsigned), hipDeviceMallocUncached) == hipSuccess &&
-            hipMemset(flags, 0, CHUNK * 128 * sizeof(unsigned)) == hipSuccess) {
-            for (int i = 0; i < CHUNK; ++i) free_sets.push_back(UcFuseWs{ws + i * per, flags + i * 128});
-            made[dev] += CHUNK;
-        } else {
-            made[dev] = MAX_SETS;      // no memory for it: stop trying
-        }
-    }
-    (void)hipGetLastError();
-    const auto key = std::make_tuple(dev, st, cap_id);
-    auto it = sets.find(key);
-    if (it != sets.end()) return it->second;
-    if (free_sets.empty()) return UcFuseWs{nullptr, nullptr};
-    const UcFuseWs w = free_sets.back();
-    free_sets.pop_back();
-    sets[key] = w;
-    return w;
-}
+// Hand-over buffer of the small-M path (fuse_split2): caller-provided through uc_gemm_desc.fuse_ws (ABI 11) — 128 tiles x 128 x 128 fp32
+// partial sums followed by 128 flag words.  UNCACHED device memory: the partners of a split tile may run on different XCDs (separate,
+// non-coherent L2s).  Round 3 kept a lazily grown, never-freed pool of such buffers in here, keyed by (device, stream, capture id):
+// allocation and a synchronous memset inside a launch path, state a C caller could neither size nor release — removed.
+static constexpr int64_t UC_FUSE_TILES = 128;
+static constexpr int64_t UC_FUSE_WS_FLOATS = UC_FUSE_TILES * 128 * 128;
+extern "C" int64_t uc_gemm_fuse_ws_bytes(void) { return UC_FUSE_WS_FLOATS * (int64_t)sizeof(float) + UC_FUSE_TILES * (int64_t)sizeof(unsigned); }
 
 extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
     UC_REQUIRE(d, "uc_gemm: null descriptor");
@@ -683,9 +640,10 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             const int small_m_k = g_uc_small_m_split.load(std::memory_order_relaxed);
             if (forced_variant < 0 && variant == 0 && d->split_k <= 1 && !d->tail_out && small_m_k > 0 &&
                 d->K >= small_m_k && d->K % 128 == 0 &&
-                2 * ceil_div64(d->M, 128) * ceil_div64(d->N, 128) <= uc_num_cus()) {
-                const UcFuseWs w = uc_fuse_ws(st);
-                if (w.ws) { g.fuse_split2 = 1; g.fs_ws = w.ws; g.fs_flags = w.flags; }
+                2 * ceil_div64(d->M, 128) * ceil_div64(d->N, 128) <= uc_num_cus() &&
+                ceil_div64(d->M, 128) * ceil_div64(d->N, 128) <= UC_FUSE_TILES && d->fuse_ws) {
+                UC_REQUIRE((uintptr_t)d->fuse_ws % 256 == 0, "uc_gemm: fuse_ws must be 256-byte aligned");
+                g.fuse_split2 = 1; g.fs_ws = (float*)d->fuse_ws; g.fs_flags = (unsigned*)((float*)d->fuse_ws + UC_FUSE_WS_FLOATS);
             }
             { const int nt = knobs.gemm_nt;
               const int64_t out_bytes = d->M * d->N * (d->out_dtype == UC_F32 ? 4 : 2);

@@ -15,7 +15,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from . import engine
+from . import engine, ops
 
 
 class GraphedTwoView:
@@ -47,9 +47,20 @@ class GraphedTwoView:
                 self._forward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # hand-over buffers of the small-M GEMM path: the launches recorded below own theirs for as long as this graph lives
+        # (ops.capture_scope); they come from a reserve filled here, outside the capture (allocation is not allowed inside one)
+        ops.fuse_ws_release(id(self))
+        ops.fuse_ws_reserve(4)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with ops.capture_scope(id(self)), torch.cuda.graph(self.graph):
             self.out = self._forward()
+
+    def __del__(self):
+        try:
+            self.graph = None
+            ops.fuse_ws_release(id(self))
+        except Exception:
+            pass
 
     def __call__(self, view1: Dict, view2: Dict) -> Tuple[Dict, Dict]:
         """Replays the captured forward on new images of the captured shape.  The returned tensors are the graph's static

@@ -51,6 +51,8 @@ def tuning_set(name: str, value: int) -> None:
     the CUs splits K in two inside the kernel; 0: never — results are then bit-identical across batch sizes).  Every value selects a correct
     kernel; everything else the library reads from the environment, once (csrc/knobs.h)."""
     _lib.check(_lib.load().uc_tuning_set(name.encode(), int(value)), f"uc_tuning_set({name})")
+    if name == "small_m_split":
+        _small_m_cache[0] = int(value)
 
 
 def tuning_get(name: str) -> int:
@@ -133,6 +135,153 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     if twin:
         y.uc_twin = tw
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# Hand-over buffers of uc_gemm's small-M path (uc_gemm_desc.fuse_ws, ABI 11): the library allocates nothing, the HOST does.
+# A buffer is uc_gemm_fuse_ws_bytes() (8 MiB) of UNCACHED device memory — the two halves of a split tile may run on different
+# XCDs, whose L2s are not coherent; PyTorch's allocator has no such flavour, so the HIP runtime is called directly (ctypes on the
+# libamdhip64 the process already has) — zero-filled once, used by one launch at a time: one per (device, stream), and one per
+# (device, stream, graph) for launches recorded into a hipGraph (its replays may overlap eager launches on the same stream handle).
+# Allocation is not allowed while a stream is capturing: captures draw from a reserve filled beforehand (fuse_ws_reserve, called by
+# graphs.GraphedTwoView); an empty reserve means the launch runs unsplit (uc_gemm's documented behaviour without a buffer).
+# ---------------------------------------------------------------------------------------------
+_HIP_MALLOC_UNCACHED = 0x3      # hipDeviceMallocUncached
+_hip_rt = None
+_fuse_ws_sets = {}              # (device, stream handle, capture token | 0) -> device pointer
+_fuse_ws_free = {}              # device -> [device pointers not handed out]
+_capture_token = 0              # set by capture_scope(): identifies the graph being recorded
+
+
+def _hip_runtime():
+    "The HIP runtime library this process has loaded (PyTorch's): hipExtMallocWithFlags / hipMemset / hipFree."
+    global _hip_rt
+    if _hip_rt is None:
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        _hip_rt = C.CDLL(path or "libamdhip64.so")
+        _hip_rt.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        _hip_rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        _hip_rt.hipFree.argtypes = [C.c_void_p]
+    return _hip_rt
+
+
+def _fuse_ws_new(device_index: int) -> Optional[int]:
+    hip = _hip_runtime()
+    nbytes = int(_lib.load().uc_gemm_fuse_ws_bytes())
+    ptr = C.c_void_p()
+    with torch.cuda.device(device_index):
+        if hip.hipExtMallocWithFlags(C.byref(ptr), nbytes, _HIP_MALLOC_UNCACHED) != 0 or not ptr.value:
+            return None
+        if hip.hipMemset(ptr, 0, nbytes) != 0:        # (synchronous; the flag words must start at zero)
+            hip.hipFree(ptr)
+            return None
+    return ptr.value
+
+
+def fuse_ws_reserve(n: int = 4, device=None) -> None:
+    """Make sure n hand-over buffers are ready to be handed to streams (call OUTSIDE a stream capture, e.g. before recording a graph
+    whose small-M launches should split)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    free = _fuse_ws_free.setdefault(dev, [])
+    while len(free) < n:
+        ptr = _fuse_ws_new(dev)
+        if ptr is None:
+            break
+        free.append(ptr)
+
+
+def fuse_ws_release(token: int) -> None:
+    "Return the buffers of a destroyed graph (capture token) to the reserve."
+    for key in [k for k in _fuse_ws_sets if k[2] == token and token != 0]:
+        _fuse_ws_free.setdefault(key[0], []).append(_fuse_ws_sets.pop(key))
+
+
+def fuse_ws_free_all() -> None:
+    "hipFree every hand-over buffer (only when no launch that uses one can still be in flight: synchronizes first)."
+    torch.cuda.synchronize()
+    hip = _hip_runtime()
+    for ptr in list(_fuse_ws_sets.values()) + [p for v in _fuse_ws_free.values() for p in v]:
+        hip.hipFree(C.c_void_p(ptr))
+    _fuse_ws_sets.clear()
+    _fuse_ws_free.clear()
+
+
+@contextlib.contextmanager
+def capture_scope(token: int):
+    "Launches recorded inside belong to the graph identified by `token` (their hand-over buffers live as long as it does)."
+    global _capture_token
+    prev = _capture_token
+    _capture_token = token
+    try:
+        yield
+    finally:
+        _capture_token = prev
+
+
+def _fuse_ws_for_launch(M: int, N: int, K: int) -> Optional[int]:
+    """The buffer a dense bf16 launch of this shape may use for the in-kernel K split (None: it runs unsplit).  Only shapes uc_gemm
+    can split get one (at most 128 tiles of 128 x 128 on at most half the CUs, K at least the small_m_split knob)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles > 128 or K % 128 != 0:
+        return None
+    smk = _small_m_k()
+    if smk <= 0 or K < smk or 2 * tiles > _num_cus():
+        return None
+    dev = torch.cuda.current_device()
+    capturing = torch.cuda.is_current_stream_capturing()
+    # a captured launch belongs to its GRAPH, not to the stream it was recorded on (PyTorch records every graph on a capture stream, and
+    # two graphs may be replayed at the same time on different streams): keyed by the capture_scope token, else by the capture's own id
+    token = 0
+    if capturing:
+        token = _capture_token or _capture_id(_stream())
+    key = (dev, _stream(), token)
+    ptr = _fuse_ws_sets.get(key)
+    if ptr is None:
+        free = _fuse_ws_free.setdefault(dev, [])
+        if not capturing and len(free) < _FUSE_WS_SPARE + 1:
+            fuse_ws_reserve(_FUSE_WS_SPARE + 1, dev)      # this one + spares for the streams a later capture brings along
+        if not free:
+            return None
+        ptr = free.pop()
+        _fuse_ws_sets[key] = ptr
+    return ptr
+
+
+_FUSE_WS_SPARE = 3
+
+
+def _capture_id(stream_handle: int) -> int:
+    "Id of the capture `stream_handle` is recording into (hipStreamGetCaptureInfo); -1 if it cannot be read."
+    hip = _hip_runtime()
+    status, cid = C.c_int(0), C.c_ulonglong(0)
+    try:
+        if hip.hipStreamGetCaptureInfo(C.c_void_p(stream_handle), C.byref(status), C.byref(cid)) == 0 and cid.value:
+            return -int(cid.value) - 2          # (negative: never collides with an id(...) token or 0)
+    except AttributeError:
+        pass
+    return -1
+
+
+_small_m_cache = [None]
+_num_cus_cache = {}
+
+
+def _small_m_k() -> int:
+    if _small_m_cache[0] is None:
+        _small_m_cache[0] = tuning_get("small_m_split")
+    return _small_m_cache[0]
+
+
+def _num_cus() -> int:
+    dev = torch.cuda.current_device()
+    if dev not in _num_cus_cache:
+        _num_cus_cache[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return _num_cus_cache[dev]
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
@@ -261,6 +410,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
             assert out.dtype == torch.float32
             side = LnSide(torch.empty((M, N), dtype=torch.bfloat16, device=a.device), partial)
             d.twin_out, d.ldt, d.stats_out = side.twin.data_ptr(), N, side.partial.data_ptr()
+    if cd != UC_F32 and split_k <= 1:      # small-M path: hand uc_gemm a hand-over buffer when this launch can split K inside the kernel
+        ws = _fuse_ws_for_launch(M, N, K)
+        if ws is not None:
+            d.fuse_ws = ws
     _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
     if side is not None:
         out.uc_ln = side
