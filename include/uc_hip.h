@@ -191,6 +191,11 @@ typedef struct uc_gemm_desc {
        by ONE launch at a time — one buffer per stream that issues such launches, and one per stream of a captured graph for as
        long as the graph lives.  The library leaves its flag words zero after every launch. */
     void* fuse_ws;
+    /* fp16 operand form (compute_dtype UC_F16, the TF32-class prediction heads): fp16 stores SATURATE at +-65504 instead of
+       becoming inf (fp16 has TF32's mantissa, not its exponent); with sat_flag non-NULL the launch ORs 1 into *sat_flag (device
+       int, zeroed by the caller) when it saturated a value — the host then knows the maps left fp16's range and can rerun /
+       continue with a wider head format (engine: "follow" = bf16, or "fp32").  NULL: not reported. */
+    int* sat_flag;
 } uc_gemm_desc;
 
 /* Notes on uc_gemm's behaviour outside the descriptor:
@@ -304,8 +309,9 @@ int uc_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, in
                     int H, int W, uc_stream_t stream);
 int uc_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C,
                     int H, int W, uc_stream_t stream);
-/* contiguous element-wise dtype conversion (n elements) */
-int uc_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
+/* contiguous element-wise dtype conversion (n elements).  Conversions INTO fp16 saturate at +-65504; with sat_flag non-NULL they OR 1
+   into *sat_flag (device int) when a value was beyond the fp16 range (see uc_gemm_desc.sat_flag).  NULL: not reported. */
+int uc_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, int* sat_flag,
                uc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -121,27 +121,40 @@ def mlp(x: Tensor, sd: SD, prefix: str) -> Tensor:
     return linear(F.gelu(linear(x, sd, prefix + ".fc1")), sd, prefix + ".fc2")
 
 
-def self_attention(x: Tensor, pos: Tensor, sd: SD, prefix: str, num_heads: int, base: float) -> Tensor:
-    """qkv -> RoPE(q), RoPE(k) -> SDPA -> proj (libs/croco/blocks.py:105-129; utils/transformer_blocks.py:219-256).
-    Wqkv rows: [0:D]=Q, [D:2D]=K, [2D:3D]=V, head-major."""
+def _qk_norm(t: Tensor, sd: SD, prefix: str) -> Tensor:
+    """qk_norm=True: nn.LayerNorm(head_dim) (default eps 1e-5: the layers' norm_layer default, utils/transformer_blocks.py:150, 196-197)
+    on q / k [B,H,N,Dh] BEFORE the positional encoding (:229); identity when the layer has no such parameters."""
+    if prefix + ".weight" not in sd:
+        return t
+    return F.layer_norm(t, (t.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
+
+
+def self_attention(x: Tensor, pos: Optional[Tensor], sd: SD, prefix: str, num_heads: int, base: float) -> Tensor:
+    """qkv -> [q_norm, k_norm] -> RoPE(q), RoPE(k) -> SDPA -> proj (libs/croco/blocks.py:105-129; utils/transformer_blocks.py:219-256).
+    Wqkv rows: [0:D]=Q, [D:2D]=K, [2D:3D]=V, head-major.  pos None: no positional encoding."""
     B, N, Cd = x.shape
     qkv = linear(x, sd, prefix + ".qkv").view(B, N, 3, num_heads, Cd // num_heads).permute(2, 0, 3, 1, 4)
-    q, k, v = rope2d(qkv[0], pos, base), rope2d(qkv[1], pos, base), qkv[2]
+    q, k, v = _qk_norm(qkv[0], sd, prefix + ".q_norm"), _qk_norm(qkv[1], sd, prefix + ".k_norm"), qkv[2]
+    if pos is not None:
+        q, k = rope2d(q, pos, base), rope2d(k, pos, base)
     o = sdpa(q, k, v).transpose(1, 2).reshape(B, N, Cd)
     return linear(o, sd, prefix + ".proj")
 
 
-def cross_attention(xq: Tensor, y: Tensor, qpos: Tensor, kpos: Tensor, sd: SD, prefix: str, num_heads: int,
-                    base: float) -> Tensor:
-    """projq/projk/projv, RoPE on q (own positions) and k (other view's), SDPA, proj
-    (utils/transformer_blocks.py:345-386)."""
+def cross_attention(xq: Tensor, y: Tensor, qpos: Optional[Tensor], kpos: Optional[Tensor], sd: SD, prefix: str, num_heads: int,
+                    base: float, value: Optional[Tensor] = None) -> Tensor:
+    """projq/projk/projv, [q_norm, k_norm], RoPE on q (own positions) and k (other view's), SDPA, proj
+    (utils/transformer_blocks.py:345-386).  value: the value tokens when they are not the key tokens y (:341-348)."""
     B, Nq, Cd = xq.shape
     Nk = y.shape[1]
     Dh = Cd // num_heads
     q = linear(xq, sd, prefix + ".projq").view(B, Nq, num_heads, Dh).transpose(1, 2)
     k = linear(y, sd, prefix + ".projk").view(B, Nk, num_heads, Dh).transpose(1, 2)
-    v = linear(y, sd, prefix + ".projv").view(B, Nk, num_heads, Dh).transpose(1, 2)
-    o = sdpa(rope2d(q, qpos, base), rope2d(k, kpos, base), v).transpose(1, 2).reshape(B, Nq, Cd)
+    v = linear(y if value is None else value, sd, prefix + ".projv").view(B, Nk, num_heads, Dh).transpose(1, 2)
+    q, k = _qk_norm(q, sd, prefix + ".q_norm"), _qk_norm(k, sd, prefix + ".k_norm")
+    if qpos is not None:
+        q, k = rope2d(q, qpos, base), rope2d(k, kpos, base)
+    o = sdpa(q, k, v).transpose(1, 2).reshape(B, Nq, Cd)
     return linear(o, sd, prefix + ".proj")
 
 

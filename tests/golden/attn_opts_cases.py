@@ -1,0 +1,22 @@
+"""Cases of tests/golden/attn_opts.npz (shared by the generator, which imports the reference, and the tests, which do not)."""
+import torch
+
+CASES = {
+    "self_qknorm_rope": dict(kind="self", dim=128, heads=2, qk_norm=True, rope=True, sep_v=False, B=2, gh=6, gw=5, gkh=6, gkw=5, seed=11),
+    "self_qknorm": dict(kind="self", dim=192, heads=3, qk_norm=True, rope=False, sep_v=False, B=1, gh=4, gw=7, gkh=4, gkw=7, seed=12),
+    "cross_qknorm_rope": dict(kind="cross", dim=128, heads=2, qk_norm=True, rope=True, sep_v=False, B=2, gh=5, gw=4, gkh=6, gkw=7, seed=13),
+    "cross_sepv_rope": dict(kind="cross", dim=128, heads=2, qk_norm=False, rope=True, sep_v=True, B=2, gh=5, gw=4, gkh=3, gkw=8, seed=14),
+    "cross_sepv_qknorm": dict(kind="cross", dim=192, heads=3, qk_norm=True, rope=False, sep_v=True, B=1, gh=4, gw=4, gkh=5, gkw=5, seed=15),
+}
+
+
+def make_inputs(c):
+    g = torch.Generator().manual_seed(1000 + c["seed"])
+    Nq, Nk = c["gh"] * c["gw"], c["gkh"] * c["gkw"]
+
+    def pos(h, w):
+        return torch.cartesian_prod(torch.arange(h), torch.arange(w)).unsqueeze(0).repeat(c["B"], 1, 1).contiguous()
+    if c["kind"] == "self":
+        return {"x": torch.randn(c["B"], Nq, c["dim"], generator=g), "xpos": pos(c["gh"], c["gw"])}
+    return {"q": torch.randn(c["B"], Nq, c["dim"], generator=g), "k": torch.randn(c["B"], Nk, c["dim"], generator=g),
+            "v": torch.randn(c["B"], Nk, c["dim"], generator=g), "qpos": pos(c["gh"], c["gw"]), "kpos": pos(c["gkh"], c["gkw"])}

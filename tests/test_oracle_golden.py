@@ -2,6 +2,8 @@
 tests/golden/make_golden.py).  Weights come from the name-keyed filler applied to the state_dict of the
 uniception_amd modules, so this also proves their state_dict keys/shapes equal the reference's — any missing
 or renamed parameter would change the weights and break parity."""
+import os
+
 import pytest
 import torch
 
@@ -73,3 +75,23 @@ def test_oracle_dinov2_matches_huggingface_transformers(name):
     e_r = rel_l2(regs, gold[f"{name}/registers"])
     print(f"\n[oracle vs transformers {gold['transformers_version']}] {name}: features {e_f:.2e} (norm {e_n:.1e}), cls/registers {e_r:.2e}")
     assert e_f < 2e-5 and e_n < 2e-5 and e_r < 2e-5
+
+
+def test_oracle_attention_options_match_reference_golden():
+    """qk_norm=True and value tokens that are not the key tokens (utils/transformer_blocks.py:196-197, 229, 341-348): the oracle's
+    self_attention / cross_attention against outputs of the reference's Attention / CrossAttention (tests/golden/attn_opts.npz,
+    make_golden_attn_opts.py)."""
+    import numpy as np
+    from tests.golden.attn_opts_cases import CASES as ACASES, make_inputs
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "attn_opts.npz"))
+    for name, c in ACASES.items():
+        sd = {"l." + k[len(name) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "/sd/")}
+        ins = make_inputs(c)
+        if c["kind"] == "self":
+            out = O.self_attention(ins["x"], ins["xpos"] if c["rope"] else None, sd, "l", c["heads"], 100.0)
+        else:
+            out = O.cross_attention(ins["q"], ins["k"], ins["qpos"] if c["rope"] else None, ins["kpos"] if c["rope"] else None, sd, "l",
+                                    c["heads"], 100.0, value=ins["v"] if c["sep_v"] else None)
+        ref = torch.from_numpy(z[name + "/out"])
+        err = float((out - ref).norm() / ref.norm())
+        assert err < 2e-5, (name, err)

@@ -197,3 +197,56 @@ def test_reference_policy_bf16_transformer_fp32_class_heads(gpu, name):
         assert rel_l2(ref_pol[k].cpu(), exact[k].cpu()) < 1e-4, k   # ~2^-16 per product through ~15 chained convolutions
     print(f"\n[reference policy] {name}: bf16 transformer + fp32-class heads " + ", ".join(f"{k}={rep_pol[k]:.1e}" for k in HEAD_OUTPUTS) +
           " | bf16 heads " + ", ".join(f"{k}={rep_fol[k]:.1e}" for k in HEAD_OUTPUTS))
+
+
+def test_fp16_heads_range_guard_saturates_reports_and_falls_back(gpu):
+    """VERDICT r3 #7 / ADVICE r3: fp16 operands carry TF32's mantissa, not its exponent.  A DPT head whose scratch maps reach 1e5-1e6
+    (the layer_rn convolutions scaled up by F, the last 1x1 convolution down by 1/F: the head is positively homogeneous up to its biases)
+    must not turn into inf / NaN under the default TF32-class policy: the fp16 stores saturate, the launches raise the device flag,
+    engine.head_range_exceeded() reports it, and from then on the policy runs the bf16 fallback — which is the "follow" policy to the
+    bit and within the bf16 bar of the exact-fp32 heads of the same scaled model.  With the unscaled model the flag stays down."""
+    from uniception_amd import engine
+    F_ = 3.0e4
+
+    def scaled_model():
+        model, c = build_case_model("tiny_dpt")
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if ".input_process." in k and k.endswith(".1.weight") and p.dim() == 4 and p.shape[-1] == 3:
+                    p.mul_(F_)                       # layer_rn 3x3 convolutions: every scratch map is F times larger
+                elif "regressor" in k and ".conv2.2." in k:
+                    p.mul_(1.0 / F_ if k.endswith("weight") else 1.0)
+        return model.to(gpu), c
+
+    def run(model, c, head_mode):
+        img1, img2 = (t.to(gpu) for t in case_images(c))
+        with engine.head_precision(head_mode), torch.no_grad(), engine.precision("bf16"):
+            r1, r2 = model(img1, img2, {})
+        torch.cuda.synchronize()
+        return dict(pts3d_1=r1["pts3d"], conf_1=r1["conf"], pts3d_2=r2["pts3d_in_other_view"], conf_2=r2["conf"])
+
+    engine.head_range_exceeded(reset=True)
+    try:
+        # unscaled: in range, flag down, fp16 heads stay fp16
+        model0, c0 = build_case_model("tiny_dpt")
+        run(model0.to(gpu), c0, "fp16")
+        assert not engine.head_range_exceeded()
+        assert engine.head_precision and engine._f16_tripped is False
+        # scaled: saturated but finite, reported, and the policy falls back
+        model, c = scaled_model()
+        exact = run(model, c, "fp32_exact")
+        assert all(torch.isfinite(v).all() for v in exact.values())
+        sat = run(model, c, "fp16")
+        assert all(torch.isfinite(v).all() for v in sat.values()), "fp16 heads must saturate, not overflow"
+        with pytest.warns(RuntimeWarning, match="fp16 range"):
+            assert engine.head_range_exceeded()
+        after = run(model, c, "fp16")               # the guard has tripped: bf16 heads now
+        follow = run(model, c, "follow")
+        for k in HEAD_OUTPUTS:
+            assert torch.equal(after[k], follow[k]), k
+            assert rel_l2(after[k].cpu(), exact[k].cpu()) < 4e-2, (k, rel_l2(after[k].cpu(), exact[k].cpu()))
+        err_sat = max(rel_l2(sat[k].cpu(), exact[k].cpu()) for k in HEAD_OUTPUTS)
+        print(f"\n[range guard] maps x{F_:.0e}: saturated fp16 heads {err_sat:.2e} from exact fp32 heads (finite, flagged); fallback (bf16) "
+              + ", ".join(f"{k}={rel_l2(after[k].cpu(), exact[k].cpu()):.1e}" for k in HEAD_OUTPUTS))
+    finally:
+        engine.head_range_exceeded(reset=True)

@@ -45,7 +45,7 @@ class GemmDesc(C.Structure):
         ("C", vp), ("out_dtype", i32), ("ldc", i64),
         ("twin_out", vp), ("ldt", i64), ("stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
         ("tail_w", vp), ("tail_b", vp), ("tail_out", vp),
-        ("ln_nblk", i32), ("ln_eps", f32), ("fuse_ws", vp),
+        ("ln_nblk", i32), ("ln_eps", f32), ("fuse_ws", vp), ("sat_flag", vp),
     ]
 
 
@@ -74,7 +74,7 @@ SIGNATURES = {
     "uc_patch_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_nchw_to_nhwc": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "uc_nhwc_to_nchw": [vp, i32, vp, i32, i32, i32, i32, i32, vp],
-    "uc_convert": [vp, i32, vp, i32, i64, vp],
+    "uc_convert": [vp, i32, vp, i32, i64, vp, vp],
     "uc_bilinear_nhwc": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "uc_convt_scatter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_pixel_shuffle": [vp, i32, vp, i32, i32, i32, i32, i32, vp],

@@ -55,8 +55,14 @@ __device__ __forceinline__ float f16_to_f32(unsigned short v) {
     __builtin_memcpy(&h, &v, 2);
     return (float)h;
 }
+// fp16 stores SATURATE at +-65504 (round 4): a plain cast turns anything beyond into inf, and the next layer turns inf into NaN.  The
+// TF32-class heads keep TF32's mantissa in fp16 operands but not its exponent; saturation keeps an out-of-range map finite, and the
+// producers that can overflow (GEMM / conv epilogues, conversions into fp16) raise a caller-provided flag when they hit the limit
+// (uc_gemm_desc.sat_flag, uc_convert's sat_flag), so the host can fall back to a wider head format.
+#define UC_F16_MAX 65504.0f
+__device__ __forceinline__ float uc_sat_f16(float f) { return __builtin_amdgcn_fmed3f(f, -UC_F16_MAX, UC_F16_MAX); }
 __device__ __forceinline__ unsigned short f32_to_f16(float f) {
-    _Float16 h = (_Float16)f;
+    _Float16 h = (_Float16)uc_sat_f16(f);
     unsigned short v;
     __builtin_memcpy(&v, &h, 2);
     return v;

@@ -4,6 +4,7 @@
 // All are single-pass streaming kernels; channel-last (NHWC) tensors are moved 8 elements per lane
 // (16 B bf16 / 2x16 B fp32).
 #include "common.h"
+#include <type_traits>
 #include "knobs.h"
 
 // ---- generic 8-element vector load/store with fp32 math in between --------------------------
@@ -33,7 +34,7 @@ __device__ __forceinline__ V8 load8<BF16Tag>(const bf16_t* p) {
 typedef _Float16 uc_half2_t __attribute__((ext_vector_type(2)));
 typedef float uc_float2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {       // round-to-nearest-even, like torch's Half
-    const uc_float2_t v = {lo, hi};
+    const uc_float2_t v = {uc_sat_f16(lo), uc_sat_f16(hi)};          // (saturating: see common.h)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, uc_half2_t));
 }
 __device__ __forceinline__ void unpack_f16x2(unsigned u, float& lo, float& hi) {
@@ -193,24 +194,61 @@ extern "C" int uc_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int ds
     return dispatch_transpose("uc_nhwc_to_nchw", src, src_dtype, dst, dst_dtype, B, H * W, C, (hipStream_t)stream);
 }
 
+// 8 elements per work item (16-byte accesses on the 16-bit side, 2 x 16 on the fp32 side); the scalar form of rounds 1-3 ran at a
+// quarter of the HBM rate.  Conversions INTO fp16 saturate and, with sat_flag, report values beyond +-65504 (see common.h).
 template <typename TI, typename TO>
-__global__ void convert_kernel(const typename TI::storage* __restrict__ s, typename TO::storage* __restrict__ d, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        TO::store(d + i, TI::load(s + i));
+__global__ void convert_kernel(const typename TI::storage* __restrict__ s, typename TO::storage* __restrict__ d, int64_t n, int* __restrict__ sat_flag, int vec) {
+    constexpr bool TO_F16 = sizeof(typename TO::storage) == 2 && !std::is_same<TO, BF16Tag>::value;
+    const int64_t n8 = vec ? n >> 3 : 0;        // (buffers that are not 16-byte aligned: everything takes the scalar loop below)
+    float amax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        if constexpr (sizeof(typename TI::storage) == 4) {
+            const float4_t a = *reinterpret_cast<const float4_t*>(s + i * 8), b = *reinterpret_cast<const float4_t*>(s + i * 8 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+            typename TI::storage raw[8];
+            *reinterpret_cast<uint4*>(raw) = *reinterpret_cast<const uint4*>(s + i * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = TI::load(raw + k);
+        }
+        if constexpr (TO_F16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
+        }
+        if constexpr (sizeof(typename TO::storage) == 4) {
+            *reinterpret_cast<float4_t*>(d + i * 8) = (float4_t){v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<float4_t*>(d + i * 8 + 4) = (float4_t){v[4], v[5], v[6], v[7]};
+        } else {
+            typename TO::storage raw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) TO::store(raw + k, v[k]);
+            *reinterpret_cast<uint4*>(d + i * 8) = *reinterpret_cast<const uint4*>(raw);
+        }
+    }
+    for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {   // ragged tail
+        const float v = TI::load(s + i);
+        if constexpr (TO_F16) amax = fmaxf(amax, fabsf(v));
+        TO::store(d + i, v);
+    }
+    if constexpr (TO_F16) {
+        if (sat_flag && !(amax <= UC_F16_MAX)) atomicOr(sat_flag, 1);
+    }
 }
 
-extern "C" int uc_convert(const void* src, int sd, void* dst, int dd, int64_t n, uc_stream_t stream) {
+extern "C" int uc_convert(const void* src, int sd, void* dst, int dd, int64_t n, int* sat_flag, uc_stream_t stream) {
     UC_REQUIRE(src && dst && n >= 0, "uc_convert: bad argument");
     if (n == 0) return UC_OK;
+    const int vec = ((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 g(EW_GRID(n)), b(256);
-    if (sd == UC_F32 && dd == UC_BF16) hipLaunchKernelGGL((convert_kernel<F32Tag, BF16Tag>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n);
-    else if (sd == UC_BF16 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<BF16Tag, F32Tag>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
-    else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<F32Tag, F32Tag>), g, b, 0, st, (const float*)src, (float*)dst, n);
-    else if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((convert_kernel<BF16Tag, BF16Tag>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
-    else if (sd == UC_F32 && dd == UC_F16) hipLaunchKernelGGL((convert_kernel<F32Tag, F16Tag>), g, b, 0, st, (const float*)src, (unsigned short*)dst, n);
-    else if (sd == UC_F16 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<F16Tag, F32Tag>), g, b, 0, st, (const unsigned short*)src, (float*)dst, n);
-    else if (sd == UC_BF16 && dd == UC_F16) hipLaunchKernelGGL((convert_kernel<BF16Tag, F16Tag>), g, b, 0, st, (const bf16_t*)src, (unsigned short*)dst, n);
+    const dim3 g(EW_GRID(vec ? (n + 7) / 8 : n)), b(256);
+    if (sd == UC_F32 && dd == UC_BF16) hipLaunchKernelGGL((convert_kernel<F32Tag, BF16Tag>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n, sat_flag, vec);
+    else if (sd == UC_BF16 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<BF16Tag, F32Tag>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n, sat_flag, vec);
+    else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<F32Tag, F32Tag>), g, b, 0, st, (const float*)src, (float*)dst, n, sat_flag, vec);
+    else if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((convert_kernel<BF16Tag, BF16Tag>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, n, sat_flag, vec);
+    else if (sd == UC_F32 && dd == UC_F16) hipLaunchKernelGGL((convert_kernel<F32Tag, F16Tag>), g, b, 0, st, (const float*)src, (unsigned short*)dst, n, sat_flag, vec);
+    else if (sd == UC_F16 && dd == UC_F32) hipLaunchKernelGGL((convert_kernel<F16Tag, F32Tag>), g, b, 0, st, (const unsigned short*)src, (float*)dst, n, sat_flag, vec);
+    else if (sd == UC_BF16 && dd == UC_F16) hipLaunchKernelGGL((convert_kernel<BF16Tag, F16Tag>), g, b, 0, st, (const bf16_t*)src, (unsigned short*)dst, n, sat_flag, vec);
     else { uc_set_error("uc_convert: unsupported dtypes %d -> %d", sd, dd); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_convert");
     return UC_OK;

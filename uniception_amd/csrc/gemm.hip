@@ -596,6 +596,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
             g.dbg = 0;
 #endif
             g.f16 = f16 ? 1 : 0;
+            g.sat_flag = f16 ? d->sat_flag : nullptr;
             g.a_mode = d->a_mode; g.relu_a = d->relu_a; g.cH = d->conv_H; g.cW = d->conv_W; g.cCin = d->conv_Cin;
             g.cStride = d->conv_stride; g.cHo = d->conv_Ho; g.cWo = d->conv_Wo;
             if (d->a_mode == UC_A_CONV3X3) {

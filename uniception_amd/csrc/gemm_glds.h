@@ -62,6 +62,7 @@ struct GldsParams {
     int stagger;  // experiment: 100-MHz ticks of start delay per phase group for the first round of workgroups (0 = off)
     int nt_out;   // output (+ residual) streams of more than half the 256 MB Infinity Cache: non-temporal epilogue loads / stores
     unsigned long long* trace;   // diagnostics (UC_GEMM_TRACE): per-workgroup {start, loop start, loop end, end} 100-MHz ticks + HW id
+    int* sat_flag; // fp16 outputs: set to 1 (atomic or) when a value beyond +-65504 was saturated; NULL: not reported
     int f16;      // operands / 16-bit outputs / 16-bit residuals are fp16 instead of bf16 (the heads' TF32-class mode): EPI_ALL family only
     int a_mode, relu_a;
     int cH, cW, cCin, cStride, cHo, cWo;

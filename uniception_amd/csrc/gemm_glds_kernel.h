@@ -49,7 +49,7 @@ __device__ __forceinline__ float4_t glds_mfma(bf16x8_t a, bf16x8_t b, float4_t c
 template <bool F16>
 __device__ __forceinline__ unsigned glds_pack2(float lo, float hi) {
     if constexpr (F16) {
-        const float2v_t v = {lo, hi};
+        const float2v_t v = {uc_sat_f16(lo), uc_sat_f16(hi)};      // (saturating: see common.h)
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, glds_half2_t));
     } else return pack_bf16x2(lo, hi);
 }
@@ -742,6 +742,7 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
         }
     }
     const int wr_off = frow * 128 + (((g & 1) ^ (frow >> 3)) << 3);       // + ((2j + (g>>1)) ^ (frow & 7)) << 4
+    float amax = 0.f;            // fp16 stores: largest magnitude this lane packs (values beyond +-65504 saturate and raise p.sat_flag)
     auto stage = [&](int i, char* buf) {
         row_stats(i);
         if (mode == 1) {
@@ -767,6 +768,7 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4_t v = glds_act4<ACT>(val4(i, j));
+                if constexpr (F16) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 *reinterpret_cast<uint2*>(buf + wr_off + (((2 * j + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){glds_pack2<F16>(v.x, v.y), glds_pack2<F16>(v.z, v.w)};
             }
         }
@@ -807,6 +809,9 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
             }
             cp += cstep;
         }
+    }
+    if constexpr (F16) {
+        if (p.sat_flag && __any(!(amax <= UC_F16_MAX)) && lane == 0) atomicOr(p.sat_flag, 1);
     }
 }
 
@@ -915,6 +920,7 @@ __device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&ac
     float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f};
     if (mode != 1 && p.bias && p.split_k <= 1) bias4 = glds_load4(p.bias, UC_F32, nb, full, nb, p.N);
     float* slab = (float*)p.C + (int64_t)ksplit * p.M * p.ldc;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
         char* buf = wbuf + (i & 1) * 4096;
@@ -942,9 +948,12 @@ __device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&ac
                 if (p.dact_act == UC_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f; }
                 else { for (int r = 0; r < 4; ++r) v[r] *= glds_dact(u[r], UC_ACT_GELU_ERF); }
             }
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             glds_store4(p.C, p.out_dtype, ci, full, nb, p.N, v);
         }
     }
+    // fp16 outputs saturate at +-65504 (glds_store4): tell the caller when they did
+    if (p.out_dtype == UC_F16 && p.sat_flag && __any(!(amax <= UC_F16_MAX)) && lane == 0) atomicOr(p.sat_flag, 1);
 }
 
 enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2, GLDS_EPI_BS = 3 };

@@ -157,8 +157,74 @@ def head_dtype() -> torch.dtype:
     if _head_mode == "fp16":
         # next to a bf16 transformer in inference; the verification modes (fp32, bf16x3) and training (bf16 backward kernels) follow
         cd = compute_dtype()
-        return torch.float16 if (cd == torch.bfloat16 and not torch.is_grad_enabled()) else cd
+        if cd == torch.bfloat16 and not torch.is_grad_enabled():
+            _poll_head_range()
+            if not _f16_tripped:
+                return torch.float16
+        return cd
     return torch.float32 if _head_mode in ("fp32", "fp32_exact") else compute_dtype()
+
+
+# ---------------------------------------------------------------------------------------------
+# Range guard of the TF32-class (fp16-operand) heads.  fp16 has TF32's 10-bit mantissa but not its 8-bit exponent: a map beyond
+# +-65504 has no fp16 value.  The kernels SATURATE there (never inf / NaN) and raise a device flag (ops.f16_sat_flag: GEMM / conv
+# epilogues with fp16 outputs, conversions into fp16).  The engine reads the flag without stalling the stream: after the heads of a
+# forward it copies the flag to pinned host memory behind an event; the next time a head asks for its dtype and that event has
+# completed with the flag set, the policy FALLS BACK for the rest of the process to the transformer's bf16 (fp32 exponent range, the
+# "follow" policy: 1.7e-2 instead of 2e-3 from exact-fp32 heads) and says so once.  head_range_exceeded() is the synchronous form —
+# call it after a forward to know whether THAT result saw saturated maps (uniception_amd/tools/verify_outputs.py does).
+# ---------------------------------------------------------------------------------------------
+_f16_tripped: bool = False
+_f16_pending = {}        # device index -> (pinned host int32, event)
+
+
+def note_heads_ran() -> None:
+    "Called by the factory after the heads of a forward (fp16 head policy only): snapshot the saturation flag asynchronously."
+    if _head_mode != "fp16" or _f16_tripped or torch.cuda.is_current_stream_capturing():
+        return
+    from . import ops
+    dev = torch.cuda.current_device()
+    host, ev = _f16_pending.get(dev) or (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+    host.copy_(ops.f16_sat_flag(), non_blocking=True)
+    ev.record()
+    _f16_pending[dev] = (host, ev)
+
+
+def _poll_head_range() -> None:
+    global _f16_tripped
+    if _f16_tripped or not _f16_pending or torch.cuda.is_current_stream_capturing():     # (an event query is not allowed inside a capture)
+        return
+    for dev, (host, ev) in list(_f16_pending.items()):
+        if ev.query() and int(host[0]) != 0:
+            _trip_head_range()
+            return
+
+
+def _trip_head_range() -> None:
+    global _f16_tripped
+    import warnings
+    from . import ops
+    _f16_tripped = True
+    for t in ops._f16_sat_flags.values():
+        t.zero_()
+    warnings.warn("uniception_amd: a prediction-head map left the fp16 range (|x| > 65504, saturated) under the TF32-class head policy; "
+                  "falling back to bf16 heads (engine.set_head_precision('follow')) for the rest of this process — "
+                  "set_head_precision('fp32') gives fp32-class heads at 2/3 of the speed", RuntimeWarning, stacklevel=3)
+
+
+def head_range_exceeded(reset: bool = False) -> bool:
+    """Synchronous: has any fp16 head launch on the current device saturated a value since the flag was last cleared?  (True also
+    switches the fp16 policy to its bf16 fallback, like the asynchronous poll.)  reset=True clears the flag AND the fallback."""
+    global _f16_tripped
+    from . import ops
+    hit = bool(int(ops.f16_sat_flag().item()) != 0) or _f16_tripped
+    if hit and not _f16_tripped:
+        _trip_head_range()
+    if reset:
+        ops.f16_sat_flag().zero_()
+        _f16_pending.clear()
+        _f16_tripped = False
+    return hit
 
 
 # ---------------------------------------------------------------------------------------------
@@ -493,18 +559,36 @@ def _folded(lin: nn.Linear, fold, dtype: torch.dtype):
     return w, b, (fold[0], cs)
 
 
+def _qk_norm(t: torch.Tensor, norm: Optional[nn.Module]) -> torch.Tensor:
+    """qk_norm (utils/transformer_blocks.py:196-197, 229): LayerNorm over head_dim of q / k, [B, N, H, Dh] view -> contiguous
+    [B, N, H, Dh] in the same dtype.  Runs BEFORE the positional encoding, so these layers take the unfused route (GEMM without
+    the RoPE / VT epilogue, uc_layernorm over B.N.H rows of Dh, uc_rope2d in place, attention)."""
+    if norm is None or isinstance(norm, nn.Identity):
+        return t
+    if not isinstance(norm, nn.LayerNorm) or norm.weight is None or norm.bias is None:
+        raise UcHipError(f"qk_norm with {type(norm).__name__} has no HIP path (nn.LayerNorm with affine parameters only)")
+    if torch.is_grad_enabled() and (t.requires_grad or norm.weight.requires_grad):
+        raise UcHipError("qk_norm=True has no HIP backward: run these layers under torch.no_grad()")
+    return ops.layernorm(t.contiguous(), norm.weight.detach().float(), norm.bias.detach().float(), norm.eps, t.dtype)
+
+
+def _has_norm(*norms) -> bool:
+    return any(n is not None and not isinstance(n, nn.Identity) for n in norms)
+
+
 def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.Linear, num_heads: int, rope, pos,
                    scale: float, residual: Optional[torch.Tensor], out_dtype: torch.dtype, proj_wb=None, fold=None,
-                   emit_ln: bool = False) -> torch.Tensor:
+                   emit_ln: bool = False, q_norm=None, k_norm=None) -> torch.Tensor:
     """proj_wb: optional prepared (W, b) overriding proj's own (e.g. with a LayerScale folded in).
     fold: from ln_operand — h2d is then the RAW bf16 stream and the LayerNorm is applied by the QKV GEMM's epilogue.
-    emit_ln: the proj GEMM also writes the twin / statistics the next sub-layer's folded LayerNorm consumes."""
+    emit_ln: the proj GEMM also writes the twin / statistics the next sub-layer's folded LayerNorm consumes.
+    q_norm / k_norm: the layer's qk_norm modules (LayerNorm over head_dim, before the positional encoding)."""
     dtype = h2d.dtype
     M, Cd = h2d.shape
     Dh = Cd // num_heads
     wq, bq, lnq = _folded(qkv, fold, dtype)
     wp, bp = proj_wb if proj_wb is not None else lin_weights(proj, dtype)
-    native = rope is None or is_native_rope(rope)
+    native = (rope is None or is_native_rope(rope)) and not _has_norm(q_norm, k_norm)      # (qk_norm: the unfused route below)
     if dtype == torch.bfloat16 and Dh == 64 and native and _fp8_attention():
         ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
         t5 = ops.gemm(h2d, wq, bq, rope=ep, ln=lnq).view(B, N, 3, num_heads, Dh)
@@ -519,7 +603,7 @@ def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.L
         if dtype == torch.bfloat16 and Dh != 64:
             raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh}); use fp32 precision for this model")
         t = ops.gemm(h2d, wq, bq, ln=lnq).view(B, N, 3, num_heads, Dh)
-        q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
+        q, k, v = _qk_norm(t[:, :, 0], q_norm), _qk_norm(t[:, :, 1], k_norm), t[:, :, 2]
         o = _x3_rope_attention(rope, q, k, v, pos, pos, scale)
         if o is None:
             q, k = _apply_rope(rope, q, k, pos, pos)
@@ -545,8 +629,26 @@ def _x3_rope_attention(rope, q, k, v, qpos, kpos, scale):
     if not (_forced_x3 and _x3_attention and rope is not None and is_native_rope(rope) and q.dtype == torch.float32 and q.shape[-1] == 64
             and not torch.is_grad_enabled() and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1):
         return None
+    # the kernel reads cos / sin from a table of ROPE_TABLE_NPOS positions and clamps beyond it: this is the VERIFICATION mode, so grids
+    # past the table (or negative positions) take the exact-angle path instead (rope_2d_ + attention_x3 without rope) — ADVICE r3
+    if not (_pos_in_table(qpos) and _pos_in_table(kpos)):
+        return None
     table = ops.rope_table(q.device, ROPE_TABLE_NPOS, rope.base, rope.F0)
     return ops.attention_x3(q, k, v, scale, rope=(_pos2d(qpos), _pos2d(kpos), table))
+
+
+_pos_range_cache = {}     # (data_ptr, version, numel) of a position tensor -> its positions all lie in [0, ROPE_TABLE_NPOS)
+
+
+def _pos_in_table(pos: torch.Tensor) -> bool:
+    key = (pos.data_ptr(), pos._version, pos.numel())
+    hit = _pos_range_cache.get(key)
+    if hit is None:
+        if len(_pos_range_cache) > 256:
+            _pos_range_cache.clear()
+        lo, hi = torch.aminmax(pos)            # (one tiny reduction per position tensor, cached: positions are built once per shape)
+        hit = _pos_range_cache[key] = bool(lo.item() >= 0 and hi.item() < ROPE_TABLE_NPOS)
+    return hit
 
 
 def _attention_generic(q, k, v, scale):
@@ -567,11 +669,16 @@ def _attention_generic(q, k, v, scale):
 def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk: int, projq: nn.Linear, projk: nn.Linear,
                     projv: nn.Linear, proj: nn.Linear, num_heads: int, rope, qpos, kpos, scale: float,
                     residual: Optional[torch.Tensor], out_dtype: torch.dtype, fold_q=None, fold_kv=None,
-                    emit_ln: bool = False) -> torch.Tensor:
-    """fold_q / fold_kv: from ln_operand for the query / key-value streams (see self_attention)."""
+                    emit_ln: bool = False, q_norm=None, k_norm=None, hv2d: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fold_q / fold_kv: from ln_operand for the query / key-value streams (see self_attention).
+    q_norm / k_norm: the layer's qk_norm modules.  hv2d: the VALUE tokens when they are not the key tokens
+    (utils/transformer_blocks.py:341-348: projk(key), projv(value) — two GEMMs instead of the fused [Wk; Wv] one)."""
     dtype = hq2d.dtype
     Cd = hq2d.shape[1]
     Dh = Cd // num_heads
+    if hv2d is not None or _has_norm(q_norm, k_norm):
+        return _cross_attention_unfused(hq2d, hkv2d, hv2d, B, Nq, Nk, projq, projk, projv, proj, num_heads, rope, qpos, kpos, scale,
+                                        residual, out_dtype, fold_q, fold_kv, emit_ln, q_norm, k_norm)
     wq, bq, lnq = _folded(projq, fold_q, dtype)
     if fold_kv is None:
         (wkv, bkv), lnkv = kv_weights(projk, projv, dtype), None
@@ -603,6 +710,39 @@ def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk
         if o is None:
             q, k = _apply_rope(rope, q, k, qpos, kpos)
             o = _attention_generic(q, k, v, scale)
+    emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cd)
+    return ops.gemm(o.reshape(B * Nq, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
+
+
+def _cross_attention_unfused(hq2d, hk2d, hv2d, B, Nq, Nk, projq, projk, projv, proj, num_heads, rope, qpos, kpos, scale, residual,
+                             out_dtype, fold_q, fold_k, emit_ln, q_norm, k_norm):
+    """CrossAttention with options the fused pipeline does not carry: qk_norm (LayerNorm of q / k over head_dim before the positional
+    encoding) and value tokens that are not the key tokens.  q, k, v from three GEMMs (the query / key LayerNorm folds still apply),
+    uc_layernorm for the norms, uc_rope2d in place, attention on row-major V."""
+    dtype = hq2d.dtype
+    Cd = hq2d.shape[1]
+    Dh = Cd // num_heads
+    if dtype == torch.bfloat16 and Dh != 64:
+        raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh}); use fp32 precision for this model")
+    if hv2d is not None and fold_k is not None:
+        raise UcHipError("a folded key LayerNorm cannot serve separate value tokens")
+    wq, bq, lnq = _folded(projq, fold_q, dtype)
+    wk, bk, lnk = _folded(projk, fold_k, dtype)
+    q = ops.gemm(hq2d, wq, bq, ln=lnq).view(B, Nq, num_heads, Dh)
+    k = ops.gemm(hk2d, wk, bk, ln=lnk).view(B, Nk, num_heads, Dh)
+    if hv2d is None:
+        wv, bv, lnv = _folded(projv, fold_k, dtype)
+        v = ops.gemm(hk2d, wv, bv, ln=lnv).view(B, Nk, num_heads, Dh)
+    else:
+        assert hv2d.shape[0] == B * Nk, "key and value must have the same number of tokens"
+        wv, bv = lin_weights(projv, dtype)
+        v = ops.gemm(hv2d, wv, bv).view(B, Nk, num_heads, Dh)
+    q, k = _qk_norm(q, q_norm), _qk_norm(k, k_norm)
+    o = _x3_rope_attention(rope, q, k, v, qpos, kpos, scale)
+    if o is None:
+        q, k = _apply_rope(rope, q, k, qpos, kpos)
+        o = _attention_generic(q, k, v, scale)
+    wp, bp = lin_weights(proj, dtype)
     emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cd)
     return ops.gemm(o.reshape(B * Nq, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 

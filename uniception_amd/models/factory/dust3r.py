@@ -181,4 +181,5 @@ class DUSt3R(nn.Module):
                                                           warm_key=("heads", tuple(feats2[-1].shape), shape1, shape2, str(engine.head_dtype())), owner=self)
             res1 = {"pts3d": p1, "conf": c1}
             res2 = {"pts3d_in_other_view": p2, "conf": c2}
+            engine.note_heads_ran()      # (fp16 head policy: asynchronous snapshot of the range-guard flag, engine.head_range_exceeded)
         return res1, res2

@@ -61,13 +61,11 @@ class Attention(nn.Module):
 
     def _run(self, h2d, B, N, xpos, residual, out_dtype, fold=None, emit_ln=False):
         _check_no_dropout(self, self.attn_drop.p, self.proj_drop.p)
-        if not isinstance(self.q_norm, nn.Identity):
-            raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
         if self.custom_positional_encoding is not None:
             assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
         scale = self.scale * _softmax_scale_multiplier(self, N)
         return engine.self_attention(h2d, B, N, self.qkv, self.proj, self.num_heads, self.custom_positional_encoding, xpos,
-                                     scale, residual, out_dtype, fold=fold, emit_ln=emit_ln)
+                                     scale, residual, out_dtype, fold=fold, emit_ln=emit_ln, q_norm=self.q_norm, k_norm=self.k_norm)
 
     def forward(self, x: torch.Tensor, xpos: torch.Tensor = None) -> torch.Tensor:
         engine.require_inference(x, self.qkv.weight)
@@ -105,29 +103,30 @@ class CrossAttention(nn.Module):
         self.base_token_count_for_entropy_scaling = base_token_count_for_entropy_scaling
         self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
 
-    def _run(self, hq2d, hkv2d, B, Nq, Nk, qpos, kpos, residual, out_dtype, fold_q=None, fold_kv=None, emit_ln=False):
+    def _run(self, hq2d, hkv2d, B, Nq, Nk, qpos, kpos, residual, out_dtype, fold_q=None, fold_kv=None, emit_ln=False, hv2d=None):
         _check_no_dropout(self, self.attn_drop.p, self.proj_drop.p)
-        if not isinstance(self.q_norm, nn.Identity):
-            raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
         if self.custom_positional_encoding is not None:
             assert qpos is not None, "Positions of queries (qpos) are a required input when using custom positional encoding"
             assert kpos is not None, "Positions of keys (kpos) are a required input when using custom positional encoding"
         scale = self.scale * _softmax_scale_multiplier(self, Nq)
         return engine.cross_attention(hq2d, hkv2d, B, Nq, Nk, self.projq, self.projk, self.projv, self.proj, self.num_heads,
                                       self.custom_positional_encoding, qpos, kpos, scale, residual, out_dtype,
-                                      fold_q=fold_q, fold_kv=fold_kv, emit_ln=emit_ln)
+                                      fold_q=fold_q, fold_kv=fold_kv, emit_ln=emit_ln, q_norm=self.q_norm, k_norm=self.k_norm, hv2d=hv2d)
 
     def forward(self, query, key, value, qpos=None, kpos=None):
         engine.require_inference(query, key, value, self.projq.weight)
-        if value is not key:
-            raise engine.UcHipError("the HIP cross-attention computes K and V from one tensor (key is value), as DUSt3R does")
         B, Nq, C = query.shape
         Nk = key.shape[1]
         dt = engine.compute_dtype()
         q2, k2 = _as_2d(query), _as_2d(key)
         hq = q2 if q2.dtype == dt else engine.ops.convert(q2, dt)
         hk = k2 if k2.dtype == dt else engine.ops.convert(k2, dt)
-        return self._run(hq, hk, B, Nq, Nk, qpos, kpos, None, dt).view(B, Nq, C)
+        hv = None
+        if value is not key:      # (utils/transformer_blocks.py:341-348: projv runs on its own tokens)
+            assert value.shape[1] == Nk, "key and value must have the same number of tokens"
+            v2 = _as_2d(value)
+            hv = v2 if v2.dtype == dt else engine.ops.convert(v2, dt)
+        return self._run(hq, hk, B, Nq, Nk, qpos, kpos, None, dt, hv2d=hv).view(B, Nq, C)
 
 
 class LayerScale(nn.Module):
@@ -181,9 +180,9 @@ class SelfAttentionBlock(nn.Module):
             assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
         sa = self.attn
         _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
-        if not isinstance(sa.q_norm, nn.Identity):
-            raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
         if autograd.grad_needed(x2d, *self.parameters()):   # HIP forward + HIP backward sub-layers
+            if not isinstance(sa.q_norm, nn.Identity):
+                raise engine.UcHipError("qk_norm=True has no HIP backward: run these blocks under torch.no_grad()")
             g1 = None if isinstance(self.ls1, nn.Identity) else self.ls1.gamma       # LayerScale: folded weights forward, unfolded gradients
             g2 = None if isinstance(self.ls2, nn.Identity) else self.ls2.gamma
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, N, sa.num_heads, sa.custom_positional_encoding,
@@ -193,7 +192,8 @@ class SelfAttentionBlock(nn.Module):
         fc2_wb = None if isinstance(self.ls2, nn.Identity) else engine.layerscale_lin_weights(self.mlp.fc2, self.ls2.gamma, dt)
         h, fold = engine.ln_operand(x2d, self.norm1, dt)
         x2d = engine.self_attention(h, B, N, sa.qkv, sa.proj, sa.num_heads, sa.custom_positional_encoding, xpos,
-                                    sa.scale * _softmax_scale_multiplier(sa, N), x2d, x2d.dtype, proj_wb=proj_wb, fold=fold, emit_ln=True)
+                                    sa.scale * _softmax_scale_multiplier(sa, N), x2d, x2d.dtype, proj_wb=proj_wb, fold=fold, emit_ln=True,
+                                    q_norm=sa.q_norm, k_norm=sa.k_norm)
         h, fold = engine.ln_operand(x2d, self.norm2, dt)
         return engine.mlp(h, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), x2d, x2d.dtype, fc2_wb=fc2_wb, fold=fold,
                           emit_ln=True)
@@ -272,7 +272,7 @@ class CrossAttentionBlock(nn.Module):
         _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, ca.attn_drop.p, ca.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
         for m in (sa, ca):
             if not isinstance(m.q_norm, nn.Identity):
-                raise engine.UcHipError("qk_norm=True is not supported by the HIP attention path")
+                raise engine.UcHipError("qk_norm=True has no HIP backward: run these blocks under torch.no_grad()")
         rope = self.custom_positional_encoding
         x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, Nx, sa.num_heads, rope, xpos,
                                           sa.scale * _softmax_scale_multiplier(sa, Nx), dt)

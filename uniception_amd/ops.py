@@ -284,6 +284,22 @@ def _num_cus() -> int:
     return _num_cus_cache[dev]
 
 
+# ---------------------------------------------------------------------------------------------
+# fp16 range guard (TF32-class heads): every launch that can push a value out of fp16's range (GEMM / conv epilogues with fp16
+# outputs, conversions into fp16) saturates at +-65504 and ORs 1 into this per-device int32 — the engine polls it (engine.
+# head_range_exceeded) and falls back to a wider head format.
+# ---------------------------------------------------------------------------------------------
+_f16_sat_flags = {}
+
+
+def f16_sat_flag() -> torch.Tensor:
+    dev = torch.cuda.current_device()
+    t = _f16_sat_flags.get(dev)
+    if t is None:
+        t = _f16_sat_flags[dev] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", dev))
+    return t
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
          residual: Optional[torch.Tensor] = None, residual2: Optional[torch.Tensor] = None,
          out_dtype: Optional[torch.dtype] = None,
@@ -365,6 +381,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         out4 = torch.empty((M, 4), dtype=torch.float32, device=a.device)
         d.tail_w, d.tail_b, d.tail_out = w4.data_ptr(), _p(b4), out4.data_ptr()
         d.C, d.out_dtype, d.ldc = None, (UC_F16 if cd == UC_F16 else UC_BF16), N      # (nothing is stored: the storage dtype of the operands)
+        if cd == UC_F16:
+            d.sat_flag = _p(f16_sat_flag())
         _lib.check(_lib.load().uc_gemm(C.byref(d), _stream()), "uc_gemm")
         return out4
     if out is None and split_k > 1:
@@ -410,6 +428,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
             assert out.dtype == torch.float32
             side = LnSide(torch.empty((M, N), dtype=torch.bfloat16, device=a.device), partial)
             d.twin_out, d.ldt, d.stats_out = side.twin.data_ptr(), N, side.partial.data_ptr()
+    if cd == UC_F16:
+        d.sat_flag = _p(f16_sat_flag())
     if cd != UC_F32 and split_k <= 1:      # small-M path: hand uc_gemm a hand-over buffer when this launch can split K inside the kernel
         ws = _fuse_ws_for_launch(M, N, K)
         if ws is not None:
@@ -663,8 +683,8 @@ def convert(x: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
     if x.dtype == out_dtype:
         return x
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    _lib.check(_lib.load().uc_convert(x.data_ptr(), _dt(x.dtype), y.data_ptr(), _dt(out_dtype), x.numel(), _stream()),
-               "uc_convert")
+    _lib.check(_lib.load().uc_convert(x.data_ptr(), _dt(x.dtype), y.data_ptr(), _dt(out_dtype), x.numel(),
+                                      _p(f16_sat_flag()) if out_dtype == torch.float16 else None, _stream()), "uc_convert")
     return y
 
 
