@@ -399,13 +399,14 @@ int uc_token_slice(const float* src, float* dst, int B, int Ns, int Nd, int src_
  * entry point below states the forward expression it differentiates.
  * ==================================================================================== */
 
-/* LayerNorm backward (forward: uc_layernorm).  x fp32 [rows,C], dy [rows,C] (dy_dtype f32|bf16), gamma fp32 [C].
+/* LayerNorm backward (forward: uc_layernorm).  x [rows,C] in x_dtype (f32, or bf16: the bf16 training stream — dres and dx are then
+ * bf16 too and dx_bf16 must be NULL), dy [rows,C] (dy_dtype f32|bf16), gamma fp32 [C].
  *   dx[r,:]  = rstd*(a - mean(a) - xhat*mean(a*xhat)) (+ dres[r,:] if dres != NULL),  a = dy*gamma, xhat = (x-mean)*rstd
  *   dgamma[c] += sum_r dy*xhat, dbeta[c] += sum_r dy     (fp32 atomic accumulation: zero them first)
- *   dx_bf16 (optional): a bf16 copy of dx written in the same pass — dx is the gradient of the residual stream, which the
- *   previous sub-layer's backward GEMMs consume in bf16.
+ *   dx_bf16 (optional, fp32 stream): a bf16 copy of dx written in the same pass — dx is the gradient of the residual stream, which
+ *   the previous sub-layer's backward GEMMs consume in bf16.
  * Any C; widths 256*{1,2,3,4,6,8} take the register-resident kernel. */
-int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
+int uc_layernorm_bwd(const void* x, int x_dtype, const float* gamma, const void* dy, int dy_dtype, const void* dres, void* dx,
                      void* dx_bf16, float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream);
 
 /* "TN" contraction over tokens / pixels for weight gradients, no operand transposes (bf16 in, fp32 out):

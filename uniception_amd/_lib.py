@@ -83,7 +83,7 @@ SIGNATURES = {
     "uc_adaptor_program": [vp, i64, i64, i64, vp, i32, i32, i32, i32, vp, i32, vp],
     "uc_assemble_tokens": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "uc_token_slice": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
-    "uc_layernorm_bwd": [vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, f32, vp],
+    "uc_layernorm_bwd": [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "uc_gemm_tn": [vp, i64, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp],
     "uc_gemm_tn_conv_tiles": [i64, i32, i32, i32, i32],
     "uc_splitk_reduce": [vp, i32, i64, i64, vp, i32, vp],

@@ -154,7 +154,9 @@ _twins = {}
 
 
 def _ln_bwd_residual(x2d, g, dh, eps, dg, db, dres, dt):
-    if dt != torch.bfloat16:
+    if dres is not None and dres.dtype != x2d.dtype:
+        dres = ops.convert(dres, x2d.dtype)
+    if dt != torch.bfloat16 or x2d.dtype == torch.bfloat16:      # (a bf16 stream's dx IS the bf16 operand of the next backward GEMMs)
         return ops.layernorm_bwd(x2d, g, dh, eps, dg, db, dres=dres)
     dx, twin = ops.layernorm_bwd(x2d, g, dh, eps, dg, db, dres=dres, bf16_twin=True)
     if len(_twins) > 8:
@@ -217,8 +219,8 @@ class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x2d, weight, bias, eps, out_dtype):
         x2d = _c(x2d)
-        if x2d.dtype != torch.float32:
-            raise UcHipError("training keeps the residual stream in fp32")
+        if x2d.dtype not in (torch.float32, torch.bfloat16):
+            raise UcHipError("the training residual stream is fp32 or bf16")
         g, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
         ctx.save_for_backward(x2d, g)
         ctx.eps = eps
@@ -278,26 +280,26 @@ class PatchEmbedFn(Function):
     """tokens = gather(img) . W^T + b (libs/croco/patch_embed.py:47,69-82); the image gets no gradient."""
 
     @staticmethod
-    def forward(ctx, img, weight, bias, owner, P, dt):
+    def forward(ctx, img, weight, bias, owner, P, dt, out_dtype=torch.float32):
         cols = ops.patch_gather(img, P, dt)
         w, b = engine.patch_weights(owner, dt)
         ctx.save_for_backward(cols)
         ctx.dt, ctx.wshape, ctx.has_bias, ctx.weight = dt, weight.shape, bias is not None, weight
-        return ops.gemm(cols, w, b, out_dtype=torch.float32)
+        return ops.gemm(cols, w, b, out_dtype=out_dtype)
 
     @staticmethod
     def backward(ctx, dtok):
         (cols,) = ctx.saved_tensors
-        dtok = _c(dtok)
+        dtok = _as_dt(_c(dtok), ctx.dt)
         dW, db = _wgrad(dtok, cols, ctx.dt, ctx.has_bias, sink=[(ctx.weight, 0, ctx.wshape[0])])
         dW = None if dW is None else dW.view(ctx.wshape)
-        return None, dW, db, None, None, None
+        return None, dW, db, None, None, None, None
 
 
-def patch_embed(img, conv, P, dt):
+def patch_embed(img, conv, P, dt, out_dtype=torch.float32):
     if img.requires_grad:
         raise UcHipError("gradients w.r.t. the input images are not implemented")
-    return PatchEmbedFn.apply(img, conv.weight, conv.bias, conv, P, dt)
+    return PatchEmbedFn.apply(img, conv.weight, conv.bias, conv, P, dt, out_dtype)
 
 
 # LayerScale behind a sub-layer's output linear (DINOv2 blocks, SelfAttentionBlock(init_values=...)): the forward runs the linear with
@@ -462,7 +464,7 @@ class CrossAttnSubLayerFn(Function):
         # key/value side (the other view's tokens)
         dWkv, dbkv = _wgrad(dkv, hy, dt, has_bk or has_bv, sink=[(projk.weight, 0, C), (projv.weight, C, 2 * C)],
                             bias_sink=[projk.bias, projv.bias] if (has_bk and has_bv) else None)
-        dhy = ops.gemm(dkv, kv_weight_t(projk, projv, dt), out_dtype=dt if lny is not None else torch.float32)
+        dhy = ops.gemm(dkv, kv_weight_t(projk, projv, dt), out_dtype=dt if lny is not None else y2d.dtype)
         if lny is not None:
             dgy, dby, sunk_y = _ln_grad_targets(lny, gy)
             dy = ops.layernorm_bwd(y2d, gy, dhy, lny.eps, dgy, dby)

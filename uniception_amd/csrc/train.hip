@@ -23,6 +23,15 @@ __device__ __forceinline__ float4_t tr_load4<BF16Tag>(const bf16_t* p) {
     return v;
 }
 
+template <typename TX>
+__device__ __forceinline__ void tr_store4(typename TX::storage* p, float4_t o);
+template <>
+__device__ __forceinline__ void tr_store4<F32Tag>(float* p, float4_t o) { *reinterpret_cast<float4_t*>(p) = o; }
+template <>
+__device__ __forceinline__ void tr_store4<BF16Tag>(bf16_t* p, float4_t o) {
+    *reinterpret_cast<uint2*>(p) = (uint2){pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
+}
+
 __device__ __forceinline__ void wave_sum2(float& a, float& b) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -31,10 +40,12 @@ __device__ __forceinline__ void wave_sum2(float& a, float& b) {
     }
 }
 
-template <typename TD, int NV>
-__global__ __launch_bounds__(512) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// TX: dtype of the residual stream (x, dres, dx): fp32, or bf16 — the bf16 training stream of round 4 (the reference's stream under
+// autocast: bf16 activations, bf16 gradients of them): 2 + 2 + 2 + 2 bytes per element instead of 4 + 2 + 4 + 4 + 2.
+template <typename TD, int NV, typename TX = F32Tag>
+__global__ __launch_bounds__(512) void layernorm_bwd_kernel(const typename TX::storage* __restrict__ x, const float* __restrict__ gamma,
                                                             const typename TD::storage* __restrict__ dy,
-                                                            const float* __restrict__ dres, float* __restrict__ dx,
+                                                            const typename TX::storage* __restrict__ dres, typename TX::storage* __restrict__ dx,
                                                             bf16_t* __restrict__ dx_b, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int64_t rows, float eps) {
     constexpr int C = NV * 256;
@@ -54,7 +65,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const float* __restr
     for (int64_t row = wave_id; row < rows; row += nwaves) {
         float4_t v[NV], d[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4_t*>(x + row * C + (i * 64 + lane) * 4);
+        for (int i = 0; i < NV; ++i) v[i] = tr_load4<TX>(x + row * C + (i * 64 + lane) * 4);
 #pragma unroll
         for (int i = 0; i < NV; ++i) d[i] = tr_load4<TD>(dy + row * C + (i * 64 + lane) * 4);
         float s = 0.f;
@@ -88,10 +99,10 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const float* __restr
             o.z = rstd * (d[i].z - s1 - v[i].z * s2);
             o.w = rstd * (d[i].w - s1 - v[i].w * s2);
             if (dres) {
-                const float4_t r = *reinterpret_cast<const float4_t*>(dres + row * C + (i * 64 + lane) * 4);
+                const float4_t r = tr_load4<TX>(dres + row * C + (i * 64 + lane) * 4);
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
-            *reinterpret_cast<float4_t*>(dx + row * C + (i * 64 + lane) * 4) = o;
+            tr_store4<TX>(dx + row * C + (i * 64 + lane) * 4, o);
             if (dx_b) {   // bf16 twin of dx: the operand the previous sub-layer's backward GEMMs will want
                 uint2 pk;
                 pk.x = pack_bf16x2(o.x, o.y);
@@ -117,73 +128,81 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const float* __restr
 }
 
 // any width: one wavefront per row, three strided passes, per-element atomics for dgamma/dbeta (small models only)
-template <typename TD>
-__global__ __launch_bounds__(256) void layernorm_bwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <typename TD, typename TX = F32Tag>
+__global__ __launch_bounds__(256) void layernorm_bwd_generic_kernel(const typename TX::storage* __restrict__ x, const float* __restrict__ gamma,
                                                                     const typename TD::storage* __restrict__ dy,
-                                                                    const float* __restrict__ dres, float* __restrict__ dx,
+                                                                    const typename TX::storage* __restrict__ dres, typename TX::storage* __restrict__ dx,
                                                                     bf16_t* __restrict__ dx_b, float* __restrict__ dgamma,
                                                                     float* __restrict__ dbeta, int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + row * C;
+    const typename TX::storage* xr = x + row * C;
     const typename TD::storage* dr = dy + row * C;
     const float invC = 1.0f / (float)C;
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += xr[c];
+    for (int c = lane; c < C; c += 64) s += TX::load(xr + c);
     const float mean = wave_sum(s) * invC;
     float q = 0.f;
-    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    for (int c = lane; c < C; c += 64) { const float d = TX::load(xr + c) - mean; q += d * d; }
     const float rstd = rsqrtf(wave_sum(q) * invC + eps);
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane; c < C; c += 64) {
-        const float xh = (xr[c] - mean) * rstd, a = TD::load(dr + c) * gamma[c];
+        const float xh = (TX::load(xr + c) - mean) * rstd, a = TD::load(dr + c) * gamma[c];
         s1 += a; s2 += a * xh;
     }
     wave_sum2(s1, s2);
     s1 *= invC; s2 *= invC;
     for (int c = lane; c < C; c += 64) {
-        const float xh = (xr[c] - mean) * rstd, d = TD::load(dr + c);
+        const float xh = (TX::load(xr + c) - mean) * rstd, d = TD::load(dr + c);
         float o = rstd * (d * gamma[c] - s1 - xh * s2);
-        if (dres) o += dres[row * C + c];
-        dx[row * C + c] = o;
+        if (dres) o += TX::load(dres + row * C + c);
+        TX::store(dx + row * C + c, o);
         if (dx_b) dx_b[row * C + c] = f32_to_bf16(o);
         unsafeAtomicAdd(dgamma + c, d * xh);
         unsafeAtomicAdd(dbeta + c, d);
     }
 }
 
-extern "C" int uc_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* dres, float* dx,
+extern "C" int uc_layernorm_bwd(const void* x, int x_dtype, const float* gamma, const void* dy, int dy_dtype, const void* dres, void* dx,
                                 void* dx_bf16, float* dgamma, float* dbeta, int64_t rows, int C, float eps, uc_stream_t stream) {
     bf16_t* dx_b = (bf16_t*)dx_bf16;
     UC_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "uc_layernorm_bwd: null pointer");
     UC_REQUIRE(rows >= 0 && C > 0, "uc_layernorm_bwd: bad shape");
     UC_REQUIRE(dy_dtype == UC_F32 || dy_dtype == UC_BF16, "uc_layernorm_bwd: bad dy dtype %d", dy_dtype);
+    UC_REQUIRE(x_dtype == UC_F32 || x_dtype == UC_BF16, "uc_layernorm_bwd: bad x dtype %d", x_dtype);
+    UC_REQUIRE(x_dtype == UC_F32 || !dx_bf16, "uc_layernorm_bwd: a bf16 stream's dx is its own bf16 copy (dx_bf16 must be NULL)");
     if (rows == 0) return UC_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nv = C / 256;
+    const bool xb = x_dtype == UC_BF16;
     if (C % 256 != 0 || !(nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8)) {
         const unsigned g = (unsigned)ceil_div64(rows, 4);
-        if (dy_dtype == UC_F32) hipLaunchKernelGGL((layernorm_bwd_generic_kernel<F32Tag>), dim3(g), dim3(256), 0, st, x, gamma, (const float*)dy, dres, dx, dx_b, dgamma, dbeta, rows, C, eps);
-        else hipLaunchKernelGGL((layernorm_bwd_generic_kernel<BF16Tag>), dim3(g), dim3(256), 0, st, x, gamma, (const bf16_t*)dy, dres, dx, dx_b, dgamma, dbeta, rows, C, eps);
+#define UC_LNG(TD_, TX_)                                                                                                                \
+        hipLaunchKernelGGL((layernorm_bwd_generic_kernel<TD_, TX_>), dim3(g), dim3(256), 0, st, (const typename TX_::storage*)x, gamma,     \
+                           (const typename TD_::storage*)dy, (const typename TX_::storage*)dres, (typename TX_::storage*)dx, dx_b, dgamma, dbeta, rows, C, eps)
+        if (dy_dtype == UC_F32) { if (xb) UC_LNG(F32Tag, BF16Tag); else UC_LNG(F32Tag, F32Tag); }
+        else { if (xb) UC_LNG(BF16Tag, BF16Tag); else UC_LNG(BF16Tag, F32Tag); }
+#undef UC_LNG
         UC_CHECK_LAUNCH("uc_layernorm_bwd");
         return UC_OK;
     }
     const unsigned grid = (unsigned)min((int64_t)256, ceil_div64(rows, 8));
-#define UC_LNB(TD_, NV_)                                                                                                \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TD_, NV_>), dim3(grid), dim3(512), 0, st, x, gamma,                            \
-                       (const typename TD_::storage*)dy, dres, dx, dx_b, dgamma, dbeta, rows, eps)
-#define UC_LNB_NV(TD_)                      \
-    switch (C / 256) {                      \
-        case 1: UC_LNB(TD_, 1); break;      \
-        case 2: UC_LNB(TD_, 2); break;      \
-        case 3: UC_LNB(TD_, 3); break;      \
-        case 4: UC_LNB(TD_, 4); break;      \
-        case 6: UC_LNB(TD_, 6); break;      \
-        case 8: UC_LNB(TD_, 8); break;      \
+#define UC_LNB(TD_, NV_, TX_)                                                                                                       \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TD_, NV_, TX_>), dim3(grid), dim3(512), 0, st, (const typename TX_::storage*)x, gamma,      \
+                       (const typename TD_::storage*)dy, (const typename TX_::storage*)dres, (typename TX_::storage*)dx, dx_b, dgamma, dbeta, rows, eps)
+#define UC_LNB_NV(TD_, TX_)                      \
+    switch (C / 256) {                           \
+        case 1: UC_LNB(TD_, 1, TX_); break;      \
+        case 2: UC_LNB(TD_, 2, TX_); break;      \
+        case 3: UC_LNB(TD_, 3, TX_); break;      \
+        case 4: UC_LNB(TD_, 4, TX_); break;      \
+        case 6: UC_LNB(TD_, 6, TX_); break;      \
+        case 8: UC_LNB(TD_, 8, TX_); break;      \
         default: uc_set_error("uc_layernorm_bwd: unsupported width %d", C); return UC_ERR_UNSUPPORTED; \
     }
-    if (dy_dtype == UC_F32) { UC_LNB_NV(F32Tag) } else { UC_LNB_NV(BF16Tag) }
+    if (dy_dtype == UC_F32) { if (xb) { UC_LNB_NV(F32Tag, BF16Tag) } else { UC_LNB_NV(F32Tag, F32Tag) } }
+    else { if (xb) { UC_LNB_NV(BF16Tag, BF16Tag) } else { UC_LNB_NV(BF16Tag, F32Tag) } }
 #undef UC_LNB_NV
 #undef UC_LNB
     UC_CHECK_LAUNCH("uc_layernorm_bwd");

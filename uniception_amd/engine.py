@@ -275,8 +275,34 @@ def bf16_stream(on: bool):
         _bf16_stream = prev
 
 
+# ... and in TRAINING (round 4): under autocast the reference's residual stream is bf16 in training too (bf16 linear outputs added to a
+# bf16 x; autograd hands bf16 gradients down it).  With the switch on (default) a bf16 training step keeps x, the sub-layer outputs and
+# the residual gradients in bf16: LayerNorm forward / backward and the residual epilogues move half the bytes (the LayerNorm backward
+# alone 8 instead of 16 bytes per element).  Weight gradients, LayerNorm statistics and every accumulation stay fp32.
+_bf16_train_stream: bool = os.environ.get("UNICEPTION_AMD_BF16_TRAIN_STREAM", "1") != "0"
+
+
+def set_bf16_train_stream(on: bool) -> None:
+    global _bf16_train_stream
+    _bf16_train_stream = bool(on)
+
+
+@contextlib.contextmanager
+def bf16_train_stream(on: bool):
+    "Scoped set_bf16_train_stream."
+    global _bf16_train_stream
+    prev = _bf16_train_stream
+    _bf16_train_stream = bool(on)
+    try:
+        yield
+    finally:
+        _bf16_train_stream = prev
+
+
 def stream_dtype(dt: torch.dtype, *dims: int) -> torch.dtype:
-    "dtype of the residual stream a sub-layer pipeline in compute dtype `dt` starts: bf16 where the folded-LayerNorm path runs."
+    "dtype of the token residual stream: bf16 next to bf16 operands (inference: with the LayerNorm fold; training: see above), else fp32."
+    if torch.is_grad_enabled():
+        return torch.bfloat16 if (_bf16_train_stream and dt == torch.bfloat16 and all(d % 64 == 0 for d in dims)) else torch.float32
     return torch.bfloat16 if (_bf16_stream and fold_ok(dt, *dims)) else torch.float32
 
 

@@ -114,7 +114,8 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
                 # differentiable layout hop (a view for the channels-last features the encoder returns)
                 x2d = f.float().permute(0, 2, 3, 1).reshape(B * N, self.input_embed_dim)
                 if not isinstance(self.proj_embed, nn.Identity):
-                    x2d = autograd.linear(x2d, self.proj_embed.weight, self.proj_embed.bias, self.proj_embed, dt, torch.float32)
+                    x2d = autograd.linear(x2d, self.proj_embed.weight, self.proj_embed.bias, self.proj_embed, dt,
+                                          engine.stream_dtype(dt, self.dim, self.input_embed_dim))
                 xs.append(x2d)
                 continue
             nlc = engine.bchw_to_nhwc(f, torch.float32 if isinstance(self.proj_embed, nn.Identity) else dt)

@@ -43,7 +43,9 @@ class PatchEmbedCroCo(nn.Module):
         img = x.float().contiguous() if (x.dtype != torch.float32 or not x.is_contiguous()) else x
         train = autograd.grad_needed(x, self.proj.weight)
         if train:
-            tok = autograd.patch_embed(img, self.proj, P, dt).view(B, (H // P) * (W // P), -1)
+            # (stream dtype: bf16 next to bf16 operands — engine.stream_dtype — unless a norm layer follows, which takes fp32)
+            sdt = engine.stream_dtype(dt, self.proj.weight.shape[0]) if isinstance(self.norm, nn.Identity) else torch.float32
+            tok = autograd.patch_embed(img, self.proj, P, dt, sdt).view(B, (H // P) * (W // P), -1)
         else:
             cols = ops.patch_gather(img, P, dt)
             w, b = engine.patch_weights(self.proj, dt)

@@ -814,20 +814,21 @@ def token_slice(src: torch.Tensor, start: int, n: int) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float, dgamma: torch.Tensor,
                   dbeta: torch.Tensor, dres: Optional[torch.Tensor] = None, bf16_twin: bool = False):
-    """dx (fp32) of y = LN(x); dgamma/dbeta are accumulated into (fp32, caller-zeroed). dres: gradient of a parallel
-    residual branch to add into dx.  bf16_twin: also return a bf16 copy of dx written in the same pass."""
+    """dx (x's dtype: fp32, or bf16 on a bf16 training stream) of y = LN(x); dgamma/dbeta are accumulated into (fp32, caller-zeroed).
+    dres: gradient of a parallel residual branch to add into dx (same dtype as x).  bf16_twin (fp32 stream only): also return a bf16
+    copy of dx written in the same pass."""
     _need_gpu(x, gamma, dy, dgamma, dbeta, dres)
-    assert x.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape
+    assert x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape
     Cn = x.shape[-1]
     rows = x.numel() // Cn
     dx = torch.empty_like(x)
-    twin = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if bf16_twin else None
+    twin = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (bf16_twin and x.dtype == torch.float32) else None
     if dres is not None:
-        assert dres.dtype == torch.float32 and dres.is_contiguous() and dres.shape == x.shape
-    _lib.check(_lib.load().uc_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy.dtype), _p(dres), dx.data_ptr(),
+        assert dres.dtype == x.dtype and dres.is_contiguous() and dres.shape == x.shape
+    _lib.check(_lib.load().uc_layernorm_bwd(x.data_ptr(), _dt(x.dtype), gamma.data_ptr(), dy.data_ptr(), _dt(dy.dtype), _p(dres), dx.data_ptr(),
                                             _p(twin), dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn, float(eps), _stream()),
                "uc_layernorm_bwd")
-    return (dx, twin) if bf16_twin else dx
+    return (dx, twin if twin is not None else dx) if bf16_twin else dx
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, split_k: int = 1, conv: Optional[Tuple[int, bool]] = None,
