@@ -508,9 +508,10 @@ int uc_im2col_t(const void* x, void* dst, int dtype, int B, int H, int W, int Ci
 int uc_dilate_nhwc(const void* src, void* dst, int dtype, int B, int h, int w, int H, int W, int C, int stride,
                    uc_stream_t stream);
 /* Backward of uc_conv1x1_to4: dfeat[p,c] = sum_o dout[p,o] w[o,c] (dtype of feat); dw [4,Cin] and db [4] are
- * accumulated with fp32 atomics (zero them first). */
+ * accumulated with fp32 atomics (zero them first).  relu_mask != 0: feat is the output of a ReLU whose backward is applied here
+ * (dfeat = 0 where feat <= 0): the regressor's conv3x3 -> ReLU -> conv1x1 tail without a mask pass of its own. */
 int uc_conv1x1_to4_bwd(const void* feat, int dtype, const float* w, const float* dout, void* dfeat, float* dw, float* db,
-                       int64_t npix, int Cin, uc_stream_t stream);
+                       int64_t npix, int Cin, int relu_mask, uc_stream_t stream);
 
 /* fp32 verification-mode attention backward: same math, row-major fp32 operands (head_dim D <= 64), no packed
  * transposes needed.  delta fp32 [B,H,Nq] is scratch. */

@@ -101,7 +101,7 @@ SIGNATURES = {
     "uc_convt_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_im2col_t": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, vp],
     "uc_dilate_nhwc": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "uc_conv1x1_to4_bwd": [vp, i32, vp, vp, vp, vp, vp, i64, i32, vp],
+    "uc_conv1x1_to4_bwd": [vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "uc_attention_bwd_f32": [vp] * 10 + [i32] * 5 + [i64] * 21 + [f32, vp],
 }
 

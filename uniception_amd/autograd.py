@@ -647,7 +647,8 @@ class Conv3x3Fn(Function):
     """y = [residual +] act(conv3x3(relu?(x)) + b) on NHWC maps (dpt_block.py:17-289, dpt.py:116-178,271-277)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, residual2, conv, relu_in, act):
+    def forward(ctx, x, weight, bias, residual, residual2, conv, relu_in, act, grad_mask_cell=None):
+        ctx.grad_mask_cell = grad_mask_cell
         x = _c(x)
         B, H, W, Cin = x.shape
         s = conv.stride[0]
@@ -672,7 +673,11 @@ class Conv3x3Fn(Function):
         dt = x.dtype
         dy = _c(dy)
         Cout = dy.shape[-1]
-        dz = ops.act_bwd(dy, y, "relu") if act == "relu" else dy
+        cell = ctx.grad_mask_cell
+        already_masked = cell is not None and cell[0]          # the only consumer's backward applied this ReLU's mask (Conv1x1To4Fn)
+        if cell is not None:
+            cell[0] = False
+        dz = ops.act_bwd(dy, y, "relu") if (act == "relu" and not already_masked) else dy
         dz2 = dz.view(-1, Cout)
         dWg, db = _wgrad_conv(dz, x, s, relu_in, has_b)                          # [Cout, 9*Cin], K ordered (ky,kx,c)
         dW = dWg.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
@@ -685,11 +690,13 @@ class Conv3x3Fn(Function):
                 dx = ops.gemm(g, _conv3x3_rot_weight(conv, dt), conv=(B, H, W, Cout, 1)).view(B, H, W, Cin)
                 if relu_in:
                     dx = ops.act_bwd(dx, x, "relu")
-        return dx, dW, db, (dy if has_r1 else None), (dy if has_r2 else None), None, None, None
+        return dx, dW, db, (dy if has_r1 else None), (dy if has_r2 else None), None, None, None, None
 
 
-def conv3x3(x, conv, relu_in=False, act=None, residual=None, residual2=None):
-    return Conv3x3Fn.apply(x, conv.weight, conv.bias, residual, residual2, conv, relu_in, act)
+def conv3x3(x, conv, relu_in=False, act=None, residual=None, residual2=None, grad_mask_cell=None):
+    """grad_mask_cell: a one-element list shared with the SOLE consumer of a fused-ReLU output (conv1x1_to4(relu_cell=...)); when that
+    consumer's backward has applied the ReLU mask it sets cell[0] and this backward skips its own mask pass."""
+    return Conv3x3Fn.apply(x, conv.weight, conv.bias, residual, residual2, conv, relu_in, act, grad_mask_cell)
 
 
 def conv1x1(x, conv):
@@ -805,10 +812,10 @@ class Conv1x1To4Fn(Function):
     """Regressor tail: features -> 4 decoded channels, fp32 output (dpt.py:271-277 conv2[2])."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w4, b4):
+    def forward(ctx, x, weight, bias, w4, b4, relu_cell=None):
         x = _c(x)
         ctx.save_for_backward(x, w4)
-        ctx.wshape, ctx.has_b = weight.shape, bias is not None
+        ctx.wshape, ctx.has_b, ctx.relu_cell = weight.shape, bias is not None, relu_cell
         return ops.conv1x1_to4(x, w4, b4)
 
     @staticmethod
@@ -816,9 +823,14 @@ class Conv1x1To4Fn(Function):
         x, w4 = ctx.saved_tensors
         dw = torch.zeros_like(w4)
         db = torch.zeros(4, dtype=torch.float32, device=x.device)
-        dfeat = ops.conv1x1_to4_bwd(x, w4, _c(dout), dw, db)
-        return dfeat, dw.view(ctx.wshape), (db if ctx.has_b else None), None, None
+        # x straight out of a fused-ReLU conv3x3 (relu_cell from conv3x3(..., grad_mask_cell=...)): that ReLU's backward rides in this
+        # kernel, and the cell tells the conv's backward not to mask again
+        masked = ctx.relu_cell is not None
+        dfeat = ops.conv1x1_to4_bwd(x, w4, _c(dout), dw, db, relu_mask=masked)
+        if masked:
+            ctx.relu_cell[0] = True
+        return dfeat, dw.view(ctx.wshape), (db if ctx.has_b else None), None, None, None
 
 
-def conv1x1_to4(x, conv, w4, b4):
-    return Conv1x1To4Fn.apply(x, conv.weight, conv.bias, w4, b4)
+def conv1x1_to4(x, conv, w4, b4, relu_cell=None):
+    return Conv1x1To4Fn.apply(x, conv.weight, conv.bias, w4, b4, relu_cell)

@@ -150,7 +150,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
     }
     const float c = p.scale * 1.44269504088896340736f;
     const float lse2 = p.LSE[((int64_t)b * p.H + h) * p.Nq + q] * 1.44269504088896340736f;
-    const float dlt = p.delta[((int64_t)b * p.H + h) * p.Nq + q];
+    // delta[q] = sum_d dO[q,d] * O[q,d] (round 4: computed HERE — the lane pair of a query already holds its dO row as dof; one more row
+    // load and a cross-half add replace the stand-alone pass of rounds 1-3) and left in p.delta for the dK / dV kernel, which runs next
+    float dlt = 0.f;
+    {
+        const bf16_t* op = p.O + (int64_t)b * p.o_sb + (int64_t)q * p.o_sn + (int64_t)h * p.o_sh + hi * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(op + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dlt = fmaf((float)of[j], (float)dof[s][j], dlt);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (q_ok && hi == 0) p.delta[((int64_t)b * p.H + h) * p.Nq + q] = dlt;
+    }
 
     float16_t dq[2];
     dq[0] = (float16_t)(0.f);
@@ -383,7 +396,7 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh; p.scale = scale;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * H * Nq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, p);
+    (void)total;      // (delta is computed by the dQ kernel since round 4; attn_delta_kernel remains for reference)
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((Nk + 127) / 128) * H * B)), dim3(256), 0, st, p);
     UC_CHECK_LAUNCH("uc_attention_bwd");

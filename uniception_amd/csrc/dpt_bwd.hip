@@ -231,7 +231,7 @@ extern "C" int uc_dilate_nhwc(const void* src, void* dst, int dtype, int B, int 
 template <typename Tag>
 __global__ __launch_bounds__(256) void conv1x1_to4_bwd_kernel(const typename Tag::storage* __restrict__ feat, const float* __restrict__ w,
                                                                const float* __restrict__ dout, typename Tag::storage* __restrict__ dfeat,
-                                                               float* __restrict__ dw, float* __restrict__ db, int64_t npix, int Cin) {
+                                                               float* __restrict__ dw, float* __restrict__ db, int64_t npix, int Cin, int relu_mask) {
     __shared__ float red[256][33];
     const int C8 = Cin / 8;
     const int lanes = 256 / C8;              // pixel lanes per block
@@ -253,6 +253,10 @@ __global__ __launch_bounds__(256) void conv1x1_to4_bwd_kernel(const typename Tag
             V8b d;
 #pragma unroll
             for (int e = 0; e < 8; ++e) d.v[e] = gv[0] * wr[0][e] + gv[1] * wr[1][e] + gv[2] * wr[2][e] + gv[3] * wr[3][e];
+            if (relu_mask) {      // feat is the OUTPUT of a ReLU: its backward rides here (the stand-alone mask pass re-read both maps)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d.v[e] = f.v[e] > 0.f ? d.v[e] : 0.f;
+            }
             st8<Tag>(dfeat + p * Cin + chunk * 8, d);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
@@ -290,14 +294,14 @@ __global__ __launch_bounds__(256) void conv1x1_to4_bwd_kernel(const typename Tag
 }
 
 extern "C" int uc_conv1x1_to4_bwd(const void* feat, int dtype, const float* w, const float* dout, void* dfeat, float* dw, float* db,
-                                  int64_t npix, int Cin, uc_stream_t stream) {
+                                  int64_t npix, int Cin, int relu_mask, uc_stream_t stream) {
     UC_REQUIRE(feat && w && dout && dfeat && dw && db, "uc_conv1x1_to4_bwd: null pointer");
     UC_REQUIRE(npix > 0 && Cin > 0 && Cin <= 256 && Cin % 8 == 0, "uc_conv1x1_to4_bwd: Cin must be a multiple of 8 and <= 256");
     const int lanes = 256 / (Cin / 8);
     const unsigned grid = (unsigned)min((int64_t)2048, ceil_div64(npix, lanes));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == UC_F32) hipLaunchKernelGGL((conv1x1_to4_bwd_kernel<F32Tag>), dim3(grid), dim3(256), 0, st, (const float*)feat, w, dout, (float*)dfeat, dw, db, npix, Cin);
-    else if (dtype == UC_BF16) hipLaunchKernelGGL((conv1x1_to4_bwd_kernel<BF16Tag>), dim3(grid), dim3(256), 0, st, (const bf16_t*)feat, w, dout, (bf16_t*)dfeat, dw, db, npix, Cin);
+    if (dtype == UC_F32) hipLaunchKernelGGL((conv1x1_to4_bwd_kernel<F32Tag>), dim3(grid), dim3(256), 0, st, (const float*)feat, w, dout, (float*)dfeat, dw, db, npix, Cin, relu_mask);
+    else if (dtype == UC_BF16) hipLaunchKernelGGL((conv1x1_to4_bwd_kernel<BF16Tag>), dim3(grid), dim3(256), 0, st, (const bf16_t*)feat, w, dout, (bf16_t*)dfeat, dw, db, npix, Cin, relu_mask);
     else { uc_set_error("uc_conv1x1_to4_bwd: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_conv1x1_to4_bwd");
     return UC_OK;

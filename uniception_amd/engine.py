@@ -819,10 +819,10 @@ def conv1x1(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
 
 
 def conv3x3(x: torch.Tensor, conv: nn.Conv2d, relu_in: bool = False, act=None, residual: Optional[torch.Tensor] = None,
-            residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
+            residual2: Optional[torch.Tensor] = None, grad_mask_cell=None) -> torch.Tensor:
     if _train(x, conv.weight, residual, residual2):
         from . import autograd
-        return autograd.conv3x3(x, conv, relu_in, act, residual, residual2)
+        return autograd.conv3x3(x, conv, relu_in, act, residual, residual2, grad_mask_cell)
     B, H, W, Cin = x.shape
     s = conv.stride[0]
     w, b = conv3x3_weights(conv, x.dtype)

@@ -138,14 +138,18 @@ class DPTRegressionProcessor(nn.Module):
         fused = engine.conv3x3_tail4(x, self.conv2[0], "relu", last)     # conv2.0 -> ReLU -> conv2.2 in one kernel (inference)
         if fused is not None:
             return PixelTaskOutput(decoded_channels=fused.permute(0, 3, 1, 2))
-        x = engine.conv3x3(x, self.conv2[0], act="relu")
-        if last.out_channels == 4 and last.in_channels <= 256 and last.in_channels % 8 == 0:
+        to4 = last.out_channels == 4 and last.in_channels <= 256 and last.in_channels % 8 == 0
+        # training: the 1x1 tail is the ONLY consumer of this ReLU's output, so the ReLU's backward rides in the tail's backward kernel
+        # (one-element cell shared by the two autograd functions: autograd.conv3x3 / conv1x1_to4)
+        cell = [False] if (to4 and engine._train(x, last.weight)) else None
+        x = engine.conv3x3(x, self.conv2[0], act="relu", grad_mask_cell=cell)
+        if to4:
             w = engine.prepared(last, "c1x4", (last.weight, last.bias),
                                 lambda: (last.weight.detach().reshape(4, -1).float().contiguous(),
                                          last.bias.detach().float().contiguous() if last.bias is not None
                                          else torch.zeros(4, device=last.weight.device)))
             if engine._train(x, last.weight):
-                out = autograd.conv1x1_to4(x, last, w[0], w[1])
+                out = autograd.conv1x1_to4(x, last, w[0], w[1], relu_cell=cell)
             else:
                 out = ops.conv1x1_to4(x, w[0], w[1])  # fp32 NHWC [B,H,W,4]
         else:

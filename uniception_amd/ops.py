@@ -1061,13 +1061,15 @@ def dilate_nhwc(src: torch.Tensor, H: int, W: int, stride: int) -> torch.Tensor:
     return out
 
 
-def conv1x1_to4_bwd(feat: torch.Tensor, w: torch.Tensor, dout: torch.Tensor, dw: torch.Tensor, db: torch.Tensor) -> torch.Tensor:
-    """feat NHWC [...,Cin], w fp32 [4,Cin], dout fp32 [...,4] -> dfeat (feat's dtype); dw/db accumulated (fp32)."""
+def conv1x1_to4_bwd(feat: torch.Tensor, w: torch.Tensor, dout: torch.Tensor, dw: torch.Tensor, db: torch.Tensor,
+                    relu_mask: bool = False) -> torch.Tensor:
+    """feat NHWC [...,Cin], w fp32 [4,Cin], dout fp32 [...,4] -> dfeat (feat's dtype); dw/db accumulated (fp32).
+    relu_mask: feat is a ReLU's output; its backward (zero where feat <= 0) is applied to dfeat in the same pass."""
     _need_gpu(feat, w, dout, dw, db)
     assert feat.is_contiguous() and dout.is_contiguous() and dout.dtype == torch.float32 and w.is_contiguous()
     Cin = feat.shape[-1]
     npix = feat.numel() // Cin
     dfeat = torch.empty_like(feat)
     _lib.check(_lib.load().uc_conv1x1_to4_bwd(feat.data_ptr(), _dt(feat.dtype), w.data_ptr(), dout.data_ptr(), dfeat.data_ptr(),
-                                              dw.data_ptr(), db.data_ptr(), npix, Cin, _stream()), "uc_conv1x1_to4_bwd")
+                                              dw.data_ptr(), db.data_ptr(), npix, Cin, 1 if relu_mask else 0, _stream()), "uc_conv1x1_to4_bwd")
     return dfeat
