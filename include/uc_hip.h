@@ -482,13 +482,17 @@ int uc_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
  *   inputs : Q,K,V,O,dO as [B,N,H,64] strided views (bf16; dO addressed with O's strides), LSE fp32 [B,H,Nq] (natural log of
  *            the softmax denominator of the scaled scores);
  *   outputs: dQ [B,Nq,H,64], dK, dV [B,Nk,H,64] bf16 (own strides, e.g. slices of one fused dqkv buffer).
- *   delta fp32 [B,H,Nq] is scratch for rowsum(dO*O).  All operands are row-major: the transposed MFMA operands are formed
- *   inside the kernels with LDS transpose-reads. */
+ *   delta fp32 [B,H,Nq] is scratch for rowsum(dO*O) (written by the dQ kernel, read by the dK / dV kernel).  All operands are
+ *   row-major: the transposed MFMA operands are formed inside the kernels with LDS transpose-reads.
+ *   rope_qpos / rope_kpos (both or neither; int64 [B*Nq,2] / [B*Nk,2] (y,x)): Q and K were rotated by RoPE-2D (base, F0) before the
+ *   forward — dQ and dK are then returned as gradients of the UN-rotated q / k (the inverse rotation rides in the kernels' epilogues
+ *   instead of two uc_rope2d passes).  NULL: gradients of the rotated operands. */
 int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                      void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb, int64_t q_sn,
                      int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh,
                      int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb,
                      int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
+                     const int64_t* rope_qpos, const int64_t* rope_kpos, float rope_base, float rope_f0,
                      uc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -225,6 +225,31 @@ def test_attention_backward_on_fused_qkv_views(gpu):
         assert rel_l2(got.cpu().float(), ref) < 1.5e-2
 
 
+def test_attention_backward_with_the_inverse_rope_inside(gpu):
+    """rope=(qpos, kpos, base, F0): dq / dk come back as gradients of the UN-rotated q / k — the arithmetic of two uc_rope2d passes with
+    -F0 over the plain backward's dq / dk (curope.cpp:21-46 with the sign flipped), done in the kernels' epilogues; cross-attention
+    shapes (Nq != Nk, ragged against the 128-row tiles) and separate q / k position grids."""
+    from uniception_amd import ops
+    B, H, D, scale = 2, 3, 64, 64 ** -0.5
+    for (gh, gw, kh, kw) in ((9, 7, 9, 7), (5, 6, 11, 13)):
+        Nq, Nk = gh * gw, kh * kw
+        g = torch.Generator().manual_seed(Nq * 7 + Nk)
+        q = torch.randn(B, Nq, H, D, generator=g).bfloat16().to(gpu)
+        kv = torch.randn(B, Nk, 2, H, D, generator=g).bfloat16().to(gpu)
+        do = torch.randn(B, Nq, H, D, generator=g).bfloat16().to(gpu)
+        qpos = torch.cartesian_prod(torch.arange(gh), torch.arange(gw)).repeat(B, 1).contiguous().to(gpu)
+        kpos = (torch.cartesian_prod(torch.arange(kh), torch.arange(kw)) + 3).repeat(B, 1).contiguous().to(gpu)
+        k, v = kv[:, :, 0], kv[:, :, 1]
+        lse = torch.empty(B, H, Nq, dtype=torch.float32, device=gpu)
+        o = ops.attention(q, k, ops.vt_pack(v.contiguous()), scale, v_packed=True, lse=lse)
+        dq0, dk0, dv0 = ops.attention_bwd(q, k, v, o, do, lse, scale)
+        ops.rope_2d_(dq0, qpos.view(B, Nq, 2), 100.0, -1.0)
+        ops.rope_2d_(dk0, kpos.view(B, Nk, 2), 100.0, -1.0)
+        dq1, dk1, dv1 = ops.attention_bwd(q, k, v, o, do, lse, scale, rope=(qpos, kpos, 100.0, 1.0))
+        assert torch.equal(dv0, dv1)
+        assert rel_l2(dq1.float().cpu(), dq0.float().cpu()) < 6e-3 and rel_l2(dk1.float().cpu(), dk0.float().cpu()) < 6e-3   # (one bf16 rounding instead of two)
+
+
 # ------------------------------------------------------------------------------------------
 # DPT head backward helpers
 # ------------------------------------------------------------------------------------------

@@ -96,7 +96,7 @@ SIGNATURES = {
     "uc_pointmap_loss": [vp, i64, i64, i64, vp, f32, f32, vp, vp, i32, i32, i32, vp],
     "uc_pixel_unshuffle": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_adamw": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
-    "uc_attention_bwd": [vp] * 10 + [i32] * 4 + [i64] * 21 + [f32, vp],
+    "uc_attention_bwd": [vp] * 10 + [i32] * 4 + [i64] * 21 + [f32, vp, vp, f32, f32, vp],
     "uc_bilinear_nhwc_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "uc_convt_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "uc_im2col_t": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, vp],

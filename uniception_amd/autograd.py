@@ -204,6 +204,13 @@ def _rope_inverse_(t4, pos, rope):
         ops.rope_2d_(t4, pos.contiguous(), rope.base, -rope.F0)
 
 
+def _bwd_rope(rope, qpos, kpos, dt):
+    "rope argument of ops.attention_bwd when the inverse rotation can ride in the bf16 backward kernels, else None."
+    if rope is None or dt != torch.bfloat16 or qpos is None or kpos is None or qpos.numel() == 0:
+        return None
+    return (engine._pos2d(qpos), engine._pos2d(kpos), rope.base, rope.F0)
+
+
 def _attention_fwd(q, k, v, scale, lse):
     if q.dtype == torch.bfloat16:
         if q.shape[-1] != 64:
@@ -376,10 +383,12 @@ class SelfAttnSubLayerFn(Function):
             do = ops.gemm(dyb, _folded_weight_t(proj, gamma, dt))
         dt3 = torch.empty_like(t)
         d5, t5 = dt3.view(B, N, 3, H, Dh), t.view(B, N, 3, H, Dh)
+        fused_rope = _bwd_rope(rope, pos, pos, dt)      # (bf16: the inverse rotation of dq / dk rides in the backward kernels)
         ops.attention_bwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale,
-                          out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]))
-        _rope_inverse_(d5[:, :, 0], pos, rope)
-        _rope_inverse_(d5[:, :, 1], pos, rope)
+                          out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]), rope=fused_rope)
+        if fused_rope is None:
+            _rope_inverse_(d5[:, :, 0], pos, rope)
+            _rope_inverse_(d5[:, :, 1], pos, rope)
         dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * C)], bias_sink=[qkv.bias])
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db, sunk = _ln_grad_targets(ln, g)
@@ -450,10 +459,12 @@ class CrossAttnSubLayerFn(Function):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         kv5, dkv5 = kv.view(B, Nk, 2, H, Dh), dkv.view(B, Nk, 2, H, Dh)
+        fused_rope = _bwd_rope(rope, qpos, kpos, dt)
         ops.attention_bwd(q.view(B, Nq, H, Dh), kv5[:, :, 0], kv5[:, :, 1], o, do.view(B, Nq, H, Dh), lse, scale,
-                          out=(dq.view(B, Nq, H, Dh), dkv5[:, :, 0], dkv5[:, :, 1]))
-        _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
-        _rope_inverse_(dkv5[:, :, 0], kpos, rope)
+                          out=(dq.view(B, Nq, H, Dh), dkv5[:, :, 0], dkv5[:, :, 1]), rope=fused_rope)
+        if fused_rope is None:
+            _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
+            _rope_inverse_(dkv5[:, :, 0], kpos, rope)
         # query side
         dWq, dbq = _wgrad(dq, hq, dt, has_bq, sink=[(projq.weight, 0, C)], bias_sink=[projq.bias])
         dhq = ops.gemm(dq, lin_weight_t(projq, dt))

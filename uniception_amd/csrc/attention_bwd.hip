@@ -18,6 +18,7 @@
 // LDS tiles are 64 rows x 128 B with the (row>>1)&7 chunk swizzle (conflict-free ds_read_b128; the transposing reads see
 // 2-way conflicts between rows r and r+2, which the MFMA/VALU work hides), single-buffered, 2-3 workgroups per CU.
 #include "common.h"
+#include <math.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -33,6 +34,11 @@ struct AttnBwdParams {
     int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
     int64_t dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh;
     float scale;
+    // inverse RoPE-2D of dQ / dK in the kernels' epilogues (round 4; NULL positions: gradients of the ROTATED q / k, as before)
+    const int64_t* rope_qpos;   // [B * Nq][2] (y, x)
+    const int64_t* rope_kpos;   // [B * Nk][2]
+    float rope_turn0;           // F0 / (2 pi): rotation per unit position of channel 0, in turns
+    float rope_ratio;           // base^(-1/16)
 };
 
 #define TB (64 * 128)   // bytes of one 64-row tile
@@ -81,6 +87,34 @@ __device__ __forceinline__ void dma_tile(const bf16_t* base, int64_t row_stride,
         if (row >= n_rows) row = n_rows - 1;
         const int c = (lane & 7) ^ ((rr >> 1) & 7);
         ab_dma16(base + (int64_t)row * row_stride + c * 8, __builtin_amdgcn_readfirstlane(lds_tile + (unsigned)(n * 1024)));
+    }
+}
+
+// Inverse RoPE-2D on a gradient held in the kernels' accumulator layout: g[db][4 g4 + r] = channel 32 db + 8 g4 + 4 hi + r of one token
+// (db = 0: y half, db = 1: x half; inside a half the pair (u, v) = channels (c, c + 16), c = 8 g4 + 4 hi + r with g4 in {0, 1}: the same
+// lane).  The forward rotated (u, v) by angle pos * F0 * base^(-c/16) (kernels.cu:36-81); the gradient goes back by the opposite
+// angle: du = du' cos + dv' sin, dv = dv' cos - du' sin.  Angles through the hardware sin / cos on fract(pos * turn), like the forward's
+// GEMM epilogue.  Replaces one uc_rope2d pass over dq and one over dk per attention (144 launches per training step).
+__device__ __forceinline__ void ab_rope_inverse(float16_t (&g)[2], const int64_t* pos2, int hi, float turn0, float ratio) {
+    const float py = (float)(int)pos2[0], px = (float)(int)pos2[1];
+    float t4 = turn0;                                   // turn of channel 4 hi (hi = 1: x ratio^4)
+    if (hi) { const float r2 = ratio * ratio; t4 *= r2 * r2; }
+    const float r8 = (ratio * ratio) * (ratio * ratio) * (ratio * ratio) * (ratio * ratio);
+#pragma unroll
+    for (int g4 = 0; g4 < 2; ++g4) {
+        float turn = g4 ? t4 * r8 : t4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const float tf = __builtin_amdgcn_fractf((db ? px : py) * turn);
+                const float cs = __builtin_amdgcn_cosf(tf), sn = __builtin_amdgcn_sinf(tf);
+                const float u = g[db][g4 * 4 + r], v = g[db][(g4 + 2) * 4 + r];
+                g[db][g4 * 4 + r] = __builtin_fmaf(u, cs, v * sn);
+                g[db][(g4 + 2) * 4 + r] = __builtin_fmaf(v, cs, -(u * sn));
+            }
+            turn *= ratio;
+        }
     }
 }
 
@@ -224,6 +258,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
                 dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_operand(smem, g, db, lane), dsf[g], dq[db], 0, 0, 0);
             }
     }
+    if (p.rope_qpos) ab_rope_inverse(dq, p.rope_qpos + ((int64_t)b * p.Nq + q) * 2, hi, p.rope_turn0, p.rope_ratio);     // (linear: the scale below commutes)
     if (q_ok) {
         bf16_t* op = p.dQ + (int64_t)b * p.dq_sb + (int64_t)q * p.dq_sn + (int64_t)h * p.dq_sh;
 #pragma unroll
@@ -353,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
                 }
         }
     }
+    if (p.rope_kpos) ab_rope_inverse(dk, p.rope_kpos + ((int64_t)b * p.Nk + key) * 2, hi, p.rope_turn0, p.rope_ratio);
     if (key_ok) {
         bf16_t* kp = p.dK + (int64_t)b * p.dk_sb + (int64_t)key * p.dk_sn + (int64_t)h * p.dk_sh;
         bf16_t* vp = p.dV + (int64_t)b * p.dv_sb + (int64_t)key * p.dv_sn + (int64_t)h * p.dv_sh;
@@ -377,8 +413,10 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
                                 int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
                                 int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh,
                                 int64_t dk_sb, int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
-                                uc_stream_t stream) {
+                                const int64_t* rope_qpos, const int64_t* rope_kpos, float rope_base, float rope_f0, uc_stream_t stream) {
     UC_REQUIRE(Q && K && V && O && dO && LSE && dQ && dK && dV && delta, "uc_attention_bwd: null pointer");
+    UC_REQUIRE((rope_qpos == nullptr) == (rope_kpos == nullptr), "uc_attention_bwd: rope_qpos and rope_kpos go together");
+    UC_REQUIRE(!rope_qpos || (rope_base > 0.f && rope_f0 != 0.f), "uc_attention_bwd: the inverse RoPE needs base > 0 and F0 != 0");
     UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B <= 65535 && H <= 65535, "uc_attention_bwd: bad shape");
     UC_REQUIRE(q_sn % 8 == 0 && k_sn % 8 == 0 && v_sn % 8 == 0 && o_sn % 8 == 0 && q_sh % 8 == 0 && k_sh % 8 == 0 && v_sh % 8 == 0 &&
                    o_sh % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0,
@@ -394,6 +432,9 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh; p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh;
     p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh; p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.dk_sb = dk_sb; p.dk_sn = dk_sn;
     p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh; p.scale = scale;
+    p.rope_qpos = rope_qpos; p.rope_kpos = rope_kpos;
+    p.rope_turn0 = rope_qpos ? (float)((double)rope_f0 / 6.283185307179586476925) : 0.f;
+    p.rope_ratio = rope_qpos ? (float)pow((double)rope_base, -1.0 / 16.0) : 1.f;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * H * Nq;
     (void)total;      // (delta is computed by the dQ kernel since round 4; attn_delta_kernel remains for reference)

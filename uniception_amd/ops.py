@@ -976,10 +976,12 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, l
                                     float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream()), "uc_adamw")
 
 
-def attention_bwd(q, k, v, o, do, lse, scale: float, out=None):
+def attention_bwd(q, k, v, o, do, lse, scale: float, out=None, rope=None):
     """q,o,do [B,Nq,H,64]; k,v [B,Nk,H,64] bf16 views (unit last stride); lse fp32 [B,H,Nq].
     Returns dq, dk, dv ([B,N,H,64] bf16): fresh contiguous tensors, or the three views passed as `out`
-    (e.g. slices of one fused dqkv buffer)."""
+    (e.g. slices of one fused dqkv buffer).
+    rope = (qpos int64 [B*Nq,2], kpos int64 [B*Nk,2], base, F0) (bf16 only): q and k were RoPE-rotated before the forward; dq / dk come
+    back as gradients of the un-rotated q / k (the inverse rotation runs inside the backward kernels)."""
     _need_gpu(q, k, v, o, do, lse)
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
@@ -998,6 +1000,9 @@ def attention_bwd(q, k, v, o, do, lse, scale: float, out=None):
         assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
         assert all(t.dtype == dt and t.stride(3) == 1 for t in out)
     delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    if rope is not None:
+        assert dt == torch.bfloat16 and rope[0].dtype == torch.int64 and rope[1].dtype == torch.int64
+        assert rope[0].is_contiguous() and rope[1].is_contiguous() and rope[0].numel() == 2 * B * Nq and rope[1].numel() == 2 * B * Nk
     if dt == torch.float32:
         _lib.check(_lib.load().uc_attention_bwd_f32(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(),
@@ -1011,7 +1016,9 @@ def attention_bwd(q, k, v, o, do, lse, scale: float, out=None):
         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk,
         q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
         o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1), dk.stride(2),
-        dv.stride(0), dv.stride(1), dv.stride(2), float(scale), _stream()), "uc_attention_bwd")
+        dv.stride(0), dv.stride(1), dv.stride(2), float(scale),
+        _p(rope[0]) if rope is not None else None, _p(rope[1]) if rope is not None else None,
+        float(rope[2]) if rope is not None else 0.0, float(rope[3]) if rope is not None else 0.0, _stream()), "uc_attention_bwd")
     return dq, dk, dv
 
 
