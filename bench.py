@@ -408,6 +408,8 @@ def train_step_leg(args, dev, pairs=32, steps=3):
                        "synthetic pointmap targets, 1 rank (the gradient exchange is a no-op at world 1)",
            "pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": pairs, "timing": st,
            "heads": engine.train_head_dtype_name() if hasattr(engine, "train_head_dtype_name") else "bf16 kernels (forward and backward)",
+           "streams": "2 (encoder views, decoder branches, heads: forward and backward)" if (engine.CONCURRENT and engine.TRAIN_CONCURRENT) else "1",
+           "residual_stream": "bf16 (the reference's stream under autocast)" if engine._bf16_train_stream else "fp32",
            "enc_dec_mfma_frac_lower_bound": round(pps * gf * 3 / 1e3 / PEAK_BF16_TFLOPS, 4),
            "note": "fraction = pairs/s x 3 x forward enc+dec flops / peak: charges heads, optimizer and the whole step to the enc+dec flops"}
     if not args.no_roofline:
@@ -591,8 +593,9 @@ def main():
                                 + ", random-init weights"),
                    "pairs_per_gpu": args.pairs, "global_pairs_per_step": world * args.pairs, "img": args.img,
                    "head": args.head, "encoder": args.encoder, "attention": args.attention, "hipgraph": bool(args.graph),
-                   "streams": ("1" if (not engine.CONCURRENT or not fwd) else
-                               "2 (the two views through the encoder, the two decoder branches and the two heads run as concurrent HIP streams)"),
+                   "streams": ("1" if (not engine.CONCURRENT or (not fwd and not engine.TRAIN_CONCURRENT)) else
+                               "2 (the two views through the encoder, the two decoder branches and the two heads run as concurrent HIP streams"
+                               + ("" if fwd else ", forward and backward") + ")"),
                    "heads": (("TF32-class: fp16 MFMA operands (10-bit mantissa), fp32 accumulate, fp32 final layer + adaptor — the reference's "
                               "fp32 heads under allow_tf32 (2e-3 from exact-fp32 heads; bf16 heads: 1.7e-2)") if (fwd and args.precision == "bf16" and engine.head_dtype_name() == "fp16")
                              else (engine.head_dtype_name() if fwd else

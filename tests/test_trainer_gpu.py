@@ -229,3 +229,49 @@ def test_one_rank_rccl_exchange_step(gpu, tmp_path, mode):
     # (two separate runs: bias gradients accumulate with fp32 atomics in arrival order, and AdamW turns a last-bit difference of a
     # near-zero gradient into an lr-sized step of that element — seen once at 1.3e-6 in a full-suite run)
     assert worst < (2e-5 if mode == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_two_stream_training_step_equals_the_single_stream_one(gpu, mode, tol):
+    """Round 4: while autograd records, the decoder's two view branches and the two heads (disjoint parameters) and the encoder's two
+    views (SHARED parameters: the forked view's weight gradients leave the read-modify-write gradient sink to autograd's accumulation)
+    run on two HIP streams, forward and backward.  On the factory model with the trainer's flat gradient buffer and sink in place, the
+    loss and every parameter gradient of the forked step equal the single-stream step's (fp32: to summation order; bf16: the encoder
+    sees two half batches instead of one — same rows, same bits per row — and the weight-gradient sums split differently)."""
+    from uniception_amd import autograd, engine
+    from uniception_amd.training import Trainer
+
+    def step(fork):
+        model, c = build_case_model("vitl_linear_224")      # the factory model (the encoder fork lives in DUSt3R._encode_image_pairs)
+        assert c.get("factory")
+        model = model.to(gpu).train()
+        tr = Trainer(model, lr=1e-3)
+        img1, img2 = (t.to(gpu) for t in case_images(c))
+        gt1, gt2 = (t.to(gpu) for t in grad_targets(c))
+        v1 = {"img": img1, "instance": [str(i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+        v2 = {"img": img2, "instance": [str(100 + i) for i in range(c["B"])], "data_norm_type": "dust3r"}
+        prev = (engine.TRAIN_CONCURRENT, engine.BRANCH_TOKENS_MAX)
+        engine.TRAIN_CONCURRENT, engine.BRANCH_TOKENS_MAX = fork, (0 if fork else prev[1])     # (0: fork whatever the batch size)
+        try:
+            losses = []
+            for _ in range(2):      # twice: the first call of a fork point runs its branches in order (warm-up), the second overlaps
+                tr.zero_grad()
+                with engine.precision(mode):
+                    r1, r2 = model(v1, v2)
+                    loss = autograd.conf_loss(r1["pts3d"], r1["conf"], gt1) + autograd.conf_loss(r2["pts3d_in_other_view"], r2["conf"], gt2)
+                loss.backward()
+                torch.cuda.synchronize()
+                losses.append(float(loss.detach()))
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        finally:
+            engine.TRAIN_CONCURRENT, engine.BRANCH_TOKENS_MAX = prev
+            tr.close() if hasattr(tr, "close") else None
+            autograd.set_grad_sink(False)
+        return losses, grads
+
+    l0, g0 = step(False)
+    l1, g1 = step(True)
+    assert abs(l0[1] - l1[1]) / abs(l0[1]) < (1e-6 if mode == "fp32" else 2e-3), (l0, l1)
+    worst = max((rel_l2(g1[k].cpu(), g0[k].cpu()), k) for k in g0)
+    print(f"\n[{mode}] forked vs single-stream training step: loss {l1[1]:.6f} vs {l0[1]:.6f}, worst gradient deviation {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < tol, worst

@@ -62,6 +62,13 @@ def _reduce_slabs(ws: torch.Tensor) -> torch.Tensor:
 # bookkeeping of the trainer needs no extra signal; should a PyTorch build skip the hook for undefined gradients, the
 # trainer's finish() reduces the buckets that never completed.
 _grad_sink = False
+# Two-stream training with SHARED parameters (the encoder's two views on two streams, engine.run_branches(shared_params=True)): the
+# sink's reduction is a plain read-modify-write of the parameter's gradient slice, and two streams doing that concurrently would race.
+# Functions whose forward ran inside the forked (second) branch therefore return their weight gradients as tensors — autograd's
+# AccumulateGrad adds them on the stream the parameter was first used on, behind the first branch's sink writes.  `_sink_fwd_ok` is what
+# a Function records at forward time (ctx._uc_sink_ok, see _sink_aware); `_grad_sink_gate` is that record during its backward.
+_sink_fwd_ok = [True]
+_grad_sink_gate = True
 
 
 def set_grad_sink(enabled) -> None:
@@ -69,9 +76,29 @@ def set_grad_sink(enabled) -> None:
     _grad_sink = bool(enabled)
 
 
+def _sink_aware(cls):
+    "Class decorator of the autograd Functions below: remember at forward time whether this node may sink, apply it in backward."
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args, **kw):
+        ctx._uc_sink_ok = _sink_fwd_ok[0]
+        return fwd(ctx, *args, **kw)
+
+    def backward(ctx, *grads):
+        global _grad_sink_gate
+        prev = _grad_sink_gate
+        _grad_sink_gate = getattr(ctx, "_uc_sink_ok", True)
+        try:
+            return bwd(ctx, *grads)
+        finally:
+            _grad_sink_gate = prev
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 def _sinkable(param, rows: int, cols: int) -> bool:
     g = param.grad
-    return (_grad_sink and g is not None and g.dtype == torch.float32 and g.is_contiguous()
+    return (_grad_sink and _grad_sink_gate and g is not None and g.dtype == torch.float32 and g.is_contiguous()
             and g.numel() == rows * cols and param.requires_grad)
 
 
@@ -88,7 +115,7 @@ def _ln_grad_targets(ln, g):
 def _bias_target(bias_sink, N: int):
     """One contiguous fp32 [N] view covering the gradient buffers of the bias parameter(s) of a linear (two adjacent ones
     for the fused K|V projection), or None when they cannot take direct accumulation."""
-    if not _grad_sink or not bias_sink or any(p is None or not _sinkable(p, p.numel(), 1) for p in bias_sink):
+    if not _grad_sink or not _grad_sink_gate or not bias_sink or any(p is None or not _sinkable(p, p.numel(), 1) for p in bias_sink):
         return None
     g0 = bias_sink[0].grad
     total, ptr = 0, g0.data_ptr()
@@ -222,6 +249,7 @@ def _attention_fwd(q, k, v, scale, lse):
 # =================================================================================================================
 # LayerNorm alone (encoder / decoder final norms, intermediate norms)
 # =================================================================================================================
+@_sink_aware
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x2d, weight, bias, eps, out_dtype):
@@ -249,6 +277,7 @@ def layer_norm(x2d, ln, out_dtype):
 # =================================================================================================================
 # Linear (proj_embed, the linear head's 1x1 conv, patch embedding GEMM)
 # =================================================================================================================
+@_sink_aware
 class LinearFn(Function):
     @staticmethod
     def forward(ctx, x2d, weight, bias, owner, dt, out_dtype):
@@ -283,6 +312,7 @@ def linear(x2d, weight, bias, owner, dt, out_dtype):
     return LinearFn.apply(x2d, weight, bias, owner, dt, out_dtype)
 
 
+@_sink_aware
 class PatchEmbedFn(Function):
     """tokens = gather(img) . W^T + b (libs/croco/patch_embed.py:47,69-82); the image gets no gradient."""
 
@@ -332,6 +362,7 @@ def _unfold_layerscale(lin, gamma, dWf, dbf):
 # =================================================================================================================
 # pre-LN sub-layers of the transformer blocks
 # =================================================================================================================
+@_sink_aware
 class SelfAttnSubLayerFn(Function):
     """x + proj(SDPA(rope(q), rope(k), v)),  q,k,v = qkv(LN(x))   (blocks.py:105-125,154-158; transformer_blocks.py:214-260)."""
 
@@ -404,6 +435,7 @@ def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=
                                     B, N, H, rope, pos, scale, dt, gamma)
 
 
+@_sink_aware
 class CrossAttnSubLayerFn(Function):
     """x + proj(SDPA(rope(projq(LN2(x)), xpos), rope(projk(LNy(y)), ypos), projv(LNy(y))))  (transformer_blocks.py:329-412,604-647)."""
 
@@ -497,6 +529,7 @@ def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, s
                                      ca.projq, ca.projk, ca.projv, ca.proj, B, Nq, Nk, H, rope, qpos, kpos, scale, dt)
 
 
+@_sink_aware
 class MlpSubLayerFn(Function):
     """x + fc2(act(fc1(LN(x))))   (blocks.py:64-86,159; transformer_blocks.py:517-560)."""
 
@@ -551,6 +584,7 @@ def mlp_sublayer(x2d, ln, fc1, fc2, act, dt, gamma=None):
 # =================================================================================================================
 # heads: pixel shuffle, adaptor, loss
 # =================================================================================================================
+@_sink_aware
 class PixelShuffleFn(Function):
     @staticmethod
     def forward(ctx, rows, B, h, w, P, Cout):
@@ -566,6 +600,7 @@ def pixel_shuffle(rows, B, h, w, P, Cout):
     return PixelShuffleFn.apply(rows, B, h, w, P, Cout)
 
 
+@_sink_aware
 class PointmapAdaptorFn(Function):
     @staticmethod
     def forward(ctx, x, vmin, vmax):
@@ -584,6 +619,7 @@ def pointmap_adaptor(x, vmin, vmax):
     return PointmapAdaptorFn.apply(x, vmin, vmax)
 
 
+@_sink_aware
 class AdaptorProgramFn(Function):
     """A channel program of the generic adaptor pass (ops.adaptor_program) and its gradient with respect to the decoded channels
     (what torch autograd computes through the reference's adaptor compositions, prediction_heads/adaptors.py:25-2300)."""
@@ -604,6 +640,7 @@ def adaptor_program(x, segs, cout):
     return AdaptorProgramFn.apply(x, segs, cout)
 
 
+@_sink_aware
 class ConfLossFn(Function):
     """mean_pix(conf * |pts - gt|) - alpha * mean_pix(log conf): the DUSt3R confidence-weighted regression objective
     (the reference ships no loss; SURVEY §8d names this one).  One kernel computes the loss and both gradients."""
@@ -631,6 +668,7 @@ def conf_loss(pts, conf, gt, alpha: float = 0.2):
 # DPT head (NHWC maps in the head dtype): 3x3 implicit-GEMM convs, 1x1 convs (LinearFn on the pixel matrix),
 # ConvTranspose2d(k=s), bilinear resize, the 4-channel regressor tail, and the dtype hop at the head's entry
 # =================================================================================================================
+@_sink_aware
 class ConvertFn(Function):
     @staticmethod
     def forward(ctx, x, dt):
@@ -654,6 +692,7 @@ def _conv3x3_rot_weight(conv, dt):
                            lambda: conv.weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(conv.in_channels, -1).to(dt).contiguous())
 
 
+@_sink_aware
 class Conv3x3Fn(Function):
     """y = [residual +] act(conv3x3(relu?(x)) + b) on NHWC maps (dpt_block.py:17-289, dpt.py:116-178,271-277)."""
 
@@ -730,6 +769,7 @@ def padded_conv1x1_weights(conv, dt, cpad):
     return engine.prepared(conv, ("c1pad", dt), (conv.weight, conv.bias), build)
 
 
+@_sink_aware
 class PaddedConv1x1Fn(Function):
     """A 1x1 convolution to a channel count that is not a multiple of 8 (DPTSegmentationProcessor's class logits, dpt.py:314-381):
     computed on `cpad` output columns (zero weight rows), fp32 output [M, cpad]; gradients of the real rows only."""
@@ -765,6 +805,7 @@ def padded_conv1x1(x, conv, dt, cpad):
     return PaddedConv1x1Fn.apply(x.reshape(-1, Cin), conv.weight, conv.bias, conv, dt, cpad).view(B, H, W, cpad)
 
 
+@_sink_aware
 class ConvTransposeFn(Function):
     """ConvTranspose2d(kernel = stride, no padding) = GEMM to (u,v,o) columns + pixel scatter (dpt.py:116-140)."""
 
@@ -802,6 +843,7 @@ def conv_transpose_ks(x, ct):
     return ConvTransposeFn.apply(x, ct.weight, ct.bias, ct)
 
 
+@_sink_aware
 class BilinearFn(Function):
     @staticmethod
     def forward(ctx, x, Ho, Wo, crop):
@@ -819,6 +861,7 @@ def bilinear(x, Ho, Wo, crop=None):
     return BilinearFn.apply(x, Ho, Wo, crop)
 
 
+@_sink_aware
 class Conv1x1To4Fn(Function):
     """Regressor tail: features -> 4 decoded channels, fp32 output (dpt.py:271-277 conv2[2])."""
 

@@ -903,16 +903,47 @@ def concurrent(on: bool):
         CONCURRENT = prev
 
 
-def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None, owner=None):
+# Two kernel streams while autograd records (round 4).  PyTorch runs every backward node on the stream its forward ran on and orders
+# nodes across streams itself, so forking the forward forks the backward too.  Only sub-graphs with DISJOINT parameters may fork in
+# training (the decoder's two view branches, the two heads): weight gradients are accumulated into the flat gradient buffer by plain
+# read-modify-write kernels, and two streams adding into the same parameter's slice would race — the encoder's two views share their
+# weights and stay on one stream.  uniception_amd.training orders its collectives behind every side stream (GradientBuckets._issue).
+TRAIN_CONCURRENT: bool = os.environ.get("UNICEPTION_AMD_TRAIN_CONCURRENT", "1") != "0"
+
+
+_acc_warn_off = [False]
+
+
+def _quiet_accumulate_grad_stream_warning() -> None:
+    """Forked branches produce gradients on a side stream for parameters whose AccumulateGrad node lives on the main stream: intended
+    here (autograd orders the two), so PyTorch's once-per-process notice about it is switched off where the API exists."""
+    if not _acc_warn_off[0]:
+        _acc_warn_off[0] = True
+        fn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if fn is not None:
+            fn(False)
+
+
+def all_side_streams(device=None):
+    "The side streams run_branches has forked to so far (for callers that must order work behind them)."
+    return [s for (d, _i), s in _side_streams.items() if device is None or torch.device(d) == torch.device(device)]
+
+
+def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None, owner=None, disjoint_params: bool = False,
+                 shared_params: bool = False):
     """Runs two independent sub-graphs; when they are small (`rows` tokens/pixels each <= BRANCH_TOKENS_MAX: their kernels
     launch fewer workgroups than the chip has CUs) or CONCURRENT is on, and no gradient is recorded, the second one goes to a
     side HIP stream.  `inputs1` are the tensors fn1 reads that were produced on the current stream (they are
     recorded on the side stream for the caching allocator); outputs of fn1 are recorded on the current stream.
+    `disjoint_params`: the two sub-graphs own different parameters — they may fork while autograd records (see TRAIN_CONCURRENT).
+    `shared_params`: they share parameters (the encoder's two views): they may fork in training too, the forked one's weight gradients
+    taking autograd's accumulation instead of the gradient sink.
     `warm_key`: the first call with a given key runs the two sub-graphs one after the other (fn1 on the side stream, fn0 behind
     it) — whatever they cache by shape (position grids, tables) is then built in order; weight-derived caches carry their own
     event (BuiltOn).  `owner`: the module the warm state belongs to (kept in a WeakKeyDictionary — a key built from id(module)
     would outlive the module and be inherited by whatever object reuses the id)."""
-    if torch.is_grad_enabled() or (rows > BRANCH_TOKENS_MAX and not CONCURRENT) or not inputs1 or not inputs1[0].is_cuda:
+    if (torch.is_grad_enabled() and not ((disjoint_params or shared_params) and TRAIN_CONCURRENT and CONCURRENT)) or (rows > BRANCH_TOKENS_MAX and not CONCURRENT) \
+            or not inputs1 or not inputs1[0].is_cuda:
         return fn0(), fn1()
     if not FORK_STREAMS:
         return fn0(), fn1()
@@ -928,7 +959,19 @@ def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None, own
     for t in inputs1:
         t.record_stream(side)
     with torch.cuda.stream(side):
-        out1 = fn1()
+        if torch.is_grad_enabled():
+            _quiet_accumulate_grad_stream_warning()
+        if shared_params and torch.is_grad_enabled():
+            # the forked branch shares parameters with fn0: its weight gradients must not take the read-modify-write gradient sink
+            # concurrently with fn0's (autograd._sink_aware) — they go through autograd's own accumulation instead
+            from . import autograd
+            prev, autograd._sink_fwd_ok[0] = autograd._sink_fwd_ok[0], False
+            try:
+                out1 = fn1()
+            finally:
+                autograd._sink_fwd_ok[0] = prev
+        else:
+            out1 = fn1()
     if serialize:
         main.wait_stream(side)
     out0 = fn0()

@@ -112,13 +112,14 @@ class DUSt3R(nn.Module):
 
     def _encode_image_pairs(self, img1, img2, data_norm_type):
         "Both views go through the encoder as one batch when their shapes agree (dust3r.py:211-225)."
-        if (img1.shape == img2.shape and engine.CONCURRENT and not torch.is_grad_enabled() and img1.is_cuda
+        if (img1.shape == img2.shape and engine.CONCURRENT and (not torch.is_grad_enabled() or engine.TRAIN_CONCURRENT) and img1.is_cuda
                 and img1.shape[0] * (img1.shape[-2] // self.encoder.patch_size) * (img1.shape[-1] // self.encoder.patch_size) > engine.BRANCH_TOKENS_MAX):
             # large batch: the two views as two concurrent kernel streams instead of one concatenated batch (engine.CONCURRENT);
             # every row of every kernel depends on its own image only, so the features are those of the concatenated run
             enc = lambda im: self.encoder(ViTEncoderInput(image=im, data_norm_type=data_norm_type)).features   # noqa: E731
             return engine.run_branches(lambda: enc(img1), lambda: enc(img2), 0, inputs1=(img2,),
-                                       warm_key=("enc", tuple(img1.shape), str(engine.compute_dtype())), owner=self.encoder)
+                                       warm_key=("enc", tuple(img1.shape), str(engine.compute_dtype()), torch.is_grad_enabled()), owner=self.encoder,
+                                       shared_params=True)
         if img1.shape[-2:] == img2.shape[-2:]:
             out = self.encoder(ViTEncoderInput(image=torch.cat((img1, img2), dim=0), data_norm_type=data_norm_type)).features
             return engine.chunk_bchw(out, 2)
@@ -178,7 +179,8 @@ class DUSt3R(nn.Module):
             feats2 = outs["2"] if isinstance(outs["2"], list) else [outs["2"]]
             n_tok = feats2[-1].shape[0] * feats2[-1].shape[2] * feats2[-1].shape[3]
             (p1, c1), (p2, c2) = engine.run_branches(lambda: head(1, shape1), lambda: head(2, shape2), n_tok, inputs1=tuple(feats2),
-                                                          warm_key=("heads", tuple(feats2[-1].shape), shape1, shape2, str(engine.head_dtype())), owner=self)
+                                                          warm_key=("heads", tuple(feats2[-1].shape), shape1, shape2, str(engine.head_dtype()), torch.is_grad_enabled()), owner=self,
+                                                          disjoint_params=self.head1 is not self.head2)      # (head1 / head2: separate parameters; the adaptor has none)
             res1 = {"pts3d": p1, "conf": c1}
             res2 = {"pts3d_in_other_view": p2, "conf": c2}
             engine.note_heads_ran()      # (fp16 head policy: asynchronous snapshot of the range-guard flag, engine.head_range_exceeded)

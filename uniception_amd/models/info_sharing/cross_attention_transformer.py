@@ -142,7 +142,7 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
                 xs = list(engine.run_branches(
                     lambda: b0.forward_tokens(x0, x1, B, N, N, pos[0], pos[1], dt),
                     lambda: b1.forward_tokens(x1, x0, B, N, N, pos[1], pos[0], dt), B * N, inputs1=(x0, x1),
-                    warm_key=("dec", B, N, str(dt)), owner=self))
+                    warm_key=("dec", B, N, str(dt), torch.is_grad_enabled()), owner=self, disjoint_params=True))
                 if d in take_indices:
                     taken.append([engine.layernorm(x, self.norm, torch.float32, twin=True) if norm_intermediate else x for x in xs])
                 continue

@@ -160,6 +160,9 @@ class GradientBuckets:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(g.device))
             self._comm_stream.wait_event(ev)
+            from . import engine
+            for s in engine.all_side_streams(g.device):       # backward nodes of forked sub-graphs (engine.run_branches) write gradients there
+                self._comm_stream.wait_stream(s)
             g.record_stream(self._comm_stream)
             with torch.cuda.stream(self._comm_stream):
                 self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
