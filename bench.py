@@ -414,7 +414,9 @@ def train_step_leg(args, dev, pairs=32, steps=3):
            "note": "fraction = pairs/s x 3 x forward enc+dec flops / peak: charges heads, optimizer and the whole step to the enc+dec flops"}
     if not args.no_roofline:
         with engine.concurrent(False):
-            roof, fams = roofline_pass(step, a1, "bf16", 1)
+            step()      # (untimed: the first single-stream step after two-stream ones draws fresh blocks from hipMalloc — inside the brackets otherwise)
+            torch.cuda.synchronize()
+            roof, fams = roofline_pass(step, a1, "bf16", 2)
         roof["traffic"], roof["traffic_source"] = None, "not collected for the training step"
         out["roofline"] = roof
         out["roofline_families"] = fams
@@ -614,10 +616,14 @@ def main():
         # training: the same kernel family carries the forward and the data-gradient GEMMs (the TN weight-gradient kernel is
         # a separate, smaller share): all dense bf16 uc_gemm launches of a step, forward and backward
         with engine.concurrent(False):
+            step()
+            torch.cuda.synchronize()
             line["roofline"], line["roofline_families"] = roofline_pass(step, v1, args.precision, min(args.steps, 2))
     if rank == 0 and world == 1 and fwd:
         if not args.no_roofline and args.precision == "bf16":
             with engine.concurrent(False):   # per-launch durations are only defined when kernels do not overlap
+                step()                       # (untimed: the allocator's blocks of the side streams are not reusable here — first step mallocs)
+                torch.cuda.synchronize()
                 line["roofline"], line["roofline_families"] = roofline_pass(step, v1, args.precision, min(args.steps, 3))
             line["roofline"]["schedule"] = ("single-stream pass (engine.concurrent(False), = bench.py --single-stream, the command of the "
                                             "committed profiles); the timed region runs two kernel streams")

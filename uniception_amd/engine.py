@@ -904,10 +904,12 @@ def concurrent(on: bool):
 
 
 # Two kernel streams while autograd records (round 4).  PyTorch runs every backward node on the stream its forward ran on and orders
-# nodes across streams itself, so forking the forward forks the backward too.  Only sub-graphs with DISJOINT parameters may fork in
-# training (the decoder's two view branches, the two heads): weight gradients are accumulated into the flat gradient buffer by plain
-# read-modify-write kernels, and two streams adding into the same parameter's slice would race — the encoder's two views share their
-# weights and stay on one stream.  uniception_amd.training orders its collectives behind every side stream (GradientBuckets._issue).
+# nodes across streams itself, so forking the forward forks the backward too.  Weight gradients are accumulated into the flat gradient
+# buffer by plain read-modify-write kernels (the gradient sink), and two streams adding into the same parameter's slice would race:
+# sub-graphs with DISJOINT parameters fork as they are (the decoder's two view branches, the two heads); for sub-graphs that SHARE
+# parameters (the encoder's two views) the forked one's Functions return their weight gradients to autograd instead, whose
+# AccumulateGrad adds them on the parameter's own stream behind the first branch's sink writes (autograd._sink_aware).
+# uniception_amd.training orders its collectives behind every side stream (GradientBuckets._issue).
 TRAIN_CONCURRENT: bool = os.environ.get("UNICEPTION_AMD_TRAIN_CONCURRENT", "1") != "0"
 
 

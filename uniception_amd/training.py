@@ -209,6 +209,9 @@ class Trainer:
             engine.bump_weight_epoch()
 
     def zero_grad(self) -> None:
+        cur = torch.cuda.current_stream(self.flat.grad.device)
+        for s in engine.all_side_streams(self.flat.grad.device):     # (a backward whose gradients were never stepped may still be writing)
+            cur.wait_stream(s)
         self.flat.zero_grad()
         self.buckets.start_step()
 
@@ -225,6 +228,10 @@ class Trainer:
 
     def step(self) -> None:
         self.buckets.finish()
+        # gradients written by forked branches' backward nodes and by the weight-gradient stream (engine.run_branches / WGRAD_STREAM)
+        cur = torch.cuda.current_stream(self.flat.grad.device)
+        for s in engine.all_side_streams(self.flat.grad.device):
+            cur.wait_stream(s)
         self.steps += 1
         gs = 1.0 / self.world_size
         b1, b2 = self.betas
