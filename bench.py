@@ -24,6 +24,8 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md §Chip-level parameters)
 PEAK_HBM_GBS = 8000.0      # HBM3E peak (same guide)
 PMC_TRAFFIC_FILE = "r4_pmc_traffic.json"
+FWD_PAIRS = 128            # pairs per GPU per forward step: 56 GB; 64 -> 96 -> 128 pairs measured +0.7 / +0.9 % (same box), 256: see DESIGN section 7
+TRAIN_PAIRS = 64           # pairs per GPU per training step: 216 GB of the 288 GB at 512x512 with DPT heads (32: 96-98 pairs/s, 64: 100-101, 80: 101.9 at 267 GB)
 
 
 def gflop_enc_dec(img, patch=16, enc_dim=1024, enc_depth=24, dec_dim=768, dec_depth=12, n_extra=0):
@@ -45,7 +47,7 @@ def parse():
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
                     help="fwd: forward inference (BASELINE configs[1], the headline); train: forward + backward + gradient "
                          "all-reduce + AdamW step (BASELINE configs[2])")
-    ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default 64 fwd, 32 train)")
+    ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default FWD_PAIRS fwd, TRAIN_PAIRS train)")
     ap.add_argument("--encoder", default="croco", choices=["croco", "dinov2"],
                     help="croco: the DUSt3R factory model; dinov2: BASELINE configs[3] — DINOv2 ViT-L/14 encoder (frozen in "
                          "train mode) + the same decoder and heads, default 518x518")
@@ -376,12 +378,14 @@ def fwd_224_leg(args, dev, pairs_list=(64, 256)):
     return out
 
 
-def train_step_leg(args, dev, pairs=32, steps=3):
+def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3):
     """BASELINE configs[2] inside the default line: forward + backward + (1-rank) gradient exchange + AdamW of the same ViT-L + DPT model
     at 512x512, `pairs` pairs, `steps` individually fenced steps (median AND block mean reported), with its own dense-GEMM roofline."""
     from uniception_amd import autograd, engine
     from uniception_amd.models.factory import DUSt3R
     from uniception_amd.training import Trainer
+    torch.cuda.empty_cache()                 # the forward legs' cached blocks: the step below wants most of the HBM
+    torch.cuda.reset_peak_memory_stats()
     torch.manual_seed(0)
     m = DUSt3R(name="bench_train", img_size=(args.img, args.img), pred_head_type=args.head).to(dev).train()
     trainer = Trainer(m, lr=1e-5, weight_decay=0.05)
@@ -407,6 +411,7 @@ def train_step_leg(args, dev, pairs=32, steps=3):
     out = {"workload": f"BASELINE configs[2]: ViT-L/16 + 12-block decoder + {args.head} head, {args.img}x{args.img} pairs, forward + backward + AdamW, "
                        "synthetic pointmap targets, 1 rank (the gradient exchange is a no-op at world 1)",
            "pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": pairs, "timing": st,
+           "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
            "heads": engine.train_head_dtype_name() if hasattr(engine, "train_head_dtype_name") else "bf16 kernels (forward and backward)",
            "streams": "2 (encoder views, decoder branches, heads: forward and backward)" if (engine.CONCURRENT and engine.TRAIN_CONCURRENT) else "1",
            "residual_stream": "bf16 (the reference's stream under autocast)" if engine._bf16_train_stream else "fp32",
@@ -421,6 +426,7 @@ def train_step_leg(args, dev, pairs=32, steps=3):
         out["roofline"] = roof
         out["roofline_families"] = fams
     del trainer, m, a1, a2, gt1, gt2
+    torch.cuda.empty_cache()
     return out
 
 
@@ -520,7 +526,7 @@ def main():
     _lib.load()  # fail loudly if the HIP extension is missing
     torch.manual_seed(0)
     if args.pairs is None:
-        args.pairs = 64 if args.mode == "fwd" else 32
+        args.pairs = FWD_PAIRS if args.mode == "fwd" else TRAIN_PAIRS
     if args.img is None:
         args.img = 512 if args.encoder == "croco" else 518
     model = DUSt3R(name="bench", img_size=(args.img, args.img), pred_head_type=args.head)
@@ -609,6 +615,7 @@ def main():
                                    f"dp{world} (replicated model, bucketed in-place gradient all-reduce over RCCL)")},
         "enc_dec_mfma_frac": round(value / world * gflop_pair * (1 if fwd else 3) / 1e3 / PEAK_BF16_TFLOPS, 4),
         "enc_dec_gflop_per_pair": round(gflop_pair, 1),
+        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
     }
     if share:
         line["config"]["shared_gpu_dry_run"] = "ranks share devices, gloo process group: control-flow check only, not a measurement"

@@ -67,3 +67,30 @@ def test_two_stream_branches_equal_single_stream(gpu):
         assert torch.equal(g1["pts3d"], s1["pts3d"]) and torch.equal(g2["conf"], s2["conf"])
     finally:
         engine.BRANCH_TOKENS_MAX = saved
+
+
+def test_capture_with_the_gpu_still_behind_the_host_at_warm_up(gpu):
+    """Prepared weights carry a completion event that consumers on other streams poll; with the GPU far behind the host (large
+    batches: seen from 40 pairs on) those events are still pending when the capture starts, and an event query inside a capture
+    invalidates it.  Here the GPU is kept busy while a FRESH model (empty caches) warms up and is captured."""
+    from uniception_amd.graphs import GraphedTwoView
+    from uniception_amd.models.factory import DUSt3R
+    from oracle import dust3r_oracle as O
+    model = DUSt3R(name="g", img_size=(64, 96), pred_head_type="dpt")
+    O.fill_state_dict_(model.state_dict())
+    model = model.to(gpu).eval()
+    gg = torch.Generator().manual_seed(5)
+    a, b = torch.randn(2, 3, 64, 96, generator=gg).to(gpu), torch.randn(2, 3, 64, 96, generator=gg).to(gpu)
+    v1 = {"img": a, "instance": ["a0", "a1"], "data_norm_type": "dust3r"}
+    v2 = {"img": b, "instance": ["b0", "b1"], "data_norm_type": "dust3r"}
+    big = torch.randn(8192, 8192, device=gpu)
+    torch.cuda.synchronize()
+    for _ in range(60):          # ~0.5 s of queued fp32 GEMMs: the warm-up's launches (and their events) wait behind them
+        big @ big
+    graphed = GraphedTwoView(model, v1, v2, precision="bf16")
+    r1, r2 = graphed(v1, v2)
+    torch.cuda.synchronize()
+    from uniception_amd import engine
+    with torch.no_grad(), engine.precision("bf16"):
+        e1, e2 = model(v1, v2)
+    assert torch.equal(r1["pts3d"], e1["pts3d"]) and torch.equal(r2["conf"], e2["conf"])

@@ -12,20 +12,20 @@ out=gpurun_out/prof_$tag
 bash tools/profile_round.sh $tag pmc > /dev/null 2>&1
 cp $out/${tag}_pmc_traffic.json profiles/r4_pmc_traffic.json
 rm -rf $out/trace $out/pmc_*
-python bench.py --steps 20 --warmup 3 > $out/${tag}_bench_forward_pairs64.json 2> $out/bench_forward.err
-cat $out/${tag}_bench_forward_pairs64.json
+python bench.py --steps 20 --warmup 3 > $out/${tag}_bench_forward_pairs128.json 2> $out/bench_forward.err
+cat $out/${tag}_bench_forward_pairs128.json
 # (the trace runs single-stream: per-kernel durations are only defined without overlap; the bench line below is the default two-stream step)
 cmd="python $root/bench.py --mode train --steps 2 --warmup 2 --no-cpu-baseline --no-roofline --single-stream"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $root/$out/train -o ${tag}_train -- $cmd) > $out/train.log 2>&1
 db=$(ls $out/train/*/*_results.db $out/train/*_results.db 2>/dev/null | head -1)
-python tools/rocpd_stats.py $db > $out/${tag}_train_step_kernel_stats_dpt_pairs32.md
+python tools/rocpd_stats.py $db > $out/${tag}_train_step_kernel_stats_dpt_pairs64.md
 rm -rf $out/train
-python bench.py --mode train --steps 10 --warmup 3 > $out/${tag}_bench_train_dpt_pairs32.json 2> $out/bench_train.err
-cat $out/${tag}_bench_train_dpt_pairs32.json
+python bench.py --mode train --steps 10 --warmup 3 > $out/${tag}_bench_train_dpt_pairs64.json 2> $out/bench_train.err
+cat $out/${tag}_bench_train_dpt_pairs64.json
 # SQ counters of the bf16 attention forward (VERDICT r3 next #9 asks for the evidence): tools/pmc_attn.sh, eight-wave workgroups
 bash tools/pmc_attn.sh "8" > $out/${tag}_probe_attention_sq_counters.txt 2>&1
 rm -rf gpurun_out/pmc_attn
 # the per-shape dense GEMM table and the two probes of the round
-python tools/bench_model_gemms2.py 64 auto,2,6,7 enc,dec 0.4 > $out/${tag}_model_gemm_shapes.txt 2>&1
+python tools/bench_model_gemms2.py 128 auto,2,6,7 enc,dec 0.4 > $out/${tag}_model_gemm_shapes.txt 2>&1
 [ -x tools/_bin/dma_seg ] && ./tools/_bin/dma_seg > $out/${tag}_probe_dma_seg.txt 2>&1
 [ -x tools/_bin/mfma_valu ] && ./tools/_bin/mfma_valu > $out/${tag}_probe_mfma_valu.txt 2>&1

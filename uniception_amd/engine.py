@@ -377,7 +377,9 @@ class BuiltOn:
 
     def __init__(self):
         self.stream = self.event = None
-        if torch.cuda.is_available() and torch.cuda.is_initialized():
+        # (built while a hipGraph records: the launches are nodes of that graph, ordered by its own edges — and an event recorded into
+        # a capture may never be queried afterwards)
+        if torch.cuda.is_available() and torch.cuda.is_initialized() and not torch.cuda.is_current_stream_capturing():
             self.stream = torch.cuda.current_stream()
             self.event = torch.cuda.Event()
             self.event.record(self.stream)
@@ -385,6 +387,11 @@ class BuiltOn:
     def sync(self):
         ev = self.event
         if ev is None:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            # hipEventQuery is not allowed while a stream captures (it invalidates the capture: seen at >= 40 pairs, where the GPU is
+            # still behind the host at the warm-up's second pass and the events survive it).  Every capture starts from a device-wide
+            # synchronize (torch.cuda.graph.__enter__, graphs.GraphedTwoView.recapture): what was built before it is complete.
             return
         if ev.query():
             self.event = None          # completed: visible to every stream from now on
