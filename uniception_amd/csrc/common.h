@@ -134,9 +134,29 @@ __device__ __forceinline__ float uc_ln_tree16(const float (&v)[16]) {
 }
 // p[b * stride] = block b of the row: stride 1 for a row-major [rows][nblk] array, `rows` for the block-major [nblk][rows] array the
 // producer GEMMs write since ABI 11 (one coalesced statistics store per 64 rows instead of a scattered 8-byte store per row)
+// BATCH: callers with 32 registers to spare at the call (the eight-wave GEMM's epilogue: 256 per lane) take the all-loads-first form.
+template <bool BATCH = false>
 __device__ __forceinline__ float2 uc_ln_merge_row(const float2* __restrict__ p, int64_t stride, int nblk, float eps) {
 #pragma clang fp contract(off)
     float s[16];
+    if (BATCH && nblk <= 16) {
+        // rows of at most 1024 channels (every transformer of this path): the row's pairs are read ONCE, all loads in flight
+        // together (the loops below are 2 x nblk dependent round trips when nblk is not a compile-time constant); same sums in
+        // the same order, so the same bits
+        float2 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = p[min(q, nblk - 1) * stride];          // (clamped, not predicated: no branch between the loads)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s[q] = q < nblk ? v[q].x : 0.f;
+        const float cnt = 64.f * (float)nblk;
+        const float mu = uc_ln_tree16(s) / cnt;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float d = v[q].x * (1.f / 64.f) - mu;
+            s[q] = q < nblk ? v[q].y + (64.f * d) * d : 0.f;
+        }
+        return make_float2(mu, 1.0f / sqrtf(uc_ln_tree16(s) / cnt + eps));
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         s[q] = 0.f;

@@ -48,6 +48,7 @@ const UcKnobs& uc_knobs() {
         g_knobs.gemm_small_stages = env_int("UC_GEMM_SMALL_STAGES", 3);
         g_knobs.gemm_4wave = env_int("UC_GEMM_4WAVE", 3);
         g_knobs.gemm_4wave_min_k = env_int("UC_GEMM_4WAVE_MIN_K", 2048);
+        g_knobs.gemm_side_lds = env_int("UC_GEMM_SIDE_LDS", 1);
         g_knobs.conv_dw_rows = env_int("UC_CONV_DW_ROWS", 1);
         g_knobs.attn_nw = env_int("UC_ATTN_NW", 0);
         g_knobs.attn_dma = env_int("UC_ATTN_DMA", 1);

@@ -60,6 +60,8 @@ struct GldsParams {
     // implicit-GEMM 3x3 convolution over an NHWC image (a_mode == UC_A_CONV3X3): K = 9*Cin, Cin % 64 == 0
     int dbg;      // diagnostics only (UC_GEMM_DBG): 1 skip the in-loop DMA, 2 skip the in-loop barrier, 4 no epilogue, 8 one K-step, 16 generic epilogue only, 32 (eight-wave kernel) no wait for the DMA, 64 (conv) A tiles staged for tap 0 only, 128 / 256 (fp32 residual epilogue) no residual read / no twin write
     int stagger;  // experiment: 100-MHz ticks of start delay per phase group for the first round of workgroups (0 = off)
+    int side_lds; // (eight-wave kernel, BF16 family; set by its launcher) the tile's row statistics / column sums / bias / RoPE positions are
+                  // DMA-staged into 8 KiB of LDS behind the ring at kernel start: the epilogue's first loads are LDS reads, not an exposed L2 / HBM round trip
     int nt_out;   // output (+ residual) streams of more than half the 256 MB Infinity Cache: non-temporal epilogue loads / stores
     unsigned long long* trace;   // diagnostics (UC_GEMM_TRACE): per-workgroup {start, loop start, loop end, end} 100-MHz ticks + HW id
     int* sat_flag; // fp16 outputs: set to 1 (atomic or) when a value beyond +-65504 was saturated; NULL: not reported

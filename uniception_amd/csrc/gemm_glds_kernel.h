@@ -170,17 +170,22 @@ __device__ __forceinline__ void dma16_buf_to_lds(unsigned voff, uint4_t srd, uns
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
+// Side panel of the eight-wave kernel (GldsParams::side_lds): 8 KiB of LDS behind the two-stage ring, filled by one DMA piece per wave
+// before the first K-step — (mean, rstd) of the tile's 256 rows, column sums and bias of its 256 columns, RoPE positions of its rows.
+constexpr int GLDS_SIDE_STATS = 0, GLDS_SIDE_COLSUM = 2048, GLDS_SIDE_BIAS = 3072, GLDS_SIDE_POS = 4096, GLDS_SIDE_BYTES = 8192;
+
 // (mean, rstd) of row m for the folded-LayerNorm epilogues: finalized by uc_ln_stats_finalize, or merged here from the producer's
 // block partials (small batches)
+template <bool BATCH = false>
 __device__ __forceinline__ float2 glds_ln_row_stats(glds_pe_t p, int64_t m) {
-    if (p.ln_partial) return uc_ln_merge_row(p.ln_partial + m, p.M, p.ln_nblk, p.ln_eps);      // partials are [nblk][M]
+    if (p.ln_partial) return uc_ln_merge_row<BATCH>(p.ln_partial + m, p.M, p.ln_nblk, p.ln_eps);      // partials are [nblk][M]
     return p.ln_stats[m];
 }
 
 // Epilogue of V tiles that are written in the packed VT layout (un-swapped orientation).
-template <int FA, bool LN = false>
+template <int FA, bool LN = false, bool BATCH = false>
 __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane,
-                                                 char* wbuf) {
+                                                 char* wbuf, const char* side = nullptr) {
     const int frow = lane & 15;
     const int g = lane >> 4;
     // Folded LayerNorm (LN): value = rstd[row] * (acc - mean[row] * colsum[channel]) + bias[channel], rows 16 i + 4 g + r,
@@ -192,9 +197,15 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
     static_assert(!LN || FA == 4, "folded LayerNorm: 64-row wave tiles");
     if constexpr (LN) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) csj[j] = p.ln_colsum[wave_n + 16 * j + frow];
-        mine = glds_ln_row_stats(p, min(wave_m + lane, p.M - 1));
+        for (int j = 0; j < 4; ++j) csj[j] = side ? reinterpret_cast<const float*>(side + GLDS_SIDE_COLSUM)[(int)(wave_n & 255) + 16 * j + frow]
+                                                  : p.ln_colsum[wave_n + 16 * j + frow];
+        mine = side ? reinterpret_cast<const float2*>(side + GLDS_SIDE_STATS)[(int)(wave_m & 255) + lane]
+                    : glds_ln_row_stats<BATCH>(p, min(wave_m + lane, p.M - 1));
     }
+    auto bias_of = [&](int j) __attribute__((always_inline)) -> float {
+        if (side) return reinterpret_cast<const float*>(side + GLDS_SIDE_BIAS)[(int)(wave_n & 255) + 16 * j + frow];     // (side panel: bias present, launcher-checked)
+        return p.bias ? p.bias[wave_n + 16 * j + frow] : 0.f;
+    };
     float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
     auto row_stats = [&](int i) __attribute__((always_inline)) {
         if constexpr (LN) {
@@ -214,7 +225,7 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
         const int nheads = (int)((p.N - p.vt_col0) >> 6);
         float bcj[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bcj[j] = p.bias ? p.bias[wave_n + 16 * j + frow] : 0.f;
+        for (int j = 0; j < 4; ++j) bcj[j] = bias_of(j);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             row_stats(i);
@@ -245,7 +256,7 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
         const bool aligned = (p.vt_ntok & 15) == 0;
         float bcol[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bcol[j] = p.bias ? p.bias[wave_n + 16 * j + frow] : 0.f;
+        for (int j = 0; j < 4; ++j) bcol[j] = bias_of(j);
 #pragma unroll
         for (int i = 0; i < FA; ++i) {
             const int64_t mb = wave_m + 16 * i + 4 * g;
@@ -691,7 +702,7 @@ __device__ __forceinline__ void glds_epilogue_bs(glds_pe_t p, float4_t (&acc)[FA
 // turn it into LN(x) . W^T:  rstd[m] * (acc - mean[m] * colsum[n]) + bias[n].
 template <int FA, int ACT, bool NT = false, bool LN = false, bool F16 = false>
 __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[FA][4], int mode, int64_t wave_m,
-                                                   int64_t wave_n, int lane, char* wbuf) {
+                                                   int64_t wave_n, int lane, char* wbuf, const char* side = nullptr) {
     const int frow = lane & 15, g = lane >> 4;
     // Folded LayerNorm (LN): value = rstd[row] * (acc - mean[row] * colsum[col]) + bias[col], rows 16 i + frow, columns
     // 16 j + 4 g + r.  Lane l holds the statistics of row l of the wave tile (one coalesced load); a row block's pair comes
@@ -701,11 +712,19 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
     // and a spill reload between global stores waits for every store before it (vmcnt counts stores, in order).
     float2 mine[FA / 4];
     float* colbuf = reinterpret_cast<float*>(wbuf + 4096);
+    const float* biasbuf = colbuf + 64;
     if constexpr (LN) {
-        colbuf[lane] = p.ln_colsum[wave_n + lane];
-        colbuf[64 + lane] = p.bias ? p.bias[wave_n + lane] : 0.f;
+        if (side) {      // staged before the K-loop (side panel): no global load at the head of the epilogue
+            colbuf = const_cast<float*>(reinterpret_cast<const float*>(side + GLDS_SIDE_COLSUM)) + (int)(wave_n & 255);
+            biasbuf = reinterpret_cast<const float*>(side + GLDS_SIDE_BIAS) + (int)(wave_n & 255);
 #pragma unroll
-        for (int q = 0; q < FA / 4; ++q) mine[q] = glds_ln_row_stats(p, min(wave_m + 64 * q + lane, p.M - 1));
+            for (int q = 0; q < FA / 4; ++q) mine[q] = reinterpret_cast<const float2*>(side + GLDS_SIDE_STATS)[(int)(wave_m & 255) + 64 * q + lane];
+        } else {
+            colbuf[lane] = p.ln_colsum[wave_n + lane];
+            colbuf[64 + lane] = p.bias ? p.bias[wave_n + lane] : 0.f;
+#pragma unroll
+            for (int q = 0; q < FA / 4; ++q) mine[q] = glds_ln_row_stats<(FA > 4)>(p, min(wave_m + 64 * q + lane, p.M - 1));
+        }
     }
     float st_mu = 0.f, st_rs = 1.f;
     auto row_stats = [&](int i) __attribute__((always_inline)) {
@@ -722,7 +741,7 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
     auto val4 = [&](int i, int j) __attribute__((always_inline)) -> float4_t {   // pre-activation values of fragment (i, j)
         if constexpr (LN) {
             const float4_t cs = *reinterpret_cast<const float4_t*>(colbuf + 16 * j + 4 * g);
-            const float4_t bb = *reinterpret_cast<const float4_t*>(colbuf + 64 + 16 * j + 4 * g);
+            const float4_t bb = *reinterpret_cast<const float4_t*>(biasbuf + 16 * j + 4 * g);
             return glds_fma4(glds_fma4(glds_splat4(-st_mu), cs, acc[i][j]), glds_splat4(st_rs), bb);
         } else return acc[i][j] + b4[j];
     };
@@ -737,7 +756,8 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
 #pragma unroll
         for (int i = 0; i < FA; ++i) {
             const int64_t m = min(wave_m + 16 * i + frow, p.M - 1);
-            const longlong2 yx = *reinterpret_cast<const longlong2*>(p.rope_pos + m * 2);
+            const longlong2 yx = (LN && side) ? *reinterpret_cast<const longlong2*>(side + GLDS_SIDE_POS + ((int)(wave_m & 255) + 16 * i + frow) * 16)
+                                              : *reinterpret_cast<const longlong2*>(p.rope_pos + m * 2);
             pyx[i] = ((unsigned)min(max((int)yx.x, 0), 65535)) | ((unsigned)min(max((int)yx.y, 0), 65535) << 16);
         }
     }
@@ -1007,7 +1027,7 @@ __device__ __forceinline__ void glds_epilogue_tail4(glds_pe_t p, float4_t (&acc)
 // compiled into the instantiation (EPI) and the wave's mode (0 plain, 1 RoPE, 2 packed-VT).
 template <int FA, int A_MODE, int EPI, bool F16 = false>
 __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&acc)[FA][4], int mode, int64_t wave_m, int64_t wave_n,
-                                                       int tid, int wave, int ksplit, char* smem) {
+                                                       int tid, int wave, int ksplit, char* smem, const char* side = nullptr) {
     static_assert(!F16 || EPI == GLDS_EPI_ALL, "the fp16 operand form exists in the EPI_ALL family only");
     constexpr int OUT16 = F16 ? UC_F16 : UC_BF16;        // the 16-bit storage dtype of this instantiation
     if (wave_n >= pe.N) return;
@@ -1024,11 +1044,11 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
             if (!F16 && A_MODE == UC_A_DENSE && (pe.ln_stats || pe.ln_partial)) {   // folded LayerNorm
                 if constexpr (A_MODE == UC_A_DENSE && !F16) {
                     if (nt) {
-                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                        else glds_epilogue_bf16<FA, UC_ACT_NONE, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf, side);
+                        else glds_epilogue_bf16<FA, UC_ACT_NONE, true, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf, side);
                     } else {
-                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
-                        else glds_epilogue_bf16<FA, UC_ACT_NONE, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
+                        if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_bf16<FA, UC_ACT_GELU_ERF, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf, side);
+                        else glds_epilogue_bf16<FA, UC_ACT_NONE, false, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf, side);
                     }
                 }
             } else if (nt) {
@@ -1059,7 +1079,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) half[i][j] = acc[4 * h + i][j];
-                        if (A_MODE == UC_A_DENSE && (pe.ln_stats || pe.ln_partial)) glds_epilogue_vt<4, A_MODE == UC_A_DENSE>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
+                        if (A_MODE == UC_A_DENSE && (pe.ln_stats || pe.ln_partial)) glds_epilogue_vt<4, A_MODE == UC_A_DENSE, true>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf, side);
                         else glds_epilogue_vt<4>(pe, half, wave_m + 64 * h, wave_n, lane, wbuf);
                     }
                 }
@@ -1528,6 +1548,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) issue_piece(stage, k0, q);
     };
+    // side panel (see GLDS_SIDE_*): one 1-KiB piece per wave, issued BEFORE the first stage's pieces — loads return in order, so the
+    // first K-step's vmcnt(0) + barrier cover it.  Out-of-range rows / columns are clamped (their products are never stored).
+    const bool side_on = EPI == GLDS_EPI_BF16 && p.side_lds != 0;
+    if (EPI == GLDS_EPI_BF16 && side_on) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(2 * STAGE_BYTES + wave * 1024));
+        if (wave < 2) {             // (mean, rstd) of rows 128 wave + 2 lane, + 1
+            const int r = (int)min((int64_t)(128 * wave + 2 * lane), p.M - 2 - m0);
+            dma16_s_to_lds((unsigned)r * 8u, p.ln_stats + m0, dst);
+        } else if (wave == 2) {     // column sums of columns 4 lane .. + 3
+            const int c = (int)min((int64_t)(4 * lane), p.N - 4 - n0);
+            dma16_s_to_lds((unsigned)c * 4u, p.ln_colsum + n0, dst);
+        } else if (wave == 3) {     // bias
+            const int c = (int)min((int64_t)(4 * lane), p.N - 4 - n0);
+            dma16_s_to_lds((unsigned)c * 4u, p.bias + n0, dst);
+        } else if (p.rope_cols > 0) {   // (y, x) of row 64 (wave - 4) + lane
+            const int r = (int)min((int64_t)(64 * (wave - 4) + lane), p.M - 1 - m0);
+            dma16_s_to_lds((unsigned)r * 16u, p.rope_pos + m0 * 2, dst);
+        }
+    }
 
     const int frow = lane & 15;
     const int fk = lane >> 4;
@@ -1651,7 +1690,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_glds8_kernel(GldsParams p) {
     __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the bounce space (8 KiB per wave)
     asm volatile("" ::: "memory");
     if (UC_TRACE(pe)) tr2 = __builtin_amdgcn_s_memrealtime();
-    glds_epilogue_dispatch<FA, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n, tid, wave, ksplit, smem);
+    glds_epilogue_dispatch<FA, A_MODE, EPI>(pe, acc, mode, wave_m, wave_n, tid, wave, ksplit, smem,
+                                            (EPI == GLDS_EPI_BF16 && pe.side_lds) ? smem + 2 * STAGE_BYTES : nullptr);
     if (UC_TRACE(pe)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1811,7 +1851,11 @@ static void launch_glds8(GldsParams p, hipStream_t st) {
     p.dGm = uc_make_fastdiv((unsigned)p.group_m);
     p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
     auto kfn = gemm_bf16_glds8_kernel<EPI>;
-    constexpr int smem = 2 * 512 * 128;
+    constexpr int smem = 2 * 512 * 128 + (EPI == GLDS_EPI_BF16 ? GLDS_SIDE_BYTES : 0);
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    p.side_lds = (EPI == GLDS_EPI_BF16 && uc_knobs().gemm_side_lds && p.ln_stats && !p.ln_partial && p.ln_colsum && p.bias && p.split_k <= 1 &&
+                  !(p.dbg & 16) && al16(p.ln_stats) && al16(p.ln_colsum) && al16(p.bias) &&
+                  (p.rope_cols <= 0 || (p.rope_pos && al16(p.rope_pos)))) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -19,6 +19,7 @@ struct UcKnobs {
     int gemm_8wave;          // UC_GEMM_8WAVE        eight-wave 256x256 kernel: 0 off, 1 bf16-store family (default), 2 all, 3 + bf16 stream
     int conv_dw_rows;        // UC_CONV_DW_ROWS      row-walking conv weight-gradient kernel where the shape allows (default 1; 0: implicit im2col everywhere)
     int gemm_4wave_min_k;    // UC_GEMM_4WAVE_MIN_K  ... for launches at least this deep (2048: where it beats the 16-wave kernel)
+    int gemm_side_lds;       // UC_GEMM_SIDE_LDS     eight-wave kernel, folded-LayerNorm family: statistics / column sums / bias / RoPE positions of a tile DMA-staged into LDS before the K-loop (1) or loaded at the head of the epilogue (0)
     int gemm_4wave;          // UC_GEMM_4WAVE        four-wave 256x256 kernel (128x128 wave tiles, asm K-loop): 0 off, 1 bf16-store family, 2 + bf16 stream, 3 all (default)
     int gemm_small_stages;   // UC_GEMM_SMALL_STAGES 3-stage ring for launches with fewer workgroups than CUs (default 3)
     int attn_nw;             // UC_ATTN_NW           waves per attention workgroup: 0 policy, 4, 8

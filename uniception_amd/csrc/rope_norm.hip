@@ -351,7 +351,7 @@ __global__ void ln_stats_finalize_kernel(const float2* __restrict__ partial, int
     // one thread per row; the merge itself is uc_ln_merge_row (common.h),
     // shared with the consumer GEMM's epilogue
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < rows) out[r] = uc_ln_merge_row(partial + r, rows, nblk, eps);     // block-major partials [nblk][rows]: coalesced across the rows of a wave
+    if (r < rows) out[r] = uc_ln_merge_row<true>(partial + r, rows, nblk, eps);     // block-major partials [nblk][rows]: coalesced across the rows of a wave
 }
 
 extern "C" int uc_ln_stats_finalize(const float* partial, int64_t rows, int nblk, float eps, float* out, uc_stream_t stream) {
