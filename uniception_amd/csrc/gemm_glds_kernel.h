@@ -598,6 +598,9 @@ __device__ __forceinline__ void glds_epilogue_resid(glds_pe_t p, float4_t (&acc)
 #ifndef GLDS_BS_RES_AHEAD
 #define GLDS_BS_RES_AHEAD 2     // row blocks of residual in flight ahead of the one being drained (bf16-stream epilogue)
 #endif
+#ifndef GLDS_BS_RES_AHEAD_WIDE
+#define GLDS_BS_RES_AHEAD_WIDE 2   // ... in the kernels whose waves own 128-row tiles (eight- and four-wave forms: 256 registers per lane)
+#endif
 // sum over the 8 lanes 8k .. 8k+7 (one row of the bf16-stream drain), result in every lane: xor 1, xor 2 inside the quad, then the
 // mirrored lane of the 8-lane half row (which lies in the other quad)
 __device__ __forceinline__ float glds_row8_sum(float v) {
@@ -639,7 +642,7 @@ __device__ __forceinline__ void glds_epilogue_bs(glds_pe_t p, float4_t (&acc)[FA
     const int64_t rstep = 8 * p.ldr * 2;
     float2* sbase = (p.stats_out && !UC_DBG(p, 512)) ? p.stats_out + (wave_n >> 6) * p.M + wave_m : nullptr;
     // the residual of the next AHEAD row blocks (2 x 16 bytes per lane each) is in flight while block i drains
-    constexpr int AHEAD = GLDS_BS_RES_AHEAD;
+    constexpr int AHEAD = FA > 4 ? GLDS_BS_RES_AHEAD_WIDE : GLDS_BS_RES_AHEAD;
     uint4_t res[AHEAD][2];
     auto load_res = [&](int i, int ps) __attribute__((always_inline)) {
         res[i % AHEAD][ps] = (uint4_t){0u, 0u, 0u, 0u};
