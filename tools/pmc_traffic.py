@@ -4,13 +4,14 @@ bench.py only reports it for the build it was measured on.  usage: python tools/
 import json, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uniception_amd import build
+from bench import FWD_PAIRS as P          # the headline's pairs per GPU: the tables are named after it (tools/profile_round.sh)
 d, tag = sys.argv[1], sys.argv[2]
 
 
 def table(counter):
     tot, n = 0.0, 0
     cur = None
-    for line in open(os.path.join(d, f"{tag}_pmc_{counter}_bench_pairs64.txt")):
+    for line in open(os.path.join(d, f"{tag}_pmc_{counter}_bench_pairs{P}.txt")):
         if not line.startswith(" "):
             cur = line.strip()
             continue
@@ -25,10 +26,10 @@ def table(counter):
 f, nf = table("FETCH_SIZE")
 w, nw = table("WRITE_SIZE")
 assert nf == nw and nf > 0, (nf, nw)
-rec = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 (64 pairs/GPU, 512x512, DPT); tables profiles/{tag}_pmc_*_bench_pairs64.txt",
+rec = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 ({P} pairs/GPU, 512x512, DPT); tables profiles/{tag}_pmc_*_bench_pairs{P}.txt",
        "kernel": "gemm_bf16_glds_kernel<*, A_MODE dense, *> + gemm_bf16_glds8_kernel<*> + gemm_bf16_glds4_kernel<*> (all dense tile variants and epilogue families)",
        "kernel_fingerprint": build.loaded_fingerprint(),
-       "config": {"pairs_per_gpu": 64, "img": 512, "head": "dpt", "precision": "bf16"},
+       "config": {"pairs_per_gpu": P, "img": 512, "head": "dpt", "precision": "bf16"},
        "dispatches": nf, "FETCH_SIZE_KB_per_launch": round(f / nf, 1), "WRITE_SIZE_KB_per_launch": round(w / nw, 1),
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
        "traffic_bytes_per_launch": int((2 * f + w) / nf * 1024)}
