@@ -533,6 +533,50 @@ def test_conv3x3_row_walking_kernel(gpu, dtype, geom):
         assert rel_l2(out.view(B, H, W, 4).cpu(), torch.einsum("bchw,oc->bhwo", ref, w4.double()) + b4.double()) < 3e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [(8, 128, 128, 64, 128), (1, 256, 512, 64, 128), (2, 256, 256, 128, 128), (1, 128, 1024, 64, 128), (1, 512, 128, 64, 256),
+                                  (3, 192, 256, 64, 128)])
+def test_conv3x3_eight_wave_row_walking_kernel(gpu, dtype, geom):
+    """conv3x3_rows8_kernel (512 pixels x 128 output channels per workgroup, eight waves of 128 x 64, 32-channel super-steps of three
+    taps, register-prefetched fragments): same contract as the implicit-GEMM kernel — against torch's conv on the same rounded
+    operands; tiles of one, two and four image-row segments, two tiles per image row (W = 1024), image borders, several images,
+    ReLU on load, bias + ReLU, two residuals, fp32 output, two column tiles, the fused 1x1 tail, bf16 and fp16 operands."""
+    from uniception_amd import ops
+    B, H, W, Cin, Cout = geom
+    g = torch.Generator().manual_seed(B * H + W + Cin + 1)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dtype)
+    wt = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
+    bias = torch.randn(Cout, generator=g)
+    r1 = torch.randn(B * H * W, Cout, generator=g).to(dtype)
+    r2 = torch.randn(B * H * W, Cout, generator=g).to(dtype)
+    w_r = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(gpu)
+    xg = x.to(gpu)
+    tol16 = 6e-3 if dtype == torch.bfloat16 else 8e-4          # 16-bit outputs: one rounding of the result
+    ops.tuning_set("conv_rows", 3)                              # conftest resets
+    for relu_a in (False, True):
+        xin = F.relu(x.double()) if relu_a else x.double()
+        ref = F.conv2d(xin.permute(0, 3, 1, 2), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+        out = ops.gemm(xg, w_r, bias.to(gpu), conv=(B, H, W, Cin, 1), relu_a=relu_a, out_dtype=torch.float32)
+        assert rel_l2(out.cpu(), ref) < 2e-5
+        out = ops.gemm(xg, w_r, bias.to(gpu), conv=(B, H, W, Cin, 1), relu_a=relu_a, act="relu")
+        assert out.dtype == dtype and rel_l2(out.float().cpu(), F.relu(ref)) < tol16
+        out = ops.gemm(xg, w_r, bias.to(gpu), conv=(B, H, W, Cin, 1), relu_a=relu_a, residual=r1.to(gpu), residual2=r2.to(gpu))
+        assert rel_l2(out.float().cpu(), ref + r1.double() + r2.double()) < tol16
+    # against the implicit-GEMM kernel: the same products in another summation order — and NOT the same launch
+    outs = {}
+    for mode in (0, 3):
+        ops.tuning_set("conv_rows", mode)
+        outs[mode] = ops.gemm(xg, w_r, bias.to(gpu), conv=(B, H, W, Cin, 1), out_dtype=torch.float32)
+    assert rel_l2(outs[3], outs[0]) < 2e-6 and not torch.equal(outs[3], outs[0])
+    ops.tuning_set("conv_rows", 3)
+    if Cout == 128 and dtype == torch.bfloat16:
+        w4 = torch.randn(4, 128, generator=g) / math.sqrt(128)
+        b4 = torch.randn(4, generator=g)
+        ref = F.relu(F.conv2d(x.double().permute(0, 3, 1, 2), wt.double(), bias.double(), padding=1))
+        out = ops.gemm(xg, w_r, bias.to(gpu), act="relu", conv=(B, H, W, Cin, 1), tail=(w4.to(gpu), b4.to(gpu)))
+        assert rel_l2(out.view(B, H, W, 4).cpu(), torch.einsum("bchw,oc->bhwo", ref, w4.double()) + b4.double()) < 3e-5
+
+
 # ------------------------------------------------------------------------------------------
 def sdpa_ref(q, k, v, scale):
     """q [B,Nq,H,D] etc. -> [B,Nq,H,D], fp32 softmax(QK^T*scale)V."""

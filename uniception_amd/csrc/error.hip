@@ -85,7 +85,7 @@ extern "C" int uc_tuning_set(const char* name, int value) {
         UC_REQUIRE(value >= 0, "uc_tuning_set: small_m_split is the smallest K a small-M launch splits in two for (0: never) (got %d)", value);
         g_uc_small_m_split.store(value);
     } else if (!strcmp(name, "conv_rows")) {
-        UC_REQUIRE(value >= 0 && value <= 2, "uc_tuning_set: conv_rows must be 0 (implicit GEMM everywhere), 1 (row-walking kernel where it wins) or 2 (wherever the shape allows) (got %d)", value);
+        UC_REQUIRE(value >= 0 && value <= 3, "uc_tuning_set: conv_rows must be 0 (implicit GEMM everywhere), 1 (row-walking kernels where they win), 2 (the 256-pixel row-walking kernel wherever the shape allows) or 3 (the eight-wave 512-pixel one wherever the shape allows) (got %d)", value);
         g_uc_conv_rows.store(value);
     } else {
         uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split, conv_rows, small_m_split; everything else is read from the environment once, see csrc/knobs.h)", name);

@@ -1100,6 +1100,22 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                     else glds_epilogue_tail4<FA, UC_ACT_NONE>(pe, acc, wave_m, wave_n, lane, wave, smem);
                     return;
                 }
+            } else if constexpr (A_MODE != UC_A_DENSE && FA == 8) {
+                if (pe.tail_out) {      // a 128-row wave tile (eight-wave conv kernel, 4 x 2 waves) drains as two 64-row halves
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float4_t half[4][4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) half[i][j] = acc[4 * h + i][j];
+                        if (h) __syncthreads();     // the left wave columns have read the first half's partial sums
+                        if (pe.act == UC_ACT_RELU) glds_epilogue_tail4<4, UC_ACT_RELU>(pe, half, wave_m + 64 * h, wave_n, lane, wave, smem);
+                        else if (pe.act == UC_ACT_GELU_ERF) glds_epilogue_tail4<4, UC_ACT_GELU_ERF>(pe, half, wave_m + 64 * h, wave_n, lane, wave, smem);
+                        else glds_epilogue_tail4<4, UC_ACT_NONE>(pe, half, wave_m + 64 * h, wave_n, lane, wave, smem);
+                    }
+                    return;
+                }
             }
             if (!F16 && mode == 2) {
                 if constexpr (F16) { }
@@ -2082,6 +2098,249 @@ static void launch_conv_rows(GldsParams p, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Eight-wave row-walking 3x3 convolution: 512 pixels x 128 output channels, 4 x 2 waves of 128 x 64 (the eight-wave GEMM's wave tile:
+// 12 fragment reads feed 32 MFMAs, 384 B of LDS per MFMA against 512 B for the 64 x 64 wave tiles above), walked in 32-channel chunks.
+//
+//   super-step (ky, 32-channel chunk) = three units kx = 0, 1, 2 of 32 MFMAs per wave each.  Staged per super-step: the slab of input
+//   pixels of kernel row ky (R row segments of seg + 2 pixels, 64-B rows: 33 pieces of 1 KiB) and the three taps' weight tiles
+//   (128 x 32: 8 pieces each) — every input pixel crosses the LDS-DMA path three times, every weight tile once per 512 pixels
+//   (57 KiB per super-step, 684 KiB per 512 x 128 tile at 128 input channels; the 256-pixel kernel above: 493 KiB per 256 pixels).
+//   Two buffers of each (2 x 33 + 2 x 24 KiB = 114 KiB), one workgroup per CU, two waves per SIMD with 256 registers:
+//
+//   unit 0:  MFMAs on (a, w)   | ds_read unit 1 -> (a, wn)      (a is refilled row block by row block behind its MFMAs)
+//   unit 1:  MFMAs on (a, wn)  | ds_read unit 2 -> (a, w)
+//   s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: everyone has READ this super-step's buffers, everyone's DMA of the next one has landed
+//   unit 2:  MFMAs on (a, w)   | ds_read unit 0 of the next super-step -> (a, wn) | DMA of the super-step after it -> the buffers just
+//            released, one piece behind each MFMA group (8 pieces per wave: 4-5 of the slab, 3 of the weights)
+//
+//   One barrier per 96 MFMAs of a wave; a piece has two units (~1 us) of flight.  The weight registers alternate roles from one
+//   super-step to the next (three units): the loop body is a PAIR of super-steps (launcher: Cin % 64 == 0), straight-line.
+//   64-B LDS rows with the chunk key 3 ((row >> 2) & 1): conflict-free ds_read_b128 fragments at every row offset (the taps shift
+//   the 16 rows of a fragment by kx, row segments by two halo pixels each).
+//   Accumulator layout = the eight-wave GEMM's (FA = 8): the shared epilogues apply; the fused 1x1 tail drains a 128-row wave tile
+//   as two 64-row halves.
+template <int EPI, bool F16, bool RELU_A>
+__global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
+    constexpr int BM_ = 512, BN_ = 128, ROWB = 64, NPIECE = 33, SLAB_BYTES = NPIECE * 1024, WT_BYTES = 3 * BN_ * ROWB;
+    constexpr int WT0 = 0, SLAB0 = 2 * WT_BYTES, DUMP = SLAB0 + 2 * SLAB_BYTES;              // LDS image: weights[2] | slab[2] | dump KiB
+    constexpr int A_MODE = UC_A_CONV3X3, FA = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int t = glds_xcd_remap((int)blockIdx.x, nwg);
+    int tm, tn;
+    {   // tile order: see the 16-wave kernel
+        const int GM = p.group_m;
+        const int per_group = GM * p.tiles_n;
+        const int grp = (int)uc_div((unsigned)t, p.dPerGroup), within = t - grp * per_group;
+        const int first_m = grp * GM;
+        const bool last = p.tiles_m - first_m < GM;
+        const int gsz = last ? p.tiles_m - first_m : GM;
+        tn = (int)uc_div((unsigned)within, last ? p.dGmLast : p.dGm);
+        tm = first_m + within - tn * gsz;
+    }
+    const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
+    const int64_t wave_m = m0 + wr * 128, wave_n = n0 + wc * 64;
+
+    // ---- tile geometry (wave-uniform): R row segments of seg pixels, first at (image row id rowid0 = b * H + oy0, ox0) ----
+    const int W_ = p.cW, H_ = p.cH, Cin = p.cCin;
+    const int seg = min(BM_, W_), R = BM_ / seg, segp = seg + 2;
+    const unsigned rowid0 = uc_div((unsigned)m0, p.dWo);
+    const int ox0 = (int)((unsigned)m0 - rowid0 * (unsigned)W_);
+    const unsigned b0 = uc_div(rowid0, p.dHo);
+    const int oy0 = (int)(rowid0 - b0 * (unsigned)H_);
+    const unsigned long long pa = (unsigned long long)(p.A + (((int64_t)rowid0 - 1) * W_ + (ox0 - 1)) * Cin);
+    const unsigned long long pw = (unsigned long long)(p.W + n0 * p.K);
+    const uint4_t srd_a = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
+    const uint4_t srd_w = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pw), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pw >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
+    // slab pieces of this wave: piece n = wave + 8 q covers slab rows 16 n .. 16 n + 15; lane -> row 16 n + lane / 4, physical chunk lane % 4
+    // (piece 32 = q 4 of wave 0 only).  sl_mask: bit 3 q + ky = the lane's pixel exists for tap row ky
+    unsigned sl_off[5], sl_mask = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int row = (wave + 8 * q) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ glds_swz<32>(row);
+        const int rr = row / segp, xs = row - rr * segp;             // (division by a wave-uniform value, once per tile)
+        const int ix = ox0 - 1 + xs;
+        // (launcher: 32-bit windows, pixel and channel counts below 2^24: 24-bit multiplies — the 32-bit product of a v_mad_u64_u32
+        //  lives in a register PAIR for the whole loop)
+        sl_off[q] = (__umul24(__umul24((unsigned)rr, (unsigned)W_) + (unsigned)xs, (unsigned)Cin) + (unsigned)c * 8u) * 2u;
+        asm volatile("" : "+v"(sl_off[q]));
+        if (rr < R && ix >= 0 && ix < W_ && (q < 4 || wave == 0)) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) sl_mask |= ((unsigned)(oy0 + rr + ky - 1) < (unsigned)H_ ? 1u : 0u) << (3 * q + ky);
+        }
+    }
+    unsigned w_off;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ glds_swz<32>(row);
+        w_off = (__umul24((unsigned)row, (unsigned)p.K) + (unsigned)c * 8u) * 2u;
+        asm volatile("" : "+v"(w_off));
+    }
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    const int nch = Cin / 32;
+    const int S = 3 * nch;                                   // super-steps, even (launcher)
+    // piece j = 0..7 of super-step s -> buffer pair b: slab pieces q = j (j < 5), weight pieces of tap kx = j - 5
+    auto issue_piece = [&](int ky, int ch, int b, int j) __attribute__((always_inline)) {
+        if (j < 5) {
+            // (piece 32 is wave 0's; the other waves' fifth slot writes zeros into a dump KiB behind the buffers: a branch here would split
+            //  the MFMA stream into basic blocks, each join draining lgkmcnt)
+            const unsigned soff = (unsigned)((((int64_t)ky * W_) * Cin + ch * 32) * 2);
+            const unsigned vo = ((sl_mask >> (3 * j + ky)) & 1u) ? sl_off[j] : 0xffffffffu;
+            const unsigned dst = (j == 4 && wave != 0) ? (unsigned)DUMP : (unsigned)(SLAB0 + b * SLAB_BYTES + (wave + 8 * j) * 1024);
+            dma16_buf_to_lds(vo, srd_a, soff, __builtin_amdgcn_readfirstlane(lds_base + dst));
+        } else {
+            const int kx = j - 5;
+            const unsigned soff_w = (unsigned)((((ky * 3 + kx) * Cin) + ch * 32) * 2);
+            dma16_buf_to_lds(w_off, srd_w, soff_w, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(WT0 + b * WT_BYTES + kx * (BN_ * ROWB) + wave * 1024)));
+        }
+    };
+
+    // ---- fragment addressing.  A fragment i of this wave = tile pixels wr * 128 + 16 i + frow = slab row mi + 2 (mi / seg) + frow + kx
+    //      (two halo pixels per row segment before it); a wave's 128 pixels lie in one segment (seg >= 128): one base per tap, 16 i rows
+    //      further = 1024 i bytes and the same chunk key.  W fragments: tile rows wc * 64 + 16 j + frow of the tap's 8-KiB tile ----
+    const int frow = lane & 15, fk = lane >> 4;
+    int a_off[3];
+    {
+        const int mi = wr * 128;
+        const int base = mi + 2 * (mi / seg) + frow;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) a_off[kx] = SLAB0 + (base + kx) * ROWB + ((fk ^ glds_swz<32>(base + kx)) << 4);
+    }
+    const int w_lane = WT0 + (wc * 64 + frow) * ROWB + ((fk ^ glds_swz<32>(frow)) << 4);
+
+    float4_t acc[FA][4];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8_t a[FA], w[4], wn[4];
+    auto rd_a = [&](int b, int kx, int i) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8_t*>(smem + a_off[kx] + (b * SLAB_BYTES + i * 16 * ROWB));
+    };
+    auto rd_w = [&](int b, int kx, int j) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8_t*>(smem + w_lane + (b * WT_BYTES + kx * (BN_ * ROWB) + j * 16 * ROWB));
+    };
+    auto mma_row = [&](int i, bf16x8_t (&wv)[4]) __attribute__((always_inline)) {
+        bf16x8_t av = a[i];
+        if constexpr (RELU_A) av = __builtin_bit_cast(bf16x8_t, glds_relu_bf16x8(__builtin_bit_cast(uint4, av)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = glds_mfma<F16>(wv[j], av, acc[i][j]);
+    };
+    // one unit: MFMAs on (a, wcur) while the next unit's fragments stream into (a, wnext); the scheduling fences keep every refill of
+    // a[i] behind the MFMAs that read the old a[i] (hoisted, both generations are live and the loop spills)
+    auto unit = [&](bf16x8_t (&wcur)[4], bf16x8_t (&wnext)[4], int nb, int nkx, auto dma) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            mma_row(i, wcur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wnext[j] = rd_w(nb, nkx, j);
+            }
+            a[i] = rd_a(nb, nkx, i);
+            dma(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto no_dma = [](int) __attribute__((always_inline)) {};
+    auto sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // prologue: super-step 0 -> buffers 0, wait, super-step 1 -> buffers 1, first fragments
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_piece(0, 0, 0, j);
+    sync();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_piece(0, 1, 1, j);          // (nch >= 2: launcher)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = rd_w(0, 0, j);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) a[i] = rd_a(0, 0, i);
+    unit(w, wn, 0, 1, no_dma);
+    unit(wn, w, 0, 2, no_dma);
+    // The loop is rotated so that its header sits at the synchronisation point (hipcc drains lgkmcnt at a loop header whatever is
+    // pending, and there the drain is wanted).  On entry (a, w) hold the fragments of unit 2 of super-step s (even, buffers 0).
+    int ky2 = 0, ch2 = 2;                                         // (ky, chunk) of super-step s + 2, carried along
+    if (ch2 >= nch) { ch2 = 0; ky2 = 1; }
+    auto advance = [&]() __attribute__((always_inline)) { if (++ch2 == nch) { ch2 = 0; ++ky2; } };
+    for (int s = 0; s + 2 < S; s += 2) {
+        sync();
+        unit(w, wn, 1, 0, [&](int i) __attribute__((always_inline)) { issue_piece(ky2, ch2, 0, i); });     // unit 2 of s | first fragments of s + 1 | DMA of s + 2
+        advance();
+        unit(wn, w, 1, 1, no_dma);
+        unit(w, wn, 1, 2, no_dma);
+        sync();
+        unit(wn, w, 0, 0, [&](int i) __attribute__((always_inline)) { issue_piece(ky2, ch2, 1, i); });     // unit 2 of s + 1 | first fragments of s + 2 | DMA of s + 3
+        advance();
+        unit(w, wn, 0, 1, no_dma);
+        unit(wn, w, 0, 2, no_dma);
+    }
+    // the last pair: nothing left to stage; the last unit has nothing to prefetch
+    sync();
+    unit(w, wn, 1, 0, no_dma);
+    unit(wn, w, 1, 1, no_dma);
+    unit(w, wn, 1, 2, no_dma);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) mma_row(i, wn);
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((opencl_constant)) GldsParams* kp =
+        (const __attribute__((opencl_constant)) GldsParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp)::"memory");
+    glds_pe_t pe = *kp;
+#else
+    glds_pe_t pe = p;
+#endif
+    __syncthreads();     // every wave is done with the buffers: they become the epilogue's bounce space (8 KiB per wave)
+    glds_epilogue_dispatch<FA, A_MODE, EPI, F16>(pe, acc, 0, wave_m, wave_n, tid, wave, 0, smem);
+}
+
+// shapes the eight-wave row-walking kernel takes: stride 1, whole 64-channel chunks (an even number of 32-channel super-steps), 128-column
+// tiles, maps 128 .. wide whose rows tile 512 pixels exactly (a tile = whole row segments of one image), 32-bit source windows
+static inline bool conv_rows8_ok(const GldsParams& p) {
+    if (p.a_mode != UC_A_CONV3X3 || p.cStride != 1 || p.cCin % 64 != 0 || p.N % 128 != 0 || p.split_k > 1) return false;
+    const int W = p.cW, H = p.cH;
+    if (W < 128 || !(W % 512 == 0 || 512 % W == 0)) return false;
+    const int R = W >= 512 ? 1 : 512 / W;
+    if (H % R != 0 || p.M % 512 != 0) return false;
+    return ((int64_t)(R + 3) * W + 4) * p.cCin * 2 < ((int64_t)1 << 31) && p.N * p.K * 2 < ((int64_t)1 << 31) && p.M < ((int64_t)1 << 30);
+}
+
+// where the eight-wave form is routed by default (measured: DESIGN.md section 7)
+static inline bool conv_rows8_wins(const GldsParams& p) { return false; }
+
+template <int EPI, bool F16>
+static void launch_conv_rows8(GldsParams p, hipStream_t st) {
+    p.tiles_m = (int)(p.M / 512);
+    p.tiles_n = (int)(p.N / 128);
+    p.dNwg = uc_make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
+    p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
+    p.dGm = uc_make_fastdiv((unsigned)p.group_m);
+    p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
+    constexpr int smem = 2 * 33 * 1024 + 2 * 3 * 128 * 64 + 1024;
+    auto launch = [&](auto kfn, bool& attr_set) {
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+    };
+    static bool set0 = false, set1 = false;
+    if (p.relu_a) launch(conv3x3_rows8_kernel<EPI, F16, true>, set1);
+    else launch(conv3x3_rows8_kernel<EPI, F16, false>, set0);
+}
+
 // Tile variants of one (A_MODE, EPI) pair: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2), 2 = 256x256 (4x4), 3 = 256x128x32 with
 // two co-resident workgroups per CU.
 template <int A_MODE, int EPI, bool F16 = false>
@@ -2095,7 +2354,12 @@ static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t s
         // tiles, which this form does not reduce, are what a conv tile's LDS-DMA traffic mostly is.  Fewer tiles than CUs: the
         // latency-regime variants below.
         const int rows_mode = g_uc_conv_rows.load(std::memory_order_relaxed);
-        if (rows_mode > 0 && conv_rows_ok(p) && (rows_mode >= 2 || (p.N == 128 && p.cCin >= 256)) && (p.M / 256) * (p.N / 128) >= 256) {
+        // conv_rows 3: the eight-wave 512-pixel form wherever the shape allows; 1 (default): where it wins
+        if ((rows_mode == 3 || (rows_mode == 1 && conv_rows8_wins(p))) && conv_rows8_ok(p) && (p.M / 512) * (p.N / 128) >= 256) {
+            launch_conv_rows8<EPI, F16>(p, st);
+            return;
+        }
+        if (rows_mode > 0 && rows_mode < 3 && conv_rows_ok(p) && (rows_mode >= 2 || (p.N == 128 && p.cCin >= 256)) && (p.M / 256) * (p.N / 128) >= 256) {
             launch_conv_rows<EPI, F16>(p, st);
             return;
         }
