@@ -49,8 +49,10 @@ const char* uc_last_error(void);
  *   10: uc_attention_fwd_x3 takes RoPE-2D positions (rotation fused into its operand split).
  *   11: the folded LayerNorm's block statistics (uc_gemm_desc.stats_out, ln_stats with ln_nblk > 0, uc_ln_stats_finalize) are
  *       block-major [N/64][M][2] instead of [M][N/64][2]; uc_gemm_desc gained fuse_ws (caller-provided hand-over buffer of the
- *       small-M path, uc_gemm_fuse_ws_bytes): the library no longer allocates. */
-#define UC_ABI_VERSION 11
+ *       small-M path, uc_gemm_fuse_ws_bytes): the library no longer allocates.
+ *   12: uc_swiglu / uc_swiglu_bwd added (DINOv2 giant's SwiGLU FFN); tuning knob conv_rows takes 3 (eight-wave row-walking 3x3
+ *       convolution wherever the shape allows). */
+#define UC_ABI_VERSION 12
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
 const char* uc_build_flavor(void);
@@ -438,6 +440,13 @@ int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, floa
 
 /* Activation backward: du = dg * act'(u), u = saved pre-activation (uc_gemm preact_out).  act: UC_ACT_GELU_ERF | UC_ACT_RELU. */
 int uc_act_bwd(const void* dg, const void* u, void* du, int dtype, int act, int64_t n, uc_stream_t stream);
+
+/* SwiGLU gate (DINOv2 giant's FFN; the hub's SwiGLUFFNFused, reference encoders/dinov2.py:68-84 loads it through torch.hub):
+ * t [M, 2H] row-major = w12(x); g[m, j] = silu(t[m, j]) * t[m, H + j], g [M, H].  dtype UC_F32 | UC_BF16, H % 8 == 0. */
+int uc_swiglu(const void* t, void* g, int dtype, int64_t M, int64_t H, uc_stream_t stream);
+/* ... and its backward: dt[m, j] = dg x2 s (1 + x1 (1 - s)), dt[m, H + j] = dg x1 s with x1 = t[m, j], x2 = t[m, H + j],
+ * s = sigmoid(x1); dg [M, H], t and dt [M, 2H]. */
+int uc_swiglu_bwd(const void* dg, const void* t, void* dt, int dtype, int64_t M, int64_t H, uc_stream_t stream);
 
 /* 2-D transpose src[R,S] -> dst[S, ld_dst] (row-major; f32->f32, bf16->bf16 or f32->bf16), used to put the reduction
  * dimension of the weight-gradient GEMMs (dW = dY^T X) on the contiguous axis.  ld_dst in [R, R+64): columns R..ld_dst-1

@@ -334,7 +334,12 @@ def dinov2_encoder(img: Tensor, sd: SD, prefix: str, *, num_heads: int, num_regi
         qkv = linear(h, sd, bp + "attn.qkv").view(B, N, 3, num_heads, Cd // num_heads).permute(2, 0, 3, 1, 4)
         a = linear(sdpa(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, N, Cd), sd, bp + "attn.proj")
         x = x + sd[bp + "ls1.gamma"] * a
-        x = x + sd[bp + "ls2.gamma"] * mlp(layer_norm(x, sd, bp + "norm2"), sd, bp + "mlp")
+        h2 = layer_norm(x, sd, bp + "norm2")
+        if bp + "mlp.w12.weight" in sd:      # giant: the hub's SwiGLUFFNFused — x1, x2 = w12(x).chunk(2); w3(silu(x1) * x2)
+            x1, x2 = linear(h2, sd, bp + "mlp.w12").chunk(2, dim=-1)
+            x = x + sd[bp + "ls2.gamma"] * linear(F.silu(x1) * x2, sd, bp + "mlp.w3")
+        else:
+            x = x + sd[bp + "ls2.gamma"] * mlp(h2, sd, bp + "mlp")
         if i in take:
             taken.append(layer_norm(x, sd, prefix + "norm") if norm else x)
     xn = layer_norm(x, sd, prefix + "norm") if norm else x

@@ -4,7 +4,8 @@ implementations resize the position embedding differently for other grids (hub: 
 size-based bicubic), so only the native grid is a common ground."""
 import torch
 
-SIZES = {"small": (384, 6), "base": (768, 12), "large": (1024, 16)}   # embed dim, heads
+SIZES = {"small": (384, 6), "base": (768, 12), "large": (1024, 16), "giant": (1536, 24)}   # embed dim, heads
+SWIGLU_HIDDEN = {"giant": 4096}      # giant: SwiGLU FFN, hidden (int(4 D * 2 / 3) + 7) // 8 * 8 (hub SwiGLUFFNFused = transformers Dinov2SwiGLUFFN)
 GAINS = {"pos_embed": 300.0, "cls_token": 10.0, "register_tokens": 20.0}
 DINOV2_HF_CASES = {
     "small_noreg": dict(size="small", regs=False, layers=2, hw=(518, 518), B=1, seed=11),
@@ -20,6 +21,9 @@ DINOV2_HF_CASES = {
     "small_reg_224": dict(size="small", regs=True, layers=2, hw=(224, 224), B=2, seed=15),
     "base_reg_448x336": dict(size="base", regs=True, layers=1, hw=(448, 336), B=1, seed=16),
     "small_reg_700x560": dict(size="small", regs=True, layers=1, hw=(700, 560), B=1, seed=17),
+    # giant (ViT-g/14: 1536 wide, 24 heads, SwiGLU FFN of 4096 hidden), the first two blocks, with and without registers
+    "giant_reg_224": dict(size="giant", regs=True, layers=2, hw=(224, 224), B=1, seed=18),
+    "giant_noreg": dict(size="giant", regs=False, layers=1, hw=(518, 518), B=1, seed=19),
 }
 
 
@@ -42,8 +46,12 @@ def dinov2_hub_state_dict(c, prefix="model."):
         b = f"blocks.{i}."
         for n, shp in (("norm1.weight", (D,)), ("norm1.bias", (D,)), ("attn.qkv.weight", (3 * D, D)), ("attn.qkv.bias", (3 * D,)),
                        ("attn.proj.weight", (D, D)), ("attn.proj.bias", (D,)), ("ls1.gamma", (D,)), ("norm2.weight", (D,)),
-                       ("norm2.bias", (D,)), ("mlp.fc1.weight", (4 * D, D)), ("mlp.fc1.bias", (4 * D,)), ("mlp.fc2.weight", (D, 4 * D)),
-                       ("mlp.fc2.bias", (D,)), ("ls2.gamma", (D,))):
+                       ("norm2.bias", (D,)), ("ls2.gamma", (D,))):
+            sd[b + n] = torch.empty(*shp)
+        Hs = SWIGLU_HIDDEN.get(c["size"])
+        ffn = ((("mlp.fc1.weight", (4 * D, D)), ("mlp.fc1.bias", (4 * D,)), ("mlp.fc2.weight", (D, 4 * D)), ("mlp.fc2.bias", (D,))) if Hs is None else
+               (("mlp.w12.weight", (2 * Hs, D)), ("mlp.w12.bias", (2 * Hs,)), ("mlp.w3.weight", (D, Hs)), ("mlp.w3.bias", (D,))))
+        for n, shp in ffn:
             sd[b + n] = torch.empty(*shp)
     sd = {prefix + k: v for k, v in sd.items()}
     O.fill_state_dict_(sd, gains=GAINS)
@@ -51,7 +59,7 @@ def dinov2_hub_state_dict(c, prefix="model."):
 
 
 # cases that also carry gradients (transformers' autograd): loss = <features, Wf> + <cls/registers, Wr>, seeded cotangents
-DINOV2_HF_GRAD_CASES = ("small_noreg", "small_reg")
+DINOV2_HF_GRAD_CASES = ("small_noreg", "small_reg", "giant_reg_224")
 
 
 def dinov2_grad_weights(name, f_shape, r_shape):

@@ -22,8 +22,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from tests.golden.cases import sample_indices  # noqa: E402
-from tests.golden.dinov2_cases import (DINOV2_HF_CASES, DINOV2_HF_GRAD_CASES, SIZES, dinov2_grad_weights, dinov2_hub_state_dict,  # noqa: E402
+from tests.golden.dinov2_cases import (DINOV2_HF_CASES, DINOV2_HF_GRAD_CASES, SIZES, SWIGLU_HIDDEN, dinov2_grad_weights, dinov2_hub_state_dict,  # noqa: E402
                                        dinov2_image)
+
+
+# FFN parameter names, hub -> transformers: GELU MLP (False) / SwiGLU (True: w12 -> weights_in, w3 -> weights_out)
+FFN_KEYS = {False: (("mlp.fc1.weight", "mlp.fc1.weight"), ("mlp.fc1.bias", "mlp.fc1.bias"), ("mlp.fc2.weight", "mlp.fc2.weight"), ("mlp.fc2.bias", "mlp.fc2.bias")),
+            True: (("mlp.w12.weight", "mlp.weights_in.weight"), ("mlp.w12.bias", "mlp.weights_in.bias"), ("mlp.w3.weight", "mlp.weights_out.weight"),
+                   ("mlp.w3.bias", "mlp.weights_out.bias"))}
 
 
 def hub_to_hf(sd, prefix, layers, D, regs):
@@ -45,9 +51,9 @@ def hub_to_hf(sd, prefix, layers, D, regs):
                     h + "attention.attention.value.weight": vw, h + "attention.attention.value.bias": vb,
                     h + "attention.output.dense.weight": g(b + "attn.proj.weight"), h + "attention.output.dense.bias": g(b + "attn.proj.bias"),
                     h + "layer_scale1.lambda1": g(b + "ls1.gamma"), h + "norm2.weight": g(b + "norm2.weight"),
-                    h + "norm2.bias": g(b + "norm2.bias"), h + "mlp.fc1.weight": g(b + "mlp.fc1.weight"),
-                    h + "mlp.fc1.bias": g(b + "mlp.fc1.bias"), h + "mlp.fc2.weight": g(b + "mlp.fc2.weight"),
-                    h + "mlp.fc2.bias": g(b + "mlp.fc2.bias"), h + "layer_scale2.lambda1": g(b + "ls2.gamma")})
+                    h + "norm2.bias": g(b + "norm2.bias"), h + "layer_scale2.lambda1": g(b + "ls2.gamma")})
+        for hub_k, hf_k in FFN_KEYS[prefix + b + "mlp.w12.weight" in sd]:
+            out[h + hf_k] = g(b + hub_k)
     return {k: v.clone() for k, v in out.items()}
 
 
@@ -57,7 +63,7 @@ def main():
         D, H = SIZES[c["size"]]
         kw = dict(hidden_size=D, num_hidden_layers=c["layers"], num_attention_heads=H, mlp_ratio=4, hidden_act="gelu",
                   layer_norm_eps=1e-6, image_size=518, patch_size=14, num_channels=3, qkv_bias=True, layerscale_value=1.0,
-                  use_swiglu_ffn=False, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, drop_path_rate=0.0)
+                  use_swiglu_ffn=c["size"] in SWIGLU_HIDDEN, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, drop_path_rate=0.0)
         model = (Dinov2WithRegistersModel(Dinov2WithRegistersConfig(num_register_tokens=4, **kw)) if c["regs"]
                  else Dinov2Model(Dinov2Config(**kw))).eval()
         sd = dinov2_hub_state_dict(c)
@@ -95,9 +101,8 @@ def main():
                 hub[b + "attn.qkv.bias"] = torch.cat([hf[a + "query.bias"], hf[a + "key.bias"], hf[a + "value.bias"]], 0)
                 for hub_k, hf_k in (("norm1.weight", "norm1.weight"), ("norm1.bias", "norm1.bias"), ("attn.proj.weight", "attention.output.dense.weight"),
                                     ("attn.proj.bias", "attention.output.dense.bias"), ("ls1.gamma", "layer_scale1.lambda1"),
-                                    ("norm2.weight", "norm2.weight"), ("norm2.bias", "norm2.bias"), ("mlp.fc1.weight", "mlp.fc1.weight"),
-                                    ("mlp.fc1.bias", "mlp.fc1.bias"), ("mlp.fc2.weight", "mlp.fc2.weight"), ("mlp.fc2.bias", "mlp.fc2.bias"),
-                                    ("ls2.gamma", "layer_scale2.lambda1")):
+                                    ("norm2.weight", "norm2.weight"), ("norm2.bias", "norm2.bias"), ("ls2.gamma", "layer_scale2.lambda1")) + \
+                        FFN_KEYS[c["size"] in SWIGLU_HIDDEN]:
                     hub[b + hub_k] = hf[h + hf_k]
             store[f"{name}/loss"] = np.float64(float(loss.detach()))
             for k, gr in hub.items():

@@ -128,3 +128,28 @@ def test_training_inputs_are_rejected_not_mishandled():
     enc = encoder_factory("croco", name="e", data_norm_type="dust3r", img_size=(32, 32), enc_embed_dim=64, enc_depth=1, enc_num_heads=1)
     with pytest.raises(UcHipError, match="HIP device only"):
         enc(ViTEncoderInput(image=torch.zeros(1, 3, 32, 32), data_norm_type="dust3r"))
+
+def test_gradient_checkpointing_wraps_blocks_like_the_reference():
+    """`gradient_checkpointing=True` swaps each block's class for a `_CheckpointingWrapper` subclass that remembers the original
+    (`_restore_cls`, encoders/base.py:139-152): state_dict names and isinstance checks are unchanged, wrapping twice is a no-op.
+    (The re-computation itself runs HIP kernels: tests/test_checkpointing_gpu.py.)"""
+    from uniception_amd.models.encoders import encoder_factory
+    from uniception_amd.models.info_sharing import INFO_SHARING_CLASSES
+    from uniception_amd.models.utils.transformer_blocks import CrossAttentionBlock, SelfAttentionBlock
+    plain = {}
+    for key, blocks_of in (("cross_attention", lambda m: [b for br in m.multi_view_branches for b in br]),
+                           ("global_attention", lambda m: list(m.self_attention_blocks)),
+                           ("alternating_attention", lambda m: list(m.self_attention_blocks))):
+        cls, _ = INFO_SHARING_CLASSES[key]
+        kw = dict(name="t", input_embed_dim=64, dim=128, num_heads=2, depth=2)
+        if key == "cross_attention":
+            kw["num_views"] = 2
+        a, b = cls(**kw), cls(**kw, gradient_checkpointing=True)
+        assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+        for blk in blocks_of(b):
+            assert type(blk).__name__.startswith("Checkpointed") and isinstance(blk, (CrossAttentionBlock, SelfAttentionBlock))
+            assert type(blk)._restore_cls in (CrossAttentionBlock, SelfAttentionBlock)
+            assert b.wrap_module_with_gradient_checkpointing(blk) is blk and type(blk)._restore_cls in (CrossAttentionBlock, SelfAttentionBlock)
+        assert not any(type(blk).__name__.startswith("Checkpointed") for blk in blocks_of(a))
+    enc = encoder_factory("dinov2", name="d", size="small", with_registers=True, keep_first_n_layers=2, gradient_checkpointing=True)
+    assert enc.gradient_checkpointing and all(type(b).__name__.startswith("Checkpointed") for b in enc.model.blocks)

@@ -523,7 +523,14 @@ def test_conv3x3_row_walking_kernel(gpu, dtype, geom):
         ops.tuning_set("conv_rows", mode)
         outs[mode] = ops.gemm(xg, w_r, bias.to(gpu), conv=(B, H, W, Cin, 1), out_dtype=torch.float32)
     assert rel_l2(outs[2], outs[0]) < 2e-6           # (one 64-channel chunk: the same K order, the same bits)
-    assert torch.equal(outs[1], outs[2] if (Cout == 128 and Cin >= 256) else outs[0])
+    # default routing: the eight-wave 512-pixel kernel wherever its shape rules hold, else the 256-pixel one where it wins
+    R8 = 1 if W >= 512 else 512 // W
+    rows8 = W >= 128 and (W % 512 == 0 or 512 % W == 0) and H % R8 == 0 and (B * H * W) % 512 == 0 and (B * H * W // 512) * (Cout // 128) >= 256
+    if rows8:
+        ops.tuning_set("conv_rows", 3)
+        assert torch.equal(outs[1], ops.gemm(xg, w_r, bias.to(gpu), conv=(B, H, W, Cin, 1), out_dtype=torch.float32))
+    else:
+        assert torch.equal(outs[1], outs[2] if (Cout == 128 and Cin >= 256) else outs[0])
     ops.tuning_set("conv_rows", 2)
     if Cout == 128 and dtype == torch.bfloat16:
         w4 = torch.randn(4, 128, generator=g) / math.sqrt(128)

@@ -89,6 +89,8 @@ SIGNATURES = {
     "uc_splitk_reduce": [vp, i32, i64, i64, vp, i32, vp],
     "uc_colsum": [vp, i32, i64, i64, i64, vp, vp],
     "uc_act_bwd": [vp, vp, vp, i32, i32, i64, vp],
+    "uc_swiglu": [vp, vp, i32, i64, i64, vp],
+    "uc_swiglu_bwd": [vp, vp, vp, i32, i64, i64, vp],
     "uc_transpose2d": [vp, i32, vp, i32, vp, i64, i64, i64, vp],
     "uc_pointmap_adaptor_bwd": [vp, i64, i64, i64, vp, vp, f32, f32, vp, i32, i32, i32, vp],
     "uc_adaptor_program_bwd": [vp, i64, i64, i64, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
@@ -108,7 +110,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 11   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 12   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

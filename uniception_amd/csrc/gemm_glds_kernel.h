@@ -2317,8 +2317,10 @@ static inline bool conv_rows8_ok(const GldsParams& p) {
     return ((int64_t)(R + 3) * W + 4) * p.cCin * 2 < ((int64_t)1 << 31) && p.N * p.K * 2 < ((int64_t)1 << 31) && p.M < ((int64_t)1 << 30);
 }
 
-// where the eight-wave form is routed by default (measured: DESIGN.md section 7)
-static inline bool conv_rows8_wins(const GldsParams& p) { return false; }
+// where the eight-wave form is routed by default: everywhere its shape rules allow — measured ahead of both other forms on every
+// DPT-head shape, bf16 and fp16, with and without ReLU on load (512^2 128->128 +16-19 %, 256^2 256->128 +24 %
+// over the 256-pixel row kernel, 256 output channels +8-12 % over the 256x256 implicit-GEMM tile)
+static inline bool conv_rows8_wins(const GldsParams&) { return true; }
 
 template <int EPI, bool F16>
 static void launch_conv_rows8(GldsParams p, hipStream_t st) {
@@ -2355,7 +2357,9 @@ static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t s
         // latency-regime variants below.
         const int rows_mode = g_uc_conv_rows.load(std::memory_order_relaxed);
         // conv_rows 3: the eight-wave 512-pixel form wherever the shape allows; 1 (default): where it wins
-        if ((rows_mode == 3 || (rows_mode == 1 && conv_rows8_wins(p))) && conv_rows8_ok(p) && (p.M / 512) * (p.N / 128) >= 256) {
+        // (fewer tiles than CUs: the latency-regime variants below — unless forced: conv_rows 3 makes the kernel choice, and with it the
+        //  summation order, independent of the batch size)
+        if (conv_rows8_ok(p) && (rows_mode == 3 || (rows_mode == 1 && conv_rows8_wins(p) && (p.M / 512) * (p.N / 128) >= 256))) {
             launch_conv_rows8<EPI, F16>(p, st);
             return;
         }

@@ -4,6 +4,7 @@
 // The reference has no hand-written backward (it is PyTorch autograd over the modules); each kernel cites the forward
 // expression it differentiates in include/uc_hip.h.
 #include "common.h"
+#include <algorithm>
 
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm backward.  One wavefront per row, exact width C = NV*256 (all loads of a row issued back to back), rows
@@ -323,6 +324,83 @@ extern "C" int uc_act_bwd(const void* dg, const void* u, void* du, int dtype, in
     else if (dtype == UC_BF16) hipLaunchKernelGGL((act_bwd_kernel<BF16Tag>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dg, (const bf16_t*)u, (bf16_t*)du, act, n);
     else { uc_set_error("uc_act_bwd: bad dtype %d", dtype); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_act_bwd");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SwiGLU gate of DINOv2's giant FFN (the hub's SwiGLUFFNFused: x1, x2 = w12(x).chunk(2); w3(silu(x1) * x2)):
+//   forward   g[m, j] = silu(t[m, j]) * t[m, H + j]                                        t [M, 2H] -> g [M, H]
+//   backward  dt[m, j] = dg x2 s (1 + x1 (1 - s)),  dt[m, H + j] = dg x1 s,  s = sigmoid(x1)
+// HBM-bound (3 / 5 values per gate element): one lane per 8 consecutive columns, 16-byte loads and stores for the 16-bit dtypes
+// (H % 8 == 0; launcher), grid-stride over M * H / 8 items.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Tag, bool BWD>
+__global__ __launch_bounds__(256) void swiglu_kernel(const typename Tag::storage* __restrict__ t, const typename Tag::storage* __restrict__ dg,
+                                                     typename Tag::storage* __restrict__ out, int64_t M, int H, uc_fastdiv dPer) {
+    typedef typename Tag::storage S;
+    const unsigned per_row = (unsigned)H / 8u;
+    const int64_t items = M * per_row;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        // (items of one launch chunk stay below 2^31: launcher)
+        const unsigned m = uc_div((unsigned)it, dPer), j = ((unsigned)it - m * per_row) * 8u;
+        const S* row = t + (int64_t)m * 2 * H;
+        S a[8], b[8], g[8];
+        __builtin_memcpy(a, row + j, sizeof(a));
+        __builtin_memcpy(b, row + H + j, sizeof(b));
+        if (BWD) __builtin_memcpy(g, dg + (int64_t)m * H + j, sizeof(g));
+        S o1[8], o2[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float x1 = Tag::load(a + r), x2 = Tag::load(b + r);
+            const float s = 1.0f / (1.0f + __expf(-x1));
+            if (BWD) {
+                const float d = Tag::load(g + r);
+                Tag::store(o1 + r, d * x2 * s * (1.0f + x1 * (1.0f - s)));
+                Tag::store(o2 + r, d * x1 * s);
+            } else {
+                Tag::store(o1 + r, x1 * s * x2);
+            }
+        }
+        if (BWD) {
+            S* orow = out + (int64_t)m * 2 * H;
+            __builtin_memcpy(orow + j, o1, sizeof(o1));
+            __builtin_memcpy(orow + H + j, o2, sizeof(o2));
+        } else {
+            __builtin_memcpy(out + (int64_t)m * H + j, o1, sizeof(o1));
+        }
+    }
+}
+
+template <bool BWD>
+static int swiglu_launch(const void* t, const void* dg, void* out, int dtype, int64_t M, int64_t H, hipStream_t st, const char* who) {
+    if (M == 0) return UC_OK;
+    const uc_fastdiv d = uc_make_fastdiv((unsigned)(H / 8));
+    const int64_t rows_per = std::max<int64_t>(1, (((int64_t)1 << 31) - 1) / (H / 8));          // 32-bit item index per launch
+    for (int64_t m0 = 0; m0 < M; m0 += rows_per) {
+        const int64_t mc = std::min(rows_per, M - m0);
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)uc_num_cus() * 16, ceil_div64(mc * (H / 8), 256));
+        const size_t es = dtype == UC_F32 ? 4 : 2;
+        const char* tp = (const char*)t + (size_t)m0 * 2 * H * es;
+        const char* gp = dg ? (const char*)dg + (size_t)m0 * H * es : nullptr;
+        char* op = (char*)out + (size_t)m0 * (BWD ? 2 : 1) * H * es;
+        if (dtype == UC_F32) hipLaunchKernelGGL((swiglu_kernel<F32Tag, BWD>), dim3(grid), dim3(256), 0, st, (const float*)tp, (const float*)gp, (float*)op, mc, (int)H, d);
+        else if (dtype == UC_BF16) hipLaunchKernelGGL((swiglu_kernel<BF16Tag, BWD>), dim3(grid), dim3(256), 0, st, (const bf16_t*)tp, (const bf16_t*)gp, (bf16_t*)op, mc, (int)H, d);
+        else { uc_set_error("%s: bad dtype %d", who, dtype); return UC_ERR_BAD_ARG; }
+    }
+    return UC_OK;
+}
+
+extern "C" int uc_swiglu(const void* t, void* g, int dtype, int64_t M, int64_t H, uc_stream_t stream) {
+    UC_REQUIRE(t && g && M >= 0 && H > 0 && H % 8 == 0 && H < ((int64_t)1 << 28), "uc_swiglu: bad argument (H must be a positive multiple of 8)");
+    if (int rc = swiglu_launch<false>(t, nullptr, g, dtype, M, H, (hipStream_t)stream, "uc_swiglu")) return rc;
+    UC_CHECK_LAUNCH("uc_swiglu");
+    return UC_OK;
+}
+
+extern "C" int uc_swiglu_bwd(const void* dg, const void* t, void* dt, int dtype, int64_t M, int64_t H, uc_stream_t stream) {
+    UC_REQUIRE(dg && t && dt && M >= 0 && H > 0 && H % 8 == 0 && H < ((int64_t)1 << 28), "uc_swiglu_bwd: bad argument (H must be a positive multiple of 8)");
+    if (int rc = swiglu_launch<true>(t, dg, dt, dtype, M, H, (hipStream_t)stream, "uc_swiglu_bwd")) return rc;
+    UC_CHECK_LAUNCH("uc_swiglu_bwd");
     return UC_OK;
 }
 

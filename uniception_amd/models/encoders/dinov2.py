@@ -161,6 +161,9 @@ class DINOv2Encoder(UniCeptionViTEncoderBase):
             print(f"Loading custom pretrained DINOv2 checkpoint from {pretrained_checkpoint_path}")
             ckpt = torch.load(pretrained_checkpoint_path, weights_only=False)
             print(self.load_state_dict(ckpt["model"]))
+        if self.gradient_checkpointing:       # (encoders/dinov2.py:125-127)
+            for i in range(len(self.model.blocks)):
+                self.model.blocks[i] = self.wrap_module_with_gradient_checkpointing(self.model.blocks[i])
 
     # ---- token-stream core ---------------------------------------------------------------------
     def _check(self, encoder_input):

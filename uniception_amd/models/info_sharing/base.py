@@ -28,10 +28,9 @@ class UniCeptionInfoSharingBase(nn.Module):
         raise NotImplementedError
 
     def wrap_module_with_gradient_checkpointing(self, module: nn.Module):
-        # 288 GB of HBM hold the activations of every supported batch, and the HIP sub-layer Functions own their saved
-        # tensors: re-computation is not implemented (the reference's own cross-attention transformer cannot enable it
-        # either)
-        raise NotImplementedError("gradient checkpointing is not supported by the HIP path")
+        "Re-compute `module`'s forward in the backward pass (info_sharing/base.py:59-72); see models/utils/checkpointing.py."
+        from ..utils.checkpointing import wrap_module_with_gradient_checkpointing
+        return wrap_module_with_gradient_checkpointing(module)
 
 
 @dataclass

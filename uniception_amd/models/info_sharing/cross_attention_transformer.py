@@ -54,9 +54,6 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
         self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
         self.pretrained_checkpoint_path = pretrained_checkpoint_path
         self.gradient_checkpointing = gradient_checkpointing
-        if gradient_checkpointing:
-            # the reference raises AttributeError here (self.cross_attention_blocks is never assigned, :163-165)
-            raise engine.UcHipError("gradient_checkpointing is not supported by the HIP cross-attention transformer")
 
         self.proj_embed = nn.Linear(input_embed_dim, dim, bias=True) if input_embed_dim != dim else nn.Identity()
         branch = nn.ModuleList([
@@ -80,6 +77,11 @@ class MultiViewCrossAttentionTransformer(UniCeptionInfoSharingBase):
             print(f"Loading pretrained multi-view cross-attention transformer weights from {pretrained_checkpoint_path} ...")
             ckpt = torch.load(pretrained_checkpoint_path, weights_only=False)
             print(self.load_state_dict(ckpt["model"]))
+        if self.gradient_checkpointing:
+            # what the reference means to do at :163-165 (it raises AttributeError there: self.cross_attention_blocks is never assigned)
+            for branch in self.multi_view_branches:
+                for i, block in enumerate(branch):
+                    branch[i] = self.wrap_module_with_gradient_checkpointing(block)
 
     def initialize_weights(self):
         self.apply(self._init_weights)

@@ -55,8 +55,6 @@ class _MultiViewSelfAttentionCore(UniCeptionInfoSharingBase):
         self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
         self.pretrained_checkpoint_path = pretrained_checkpoint_path
         self.gradient_checkpointing = gradient_checkpointing
-        if gradient_checkpointing:
-            raise engine.UcHipError(f"gradient_checkpointing is not supported by the HIP {what} transformer")
         self.proj_embed = nn.Linear(input_embed_dim, dim, bias=True) if input_embed_dim != dim else nn.Identity()
         if isinstance(self.custom_positional_encoding, str):
             if self.custom_positional_encoding != "rope":
@@ -83,6 +81,9 @@ class _MultiViewSelfAttentionCore(UniCeptionInfoSharingBase):
             print(f"Loading pretrained multi-view {what} transformer weights from {pretrained_checkpoint_path} ...")
             ckpt = torch.load(pretrained_checkpoint_path, weights_only=False)
             print(self.load_state_dict(ckpt["model"]))
+        if self.gradient_checkpointing:       # (global_attention_transformer.py:196-198, alternating_attention_transformer.py:178-180)
+            for i, block in enumerate(self.self_attention_blocks):
+                self.self_attention_blocks[i] = self.wrap_module_with_gradient_checkpointing(block)
 
     _get_sinusoid_encoding_table = staticmethod(sinusoid_encoding_table)
 

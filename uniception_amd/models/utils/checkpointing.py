@@ -1,0 +1,36 @@
+"""Gradient checkpointing of token-stream blocks (reference: encoders/base.py:139-152, info_sharing/base.py:59-72 — the class-swapping
+`_CheckpointingWrapper` around `torch.utils.checkpoint(..., use_reentrant=False)`).
+
+The HIP sub-layer Functions (autograd.py) keep what their backward needs through `ctx.save_for_backward`, so the non-reentrant
+checkpoint's saved-tensor hooks see every activation a block holds: inside a wrapped block they are dropped after the forward and the
+block's forward is run again — the same kernels on the same inputs, the same bits — when its backward needs them.  Parameter gradients
+written straight into a trainer's flat buffer (the gradient sink) and LayerScale's unfolded gradients are produced by that second
+backward exactly as without the wrapper.  Outside training (no gradient requested) the wrapper is transparent: the fused inference
+pipeline runs, nothing is recorded."""
+import torch
+from torch import nn
+from torch.utils.checkpoint import checkpoint
+
+from ... import autograd
+
+
+def wrap_module_with_gradient_checkpointing(module: nn.Module) -> nn.Module:
+    "Swap `module`'s class for a subclass whose forward_tokens / forward re-compute in the backward pass.  Returns the module."
+    if getattr(module.__class__, "_restore_cls", None) is not None:
+        return module           # already wrapped
+
+    class _CheckpointingWrapper(module.__class__):
+        _restore_cls = module.__class__
+
+        def _ckpt(self, fn, *args, **kwargs):
+            tensors = [a for a in args if isinstance(a, torch.Tensor)]
+            if not torch.is_grad_enabled() or not autograd.grad_needed(*tensors, *self.parameters()):
+                return fn(*args, **kwargs)
+            return checkpoint(fn, *args, use_reentrant=False, preserve_rng_state=False, **kwargs)
+
+        def forward_tokens(self, *args, **kwargs):
+            return self._ckpt(super().forward_tokens, *args, **kwargs)
+
+    _CheckpointingWrapper.__name__ = f"Checkpointed{module.__class__.__name__}"
+    module.__class__ = _CheckpointingWrapper
+    return module

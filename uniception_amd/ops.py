@@ -47,7 +47,7 @@ def _p(t: Optional[torch.Tensor]):
 def tuning_set(name: str, value: int) -> None:
     """Run-time switchable tuning knobs of libuc_hip.so (uc_tuning_set): "gemm_variant" (-3 automatic, -1 register-staged kernel,
     0..3 / 6 / 7 tile variants of the direct-to-LDS bf16 GEMM), "gemm_stagger" (-1 launcher policy), "attn_role_split", "conv_rows" (row-walking 3x3
-    conv kernel: 0 never, 1 where it wins, 2 wherever the shape allows), "small_m_split" (smallest K for which a dense launch on at most half
+    conv kernels: 0 never, 1 where they win, 2 the 256-pixel one wherever the shape allows, 3 the eight-wave 512-pixel one wherever the shape allows), "small_m_split" (smallest K for which a dense launch on at most half
     the CUs splits K in two inside the kernel; 0: never — results are then bit-identical across batch sizes).  Every value selects a correct
     kernel; everything else the library reads from the environment, once (csrc/knobs.h)."""
     _lib.check(_lib.load().uc_tuning_set(name.encode(), int(value)), f"uc_tuning_set({name})")
@@ -895,6 +895,26 @@ def act_bwd(dg: torch.Tensor, u: torch.Tensor, act: str) -> torch.Tensor:
     _lib.check(_lib.load().uc_act_bwd(dg.data_ptr(), u.data_ptr(), du.data_ptr(), _dt(dg.dtype), ACT[act], dg.numel(), _stream()),
                "uc_act_bwd")
     return du
+
+
+def swiglu(t: torch.Tensor) -> torch.Tensor:
+    """t [M, 2H] (= w12(x)) -> silu(t[:, :H]) * t[:, H:]  [M, H]: the gate of DINOv2 giant's SwiGLU FFN.  fp32 / bf16, H % 8 == 0."""
+    M, H2 = t.shape
+    if not t.is_contiguous() or H2 % 16 != 0 or t.dtype not in (torch.float32, torch.bfloat16):
+        raise UcHipError(f"swiglu: contiguous fp32 / bf16 [M, 2H] with H % 8 == 0 expected (got {tuple(t.shape)}, {t.dtype})")
+    g = torch.empty((M, H2 // 2), dtype=t.dtype, device=t.device)
+    _lib.check(_lib.load().uc_swiglu(t.data_ptr(), g.data_ptr(), _dt(t.dtype), M, H2 // 2, _stream()), "uc_swiglu")
+    return g
+
+
+def swiglu_bwd(dg: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    "Gradient of swiglu with respect to t: dg [M, H], t [M, 2H] -> dt [M, 2H]."
+    M, H2 = t.shape
+    if not (t.is_contiguous() and dg.is_contiguous()) or dg.shape != (M, H2 // 2) or dg.dtype != t.dtype or H2 % 16 != 0:
+        raise UcHipError("swiglu_bwd: contiguous dg [M, H] and t [M, 2H] of one dtype expected")
+    dt_ = torch.empty_like(t)
+    _lib.check(_lib.load().uc_swiglu_bwd(dg.data_ptr(), t.data_ptr(), dt_.data_ptr(), _dt(t.dtype), M, H2 // 2, _stream()), "uc_swiglu_bwd")
+    return dt_
 
 
 def transpose2d(x: torch.Tensor, out_dtype: Optional[torch.dtype] = None, pad_to: int = 1, with_copy: bool = False):
