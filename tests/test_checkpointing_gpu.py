@@ -1,7 +1,8 @@
 """Gradient checkpointing (reference: encoders/base.py:139-152, info_sharing/base.py:59-72; switched on by `gradient_checkpointing=True`
 in the DINOv2 encoder and the multi-view transformers): wrapped blocks drop what their HIP sub-layer Functions saved and run their
 forward again in the backward pass.  The property tested is the one the reference's wrapper has by construction: the same loss, the same
-gradients — here to the bit, the re-computation being the same kernels on the same inputs — with less memory held between the passes."""
+gradients (the re-computation is the same kernels on the same inputs; what differs is the order of fp32 atomic sums, 1e-7) — with less memory
+held between the passes."""
 import pytest
 import torch
 
@@ -30,12 +31,16 @@ def _run(model, leaves, forward, mode):
 def _same(a, b, what):
     la, ia, pa, _ = a
     lb, ib, pb, _ = b
+    # the forward is the same kernels on the same inputs: the same bits.  Gradients: the re-computed activations are the same bits too, but
+    # LayerNorm / bias gradients are accumulated with fp32 atomics (column sums over rows), whose order differs from run to run even
+    # without checkpointing: the last bits of a sum, 1e-7 relative
     assert la == lb, (what, la, lb)
+    from tests.helpers import rel_l2
     for i, (x, y) in enumerate(zip(ia, ib)):
-        assert torch.equal(x, y), f"{what}: gradient of input {i} differs"
+        assert rel_l2(x.double().cpu(), y.double().cpu()) < 1e-5, f"{what}: gradient of input {i} differs"
     assert pa.keys() == pb.keys() and len(pa) > 0
     for k in pa:
-        assert torch.equal(pa[k], pb[k]), f"{what}: gradient of {k} differs"
+        assert rel_l2(pa[k].double().cpu(), pb[k].double().cpu()) < 1e-5, f"{what}: gradient of {k} differs ({rel_l2(pa[k].double().cpu(), pb[k].double().cpu()):.2e})"
 
 
 @pytest.mark.parametrize("name", ["global_rope_v3", "alt_ls_v2", "global_ls_tokens_v2"])

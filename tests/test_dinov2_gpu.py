@@ -141,7 +141,8 @@ def test_config4_pipeline_matches_oracle_composition_and_trains_with_frozen_enco
     assert gnorm > 0 and torch.isfinite(torch.tensor(gnorm))
 
 
-@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg", "large_full", "small_reg_224", "base_reg_448x336", "small_reg_700x560"])     # large_full: ViT-L/14 x 24 at 518^2, the size configs[3] names
+@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg", "large_full", "small_reg_224", "base_reg_448x336", "small_reg_700x560",
+                                  "giant_reg_224", "giant_noreg"])     # large_full: ViT-L/14 x 24 at 518^2, the size configs[3] names; giant_*: the SwiGLU FFN
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2)])
 def test_matches_huggingface_transformers_golden(gpu, name, mode, tol):
     """The HIP DINOv2 encoder against goldens of an INDEPENDENT implementation of the published network (transformers'
@@ -173,7 +174,7 @@ def test_matches_huggingface_transformers_golden(gpu, name, mode, tol):
     assert e_f < tol and e_n < tol and e_r < tol
 
 
-@pytest.mark.parametrize("name", ["small_noreg", "small_reg"])
+@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "giant_reg_224"])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_gradients_match_huggingface_transformers_autograd(gpu, name, mode):
     """The DINOv2 encoder is trainable: gradients of  <features, Wf> + <class / register tokens, Wr>  with respect to every

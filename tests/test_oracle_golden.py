@@ -51,7 +51,8 @@ def test_rope_roundtrip_and_quarters():
     assert torch.equal(r[:, :, 3, 32:], t[:, :, 3, 32:]) and torch.equal(r[:, :, 1, :32], t[:, :, 1, :32])
 
 
-@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg", "large_full", "small_reg_224", "base_reg_448x336", "small_reg_700x560"])
+@pytest.mark.parametrize("name", ["small_noreg", "small_reg", "base_reg", "large_full", "small_reg_224", "base_reg_448x336", "small_reg_700x560",
+                                  "giant_reg_224", "giant_noreg"])      # giant_*: ViT-g/14's SwiGLU FFN
 def test_oracle_dinov2_matches_huggingface_transformers(name):
     """The oracle's restatement of the DINOv2 ViT (cls token, registers inserted after the position embedding, LayerScale, erf-GELU,
     final LayerNorm) against an independent implementation of the same published network: transformers' Dinov2Model /

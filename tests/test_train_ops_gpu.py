@@ -427,3 +427,25 @@ def test_gemm_tn_half_height_tile(gpu, T, I, J, sk):
     ws, cs = ops.gemm_tn(a.to(gpu), b.to(gpu), split_k=sk, colsum=True)
     assert rel_l2(ops.splitk_reduce(ws).cpu(), a.float().t() @ b.float()) < 2e-5
     assert rel_l2(cs.sum(0).cpu(), a.float().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)])
+@pytest.mark.parametrize("M,H", [(37, 8), (300, 4096), (1, 264)])
+def test_swiglu_gate_and_its_backward(gpu, dtype, tol, M, H):
+    """uc_swiglu / uc_swiglu_bwd (DINOv2 giant's FFN gate): silu(x1) * x2 of t = [x1 | x2] and its gradient against fp64 autograd
+    on the same rounded inputs; ragged row counts, one row, a width that is a multiple of 8 only."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(M + H)
+    t = (2.0 * torch.randn(M, 2 * H, generator=g)).to(dtype)
+    dg = torch.randn(M, H, generator=g).to(dtype)
+    td = t.double().requires_grad_(True)
+    ref = F.silu(td[:, :H]) * td[:, H:]
+    ref.backward(dg.double())
+    out = ops.swiglu(t.to(gpu))
+    assert out.dtype == dtype and out.shape == (M, H)
+    assert rel_l2(out.double().cpu(), ref.detach()) < tol
+    dt = ops.swiglu_bwd(dg.to(gpu), t.to(gpu))
+    assert dt.dtype == dtype and dt.shape == (M, 2 * H)
+    assert rel_l2(dt.double().cpu(), td.grad) < tol
+    with pytest.raises(Exception):
+        ops.swiglu(torch.zeros(4, 12, device=gpu))       # H = 6: not a multiple of 8

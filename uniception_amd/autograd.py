@@ -581,6 +581,54 @@ def mlp_sublayer(x2d, ln, fc1, fc2, act, dt, gamma=None):
     return MlpSubLayerFn.apply(x2d, ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln, fc1, fc2, act, dt, gamma)
 
 
+@_sink_aware
+class SwiGLUSubLayerFn(Function):
+    """x + w3(silu(x1) * x2),  x1, x2 = w12(LN(x)).chunk(2)   (DINOv2 giant: the hub's SwiGLUFFNFused behind encoders/dinov2.py:68-84)."""
+
+    @staticmethod
+    def forward(ctx, x2d, ln_w, ln_b, w12_, b12_, w3_, b3_, ln, w12, w3, dt, gamma=None):
+        x2d = _c(x2d)
+        g, bta = engine.ln_params(ln)
+        h = ops.layernorm(x2d, g, bta, ln.eps, dt)
+        w1, b1 = engine.lin_weights(w12, dt)
+        w2, b2 = engine.lin_weights(w3, dt) if gamma is None else engine.layerscale_lin_weights(w3, gamma, dt)
+        t = ops.gemm(h, w1, b1)
+        a = ops.swiglu(t)
+        out = ops.gemm(a, w2, b2, residual=x2d, out_dtype=x2d.dtype)
+        ctx.save_for_backward(x2d, g, h, t, a, *(() if gamma is None else (gamma,)))
+        ctx.meta = (ln, w12, w3, dt, b12_ is not None, b3_ is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dxo):
+        x2d, g, h, t, a, *rest = ctx.saved_tensors
+        gamma = rest[0] if rest else None
+        ln, w12, w3, dt, has_b1, has_b2 = ctx.meta
+        dxo = _c(dxo)
+        dyb = _as_dt(dxo, dt)
+        dgamma = None
+        if gamma is None:
+            dW2, db2 = _wgrad(dyb, a, dt, has_b2, sink=[(w3.weight, 0, w3.weight.shape[0])], bias_sink=[w3.bias])
+            w2t = lin_weight_t(w3, dt)
+        else:
+            dW2, db2 = _wgrad(dyb, a, dt, has_b2)
+            dW2, db2, dgamma = _unfold_layerscale(w3, gamma, dW2, db2)
+            w2t = _folded_weight_t(w3, gamma, dt)
+        dtt = ops.swiglu_bwd(ops.gemm(dyb, w2t), t)
+        dW1, db1 = _wgrad(dtt, h, dt, has_b1, sink=[(w12.weight, 0, w12.weight.shape[0])], bias_sink=[w12.bias])
+        dh = ops.gemm(dtt, lin_weight_t(w12, dt))
+        dg, db, sunk = _ln_grad_targets(ln, g)
+        dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
+        if sunk:
+            dg = db = None
+        return (dx, dg, db, dW1, db1, dW2, db2) + (None,) * 4 + (dgamma,)
+
+
+def swiglu_sublayer(x2d, ln, w12, w3, dt, gamma=None):
+    "gamma: LayerScale on the sub-layer's output (x + gamma * w3(...)), or None."
+    return SwiGLUSubLayerFn.apply(x2d, ln.weight, ln.bias, w12.weight, w12.bias, w3.weight, w3.bias, ln, w12, w3, dt, gamma)
+
+
 # =================================================================================================================
 # heads: pixel shuffle, adaptor, loss
 # =================================================================================================================

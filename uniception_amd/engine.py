@@ -792,6 +792,17 @@ def mlp(h2d: torch.Tensor, fc1: nn.Linear, fc2: nn.Linear, act: str, residual: O
     return ops.gemm(g, w2, b2, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
 
+def mlp_swiglu(h2d: torch.Tensor, w12: nn.Linear, w3: nn.Linear, residual: Optional[torch.Tensor], out_dtype: torch.dtype,
+               w3_wb=None, fold=None, emit_ln: bool = False) -> torch.Tensor:
+    """DINOv2 giant's FFN (the hub's SwiGLUFFNFused): x1, x2 = w12(h).chunk(2); residual + w3(silu(x1) * x2).  w12 takes the folded
+    LayerNorm like fc1 does, the gate is one HBM-bound pass (uc_swiglu), w3 writes the next LayerNorm's statistics (emit_ln)."""
+    w1, b1, ln1 = _folded(w12, fold, h2d.dtype)
+    w2, b2 = w3_wb if w3_wb is not None else lin_weights(w3, h2d.dtype)
+    g = ops.swiglu(ops.gemm(h2d, w1, b1, ln=ln1))
+    emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(h2d.dtype, w2.shape[0])
+    return ops.gemm(g, w2, b2, residual=residual, out_dtype=out_dtype, emit_ln=emit)
+
+
 def act_name(act_module: nn.Module) -> str:
     if isinstance(act_module, nn.GELU) and getattr(act_module, "approximate", "none") == "none":
         return "gelu"

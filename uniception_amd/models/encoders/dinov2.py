@@ -29,7 +29,8 @@ from ... import autograd, engine, ops
 from ..utils.intermediate_feature_return import IntermediateFeatureReturner, feature_take_indices
 from .base import UniCeptionViTEncoderBase, ViTEncoderInput, ViTEncoderOutput
 
-_SIZES = {"small": (384, 12, 6), "base": (768, 12, 12), "large": (1024, 24, 16)}   # embed dim, depth, heads
+_SIZES = {"small": (384, 12, 6), "base": (768, 12, 12), "large": (1024, 24, 16), "giant": (1536, 40, 24)}   # embed dim, depth, heads
+_SWIGLU = {"giant"}      # vit_giant2: ffn_layer="swiglufused" (the hub's SwiGLUFFNFused), every other size the GELU MLP
 
 
 class _Attention(nn.Module):
@@ -49,6 +50,17 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim, bias=True)
 
 
+class _SwiGLUFFN(nn.Module):
+    """The hub's SwiGLUFFNFused under its parameter names: x1, x2 = w12(x).chunk(2); w3(silu(x1) * x2), hidden width
+    (int(4 dim * 2 / 3) + 7) // 8 * 8 (giant: 4096)."""
+
+    def __init__(self, dim, hidden):
+        super().__init__()
+        hidden = (int(hidden * 2 / 3) + 7) // 8 * 8
+        self.w12 = nn.Linear(dim, 2 * hidden, bias=True)
+        self.w3 = nn.Linear(hidden, dim, bias=True)
+
+
 class _LayerScale(nn.Module):
     def __init__(self, dim, init_values=1.0):
         super().__init__()
@@ -58,19 +70,21 @@ class _LayerScale(nn.Module):
 class _Block(nn.Module):
     "x += ls1(attn(norm1(x))); x += ls2(mlp(norm2(x)))  — parameter container; the fused pipeline is in forward_tokens."
 
-    def __init__(self, dim, num_heads, mlp_ratio=4.0):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, swiglu=False):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
         self.attn = _Attention(dim, num_heads)
         self.ls1 = _LayerScale(dim)
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
-        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.mlp = _SwiGLUFFN(dim, int(dim * mlp_ratio)) if swiglu else _Mlp(dim, int(dim * mlp_ratio))
         self.ls2 = _LayerScale(dim)
 
     def forward_tokens(self, x2d, B, N, dt):
         if autograd.grad_needed(x2d, *self.parameters()):
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads, None, None,
                                               self.attn.scale, dt, gamma=self.ls1.gamma)
+            if isinstance(self.mlp, _SwiGLUFFN):
+                return autograd.swiglu_sublayer(x2d, self.norm2, self.mlp.w12, self.mlp.w3, dt, gamma=self.ls2.gamma)
             return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, "gelu", dt, gamma=self.ls2.gamma)
         # (the same pipeline as utils/transformer_blocks.SelfAttentionBlock: LayerNorms folded into the QKV / fc1 GEMMs once a producer
         # GEMM has left the row statistics — from the first proj on —, LayerScale folded into the proj / fc2 weights)
@@ -79,6 +93,9 @@ class _Block(nn.Module):
                                     x2d, x2d.dtype, proj_wb=engine.layerscale_lin_weights(self.attn.proj, self.ls1.gamma, dt),
                                     fold=fold, emit_ln=True)
         h, fold = engine.ln_operand(x2d, self.norm2, dt)
+        if isinstance(self.mlp, _SwiGLUFFN):
+            return engine.mlp_swiglu(h, self.mlp.w12, self.mlp.w3, x2d, x2d.dtype,
+                                     w3_wb=engine.layerscale_lin_weights(self.mlp.w3, self.ls2.gamma, dt), fold=fold, emit_ln=True)
         return engine.mlp(h, self.mlp.fc1, self.mlp.fc2, "gelu", x2d, x2d.dtype,
                           fc2_wb=engine.layerscale_lin_weights(self.mlp.fc2, self.ls2.gamma, dt), fold=fold, emit_ln=True)
 
@@ -103,7 +120,7 @@ class DinoVisionTransformerParams(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, 1 + pretrain_grid * pretrain_grid, dim))
         self.register_tokens = nn.Parameter(torch.zeros(1, num_register_tokens, dim)) if num_register_tokens else None
-        self.blocks = nn.ModuleList([_Block(dim, heads) for _ in range(depth)])
+        self.blocks = nn.ModuleList([_Block(dim, heads, swiglu=size in _SWIGLU) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         nn.init.trunc_normal_(self.pos_embed, std=0.02)
         nn.init.normal_(self.cls_token, std=1e-6)
@@ -144,8 +161,7 @@ class DINOv2Encoder(UniCeptionViTEncoderBase):
         super().__init__(name=name, data_norm_type=data_norm_type, patch_size=patch_size,
                          gradient_checkpointing=gradient_checkpointing, *args, **kwargs)
         if size not in _SIZES:
-            raise engine.UcHipError(f"DINOv2 size '{size}' is not supported by the HIP path (giant uses a SwiGLU FFN); "
-                                    f"supported: {sorted(_SIZES)}")
+            raise engine.UcHipError(f"unknown DINOv2 size '{size}'; supported: {sorted(_SIZES)}")
         self.version = size
         self.with_registers = with_registers
         self.norm_returned_features = norm_returned_features
