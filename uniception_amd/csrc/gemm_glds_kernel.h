@@ -2256,12 +2256,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    // prologue: super-step 0 -> buffers 0, wait, super-step 1 -> buffers 1, first fragments
+    // prologue: super-steps 0 and 1 -> buffers 0 and 1 back to back (both are free; every wave issues exactly 8 pieces per super-step and
+    // loads return in order: vmcnt(8) = this wave's pieces of super-step 0 have landed, the second batch keeps flying under units 0 and 1)
 #pragma unroll
     for (int j = 0; j < 8; ++j) issue_piece(0, 0, 0, j);
-    sync();
 #pragma unroll
     for (int j = 0; j < 8; ++j) issue_piece(0, 1, 1, j);          // (nch >= 2: launcher)
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = rd_w(0, 0, j);
 #pragma unroll
