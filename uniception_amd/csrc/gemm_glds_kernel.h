@@ -167,6 +167,27 @@ __device__ __forceinline__ void dma16_buf_to_lds(unsigned voff, uint4_t srd, uns
         : "memory");
 }
 
+// ... under a wave-uniform execution mask (all lanes or none): a slot of a fixed per-wave DMA schedule that only some waves fill is
+// issued with EXEC = 0 by the others — no branch in the instruction stream (a branch splits the MFMA stream into basic blocks),
+// no work in the memory pipeline.
+__device__ __forceinline__ void dma16_buf_to_lds_if(unsigned exec_half, unsigned voff, uint4_t srd, unsigned soff, unsigned lds_byte_addr) {
+    unsigned keep;
+    unsigned long long keep_exec;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_mov_b32 %1, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_mov_b32 exec_lo, %6\n\t"
+        "s_mov_b32 exec_hi, %6\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %2, %3, %5 offen lds\n\t"
+        "s_mov_b64 exec, %0\n\t"
+        "s_mov_b32 m0, %1"
+        : "=&s"(keep_exec), "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff), "s"(exec_half)
+        : "memory");
+}
+
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
@@ -2110,12 +2131,17 @@ static void launch_conv_rows(GldsParams p, hipStream_t st) {
 //
 //   unit 0:  MFMAs on (a, w)   | ds_read unit 1 -> (a, wn)      (a is refilled row block by row block behind its MFMAs)
 //   unit 1:  MFMAs on (a, wn)  | ds_read unit 2 -> (a, w)
-//   s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: everyone has READ this super-step's buffers, everyone's DMA of the next one has landed
-//   unit 2:  MFMAs on (a, w)   | ds_read unit 0 of the next super-step -> (a, wn) | DMA of the super-step after it -> the buffers just
-//            released, one piece behind each MFMA group (8 pieces per wave: 4-5 of the slab, 3 of the weights)
+//   unit 2, first four MFMA groups on (a, w)
+//   s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: everyone has READ this super-step's buffers, everyone's DMA of the next one has landed —
+//            with 256 matrix-pipe cycles per wave queued, so the pipe works through the barrier's skew
+//   unit 2, last four groups   | ds_read unit 0 of the next super-step -> (a, wn)
+//   DMA of the super-step after the next -> the buffers just released: 7-8 pieces per wave (4-5 of the slab, 3 of the weights), one
+//            behind every other MFMA group from the synchronisation to the middle of the next unit 1 (the global -> LDS path takes ~40
+//            cycles per piece and CU: 57 pieces are most of a super-step; >= 1.5 units of flight each)
 //
-//   One barrier per 96 MFMAs of a wave; a piece has two units (~1 us) of flight.  The weight registers alternate roles from one
-//   super-step to the next (three units): the loop body is a PAIR of super-steps (launcher: Cin % 64 == 0), straight-line.
+//   One barrier per 96 MFMAs of a wave.  The weight registers alternate roles from one super-step to the next (three units): the loop
+//   body is a PAIR of super-steps (launcher: Cin % 64 == 0), straight-line.  Measured against the first form (synchronisation at the
+//   head of unit 2, all pieces inside unit 2, a zero-writing dump piece in the odd slot of seven waves): +1-3 % (fp16 operands), level (bf16).
 //   64-B LDS rows with the chunk key 3 ((row >> 2) & 1): conflict-free ds_read_b128 fragments at every row offset (the taps shift
 //   the 16 rows of a fragment by kx, row segments by two halo pixels each).
 //   Accumulator layout = the eight-wave GEMM's (FA = 8): the shared epilogues apply; the fused 1x1 tail drains a 128-row wave tile
@@ -2123,7 +2149,7 @@ static void launch_conv_rows(GldsParams p, hipStream_t st) {
 template <int EPI, bool F16, bool RELU_A>
 __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
     constexpr int BM_ = 512, BN_ = 128, ROWB = 64, NPIECE = 33, SLAB_BYTES = NPIECE * 1024, WT_BYTES = 3 * BN_ * ROWB;
-    constexpr int WT0 = 0, SLAB0 = 2 * WT_BYTES, DUMP = SLAB0 + 2 * SLAB_BYTES;              // LDS image: weights[2] | slab[2] | dump KiB
+    constexpr int WT0 = 0, SLAB0 = 2 * WT_BYTES;              // LDS image: weights[2] | slab[2]
     constexpr int A_MODE = UC_A_CONV3X3, FA = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -2183,17 +2209,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
         asm volatile("" : "+v"(w_off));
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    const unsigned wave0_exec = (unsigned)__builtin_amdgcn_readfirstlane(wave == 0 ? -1 : 0);      // both halves of the fifth slot's EXEC
     const int nch = Cin / 32;
     const int S = 3 * nch;                                   // super-steps, even (launcher)
     // piece j = 0..7 of super-step s -> buffer pair b: slab pieces q = j (j < 5), weight pieces of tap kx = j - 5
     auto issue_piece = [&](int ky, int ch, int b, int j) __attribute__((always_inline)) {
         if (j < 5) {
-            // (piece 32 is wave 0's; the other waves' fifth slot writes zeros into a dump KiB behind the buffers: a branch here would split
-            //  the MFMA stream into basic blocks, each join draining lgkmcnt)
+            // (piece 32 is wave 0's; the other waves issue their fifth slot with EXEC = 0: a branch here would split the MFMA stream into
+            //  basic blocks, each join draining lgkmcnt — and accumulators spilled)
             const unsigned soff = (unsigned)((((int64_t)ky * W_) * Cin + ch * 32) * 2);
             const unsigned vo = ((sl_mask >> (3 * j + ky)) & 1u) ? sl_off[j] : 0xffffffffu;
-            const unsigned dst = (j == 4 && wave != 0) ? (unsigned)DUMP : (unsigned)(SLAB0 + b * SLAB_BYTES + (wave + 8 * j) * 1024);
-            dma16_buf_to_lds(vo, srd_a, soff, __builtin_amdgcn_readfirstlane(lds_base + dst));
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(SLAB0 + b * SLAB_BYTES + (wave + 8 * j) * 1024));
+            if (j == 4) dma16_buf_to_lds_if(wave0_exec, vo, srd_a, soff, dst);      // piece 32: wave 0's
+            else dma16_buf_to_lds(vo, srd_a, soff, dst);
         } else {
             const int kx = j - 5;
             const unsigned soff_w = (unsigned)((((ky * 3 + kx) * Cin) + ch * 32) * 2);
@@ -2256,13 +2284,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    // prologue: super-steps 0 and 1 -> buffers 0 and 1 back to back (both are free; every wave issues exactly 8 pieces per super-step and
-    // loads return in order: vmcnt(8) = this wave's pieces of super-step 0 have landed, the second batch keeps flying under units 0 and 1)
+    // prologue: super-steps 0 and 1 -> buffers 0 and 1 back to back (both are free; loads return in order: this wave's pieces of
+    // super-step 0 have landed, the second batch keeps flying under units 0 and 1)
 #pragma unroll
     for (int j = 0; j < 8; ++j) issue_piece(0, 0, 0, j);
 #pragma unroll
     for (int j = 0; j < 8; ++j) issue_piece(0, 1, 1, j);          // (nch >= 2: launcher)
-    wait_vmcnt<8>();
+    wait_vmcnt<7>();      // (waves 1-7 have 7 + 7 pieces in flight, wave 0 8 + 8: at most 7 outstanding = the first batch has landed)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -2272,25 +2300,60 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
     unit(w, wn, 0, 1, no_dma);
     unit(wn, w, 0, 2, no_dma);
     // The loop is rotated so that its header sits at the synchronisation point (hipcc drains lgkmcnt at a loop header whatever is
-    // pending, and there the drain is wanted).  On entry (a, w) hold the fragments of unit 2 of super-step s (even, buffers 0).
+    // pending, and there the drain is wanted).
     int ky2 = 0, ch2 = 2;                                         // (ky, chunk) of super-step s + 2, carried along
     if (ch2 >= nch) { ch2 = 0; ky2 = 1; }
     auto advance = [&]() __attribute__((always_inline)) { if (++ch2 == nch) { ch2 = 0; ++ky2; } };
-    for (int s = 0; s + 2 < S; s += 2) {
+    {
+        // The synchronisation sits in the MIDDLE of unit 2: its first four MFMA groups (256 matrix-pipe cycles per wave, operands long in
+        // registers) are queued when a wave reaches the s_waitcnt + barrier, so the pipe works through the barrier's skew instead of
+        // draining behind the last fragment read; behind it the second half reads the next super-step's first fragments from the other
+        // buffers; the pieces of super-step s + 2 follow one behind every other MFMA group: slots 0-1 in the rest of unit 2, 2-5 in the next
+        // unit 0, 6-7 in the first half of unit 1 (>= 1.5 units of flight to the next synchronisation each).
+        auto unit2a = [&](bf16x8_t (&wcur)[4]) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma_row(i, wcur);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto unit2b = [&](bf16x8_t (&wcur)[4], bf16x8_t (&wnext)[4], int nb, auto dma) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wnext[j] = rd_w(nb, 0, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = rd_a(nb, 0, i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 4; i < FA; ++i) {
+                mma_row(i, wcur);
+                __builtin_amdgcn_sched_barrier(0);
+                a[i] = rd_a(nb, 0, i);
+                dma(i - 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // DMA schedule of super-step s + 2 (8 slots per wave), one piece behind every other MFMA group from the synchronisation on:
+        // slots 0-1 in the rest of unit 2, 2-5 in unit 0, 6-7 in the first half of unit 1 — the global -> LDS path takes ~40 cycles
+        // per piece and CU (tools/probes/dma_seg.hip): 57 pieces are 2300 of a super-step's 3072 matrix-pipe cycles, so they are spread
+        // over as much of it as the buffers' release (the synchronisation) and the pieces' flight (>= 1.5 units) allow
+        unit2a(w);
+        for (int s = 0; s + 2 < S; s += 2) {
+            sync();
+            unit2b(w, wn, 1, [&](int g) __attribute__((always_inline)) { if (g & 1) issue_piece(ky2, ch2, 0, g >> 1); });                      // rest of unit 2 of s
+            unit(wn, w, 1, 1, [&](int i) __attribute__((always_inline)) { if (i & 1) issue_piece(ky2, ch2, 0, 2 + (i >> 1)); });             // unit 0 of s + 1
+            unit(w, wn, 1, 2, [&](int i) __attribute__((always_inline)) { if ((i & 1) && i < 4) issue_piece(ky2, ch2, 0, 6 + (i >> 1)); });  // unit 1
+            advance();
+            unit2a(wn);
+            sync();
+            unit2b(wn, w, 0, [&](int g) __attribute__((always_inline)) { if (g & 1) issue_piece(ky2, ch2, 1, g >> 1); });
+            unit(w, wn, 0, 1, [&](int i) __attribute__((always_inline)) { if (i & 1) issue_piece(ky2, ch2, 1, 2 + (i >> 1)); });
+            unit(wn, w, 0, 2, [&](int i) __attribute__((always_inline)) { if ((i & 1) && i < 4) issue_piece(ky2, ch2, 1, 6 + (i >> 1)); });
+            advance();
+            unit2a(w);
+        }
         sync();
-        unit(w, wn, 1, 0, [&](int i) __attribute__((always_inline)) { issue_piece(ky2, ch2, 0, i); });     // unit 2 of s | first fragments of s + 1 | DMA of s + 2
-        advance();
-        unit(wn, w, 1, 1, no_dma);
-        unit(w, wn, 1, 2, no_dma);
-        sync();
-        unit(wn, w, 0, 0, [&](int i) __attribute__((always_inline)) { issue_piece(ky2, ch2, 1, i); });     // unit 2 of s + 1 | first fragments of s + 2 | DMA of s + 3
-        advance();
-        unit(w, wn, 0, 1, no_dma);
-        unit(wn, w, 0, 2, no_dma);
+        unit2b(w, wn, 1, no_dma);
     }
-    // the last pair: nothing left to stage; the last unit has nothing to prefetch
-    sync();
-    unit(w, wn, 1, 0, no_dma);
     unit(wn, w, 1, 1, no_dma);
     unit(w, wn, 1, 2, no_dma);
     __builtin_amdgcn_sched_barrier(0);
@@ -2333,7 +2396,7 @@ static void launch_conv_rows8(GldsParams p, hipStream_t st) {
     p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
     p.dGm = uc_make_fastdiv((unsigned)p.group_m);
     p.dGmLast = uc_make_fastdiv((unsigned)std::max(1, p.tiles_m % p.group_m));
-    constexpr int smem = 2 * 33 * 1024 + 2 * 3 * 128 * 64 + 1024;
+    constexpr int smem = 2 * 33 * 1024 + 2 * 3 * 128 * 64;
     auto launch = [&](auto kfn, bool& attr_set) {
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
