@@ -722,6 +722,83 @@ __device__ __forceinline__ void glds_epilogue_bs(glds_pe_t p, float4_t (&acc)[FA
     }
 }
 
+// 16-bit output + bias + one or two 16-bit residuals laid out like C (the residual conv units of the DPT head: conv2(...) + x (+ the
+// other path), libs/croco/dpt_block.py:56-63) — the bf16-stream drain above without the statistics, for bf16 or fp16 storage: the
+// accumulator rows bounce through LDS in fp32, a lane adds bias and the residuals of its 8 columns in fp32 (16-byte residual loads, the
+// next two row blocks' in flight), ONE rounding, 16-byte stores.  Before round 4's last session these launches took the generic drain
+// (scalar-ish 8-byte traffic): the same 128^2 256->256 convolution cost 3.48 ms with its two residuals and 2.17 ms without.
+template <int FA, bool NT, bool F16>
+__device__ __forceinline__ void glds_epilogue_res16(glds_pe_t p, float4_t (&acc)[FA][4], int64_t wave_m, int64_t wave_n, int lane, char* wbuf) {
+    const int frow = lane & 15, g = lane >> 4;
+    const int crow = lane >> 3, cc = lane & 7;
+    const int64_t nb = wave_n + 8 * cc;
+    float4_t bias4 = (float4_t){0.f, 0.f, 0.f, 0.f}, bias4b = bias4;
+    if (p.bias) {
+        bias4 = *reinterpret_cast<const float4_t*>(p.bias + nb);
+        bias4b = *reinterpret_cast<const float4_t*>(p.bias + nb + 4);
+    }
+    const int rows_total = (int)min((int64_t)(16 * FA), p.M - wave_m);
+    const int rows_left = rows_total - crow;              // row 16i + 8ps + crow exists iff 16i + 8ps < rows_left
+    char* cbase = (char*)p.C + (wave_m * p.ldc + wave_n) * 2;
+    const unsigned coff = (unsigned)(crow * (int)p.ldc + 8 * cc) * 2u;
+    const int64_t cstep = 8 * p.ldc * 2;
+    const char* rbase = (const char*)p.residual + (wave_m * p.ldr + wave_n) * 2;
+    const char* r2base = p.residual2 ? (const char*)p.residual2 + (wave_m * p.ldr + wave_n) * 2 : nullptr;
+    const unsigned roff = (unsigned)(crow * (int)p.ldr + 8 * cc) * 2u;
+    const int64_t rstep = 8 * p.ldr * 2;
+    constexpr int AHEAD = 2;
+    uint4_t res[AHEAD][2], res2[AHEAD][2];
+    auto load_res = [&](int i, int ps) __attribute__((always_inline)) {
+        res[i % AHEAD][ps] = (uint4_t){0u, 0u, 0u, 0u};
+        res2[i % AHEAD][ps] = (uint4_t){0u, 0u, 0u, 0u};
+        if (16 * i + 8 * ps < rows_left) {
+            const uint4_t* q = reinterpret_cast<const uint4_t*>(rbase + (2 * i + ps) * rstep + roff);
+            if constexpr (NT) res[i % AHEAD][ps] = __builtin_nontemporal_load(q); else res[i % AHEAD][ps] = *q;
+            if (r2base) {
+                const uint4_t* q2 = reinterpret_cast<const uint4_t*>(r2base + (2 * i + ps) * rstep + roff);
+                if constexpr (NT) res2[i % AHEAD][ps] = __builtin_nontemporal_load(q2); else res2[i % AHEAD][ps] = *q2;
+            }
+        }
+    };
+    auto add16 = [](float4_t& v, float4_t& w, uint4_t rr) __attribute__((always_inline)) {
+        if constexpr (F16) {
+            v += glds_unpack_f16x4((uint2){rr.x, rr.y});
+            w += glds_unpack_f16x4((uint2){rr.z, rr.w});
+        } else {
+            v += (float4_t){__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u), __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)};
+            w += (float4_t){__uint_as_float(rr.z << 16), __uint_as_float(rr.z & 0xffff0000u), __uint_as_float(rr.w << 16), __uint_as_float(rr.w & 0xffff0000u)};
+        }
+    };
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < AHEAD && i < FA; ++i) { load_res(i, 0); load_res(i, 1); }
+    glds_stage_rows<FA>(p, acc, 0, 0, wave_m, wave_n, frow, g, wbuf);
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+        const char* buf = wbuf + (i & 1) * 4096;
+        if (i + 1 < FA) glds_stage_rows<FA>(p, acc, i + 1, 0, wave_m, wave_n, frow, g, wbuf + ((i + 1) & 1) * 4096);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int R = 8 * ps + crow;
+            float4_t v = glds_bounce_read(buf, R, 2 * cc), w = glds_bounce_read(buf, R, 2 * cc + 1);
+            v += bias4; w += bias4b;
+            add16(v, w, res[i % AHEAD][ps]);
+            add16(v, w, res2[i % AHEAD][ps]);             // (zeros without a second residual)
+            if (i + AHEAD < FA) load_res(i + AHEAD, ps);
+            if constexpr (F16) amax = fmaxf(fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))),
+                                            fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
+            const uint4_t pk = {glds_pack2<F16>(v.x, v.y), glds_pack2<F16>(v.z, v.w), glds_pack2<F16>(w.x, w.y), glds_pack2<F16>(w.z, w.w)};
+            if (16 * i + 8 * ps < rows_left) {
+                uint4_t* cq = reinterpret_cast<uint4_t*>(cbase + (2 * i + ps) * cstep + coff);
+                if constexpr (NT) __builtin_nontemporal_store(pk, cq); else *cq = pk;
+            }
+        }
+    }
+    if constexpr (F16) {
+        if (p.sat_flag && __any(!(amax <= UC_F16_MAX)) && lane == 0) atomicOr(p.sat_flag, 1);
+    }
+}
+
 // LN: the folded-LayerNorm form — the accumulator holds x . W'^T of the RAW rows; row statistics and the column sums of W'
 // turn it into LN(x) . W^T:  rstd[m] * (acc - mean[m] * colsum[n]) + bias[n].
 template <int FA, int ACT, bool NT = false, bool LN = false, bool F16 = false>
@@ -1153,6 +1230,14 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                     }
                 }
             } else if (plain && pe.out_dtype == OUT16 && !pe.residual) bf16_family();
+            else if (A_MODE != UC_A_DENSE && mode == 0 && plain && pe.out_dtype == OUT16 && pe.residual && pe.res_dtype == OUT16 && pe.act == UC_ACT_NONE &&
+                     !pe.ln_stats && !pe.ln_partial && !pe.stats_out && !pe.twin && (pe.ldr & 7) == 0) {
+                // a convolution with 16-bit residual(s) laid out like its 16-bit output (the DPT head's residual conv units)
+                if constexpr (A_MODE != UC_A_DENSE) {
+                    if (pe.nt_out & 2) glds_epilogue_res16<FA, true, F16>(pe, acc, wave_m, wave_n, lane, wbuf);
+                    else glds_epilogue_res16<FA, false, F16>(pe, acc, wave_m, wave_n, lane, wbuf);
+                }
+            }
             else if (!F16 && mode == 0 && pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && pe.out_dtype == UC_BF16 && !pe.residual &&
                      !UC_DBG(pe, 16) && !pe.ln_stats && !pe.ln_partial && (pe.preact != nullptr) != (pe.dact_u != nullptr)) {
                 // training: fc1 with its pre-activation copy / a data-gradient GEMM with the activation backward fused
