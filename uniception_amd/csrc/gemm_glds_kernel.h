@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&ac
     if (p.out_dtype == UC_F16 && p.sat_flag && __any(!(amax <= UC_F16_MAX)) && lane == 0) atomicOr(p.sat_flag, 1);
 }
 
-enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2, GLDS_EPI_BS = 3 };
+enum { GLDS_EPI_ALL = 0, GLDS_EPI_BF16 = 1, GLDS_EPI_F32 = 2, GLDS_EPI_BS = 3, GLDS_EPI_RES16 = 4 };
 
 // Fused narrow tail of a 128-wide tile (two wave columns of 64): out4[m][o] = tail_b[o] + sum_n act(acc[m][n] + bias[n]) * tail_w[o][n].
 // The DPT regressor's conv3x3 -> ReLU -> Conv2d(128 -> 4, 1x1): the 128-channel map is never stored.  Per wave: its 64 columns of
@@ -1129,7 +1129,7 @@ __device__ __forceinline__ void glds_epilogue_tail4(glds_pe_t p, float4_t (&acc)
 template <int FA, int A_MODE, int EPI, bool F16 = false>
 __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&acc)[FA][4], int mode, int64_t wave_m, int64_t wave_n,
                                                        int tid, int wave, int ksplit, char* smem, const char* side = nullptr) {
-    static_assert(!F16 || EPI == GLDS_EPI_ALL, "the fp16 operand form exists in the EPI_ALL family only");
+    static_assert(!F16 || EPI == GLDS_EPI_ALL || EPI == GLDS_EPI_RES16, "the fp16 operand form exists in the EPI_ALL and RES16 families only");
     constexpr int OUT16 = F16 ? UC_F16 : UC_BF16;        // the 16-bit storage dtype of this instantiation
     if (wave_n >= pe.N) return;
     {
@@ -1187,6 +1187,9 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
             } else bf16_family();
         } else if constexpr (EPI == GLDS_EPI_F32) {
             f32_family();
+        } else if constexpr (EPI == GLDS_EPI_RES16) {       // convolution with 16-bit residual(s) laid out like its 16-bit output (launcher: glds_res16_ok)
+            if (pe.nt_out & 2) glds_epilogue_res16<FA, true, F16>(pe, acc, wave_m, wave_n, lane, wbuf);
+            else glds_epilogue_res16<FA, false, F16>(pe, acc, wave_m, wave_n, lane, wbuf);
         } else if constexpr (EPI == GLDS_EPI_BS) {          // bf16 residual stream: bf16 output + bf16 residual(s) + row statistics
             if (pe.nt_out & 1) glds_epilogue_bs<FA, true>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
             else glds_epilogue_bs<FA, false>(pe, acc, mode, wave_m, wave_n, lane, wbuf);
@@ -1230,14 +1233,7 @@ __device__ __forceinline__ void glds_epilogue_dispatch(glds_pe_t pe, float4_t (&
                     }
                 }
             } else if (plain && pe.out_dtype == OUT16 && !pe.residual) bf16_family();
-            else if (A_MODE != UC_A_DENSE && mode == 0 && plain && pe.out_dtype == OUT16 && pe.residual && pe.res_dtype == OUT16 && pe.act == UC_ACT_NONE &&
-                     !pe.ln_stats && !pe.ln_partial && !pe.stats_out && !pe.twin && (pe.ldr & 7) == 0) {
-                // a convolution with 16-bit residual(s) laid out like its 16-bit output (the DPT head's residual conv units)
-                if constexpr (A_MODE != UC_A_DENSE) {
-                    if (pe.nt_out & 2) glds_epilogue_res16<FA, true, F16>(pe, acc, wave_m, wave_n, lane, wbuf);
-                    else glds_epilogue_res16<FA, false, F16>(pe, acc, wave_m, wave_n, lane, wbuf);
-                }
-            }
+
             else if (!F16 && mode == 0 && pe.vec_ok && wave_n + 64 <= pe.N && pe.split_k <= 1 && pe.out_dtype == UC_BF16 && !pe.residual &&
                      !UC_DBG(pe, 16) && !pe.ln_stats && !pe.ln_partial && (pe.preact != nullptr) != (pe.dact_u != nullptr)) {
                 // training: fc1 with its pre-activation copy / a data-gradient GEMM with the activation backward fused
@@ -2490,8 +2486,34 @@ static void launch_conv_rows8(GldsParams p, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
     };
     static bool set0 = false, set1 = false;
-    if (p.relu_a) launch(conv3x3_rows8_kernel<EPI, F16, true>, set1);
+    if constexpr (EPI == GLDS_EPI_RES16) launch(conv3x3_rows8_kernel<EPI, F16, false>, set0);      // (glds_launch_conv_res16: no ReLU on load)
+    else if (p.relu_a) launch(conv3x3_rows8_kernel<EPI, F16, true>, set1);
     else launch(conv3x3_rows8_kernel<EPI, F16, false>, set0);
+}
+
+// A convolution whose every tile takes the 16-bit residual epilogue (glds_epilogue_res16): 16-bit output, one or two residuals of the
+// same dtype laid out like it, bias or none, no activation — the residual conv units' second convolution.  Its own epilogue family
+// (one kernel per family: inlined next to the other drains it cost the fused-tail launches 5 % through the register allocation).
+static inline bool glds_res16_ok(const GldsParams& p) {
+    const int out16 = p.f16 ? UC_F16 : UC_BF16;
+    return p.a_mode == UC_A_CONV3X3 && p.vec_ok && p.N % 64 == 0 && p.split_k <= 1 && !p.preact && !p.dact_u && !UC_DBG(p, 16) && p.out_dtype == out16 &&
+           p.residual && p.res_dtype == out16 && p.act == UC_ACT_NONE && !p.relu_a && !p.tail_out && !p.ln_stats && !p.ln_partial && !p.stats_out && !p.twin &&
+           (p.ldr & 7) == 0 && p.vt_col0 < 0 && p.rope_cols <= 0;
+}
+// the eight-wave row kernel where the default routing takes it, else the 256x256 implicit-GEMM tile; false: not a shape of this family's kernels
+template <bool F16>
+static bool glds_launch_conv_res16(const GldsParams& p, int variant, hipStream_t st) {
+    if (!glds_res16_ok(p)) return false;
+    const int rows_mode = g_uc_conv_rows.load(std::memory_order_relaxed);
+    if (conv_rows8_ok(p) && (rows_mode == 3 || (rows_mode == 1 && conv_rows8_wins(p) && (p.M / 512) * (p.N / 128) >= 256))) {
+        launch_conv_rows8<GLDS_EPI_RES16, F16>(p, st);
+        return true;
+    }
+    if (variant == 2 && !(rows_mode > 0 && rows_mode < 3 && conv_rows_ok(p))) {
+        launch_variant_mode<256, 256, 4, 4, 2, UC_A_CONV3X3, 64, 1, GLDS_EPI_RES16, F16>(p, st);
+        return true;
+    }
+    return false;
 }
 
 // Tile variants of one (A_MODE, EPI) pair: 0 = 128x128 (2x2 waves of 64x64), 1 = 256x128 (4x2), 2 = 256x256 (4x4), 3 = 256x128x32 with
