@@ -2509,7 +2509,9 @@ static bool glds_launch_conv_res16(const GldsParams& p, int variant, hipStream_t
         launch_conv_rows8<GLDS_EPI_RES16, F16>(p, st);
         return true;
     }
-    if (variant == 2 && !(rows_mode > 0 && rows_mode < 3 && conv_rows_ok(p))) {
+    // (not the launches the 256-pixel row kernel takes: glds_launch_variants' rule)
+    const bool rows256 = rows_mode > 0 && rows_mode < 3 && conv_rows_ok(p) && (rows_mode >= 2 || (p.N == 128 && p.cCin >= 256)) && (p.M / 256) * (p.N / 128) >= 256;
+    if (variant == 2 && !rows256) {
         launch_variant_mode<256, 256, 4, 4, 2, UC_A_CONV3X3, 64, 1, GLDS_EPI_RES16, F16>(p, st);
         return true;
     }
