@@ -15,6 +15,7 @@
 // attn_f32_kernel — verification mode: one thread per query row, fp32 FMA chains, expf.
 #include "common.h"
 #include "knobs.h"
+#include "attention_p64.h"
 #include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -44,15 +45,15 @@ __device__ __forceinline__ int vt_key_of_pos(int pp) {
     return (j & 3) + 8 * (j >> 2) + 4 * hi;
 }
 
-__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE_BYTES];  // 2 stages x (K tile + VT tile)
+// the body of attn_bf16_kernel for the 128 queries from q0w of (batch b, head h): also what attn_bf16_fixup_kernel recomputes a
+// flagged block of the persistent kernel with (attention_p64.h)
+__device__ __forceinline__ void attn_bf16_body(const AttnParams& p, const int b, const int h, const int q0w, char* smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int hi = lane >> 5;
     const int l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = q0w + wave * 32;
 
     const bf16_t* Qb = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const bf16_t* Kb = (const bf16_t*)p.K + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
@@ -228,6 +229,46 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
                 pk.y = pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv);
                 *reinterpret_cast<uint2*>(op + d) = pk;
             }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE_BYTES];  // 2 stages x (K tile + VT tile)
+    attn_bf16_body(p, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x * 128, smem);
+}
+
+// ---------------------------------------------------------------------------------------
+// attn_bf16_fixup_kernel — launched behind attn_bf16_p64_kernel: that kernel takes every exponential against the row maximum of an
+// item's FIRST 32 keys and flags a 64-query block whose row sums left [2^-100, 2^100] (a score ~69 nats above / below that
+// maximum: P or O may have over- / underflowed) with a sentinel in the block's first output word.  One thread per block reads
+// that word; a flagged block is recomputed by the whole workgroup with the exact online softmax above (the 128 queries from the
+// block's first one: the second half re-does an unflagged neighbour, or finds it flagged and is simply ahead of its own scan).
+// Flags are rare by construction; the scan is one 4-byte load per 64 x 64 outputs.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bf16_fixup_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE_BYTES];
+    __shared__ int s_list[256];
+    __shared__ int s_cnt;
+    const int nblk = (p.Nq + 63) >> 6;
+    const long long total = (long long)p.B * p.H * nblk;
+    for (long long c0 = (long long)blockIdx.x * 256; c0 < total; c0 += (long long)gridDim.x * 256) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const long long id = c0 + threadIdx.x;
+        if (id < total) {
+            const int blk = (int)(id % nblk), bh = (int)(id / nblk), b = bh / p.H, h = bh - b * p.H;
+            const unsigned* w = reinterpret_cast<const unsigned*>((const bf16_t*)p.O + (int64_t)b * p.o_sb + (int64_t)(blk * 64) * p.o_sn + (int64_t)h * p.o_sh);
+            if (__builtin_nontemporal_load(w) == P64_SENTINEL) s_list[atomicAdd(&s_cnt, 1)] = (int)threadIdx.x;
+        }
+        __syncthreads();
+        const int n = s_cnt;
+        for (int i = 0; i < n; ++i) {
+            const long long fid = c0 + s_list[i];
+            const int blk = (int)(fid % nblk), bh = (int)(fid / nblk), b = bh / p.H, h = bh - b * p.H;
+            __syncthreads();                              // (the body's LDS ring and s_list: the previous body is done)
+            attn_bf16_body(p, b, h, blk * 64, smem);
+        }
+        __syncthreads();
     }
 }
 
@@ -902,6 +943,32 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
             else hipLaunchKernelGGL((attn_bf16_dma_kernel<4, 24>), g, dim3(256), 0, st, p);
         } else
 #endif
+        // persistent 64-queries-per-wave kernel (attention_p64.h) + its fix-up scan: 32-bit DMA offsets as above, at least two key
+        // tiles, and (policy) enough (batch, head, 256-query tile) items to give every one of 2 x 256 workgroups a few
+        const int p64_mode = g_uc_attn_p64.load(std::memory_order_relaxed);
+        const int64_t p64_items = (int64_t)B * H * ((Nq + 255) / 256);
+        const int waste256 = (Nq + 255) / 256 * 256 - Nq;
+        const bool p64_ok = dma_ok && p64_mode && Nk > 64 && p64_items < ((int64_t)1 << 28) && (int64_t)64 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * o_sn * 2 < ((int64_t)1 << 31) &&
+                            (p64_mode == 2 || (p64_items >= 1024 && waste256 * 4 <= Nq));
+        if (p64_ok && !g_uc_attn_rs.load(std::memory_order_relaxed)) {
+            AttnP64Params pp;
+            pp.Q = Q; pp.K = K; pp.V = V; pp.O = O; pp.lse = lse; pp.B = B; pp.H = H; pp.Nq = Nq; pp.Nk = Nk;
+            pp.q_sb = q_sb; pp.q_sn = q_sn; pp.q_sh = q_sh; pp.k_sb = k_sb; pp.k_sn = k_sn; pp.k_sh = k_sh; pp.o_sb = o_sb; pp.o_sn = o_sn; pp.o_sh = o_sh;
+            pp.npad = p.npad; pp.c = scale * 1.44269504088896340736f; pp.q_prescaled = 0;
+            pp.nq = (Nq + 255) / 256; pp.dNq = uc_make_fastdiv((unsigned)pp.nq); pp.dH = uc_make_fastdiv((unsigned)H);
+            pp.dbg = nullptr;
+            const int per_cu = 2, ncu = uc_num_cus();
+            int grid = per_cu * ncu / 8 * 8;
+            if (grid < 8) grid = 8;
+            const int64_t items8 = (p64_items + 7) / 8 * 8;
+            if ((int64_t)grid > items8) grid = (int)items8;
+            if (Nk & 63) hipLaunchKernelGGL(attn_bf16_p64_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, pp);
+            else hipLaunchKernelGGL(attn_bf16_p64_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, pp);
+            UC_CHECK_LAUNCH("uc_attention_fwd (persistent kernel)");
+            const int64_t nblocks = (int64_t)B * H * ((Nq + 63) / 64);
+            int fgrid = (int)((nblocks + 255) / 256 < ncu ? (nblocks + 255) / 256 : ncu);
+            hipLaunchKernelGGL(attn_bf16_fixup_kernel, dim3((unsigned)fgrid), dim3(256), 0, st, p);
+        } else
         if (dma_ok && nw == 8 && g_uc_attn_rs.load(std::memory_order_relaxed)) hipLaunchKernelGGL(attn_bf16_rs_kernel, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
         else if (dma_ok && nw == 8) hipLaunchKernelGGL(attn_bf16_dma_kernel<8>, dim3((unsigned)(nqt * H * B)), dim3(512), 0, st, p);
         else if (dma_ok) hipLaunchKernelGGL(attn_bf16_dma_kernel<4>, dim3((unsigned)(nqt * H * B)), dim3(256), 0, st, p);

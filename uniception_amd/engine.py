@@ -925,8 +925,10 @@ def concurrent(on: bool):
 # nodes across streams itself, so forking the forward forks the backward too.  Weight gradients are accumulated into the flat gradient
 # buffer by plain read-modify-write kernels (the gradient sink), and two streams adding into the same parameter's slice would race:
 # sub-graphs with DISJOINT parameters fork as they are (the decoder's two view branches, the two heads); for sub-graphs that SHARE
-# parameters (the encoder's two views) the forked one's Functions return their weight gradients to autograd instead, whose
-# AccumulateGrad adds them on the parameter's own stream behind the first branch's sink writes (autograd._sink_aware).
+# parameters (the encoder's two views) the Functions of BOTH halves return their weight gradients to autograd instead
+# (autograd._sink_aware): the two contributions meet in one AccumulateGrad node per parameter, and the autograd engine orders the
+# producing streams with that node (round 4 kept the sink for the first half: nothing ordered its read-modify-write kernels on the
+# main stream against the AccumulateGrad of the forked half).
 # uniception_amd.training orders its collectives behind every side stream (GradientBuckets._issue).
 TRAIN_CONCURRENT: bool = os.environ.get("UNICEPTION_AMD_TRAIN_CONCURRENT", "1") != "0"
 
@@ -994,7 +996,19 @@ def run_branches(fn0, fn1, rows: int, inputs0=(), inputs1=(), warm_key=None, own
             out1 = fn1()
     if serialize:
         main.wait_stream(side)
-    out0 = fn0()
+    if shared_params and torch.is_grad_enabled():
+        # fn0 shares parameters with the forked fn1: BOTH leave the gradient sink (a sink kernel of fn0's backward on the main stream
+        # and AccumulateGrad of fn1's dW — whose node lives on whichever stream touched the parameter first — would read-modify-write
+        # the same slice of the flat buffer with nothing ordering them).  With both returning dW, the two contributions meet in ONE
+        # AccumulateGrad node and the autograd engine synchronises the producing streams with it.
+        from . import autograd
+        prev0, autograd._sink_fwd_ok[0] = autograd._sink_fwd_ok[0], False
+        try:
+            out0 = fn0()
+        finally:
+            autograd._sink_fwd_ok[0] = prev0
+    else:
+        out0 = fn0()
     main.wait_stream(side)
     for t in (out1 if isinstance(out1, (tuple, list)) else (out1,)):
         if torch.is_tensor(t):

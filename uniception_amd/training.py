@@ -111,6 +111,7 @@ class GradientBuckets:
         self._bucket_of = {n: i for i, b in enumerate(flat.buckets) for n in b["names"]}
         self.accumulating = False          # inside Trainer.no_sync(): gradients accumulate locally, nothing is reduced
         self._comm_stream = torch.cuda.Stream(device=flat.grad.device) if flat.grad.is_cuda else None
+        self._main_stream = torch.cuda.current_stream(flat.grad.device) if flat.grad.is_cuda else None   # re-recorded by start_step()
         self._hooks = []
         if self.active:
             for n, p in flat.order:
@@ -118,6 +119,8 @@ class GradientBuckets:
         self.start_step()
 
     def start_step(self) -> None:
+        if self._comm_stream is not None:
+            self._main_stream = torch.cuda.current_stream(self.flat.grad.device)   # the stream forward / backward are launched from
         self._left = list(self._pending)
         self._done = set()
         self._complete = [False] * len(self.buckets)
@@ -161,6 +164,10 @@ class GradientBuckets:
             ev.record(torch.cuda.current_stream(g.device))
             self._comm_stream.wait_event(ev)
             from . import engine
+            # a hook can fire inside an AccumulateGrad node that lives on a SIDE stream (parameters first used in a forked branch):
+            # the "current stream" is then that side stream, and the sink kernels of the other branch were launched on the main one
+            if self._main_stream is not None:
+                self._comm_stream.wait_stream(self._main_stream)
             for s in engine.all_side_streams(g.device):       # backward nodes of forked sub-graphs (engine.run_branches) write gradients there
                 self._comm_stream.wait_stream(s)
             g.record_stream(self._comm_stream)
