@@ -62,7 +62,7 @@ def parse():
                     help="skip the extra legs: fp32-class heads beside the bf16 transformer, everything fp32-class, linear-head (enc+dec) run")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
-                    help="skip the `fwd_224` (224x224 pairs) and `train_step` (BASELINE configs[2], 32 pairs, 3 fenced steps) legs of the default line")
+                    help="skip the `fwd_224` (224x224 pairs), `batch_sweep` (1 / 2 / 4 / 8 pairs), `other_configs` (BASELINE configs[3], [4]) and `train_step` (BASELINE configs[2]) legs of the default line")
     ap.add_argument("--single-stream", action="store_true",
                     help="no two-stream execution of independent sub-graphs at large batch (engine.concurrent(False)): what the "
                          "roofline pass and the committed kernel profiles use — per-kernel durations are only defined without overlap")
@@ -224,22 +224,97 @@ def cpu_topology():
     return max(1, len(sockets)), (len(phys) or n), (logical or n)
 
 
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _cpulist(txt):
+    "'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"
+    out = []
+    for part in (txt or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def host_cpu_limits():
+    """What bounds a CPU job in this container, beyond the core count of /proc/cpuinfo: the affinity mask, the cgroup CPU quota (v2
+    cpu.max or v1 cfs_quota / cfs_period: quota / period = the number of CPUs' worth of time the cgroup may use), the NUMA nodes."""
+    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    quota = None
+    v2 = _read("/sys/fs/cgroup/cpu.max")
+    if v2:
+        q, per = (v2.split() + ["100000"])[:2]
+        quota = None if q == "max" else round(float(q) / float(per), 2)
+    else:
+        q, per = _read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), _read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+        if q and per and int(q) > 0:
+            quota = round(float(q) / float(per), 2)
+    nodes = {}
+    base = "/sys/devices/system/node"
+    try:
+        for n in sorted(os.listdir(base)):
+            if n.startswith("node") and n[4:].isdigit():
+                nodes[int(n[4:])] = _cpulist(_read(f"{base}/{n}/cpulist"))
+    except OSError:
+        pass
+    siblings = {}
+    for c in aff:
+        t = _read(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list")
+        siblings[c] = min(_cpulist(t)) if t else c
+    return {"affinity_cpus": len(aff), "cgroup_cpu_quota": quota, "numa_nodes": {str(k): len(v) for k, v in nodes.items()}}, aff, nodes, siblings
+
+
 def cpu_baseline(model, H, W, head, max_s):
     """The oracle (CPU restatement of the reference path, validated against the real reference in tests/golden) timed on the host
     cores on ONE pair — a bounded sample of the same workload.  torch's default thread count (= logical CPUs) oversubscribes
-    a multi-socket SMT host (round 3: 128 threads of an EPYC 9575F ran 4x slower than 8 Xeon vCPUs), so the thread count is SWEPT
-    ({8, 12, 16, 24, 32, 64, physical cores, physical cores of one socket}, one forward each after a warm-up at the first count), and the best count
-    is then sampled n >= 3 times (median reported, the reference's own method — utils/profile.py:4-6 — is a Timer over the forward)."""
+    a multi-socket SMT host (round 3: 128 threads of an EPYC 9575F ran 4x slower than 8 Xeon vCPUs), and threads spread over both
+    sockets pay the inter-socket fabric for every GEMM panel (round 4: 12 threads were the best of a sweep cut at 24).  So (round
+    5): the process is PINNED to the allowed CPUs of one NUMA node, one hardware thread per core (os.sched_setaffinity), the thread
+    count is swept over {16, 32, 64, cores of that node} on the ENCODER of one view (24 of the pair's 60 transformer blocks: a sixth
+    of the forward, so the whole sweep fits the time cap), and the full pair is then timed n >= 3 times at the winner (median).
+    The line carries what bounds the job here — affinity mask, cgroup CPU quota, NUMA nodes — so that a low figure can be read."""
     from oracle import dust3r_oracle as O
 
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     img1, img2 = O.make_images(7, 1, H, W)
     sockets, phys, logical = cpu_topology()
+    limits, aff, nodes, siblings = host_cpu_limits()
     default_threads = torch.get_num_threads()
-    cands = sorted({c for c in (8, 12, 16, 24, 32, 64, phys, max(1, phys // sockets)) if 1 <= c <= logical})
+    # one NUMA node's allowed CPUs, one hardware thread per physical core
+    node_cpus = max(({n: [c for c in cpus if c in set(aff)] for n, cpus in nodes.items()} or {0: list(aff)}).items(), key=lambda kv: len(kv[1]))
+    pin = sorted({siblings.get(c, c) for c in node_cpus[1]} & set(aff)) or list(aff)
     t_begin = time.perf_counter()
+    pinned = False
+    if hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, pin)
+            pinned = True
+        except OSError:
+            pass
+    avail = len(pin) if pinned else len(aff)
+    if limits["cgroup_cpu_quota"]:
+        avail = max(1, min(avail, int(limits["cgroup_cpu_quota"] + 0.5)))
+    cands = sorted({c for c in (8, 16, 32, 64, avail) if 1 <= c <= avail}) or [1]
 
-    def one(nthreads):
+    def enc_one(nthreads):
+        torch.set_num_threads(nthreads)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.croco_encoder(img1, sd, "encoder.", depth=24, num_heads=16)
+            return time.perf_counter() - t0
+
+    def pair_one(nthreads):
         torch.set_num_threads(nthreads)
         with torch.no_grad():
             t0 = time.perf_counter()
@@ -248,24 +323,30 @@ def cpu_baseline(model, H, W, head, max_s):
 
     sweep = {}
     try:
-        one(cands[len(cands) // 2])       # warm-up (allocator, oneDNN primitive caches)
-        for c in cands:
-            if time.perf_counter() - t_begin > 0.6 * max_s and sweep:
+        enc_one(cands[-1])                # warm-up (allocator, oneDNN primitive caches)
+        for c in reversed(cands):          # (largest first: the likely winner is measured even if the cap cuts the sweep)
+            if time.perf_counter() - t_begin > 0.4 * max_s and sweep:
                 break
-            sweep[c] = one(c)
+            sweep[c] = enc_one(c)
         best = min(sweep, key=sweep.get)
-        times = [sweep[best]]
+        times = []
         while len(times) < 3 or (len(times) < 5 and time.perf_counter() - t_begin < max_s):
-            times.append(one(best))
+            times.append(pair_one(best))
     finally:
         torch.set_num_threads(default_threads)
+        if pinned:
+            try:
+                os.sched_setaffinity(0, aff)
+            except OSError:
+                pass
     times.sort()
     t = times[len(times) // 2]
     return {"value": round(1.0 / t, 4), "unit": "image-pairs/s", "cores": best, "cpu": cpu_model_name(), "kind": "port",
-            "n_samples": len(times), "host": {"sockets": sockets, "physical_cores": phys, "logical_cpus": logical},
-            "thread_sweep_s_per_pair": {str(k): round(v, 2) for k, v in sorted(sweep.items())},
-            "sample": f"1 pair (2x{H}x{W}) fp32 forward incl. heads: thread sweep {sorted(sweep)} (one forward each), then n={len(times)} forwards at the "
-                      f"best count ({best} threads, median {t:.2f}s each), torch CPU"}
+            "n_samples": len(times), "host": {"sockets": sockets, "physical_cores": phys, "logical_cpus": logical, **limits,
+                                              "pinned_to": f"{len(pin)} CPUs of NUMA node {node_cpus[0]} (one per core)" if pinned else "not pinned"},
+            "thread_sweep_s_per_encoder_view": {str(k): round(v, 2) for k, v in sorted(sweep.items())},
+            "sample": f"1 pair (2x{H}x{W}) fp32 forward incl. heads, pinned to one NUMA node: thread sweep {sorted(sweep)} on the encoder of one view, "
+                      f"then n={len(times)} full forwards at the best count ({best} threads, median {t:.2f}s each), torch CPU"}
 
 
 def timed(step, steps, world):
@@ -375,6 +456,54 @@ def fwd_224_leg(args, dev, pairs_list=(64, 256)):
                                         "enc_dec_mfma_frac_lower_bound": round(pps * gf / 1e3 / PEAK_BF16_TFLOPS, 4)})
         del a1, a2
     del m
+    return out
+
+
+def other_configs_leg(args, dev):
+    """BASELINE configs[3] and [4] inside the default line (round 5): DINOv2 ViT-L/14 at 518x518 (32 pairs) and the ViT-L/16 model at
+    1024x1024 (8 pairs) with bf16 AND e4m3 attention — forward, bf16 transformer, the headline's head policy; five fenced steps each
+    (median and block mean); `enc_dec_mfma_frac_lower_bound` = all-in pairs/s x the encoder + decoder flops of SURVEY section 8d over
+    the bf16 peak (the heads' time is in the denominator, their flops are not in the numerator)."""
+    from uniception_amd import engine
+    from uniception_amd.models.encoders import encoder_factory
+    from uniception_amd.models.factory import DUSt3R
+    out = {}
+
+    def run(m, img, pairs, attention, norm_type, gf):
+        a1, a2 = make_views(pairs, img, img, 0, dev)
+        a1["data_norm_type"] = a2["data_norm_type"] = norm_type
+
+        def f():
+            with torch.no_grad(), engine.precision("bf16"), engine.attention_precision(attention):
+                return m(a1, a2)
+        f(); f(); f()
+        n = 5
+        dt, st = timed_each(f, n)
+        pps = pairs * n / dt
+        del a1, a2
+        return {"pairs_per_gpu": pairs, "pairs_per_s": round(pps, 2), "ms_per_step": round(dt / n * 1e3, 2), "attention": attention, "timing": st,
+                "enc_dec_gflop_per_pair": round(gf, 1), "enc_dec_mfma_frac_lower_bound": round(pps * gf / 1e3 / PEAK_BF16_TFLOPS, 4)}
+
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    m = DUSt3R(name="bench_c3", img_size=(518, 518), pred_head_type=args.head)
+    m.encoder = encoder_factory("dinov2", name="bench_dinov2", size="large")
+    m = m.to(dev).eval()
+    e = run(m, 518, 32, "bf16", "dinov2", gflop_enc_dec(518, patch=14, n_extra=1))
+    e["workload"] = f"BASELINE configs[3]: DINOv2 ViT-L/14 encoder + 12-block CroCo decoder + {args.head} head, 518x518 pairs (37x37 patches + cls token), forward, bf16"
+    out["dinov2_518"] = e
+    del m
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    m = DUSt3R(name="bench_c4", img_size=(1024, 1024), pred_head_type=args.head).to(dev).eval()
+    for att in ("bf16", "fp8"):
+        e = run(m, 1024, 8, att, "dust3r", gflop_enc_dec(1024))
+        e["workload"] = (f"BASELINE configs[4]: ViT-L/16 encoder + 12-block decoder + {args.head} head, 1024x1024 pairs (4096 tokens), forward, bf16 transformer, "
+                         f"{'e4m3 K=64 MFMA' if att == 'fp8' else 'bf16'} attention")
+        out[f"vitl_1024_{att}_attention"] = e
+    out["vitl_1024_fp8_over_bf16"] = round(out["vitl_1024_fp8_attention"]["pairs_per_s"] / out["vitl_1024_bf16_attention"]["pairs_per_s"], 3)
+    del m
+    torch.cuda.empty_cache()
     return out
 
 
@@ -639,8 +768,10 @@ def main():
         if (not args.no_extra_legs and args.precision == "bf16" and not args.graph and args.encoder == "croco" and args.img == 512
                 and args.attention == "bf16"):
             line["fwd_224"] = fwd_224_leg(args, dev)
+            line["batch_sweep"] = batch_sweep(model, [1, 2, 4, 8], args, dev)      # the reference harness's own sizes (profile_dust3r.py:12-46)
+            line["other_configs"] = other_configs_leg(args, dev)
             line["train_step"] = train_step_leg(args, dev)
-        if args.sweep:
+        if args.sweep and "batch_sweep" not in line:
             line["batch_sweep"] = batch_sweep(model, [int(x) for x in args.sweep.split(",")], args, dev)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.img, args.img, args.head, args.cpu_baseline_max_s)

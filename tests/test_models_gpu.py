@@ -272,16 +272,18 @@ def test_bench_sized_batch_reproduces_the_golden_pair_to_the_bit(gpu):
         return dict(pts3d_1=r1["pts3d"], conf_1=r1["conf"], pts3d_2=r2["pts3d_in_other_view"], conf_2=r2["conf"])
 
     from uniception_amd import ops
-    # (two default choices follow the number of tiles of a launch, i.e. the batch size, and each changes a summation order: the small-M
-    #  path sums K >= 2048 in two halves, and a 3x3 conv with fewer eight-wave row tiles than CUs stays on the implicit-GEMM kernel.
-    #  Pinned — small_m_split 0, conv_rows 3: the eight-wave conv kernel wherever the shape allows — a pair's bits do not depend on its batch)
-    with ops.tuning("small_m_split", 0), ops.tuning("conv_rows", 3):
+    # (three default choices follow the number of tiles of a launch, i.e. the batch size, and each changes a summation order: the small-M
+    #  path sums K >= 2048 in two halves, a 3x3 conv with fewer eight-wave row tiles than CUs stays on the implicit-GEMM kernel, and an
+    #  attention call with fewer than 1024 (batch, head, 256-query) items stays on the eight-wave kernel.
+    #  Pinned — small_m_split 0, conv_rows 3: the eight-wave conv kernel, attn_p64 2: the persistent attention kernel wherever the shape
+    #  allows — a pair's bits do not depend on its batch)
+    with ops.tuning("small_m_split", 0), ops.tuning("conv_rows", 3), ops.tuning("attn_p64", 2):
         alone = run(img1[:1], img2[:1])
     alone_split = run(img1[:1], img2[:1])
     diffs = {k: rel_l2(alone_split[k].float().cpu(), v.float().cpu()) for k, v in alone.items()}
     print("\n[bf16] one pair, K >= 2048 summed in two halves vs in one chain: " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(diffs.items())))
     assert max(diffs.values()) < BF16_TOL["default"]        # two bf16 roundings of the same forward: apart by what each is from fp32
-    with ops.tuning("small_m_split", 0), ops.tuning("conv_rows", 3):      # (at 20 pairs the heads' smallest maps still make small-M launches)
+    with ops.tuning("small_m_split", 0), ops.tuning("conv_rows", 3), ops.tuning("attn_p64", 2):      # (at 20 pairs the heads' smallest maps still make small-M launches)
         batch = run(img1, img2)
         again = run(img1, img2)            # second call: every fork point past its warm-up call
     for k, v in alone.items():

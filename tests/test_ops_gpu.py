@@ -640,6 +640,95 @@ def test_attention_bf16_spiked_keys(gpu):
     assert rel_l2(out.cpu().float(), ref) < 8e-3
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 1024, 1024), (1, 2, 1369, 1369), (2, 1, 300, 1370), (1, 2, 256, 100), (3, 2, 512, 700), (1, 1, 260, 4096),
+                                       (1, 2, 130, 65), (9, 16, 196, 196)])
+def test_attention_persistent_kernel(gpu, B, H, Nq, Nk):
+    """attn_bf16_p64_kernel (tuning knob attn_p64 = 2: wherever the shape allows): 64 queries per wave, persistent workgroups, every
+    exponential against the row maximum of the item's first 32 keys.  Whole and ragged key tiles, query counts that are not a
+    multiple of 64 or 256, more and fewer items than workgroups, strided q | k views, the log-sum-exp output."""
+    from uniception_amd import ops
+    D = 64
+    g = torch.Generator().manual_seed(2000 + Nq + Nk)
+    q = (torch.randn(B, Nq, H, D, generator=g) * 1.5).bfloat16()
+    k = (torch.randn(B, Nk, H, D, generator=g) * 1.5).bfloat16()
+    v = torch.randn(B, Nk, H, D, generator=g).bfloat16()
+    ref = sdpa_ref(q, k, v, D ** -0.5)
+    ref_lse = torch.logsumexp(torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * D ** -0.5, dim=-1)
+    vt = ops.vt_pack(v.to(gpu))
+    with ops.tuning("attn_p64", 2):
+        lse = torch.full((B, H, Nq), float("nan"), device=gpu)
+        out = ops.attention(q.to(gpu), k.to(gpu), vt, D ** -0.5, v_packed=True, lse=lse)
+        assert torch.isfinite(out).all()
+        assert rel_l2(out.cpu().float(), ref) < 8e-3
+        assert (lse.cpu() - ref_lse).abs().max() < 2e-2
+        if Nq == Nk:
+            qk = torch.stack([q, k], dim=2).to(gpu)
+            out2 = ops.attention(qk[:, :, 0], qk[:, :, 1], vt, D ** -0.5, v_packed=True)
+            assert torch.equal(out2, out)
+    with ops.tuning("attn_p64", 0):
+        old = ops.attention(q.to(gpu), k.to(gpu), vt, D ** -0.5, v_packed=True)
+    assert (old.float() - out.float()).abs().max() < 6.5e-2      # (two bf16 output steps at |o| < 8)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 196, 196), (2, 2, 65, 65), (1, 2, 130, 1370), (2, 12, 300, 130)])
+def test_attention_persistent_kernel_ragged_keys_next_to_poisoned_memory(gpu, B, H, Nq, Nk):
+    "The persistent kernel's descriptors: a key row past Nk must read as zeros (and be masked), never as the NaNs next to it."
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(19 * Nq + Nk)
+    buf = torch.full((B, Nk, 3, H, 64), float("nan")).bfloat16()
+    buf[:, :, 1] = torch.randn(B, Nk, H, 64, generator=g).bfloat16()
+    buf = buf.to(gpu)
+    k = buf[:, :, 1]
+    qbuf = torch.full((B, Nq, 2, H, 64), float("nan")).bfloat16()
+    qbuf[:, :, 0] = torch.randn(B, Nq, H, 64, generator=g).bfloat16()
+    q = qbuf.to(gpu)[:, :, 0]
+    v = torch.randn(B, Nk, H, 64, generator=g).bfloat16().to(gpu)
+    with ops.tuning("attn_p64", 2):
+        o = ops.attention(q, k, ops.vt_pack(v), 0.125, v_packed=True)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * 0.125
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v.float())
+    assert torch.isfinite(o).all()
+    assert rel_l2(o.float().cpu(), ref.cpu()) < 4e-3
+
+
+@pytest.mark.parametrize("case", ["stale_maximum", "overflow_late", "underflow_partner_row", "overflow_last_ragged_tile"])
+def test_attention_persistent_kernel_score_range(gpu, case):
+    """The stale maximum and its way out.  A key ~69 scaled nats above the first 32 keys' maximum is still handled in the kernel
+    (P up to 2^100); beyond that — or when the lane's OTHER row (32 queries on) owns a first-tile maximum that pushes this row's
+    exponentials under 2^-100 — the wave flags its 64-query block and attn_bf16_fixup_kernel recomputes it with the exact online
+    softmax: the outputs must match the reference either way, with no sentinel (NaN) left behind."""
+    from uniception_amd import ops
+    B, H, D = 2, 2, 64
+    Nq, Nk = (300, 1000) if case == "overflow_last_ragged_tile" else (512, 768)
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B, Nq, H, D, generator=g).bfloat16()
+    k = torch.randn(B, Nk, H, D, generator=g).bfloat16()
+    v = torch.randn(B, Nk, H, D, generator=g).bfloat16()
+    if case == "stale_maximum":
+        k[0, 700, 0] = q[0, 17, 0] * 6          # ~ +69 in the exp2 domain against a first-tile maximum of a few: inside the range
+        k[1, 300, 1] = q[1, 400, 1] * 5
+    elif case == "overflow_late":
+        k[0, 700, 0] = q[0, 17, 0] * 16         # ~ +185: the row sum overflows 2^100
+        k[1, 40, 1] = q[1, 500, 1] * 14         # second half of the first tile: after the maximum was taken
+    elif case == "underflow_partner_row":
+        k[0, 5, 0] = q[0, 17, 0] * 16           # row 17's first-tile maximum ~185 is row 49's stale maximum too: row 49 underflows
+        k[1, 20, 1] = q[1, 300, 1] * 15
+    else:
+        k[0, 990, 0] = q[0, 280, 0] * 16        # in the ragged last tile, for a query of the ragged last block
+        k[1, 970, 1] = q[1, 3, 1] * 16
+    ref = sdpa_ref(q, k, v, D ** -0.5)
+    ref_lse = torch.logsumexp(torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * D ** -0.5, dim=-1)
+    with ops.tuning("attn_p64", 2):
+        lse = torch.empty(B, H, Nq, device=gpu)
+        out = ops.attention(q.to(gpu), k.to(gpu), ops.vt_pack(v.to(gpu)), D ** -0.5, v_packed=True, lse=lse)
+    assert torch.isfinite(out).all()
+    assert (out.cpu().float() - ref).abs().max() < 6.5e-2       # (two bf16 output steps at |o| < 8)
+    assert rel_l2(out.cpu().float(), ref) < 8e-3
+    # (Q is pre-multiplied by scale * log2(e) and re-rounded to bf16 inside the kernel: against a key 16 x a query, |q| |k| scale ~ 130 nats,
+    #  every score carries ~5e-4 of that — the launcher keeps calls that want the log-sum-exp on the eight-wave kernel for this reason)
+    assert (lse.cpu() - ref_lse).abs().max() < 0.12
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("P,H,W", [(16, 32, 48), (14, 28, 42), (4, 8, 8)])
 def test_patch_gather(gpu, P, H, W):
@@ -651,6 +740,28 @@ def test_patch_gather(gpu, P, H, W):
     assert torch.equal(out.cpu(), ref)
     outb = ops.patch_gather(img.to(gpu), P, torch.bfloat16)
     assert torch.equal(outb.cpu(), ref.bfloat16())
+
+
+def test_convert_to_fp16_saturates_flags_and_keeps_nan(gpu):
+    """the fp16 saturation must not hide NaN producers — a NaN stays NaN in the fp16 output (v_med3 alone would turn it into
+    65504) and trips the range flag like an overflow does (the detector's maximum is the NaN-propagating one)."""
+    from uniception_amd import ops
+    flag = ops.f16_sat_flag()
+    for bad, expect_flag in ((None, False), (1.0e6, True), (float("nan"), True), (float("-inf"), True)):
+        flag.zero_()
+        x = torch.linspace(-4, 4, 4096 + 7, device=gpu)
+        if bad is not None:
+            x[1234] = bad
+        y = ops.convert(x.contiguous(), torch.float16)
+        torch.cuda.synchronize()
+        assert bool(flag.item()) == expect_flag, (bad, flag.item())
+        if bad is None:
+            assert torch.equal(y, x.half())
+        elif bad != bad:
+            assert torch.isnan(y[1234]) and torch.isfinite(torch.cat([y[:1234], y[1235:]])).all()
+        else:
+            assert y[1234].item() == (65504.0 if bad > 0 else -65504.0)
+    flag.zero_()
 
 
 def test_layout_conversions(gpu):

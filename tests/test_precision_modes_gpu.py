@@ -203,8 +203,9 @@ def test_fp16_heads_range_guard_saturates_reports_and_falls_back(gpu):
     """VERDICT r3 #7 / ADVICE r3: fp16 operands carry TF32's mantissa, not its exponent.  A DPT head whose scratch maps reach 1e5-1e6
     (the layer_rn convolutions scaled up by F, the last 1x1 convolution down by 1/F: the head is positively homogeneous up to its biases)
     must not turn into inf / NaN under the default TF32-class policy: the fp16 stores saturate, the launches raise the device flag,
-    engine.head_range_exceeded() reports it, and from then on the policy runs the bf16 fallback — which is the "follow" policy to the
-    bit and within the bf16 bar of the exact-fp32 heads of the same scaled model.  With the unscaled model the flag stays down."""
+    engine.head_range_exceeded() reports it, and the policy runs the bf16 fallback — which is the "follow" policy to the bit and within
+    the bf16 bar of the exact-fp32 heads of the same scaled model — for the SAME forward already (eager inference reads the flag at the
+    end of the forward and re-runs the heads) and from then on.  With the unscaled model the flag stays down."""
     from uniception_amd import engine
     F_ = 3.0e4
 
@@ -232,7 +233,7 @@ def test_fp16_heads_range_guard_saturates_reports_and_falls_back(gpu):
         run(model0.to(gpu), c0, "fp16")
         assert not engine.head_range_exceeded()
         assert engine.head_precision and engine._f16_tripped is False
-        # scaled: saturated but finite, reported, and the policy falls back
+        # scaled, a pipeline COMPOSED from the modules (nobody owns the whole forward): saturated but finite, reported, and the policy falls back
         model, c = scaled_model()
         exact = run(model, c, "fp32_exact")
         assert all(torch.isfinite(v).all() for v in exact.values())
@@ -248,5 +249,54 @@ def test_fp16_heads_range_guard_saturates_reports_and_falls_back(gpu):
         err_sat = max(rel_l2(sat[k].cpu(), exact[k].cpu()) for k in HEAD_OUTPUTS)
         print(f"\n[range guard] maps x{F_:.0e}: saturated fp16 heads {err_sat:.2e} from exact fp32 heads (finite, flagged); fallback (bf16) "
               + ", ".join(f"{k}={rel_l2(after[k].cpu(), exact[k].cpu()):.1e}" for k in HEAD_OUTPUTS))
+    finally:
+        engine.head_range_exceeded(reset=True)
+
+
+def test_fp16_heads_range_guard_protects_the_forward_that_trips_it(gpu):
+    """DUSt3R.forward (the factory model owns the whole forward) reads the saturation flag at the end of an eager inference
+    forward; when a head map left the fp16 range in THAT call, the policy falls back and the two heads are re-run in the transformer's
+    bf16 before anything is returned: the caller gets the "follow" policy's maps — to the bit — from the call that tripped the guard,
+    not the saturated ones.  With UNICEPTION_AMD_HEAD_RANGE_SYNC off (and inside hipGraph captures) the asynchronous form remains."""
+    from uniception_amd import engine
+    F_ = 3.0e4
+    model, c = build_case_model("vitl_dpt_512")
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if ".input_process." in k and k.endswith(".1.weight") and p.dim() == 4 and p.shape[-1] == 3:
+                p.mul_(F_)
+            elif "regressor" in k and ".conv2.2." in k:
+                p.mul_(1.0 / F_ if k.endswith("weight") else 1.0)
+    model = model.to(gpu)
+    a, b = case_images(c)
+    v1 = {"img": a.to(gpu), "instance": ["a"], "data_norm_type": "dust3r"}
+    v2 = {"img": b.to(gpu), "instance": ["b"], "data_norm_type": "dust3r"}
+
+    def run(head_mode):
+        with engine.head_precision(head_mode), torch.no_grad(), engine.precision("bf16"):
+            r1, r2 = model(v1, v2)
+        torch.cuda.synchronize()
+        return dict(pts3d_1=r1["pts3d"], conf_1=r1["conf"], pts3d_2=r2["pts3d_in_other_view"], conf_2=r2["conf"])
+
+    engine.head_range_exceeded(reset=True)
+    try:
+        follow = run("follow")
+        assert all(torch.isfinite(v).all() for v in follow.values())
+        with pytest.warns(RuntimeWarning, match="fp16 range"):
+            first = run("fp16")
+        for k in HEAD_OUTPUTS:
+            assert torch.equal(first[k], follow[k]), f"{k}: the forward that saturated did not return the fallback's maps"
+        assert engine._f16_tripped
+        # asynchronous form: the saturated (finite) maps come back, the flag is seen afterwards
+        engine.head_range_exceeded(reset=True)
+        prev, engine.HEAD_RANGE_SYNC = engine.HEAD_RANGE_SYNC, False
+        try:
+            sat = run("fp16")
+            assert all(torch.isfinite(v).all() for v in sat.values())
+            assert any(not torch.equal(sat[k], follow[k]) for k in HEAD_OUTPUTS)
+            with pytest.warns(RuntimeWarning, match="fp16 range"):
+                assert engine.head_range_exceeded()
+        finally:
+            engine.HEAD_RANGE_SYNC = prev
     finally:
         engine.head_range_exceeded(reset=True)

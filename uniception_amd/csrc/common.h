@@ -59,8 +59,12 @@ __device__ __forceinline__ float f16_to_f32(unsigned short v) {
 // TF32-class heads keep TF32's mantissa in fp16 operands but not its exponent; saturation keeps an out-of-range map finite, and the
 // producers that can overflow (GEMM / conv epilogues, conversions into fp16) raise a caller-provided flag when they hit the limit
 // (uc_gemm_desc.sat_flag, uc_convert's sat_flag), so the host can fall back to a wider head format.
+// NaN is NOT a range problem and must not be hidden: v_med3_f32 returns a finite bound for a NaN input, so the NaN is passed through
+// (the stored fp16 is NaN), and the detectors use the NaN-PROPAGATING maximum (uc_amax: v_maximum3_f32, IEEE 754-2019 maximum) — a
+// NaN anywhere makes `!(amax <= UC_F16_MAX)` true, the flag trips and the host leaves the fp16 policy like for any overflow.
 #define UC_F16_MAX 65504.0f
-__device__ __forceinline__ float uc_sat_f16(float f) { return __builtin_amdgcn_fmed3f(f, -UC_F16_MAX, UC_F16_MAX); }
+__device__ __forceinline__ float uc_sat_f16(float f) { return f != f ? f : __builtin_amdgcn_fmed3f(f, -UC_F16_MAX, UC_F16_MAX); }
+__device__ __forceinline__ float uc_amax(float a, float b) { return __builtin_elementwise_maximum(a, b); }
 __device__ __forceinline__ unsigned short f32_to_f16(float f) {
     _Float16 h = (_Float16)uc_sat_f16(f);
     unsigned short v;

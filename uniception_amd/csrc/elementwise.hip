@@ -214,7 +214,7 @@ __global__ void convert_kernel(const typename TI::storage* __restrict__ s, typen
         }
         if constexpr (TO_F16) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
+            for (int k = 0; k < 8; ++k) amax = uc_amax(amax, fabsf(v[k]));      // (NaN-propagating: a NaN trips the flag too)
         }
         if constexpr (sizeof(typename TO::storage) == 4) {
             *reinterpret_cast<float4_t*>(d + i * 8) = (float4_t){v[0], v[1], v[2], v[3]};
@@ -228,7 +228,7 @@ __global__ void convert_kernel(const typename TI::storage* __restrict__ s, typen
     }
     for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {   // ragged tail
         const float v = TI::load(s + i);
-        if constexpr (TO_F16) amax = fmaxf(amax, fabsf(v));
+        if constexpr (TO_F16) amax = uc_amax(amax, fabsf(v));
         TO::store(d + i, v);
     }
     if constexpr (TO_F16) {

@@ -785,8 +785,8 @@ __device__ __forceinline__ void glds_epilogue_res16(glds_pe_t p, float4_t (&acc)
             add16(v, w, res[i % AHEAD][ps]);
             add16(v, w, res2[i % AHEAD][ps]);             // (zeros without a second residual)
             if (i + AHEAD < FA) load_res(i + AHEAD, ps);
-            if constexpr (F16) amax = fmaxf(fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))),
-                                            fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
+            if constexpr (F16) amax = uc_amax(uc_amax(amax, uc_amax(uc_amax(fabsf(v.x), fabsf(v.y)), uc_amax(fabsf(v.z), fabsf(v.w)))),
+                                              uc_amax(uc_amax(fabsf(w.x), fabsf(w.y)), uc_amax(fabsf(w.z), fabsf(w.w))));      // (NaN-propagating: common.h)
             const uint4_t pk = {glds_pack2<F16>(v.x, v.y), glds_pack2<F16>(v.z, v.w), glds_pack2<F16>(w.x, w.y), glds_pack2<F16>(w.z, w.w)};
             if (16 * i + 8 * ps < rows_left) {
                 uint4_t* cq = reinterpret_cast<uint4_t*>(cbase + (2 * i + ps) * cstep + coff);
@@ -889,7 +889,7 @@ __device__ __forceinline__ void glds_epilogue_bf16(glds_pe_t p, float4_t (&acc)[
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4_t v = glds_act4<ACT>(val4(i, j));
-                if constexpr (F16) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                if constexpr (F16) amax = uc_amax(uc_amax(amax, uc_amax(fabsf(v.x), fabsf(v.y))), uc_amax(fabsf(v.z), fabsf(v.w)));
                 *reinterpret_cast<uint2*>(buf + wr_off + (((2 * j + (g >> 1)) ^ (frow & 7)) << 4)) = (uint2){glds_pack2<F16>(v.x, v.y), glds_pack2<F16>(v.z, v.w)};
             }
         }
@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void glds_epilogue_generic(glds_pe_t p, float4_t (&ac
                 if (p.dact_act == UC_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f; }
                 else { for (int r = 0; r < 4; ++r) v[r] *= glds_dact(u[r], UC_ACT_GELU_ERF); }
             }
-            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            amax = uc_amax(uc_amax(amax, uc_amax(fabsf(v.x), fabsf(v.y))), uc_amax(fabsf(v.z), fabsf(v.w)));
             glds_store4(p.C, p.out_dtype, ci, full, nb, p.N, v);
         }
     }

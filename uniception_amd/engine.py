@@ -190,6 +190,30 @@ def note_heads_ran() -> None:
     _f16_pending[dev] = (host, ev)
 
 
+HEAD_RANGE_SYNC: bool = os.environ.get("UNICEPTION_AMD_HEAD_RANGE_SYNC", "1") != "0"
+
+
+def heads_saturated_now() -> bool:
+    """Round 5: the guard protects the forward that trips it.  Called by the factory right after the heads of an eager
+    (non-captured) inference forward that ran them in fp16: reads the 4-byte flag synchronously — the caller is about to consume the
+    outputs anyway — and, if a map saturated, trips the fallback NOW; the factory then re-runs the two heads in the transformer's bf16
+    and returns those maps.  (Inside a hipGraph capture no read is possible: the asynchronous path below stays, documented in
+    INTEGRATION.md section 3b.  UNICEPTION_AMD_HEAD_RANGE_SYNC=0 restores the asynchronous behaviour everywhere.)"""
+    if not HEAD_RANGE_SYNC or _head_mode != "fp16" or _f16_tripped or torch.cuda.is_current_stream_capturing():
+        return False
+    from . import ops
+    dev = torch.cuda.current_device()
+    host, ev = _f16_pending.get(dev) or (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+    host.copy_(ops.f16_sat_flag(), non_blocking=True)
+    ev.record()
+    _f16_pending[dev] = (host, ev)
+    ev.synchronize()
+    if int(host[0]) != 0:
+        _trip_head_range()
+        return True
+    return False
+
+
 def _poll_head_range() -> None:
     global _f16_tripped
     if _f16_tripped or not _f16_pending or torch.cuda.is_current_stream_capturing():     # (an event query is not allowed inside a capture)

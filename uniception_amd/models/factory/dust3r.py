@@ -178,10 +178,18 @@ class DUSt3R(nn.Module):
             # the two heads are independent: on two streams when the batch is too small to fill the chip
             feats2 = outs["2"] if isinstance(outs["2"], list) else [outs["2"]]
             n_tok = feats2[-1].shape[0] * feats2[-1].shape[2] * feats2[-1].shape[3]
-            (p1, c1), (p2, c2) = engine.run_branches(lambda: head(1, shape1), lambda: head(2, shape2), n_tok, inputs1=tuple(feats2),
-                                                          warm_key=("heads", tuple(feats2[-1].shape), shape1, shape2, str(engine.head_dtype()), torch.is_grad_enabled()), owner=self,
-                                                          disjoint_params=self.head1 is not self.head2)      # (head1 / head2: separate parameters; the adaptor has none)
+
+            def run_heads():
+                return engine.run_branches(lambda: head(1, shape1), lambda: head(2, shape2), n_tok, inputs1=tuple(feats2),
+                                           warm_key=("heads", tuple(feats2[-1].shape), shape1, shape2, str(engine.head_dtype()), torch.is_grad_enabled()), owner=self,
+                                           disjoint_params=self.head1 is not self.head2)      # (head1 / head2: separate parameters; the adaptor has none)
+            ran_f16 = engine.head_dtype() == torch.float16
+            (p1, c1), (p2, c2) = run_heads()
+            if ran_f16 and not torch.is_grad_enabled() and engine.heads_saturated_now():
+                # a scratch map left the fp16 range in THIS forward: the policy has fallen back to the transformer's bf16 — redo the two
+                # heads with it and return those maps instead of the saturated ones
+                (p1, c1), (p2, c2) = run_heads()
             res1 = {"pts3d": p1, "conf": c1}
             res2 = {"pts3d_in_other_view": p2, "conf": c2}
-            engine.note_heads_ran()      # (fp16 head policy: asynchronous snapshot of the range-guard flag, engine.head_range_exceeded)
+            engine.note_heads_ran()      # (captured forwards: asynchronous snapshot of the range-guard flag, engine.head_range_exceeded)
         return res1, res2
