@@ -184,6 +184,19 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
     }
     const float c = p.scale * 1.44269504088896340736f;
     const float lse2 = p.LSE[((int64_t)b * p.H + h) * p.Nq + q] * 1.44269504088896340736f;
+    // Softmax diet (round 5, the forward's attention_p64.h): the wave's STATIONARY operand Q is pre-multiplied by scale * log2(e)
+    // (once per workgroup; re-rounded to bf16: scores carry ~2^-9 |q| |k| scale of noise, below P's own bf16 rounding for the scores
+    // that matter), the score chain starts at -lse2 and the dP chain at -delta (C operand of the first MFMA: two register blocks
+    // holding the lane's query scalars) — per element P = exp2(acc), dS = P * acc': exp + mul + half a conversion instead of
+    // fma + exp + sub + mul + half a conversion.
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        union { bf16x8_t v; unsigned u[4]; } a;
+        a.v = qf[s];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a.u[j] = pack_bf16x2(__uint_as_float(a.u[j] << 16) * c, __uint_as_float(a.u[j] & 0xffff0000u) * c);
+        qf[s] = a.v;
+    }
     // delta[q] = sum_d dO[q,d] * O[q,d] (round 4: computed HERE — the lane pair of a query already holds its dO row as dof; one more row
     // load and a cross-half add replace the stand-alone pass of rounds 1-3) and left in p.delta for the dK / dV kernel, which runs next
     float dlt = 0.f;
@@ -202,6 +215,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
     float16_t dq[2];
     dq[0] = (float16_t)(0.f);
     dq[1] = (float16_t)(0.f);
+    float16_t neg_lse, neg_dlt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { neg_lse[r] = -lse2; neg_dlt[r] = -dlt; }
+    asm volatile("" : "+v"(neg_lse), "+v"(neg_dlt));      // opaque: a splat hipcc recognises is re-materialised (16 v_mov) per use
 
     int r_off[4];
 #pragma unroll
@@ -226,13 +243,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
         bf16x8_t dsf[4];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            float16_t s = (float16_t)(0.f), dp = (float16_t)(0.f);
+            float16_t s = neg_lse, dp = neg_dlt;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + r_off[st] + kb * (32 * 128));
                 const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(smem + TB + r_off[st] + kb * (32 * 128));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[st], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);          // scale log2(e) Q K^T - lse2
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[st], dp, 0, 0, 0);       // dO V^T - delta
             }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
@@ -240,9 +257,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int r = hf * 8 + j;
-                    float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
+                    float pv = __builtin_amdgcn_exp2f(s[r]);
                     if (tail && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Nk) pv = 0.f;   // ragged last tile only (uniform test first)
-                    e[j] = pv * (dp[r] - dlt);
+                    e[j] = pv * dp[r];
                 }
                 union { bf16x8_t v; unsigned u[4]; } pk;
 #pragma unroll
@@ -307,6 +324,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
         }
     }
     const float c = p.scale * 1.44269504088896340736f;
+    // softmax diet (see the dQ kernel): K, this wave's stationary operand, carries scale * log2(e); the per-QUERY scalars -lse2 and
+    // -delta are the C operands of the first MFMAs — here one value per accumulator ROW, read as they lie in LDS
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        union { bf16x8_t v; unsigned u[4]; } a;
+        a.v = kf[s];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a.u[j] = pack_bf16x2(__uint_as_float(a.u[j] << 16) * c, __uint_as_float(a.u[j] & 0xffff0000u) * c);
+        kf[s] = a.v;
+    }
     float16_t dk[2], dv[2];
     dk[0] = (float16_t)(0.f); dk[1] = (float16_t)(0.f);
     dv[0] = (float16_t)(0.f); dv[1] = (float16_t)(0.f);
@@ -320,8 +347,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     auto stage_aux = [&](int stage, int q0) {   // per-query scalars of the tile: plain loads, 64 threads
         if (tid < 64) {
             const int q = q0 + tid;
-            s_aux[stage * 128 + tid] = (q < p.Nq) ? lse_b[q] * 1.44269504088896340736f : 1e30f;   // absent query: P = exp2(-1e30) = 0
-            s_aux[stage * 128 + 64 + tid] = (q < p.Nq) ? dl_b[q] : 0.f;
+            s_aux[stage * 128 + tid] = (q < p.Nq) ? -lse_b[q] * 1.44269504088896340736f : -1e30f;   // (negated: accumulator start values) absent query: P = exp2(-1e30) = 0
+            s_aux[stage * 128 + 64 + tid] = (q < p.Nq) ? -dl_b[q] : 0.f;
         }
     };
     dma_tile(Qb, p.q_sn, 0, p.Nq, lds0, wave, lane);
@@ -343,7 +370,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            float16_t s = (float16_t)(0.f), dp = (float16_t)(0.f);
+            // accumulator row r = query qb*32 + (r & 3) + 8 (r >> 2) + 4 hi: registers 4k .. 4k+3 = one 16-byte LDS read
+            float16_t s, dp;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const float4_t l4 = *reinterpret_cast<const float4_t*>(s_lse + qb * 32 + 8 * k4 + 4 * hi);
+                const float4_t d4 = *reinterpret_cast<const float4_t*>(s_dl + qb * 32 + 8 * k4 + 4 * hi);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { s[4 * k4 + jj] = l4[jj]; dp[4 * k4 + jj] = d4[jj]; }
+            }
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(smem + r_off[st] + qb * (32 * 128));
@@ -356,17 +391,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
             for (int hf = 0; hf < 2; ++hf) {
                 float pe[8], de[8];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    // queries qb*32 + 8*(2hf+k) + 4hi + (0..3): four consecutive per-query scalars = one 16-byte LDS read each
-                    const float4_t l4 = *reinterpret_cast<const float4_t*>(s_lse + qb * 32 + 8 * (2 * hf + k) + 4 * hi);
-                    const float4_t d4 = *reinterpret_cast<const float4_t*>(s_dl + qb * 32 + 8 * (2 * hf + k) + 4 * hi);
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int r = hf * 8 + 4 * k + jj;
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[jj]));
-                        pe[4 * k + jj] = pv;
-                        de[4 * k + jj] = pv * (dp[r] - d4[jj]);
-                    }
+                for (int j8 = 0; j8 < 8; ++j8) {
+                    const int r = hf * 8 + j8;
+                    const float pv = __builtin_amdgcn_exp2f(s[r]);
+                    pe[j8] = pv;
+                    de[j8] = pv * dp[r];
                 }
                 union { bf16x8_t v; unsigned u[4]; } a, d2;
 #pragma unroll
