@@ -111,13 +111,12 @@ def test_product_path_fails_loudly_without_gpu():
 def test_four_wave_gemm_hands_its_accumulators_over_in_untouched_agprs():
     """gemm_bf16_glds4_kernel: the asm K-loop leaves its accumulators in a0..a255 and 256 single-register asm statements read them
     back for the C++ epilogues.  Sound only if the compiler itself never allocates an AGPR in that kernel — checked on the generated
-    code of the two instantiations the forward uses (tools/check_glds4_agprs.py); also: the committed loop text is what the generator
+    code of the two instantiations the forward uses (uniception_amd/check_kernels.py); also: the committed loop text is what the generator
     produces."""
     import subprocess
     import sys
     from concurrent.futures import ThreadPoolExecutor
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import check_glds4_agprs as chk
+    from uniception_amd import check_kernels as chk
     with ThreadPoolExecutor(4) as ex:       # all four translation units that instantiate the kernel (ADVICE r3): the default UC_GEMM_4WAVE=3 routes the f32 and 'all' families too
         reports = list(ex.map(chk.check, chk.TUS))
     seen = 0
@@ -126,6 +125,9 @@ def test_four_wave_gemm_hands_its_accumulators_over_in_untouched_agprs():
             seen += 1
             assert blocks >= 257 and not bad, (name, blocks, bad[:3])
     assert seen == 4
+    # the persistent attention kernel: every MFMA through inline asm — no scratch, no spills, no AGPRs in the generated code
+    p64 = chk.check_p64()
+    assert len(p64) == 2 and all(r["scratch"] == 0 and r["vgpr_spills"] == 0 and r["agprs"] == 0 and 0 < r["vgprs"] <= 256 for r in p64.values()), p64
     # ... and build() runs the same check whenever it links a new library (a violation fails the build)
     from uniception_amd import build as B
     assert open(B.LIB + ".agpr").read().strip() == B.loaded_fingerprint()

@@ -1,5 +1,9 @@
 """BASELINE configs[4]: ViT-L encoder + decoder at 1024x1024 pairs (N = 4096 tokens per view) with the fp8 MFMA attention path
-running INSIDE the model — dispatch asserted, outputs held against the bf16 run and against the CPU oracle."""
+running INSIDE the model — dispatch asserted, outputs held against the bf16 run and against the CPU oracle (its outputs on every
+16th pixel: tests/golden/fullsize.npz, written by tests/golden/make_golden_fullsize.py — the oracle at this size is ~80 s of host time)."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -9,7 +13,7 @@ from tests.helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-# (24, 12): the depth BASELINE configs[4] names (ViT-L encoder + 12-block decoder), the oracle on the host cores (~80 s of the test);
+# (24, 12): the depth BASELINE configs[4] names (ViT-L encoder + 12-block decoder);
 # observed 1.1e-2 for the e4m3 attention against the oracle, the same as bf16 attention: the bar is 2e-2
 @pytest.mark.parametrize("ENC,DEC,bar8", [(24, 12, 2e-2)])
 def test_1024_fp8_attention_inside_the_model(gpu, monkeypatch, ENC, DEC, bar8):
@@ -22,10 +26,10 @@ def test_1024_fp8_attention_inside_the_model(gpu, monkeypatch, ENC, DEC, bar8):
         del br[DEC:]
     model.info_sharing.depth = DEC
     O.fill_state_dict_(model.state_dict(), gains=GAINS)
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     img1, img2 = O.make_images(21, 1, 1024, 1024)
-    with torch.no_grad():
-        o1, o2 = O.dust3r_forward(sd, img1, img2, head="linear", enc_depth=ENC, dec_depth=DEC)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize.npz"))
+    step = int(gold["c5_step"])
+    ref = {k: torch.from_numpy(gold["c5_" + k]) for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2")}
     model = model.to(gpu)
     v1 = {"img": img1.to(gpu), "instance": ["a"], "data_norm_type": "dust3r"}
     v2 = {"img": img2.to(gpu), "instance": ["b"], "data_norm_type": "dust3r"}
@@ -53,10 +57,10 @@ def test_1024_fp8_attention_inside_the_model(gpu, monkeypatch, ENC, DEC, bar8):
     assert calls["fp8"] == ENC + 2 * 2 * DEC and calls["bf16"] == ENC + 2 * 2 * DEC and calls["nk"] == {4096}
     assert f1["pts3d"].shape == (1, 1024, 1024, 3) and torch.isfinite(f1["pts3d"]).all() and torch.isfinite(f2["conf"]).all()
     errs = {}
-    for name, got8, got16, ref in (("pts3d_1", f1["pts3d"], b1["pts3d"], o1["pts3d"]), ("conf_1", f1["conf"], b1["conf"], o1["conf"]),
-                                   ("pts3d_2", f2["pts3d_in_other_view"], b2["pts3d_in_other_view"], o2["pts3d_in_other_view"]),
-                                   ("conf_2", f2["conf"], b2["conf"], o2["conf"])):
-        errs[name] = (rel_l2(got8.cpu(), ref), rel_l2(got16.cpu(), ref), rel_l2(got8.cpu(), got16.cpu()))
+    for name, got8, got16 in (("pts3d_1", f1["pts3d"], b1["pts3d"]), ("conf_1", f1["conf"], b1["conf"]),
+                              ("pts3d_2", f2["pts3d_in_other_view"], b2["pts3d_in_other_view"]), ("conf_2", f2["conf"], b2["conf"])):
+        sub8, sub16 = got8[:, ::step, ::step].cpu(), got16[:, ::step, ::step].cpu()       # the oracle's pixel sub-grid
+        errs[name] = (rel_l2(sub8, ref[name]), rel_l2(sub16, ref[name]), rel_l2(got8.cpu(), got16.cpu()))
     print(f"\n[config 5, 1024x1024, {ENC}+{DEC} blocks] rel-L2 (fp8 vs oracle, bf16 vs oracle, fp8 vs bf16): " +
           ", ".join(f"{k}={a:.1e}/{b:.1e}/{c:.1e}" for k, (a, b, c) in errs.items()))
     for k, (e8, e16, d) in errs.items():

@@ -3,6 +3,8 @@ here): at the native 37x37 grid the module is pinned to goldens of an independen
 Dinov2WithRegistersModel, test_matches_huggingface_transformers_golden); for other grids (resized position embedding — PARITY
 UNPINNED) the tests prove that the HIP module and the oracle's restatement implement the same reading of the published code (cls
 token, resized position embedding, registers, LayerScale, output split)."""
+import os
+
 import pytest
 import torch
 
@@ -244,19 +246,14 @@ def test_config3_full_size_pipeline_matches_oracle(gpu):
     model.encoder = encoder_factory("dinov2", name="c3_dinov2", size="large")
     model = model.eval()
     O.fill_state_dict_(model.state_dict(), gains=dict(GAINS, **G2))
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(33)
     img1, img2 = torch.randn(1, 3, 518, 518, generator=g), torch.randn(1, 3, 518, 518, generator=g)
-    with torch.no_grad():
-        enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
-        feats, _ = O.dinov2_encoder(torch.cat([img1, img2], 0), enc_sd, "model.", num_heads=16)
-        final, taken = O.cross_attention_transformer([feats[:1], feats[1:]], sd, "info_sharing.", depth=12, num_heads=12, indices=(5, 8),
-                                                     norm_intermediate=False)
-        ref = []
-        for v in range(2):
-            up8 = O.dpt_feature([feats[v:v + 1], taken[0][v], taken[1][v], final[v]], sd, f"dpt_feature_head{v + 1}.")
-            pts, conf = O.pointmap_adaptor(O.dpt_regressor(up8, (518, 518), sd, f"dpt_regressor_head{v + 1}."))
-            ref += [pts.permute(0, 2, 3, 1), conf.permute(0, 2, 3, 1)]
+    # the oracle's composition at this size on every 7th pixel (tests/golden/fullsize.npz <- tests/golden/make_golden_fullsize.py: ~40 s of
+    # host time that used to run inside this test)
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize.npz"))
+    step = int(gold["c3_step"])
+    ref = [torch.from_numpy(gold[k]) for k in ("c3_pts3d_1", "c3_conf_1", "c3_pts3d_2", "c3_conf_2")]
     model = model.to(gpu)
     v1 = {"img": img1.to(gpu), "instance": ["0"], "data_norm_type": "dinov2"}
     v2 = {"img": img2.to(gpu), "instance": ["1"], "data_norm_type": "dinov2"}
@@ -264,8 +261,8 @@ def test_config3_full_size_pipeline_matches_oracle(gpu):
         with torch.no_grad(), engine.precision(mode):
             r1, r2 = model(v1, v2)
         got = [r1["pts3d"], r1["conf"], r2["pts3d_in_other_view"], r2["conf"]]
-        errs = [rel_l2(a.float().cpu(), b) for a, b in zip(got, ref)]
-        aerr = [float((a.float().cpu() - b).abs().max()) for a, b in zip(got, ref)]
+        errs = [rel_l2(a[:, ::step, ::step].float().cpu(), b) for a, b in zip(got, ref)]
+        aerr = [float((a[:, ::step, ::step].float().cpu() - b).abs().max()) for a, b in zip(got, ref)]
         print(f"\n[config 3 full size, {mode}] rel-L2 pts1 {errs[0]:.2e} conf1 {errs[1]:.2e} pts2 {errs[2]:.2e} conf2 {errs[3]:.2e}; max-abs {max(aerr):.2e}")
         assert got[0].shape == (1, 518, 518, 3) and max(errs) < tol
         if atol is not None:

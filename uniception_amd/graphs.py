@@ -49,7 +49,7 @@ class GraphedTwoView:
         torch.cuda.synchronize()
         # hand-over buffers of the small-M GEMM path: the launches recorded below own theirs for as long as this graph lives
         # (ops.capture_scope); they come from a reserve filled here, outside the capture (allocation is not allowed inside one)
-        ops.fuse_ws_release(id(self))
+        ops.fuse_ws_release(id(self))          # (recapture: the device was synchronised above, no replay of the old graph is in flight)
         ops.fuse_ws_reserve(4)
         self.graph = torch.cuda.CUDAGraph()
         with ops.capture_scope(id(self)), torch.cuda.graph(self.graph):
@@ -57,6 +57,9 @@ class GraphedTwoView:
 
     def __del__(self):
         try:
+            # a replay may still be in flight: its split GEMMs own the hand-over buffers until it has finished — wait before the
+            # buffers return to the free list (the next stream that pops one would share flag words and partial sums with it)
+            torch.cuda.synchronize()
             self.graph = None
             ops.fuse_ws_release(id(self))
         except Exception:

@@ -238,7 +238,12 @@ def _fuse_ws_for_launch(M: int, N: int, K: int) -> Optional[int]:
     # two graphs may be replayed at the same time on different streams): keyed by the capture_scope token, else by the capture's own id
     token = 0
     if capturing:
-        token = _capture_token or _capture_id(_stream())
+        if not _capture_token:
+            # a capture outside ops.capture_scope has no owner to hand the buffer back when the graph dies (every such graph would
+            # keep 8 MiB for good, and once the reserve is drained later captures would silently run unsplit): it runs unsplit,
+            # always — wrap captures in ops.capture_scope(token) + fuse_ws_release(token) (uniception_amd.graphs does)
+            return None
+        token = _capture_token
     key = (dev, _stream(), token)
     ptr = _fuse_ws_sets.get(key)
     if ptr is None:
@@ -253,18 +258,6 @@ def _fuse_ws_for_launch(M: int, N: int, K: int) -> Optional[int]:
 
 
 _FUSE_WS_SPARE = 3
-
-
-def _capture_id(stream_handle: int) -> int:
-    "Id of the capture `stream_handle` is recording into (hipStreamGetCaptureInfo); -1 if it cannot be read."
-    hip = _hip_runtime()
-    status, cid = C.c_int(0), C.c_ulonglong(0)
-    try:
-        if hip.hipStreamGetCaptureInfo(C.c_void_p(stream_handle), C.byref(status), C.byref(cid)) == 0 and cid.value:
-            return -int(cid.value) - 2          # (negative: never collides with an id(...) token or 0)
-    except AttributeError:
-        pass
-    return -1
 
 
 _small_m_cache = [None]
