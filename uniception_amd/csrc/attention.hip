@@ -300,7 +300,7 @@ __device__ __forceinline__ att_uint4_t att_make_srd(const void* base) {
                          (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
 }
 
-// What bounds it (round 2, tools/probe_attn_anatomy.py + tools/pmc_attn.sh, B = 64, H = 16, N = 1024): the costs of the exp2
+// What bounds it (round 2, tools/scratch/probe_attn_anatomy.py + tools/pmc_attn.sh, B = 64, H = 16, N = 1024): the costs of the exp2
 // work and of the PV products are ADDITIVE (-18 % without the exps, -20 % without the PV MFMAs, -2 % without the per-tile
 // barrier; static priorities or a start stagger per workgroup slot: nothing).  SQ_ACTIVE_INST_VALU — which includes a matrix
 // instruction for its whole 32 cycles — is 81-86 % of the wave-resident time of a SIMD: matrix and vector instructions of the

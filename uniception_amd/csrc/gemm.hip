@@ -615,7 +615,7 @@ extern "C" int uc_gemm(const uc_gemm_desc* d, uc_stream_t stream) {
                 if (d->a_mode == UC_A_DENSE) {
                     // Dense launches of a few rounds of tiles (the batch sweep's 2 - 16 pairs): what matters is how many ROUNDS of
                     // workgroups a tile size needs on the 256 CUs, times what a round of that tile costs — measured per round at
-                    // K = 768 / 1024 (tools/bench_midsize_variants.py): 128x128 ~13 / 19 us, 256x128 ~16 / 23 us, 256x256 ~22 / 29 us,
+                    // K = 768 / 1024 (tools/scratch/bench_midsize_variants.py): 128x128 ~13 / 19 us, 256x128 ~16 / 23 us, 256x256 ~22 / 29 us,
                     // i.e. 1 : 1.25 : 1.7.  The thresholds above missed the quantisation: 144 tiles of 256x256 beat 288 of 256x128 by
                     // 38 % (decoder qkv at 4 pairs), 144 of 256x128 beat 288 of 128x128 by 47 % (at 2 pairs).
                     const int64_t cus = uc_num_cus();
