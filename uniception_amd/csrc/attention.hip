@@ -923,7 +923,10 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         // eight waves per workgroup (256 queries share each K / VT tile) when that does not add a mostly empty query tile
         const int nw_env = uc_knobs().attn_nw;
         const int waste8 = (Nq + 255) / 256 * 256 - Nq, waste4 = (Nq + 127) / 128 * 128 - Nq;
-        const int nw = nw_env == 4 || nw_env == 8 ? nw_env : ((Nq >= 256 && waste8 - waste4 < 64) ? 8 : 4);
+        // (a launch whose 256-query tiles would not give every CU two workgroups takes 128-query tiles: one pair of 512 x 512 views is
+        //  128 tiles of 256 queries — half the chip idle — or 256 of 128)
+        const bool few8 = (int64_t)((Nq + 255) / 256) * H * B < 2 * (int64_t)uc_num_cus();
+        const int nw = nw_env == 4 || nw_env == 8 ? nw_env : ((Nq >= 256 && waste8 - waste4 < 64 && !few8) ? 8 : 4);
         const int qtile = 32 * nw, nqt = (Nq + qtile - 1) / qtile;
         p.dGroup = uc_make_fastdiv((unsigned)(8 * nqt)); p.dNq = uc_make_fastdiv((unsigned)nqt); p.dH = uc_make_fastdiv((unsigned)H);
         const int use_dma = uc_knobs().attn_dma;

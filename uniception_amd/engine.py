@@ -517,6 +517,16 @@ def patch_weights(conv: nn.Conv2d, dtype: torch.dtype):
                     lambda: (conv.weight.detach().reshape(conv.out_channels, -1).to(dtype).contiguous(), _f32c(conv.bias)))
 
 
+def patch_weights_padded(conv: nn.Conv2d, dtype: torch.dtype, kpad: int):
+    "patch_weights with the K dimension (Cin P P) zero-padded to `kpad` columns: a 14 x 14 patch has 588, not a multiple of the MFMA kernels' 64"
+    def build():
+        w = conv.weight.detach().reshape(conv.out_channels, -1).to(dtype)
+        wp = torch.zeros((conv.out_channels, kpad), dtype=dtype, device=w.device)
+        wp[:, :w.shape[1]] = w
+        return wp, _f32c(conv.bias)
+    return prepared(conv, ("pe_pad", dtype, kpad), (conv.weight, conv.bias), build)
+
+
 def layerscale_lin_weights(lin: nn.Linear, gamma: torch.Tensor, dtype: torch.dtype):
     """LayerScale folded into the preceding linear: gamma * (x W^T + b) = x (gamma[:,None] W)^T + gamma*b — zero kernel work."""
     def build():
