@@ -23,7 +23,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md §Chip-level parameters)
 PEAK_HBM_GBS = 8000.0      # HBM3E peak (same guide)
-PMC_TRAFFIC_FILE = "r4_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"
 FWD_PAIRS = 128            # pairs per GPU per forward step: 56 GB; 64 -> 96 -> 128 pairs measured +0.7 / +0.9 % (same box), 256: see DESIGN section 7
 TRAIN_PAIRS = 64           # pairs per GPU per training step: 216 GB of the 288 GB at 512x512 with DPT heads (32: 96-98 pairs/s, 64: 100-101, 80: 101.9 at 267 GB)
 

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 root=$(pwd)
 out=gpurun_out/prof_$tag
 bash tools/profile_round.sh $tag pmc > /dev/null 2>&1
-cp $out/${tag}_pmc_traffic.json profiles/r4_pmc_traffic.json
+cp $out/${tag}_pmc_traffic.json profiles/r5_pmc_traffic.json
 rm -rf $out/trace $out/pmc_*
 python bench.py --steps 20 --warmup 3 > $out/${tag}_bench_forward_pairs128.json 2> $out/bench_forward.err
 cat $out/${tag}_bench_forward_pairs128.json
@@ -27,5 +27,8 @@ bash tools/pmc_attn.sh "8" > $out/${tag}_probe_attention_sq_counters.txt 2>&1
 rm -rf gpurun_out/pmc_attn
 # the per-shape dense GEMM table and the two probes of the round
 python tools/bench_model_gemms2.py 128 auto,2,6,7 enc,dec 0.4 > $out/${tag}_model_gemm_shapes.txt 2>&1
-[ -x tools/_bin/dma_seg ] && ./tools/_bin/dma_seg > $out/${tag}_probe_dma_seg.txt 2>&1
-[ -x tools/_bin/mfma_valu ] && ./tools/_bin/mfma_valu > $out/${tag}_probe_mfma_valu.txt 2>&1
+python tools/bench_attention_ab.py > $out/${tag}_attention_ab_same_box.txt 2>&1
+python tools/bench_attention_bwd.py > $out/${tag}_attention_bwd.txt 2>&1
+if [ -x tools/_bin/dma_seg ]; then ./tools/_bin/dma_seg > $out/${tag}_probe_dma_seg.txt 2>&1; fi
+if [ -x tools/_bin/mfma_valu ]; then ./tools/_bin/mfma_valu > $out/${tag}_probe_mfma_valu.txt 2>&1; fi
+exit 0
