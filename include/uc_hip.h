@@ -52,7 +52,7 @@ const char* uc_last_error(void);
  *       small-M path, uc_gemm_fuse_ws_bytes): the library no longer allocates.
  *   12: uc_swiglu / uc_swiglu_bwd added (DINOv2 giant's SwiGLU FFN); tuning knob conv_rows takes 3 (eight-wave row-walking 3x3
  *       convolution wherever the shape allows). */
-#define UC_ABI_VERSION 12
+#define UC_ABI_VERSION 13
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
 const char* uc_build_flavor(void);
@@ -491,8 +491,9 @@ int uc_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
  *   inputs : Q,K,V,O,dO as [B,N,H,64] strided views (bf16; dO addressed with O's strides), LSE fp32 [B,H,Nq] (natural log of
  *            the softmax denominator of the scaled scores);
  *   outputs: dQ [B,Nq,H,64], dK, dV [B,Nk,H,64] bf16 (own strides, e.g. slices of one fused dqkv buffer).
- *   delta fp32 [B,H,Nq] is scratch for rowsum(dO*O) (written by the dQ kernel, read by the dK / dV kernel).  All operands are
- *   row-major: the transposed MFMA operands are formed inside the kernels with LDS transpose-reads.
+ *   delta is fp32 scratch of 2 * B * H * (Nq rounded up to 128) floats (ABI 13; before: B * H * Nq): per (batch, head) the dQ kernel
+ *   leaves -LSE * log2(e) (absent queries: -1e30) and -rowsum(dO*O) (0) there, the dK / dV kernel starts its accumulators from them.
+ *   All operands are row-major: the transposed MFMA operands are formed inside the kernels with LDS transpose-reads.
  *   rope_qpos / rope_kpos (both or neither; int64 [B*Nq,2] / [B*Nk,2] (y,x)): Q and K were rotated by RoPE-2D (base, F0) before the
  *   forward — dQ and dK are then returned as gradients of the UN-rotated q / k (the inverse rotation rides in the kernels' epilogues
  *   instead of two uc_rope2d passes).  NULL: gradients of the rotated operands. */

@@ -110,7 +110,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 12   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 13   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

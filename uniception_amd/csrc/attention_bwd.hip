@@ -18,6 +18,7 @@
 // LDS tiles are 64 rows x 128 B with the (row>>1)&7 chunk swizzle (conflict-free ds_read_b128; the transposing reads see
 // 2-way conflicts between rows r and r+2, which the MFMA/VALU work hides), single-buffered, 2-3 workgroups per CU.
 #include "common.h"
+#include "knobs.h"
 #include <math.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -29,6 +30,8 @@ struct AttnBwdParams {
     const bf16_t *Q, *K, *V, *O, *dO;
     const float* LSE;
     float* delta;
+    float* aux;                 // [B H][2][nq_pad]: -lse * log2(e) (absent queries: -1e30) | -delta (0): the dK / dV kernel's accumulator start values
+    int nq_pad;                 // Nq rounded up to 128
     bf16_t *dQ, *dK, *dV;
     int B, H, Nq, Nk;
     int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
@@ -39,6 +42,7 @@ struct AttnBwdParams {
     const int64_t* rope_kpos;   // [B * Nk][2]
     float rope_turn0;           // F0 / (2 pi): rotation per unit position of channel 0, in turns
     float rope_ratio;           // base^(-1/16)
+    unsigned long long* dbg;    // probe builds (-DB64_TIMING): per-workgroup cycle stamps
 };
 
 #define TB (64 * 128)   // bytes of one 64-row tile
@@ -209,7 +213,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
             for (int j = 0; j < 8; ++j) dlt = fmaf((float)of[j], (float)dof[s][j], dlt);
         }
         dlt += __shfl_xor(dlt, 32, 64);
-        if (q_ok && hi == 0) p.delta[((int64_t)b * p.H + h) * p.Nq + q] = dlt;
+        if (hi == 0) {      // (every query slot up to nq_pad gets its pair: the 64-key dK / dV kernel reads whole 64-query tiles of them)
+            float* ax = p.aux + ((int64_t)b * p.H + h) * 2 * p.nq_pad + (q0 + l31);
+            ax[0] = q_ok ? -lse2 : -1e30f;
+            ax[p.nq_pad] = q_ok ? -dlt : 0.f;
+        }
     }
 
     float16_t dq[2];
@@ -309,8 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 
     const bf16_t* Qb = p.Q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
     const bf16_t* dOb = p.dO + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
-    const float* lse_b = p.LSE + ((int64_t)b * p.H + h) * p.Nq;
-    const float* dl_b = p.delta + ((int64_t)b * p.H + h) * p.Nq;
+    const float* ax_b = p.aux + ((int64_t)b * p.H + h) * 2 * p.nq_pad;      // written by the dQ kernel
     float* s_aux = reinterpret_cast<float*>(smem_all + 4 * TB);   // [stage][lse2 64 | delta 64]
 
     bf16x8_t kf[4], vf[4];   // B operands: lane key = l31, channels 16s + 8hi .. +7
@@ -347,8 +354,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     auto stage_aux = [&](int stage, int q0) {   // per-query scalars of the tile: plain loads, 64 threads
         if (tid < 64) {
             const int q = q0 + tid;
-            s_aux[stage * 128 + tid] = (q < p.Nq) ? -lse_b[q] * 1.44269504088896340736f : -1e30f;   // (negated: accumulator start values) absent query: P = exp2(-1e30) = 0
-            s_aux[stage * 128 + 64 + tid] = (q < p.Nq) ? -dl_b[q] : 0.f;
+            s_aux[stage * 128 + tid] = (q < p.Nq) ? ax_b[q] : -1e30f;       // (negated: accumulator start values) absent query: P = exp2(-1e30) = 0
+            s_aux[stage * 128 + 64 + tid] = (q < p.Nq) ? ax_b[p.nq_pad + q] : 0.f;
         }
     };
     dma_tile(Qb, p.q_sn, 0, p.Nq, lds0, wave, lane);
@@ -437,6 +444,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     }
 }
 
+#include "attention_bwd64.h"
+
 extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                                 void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb,
                                 int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
@@ -455,20 +464,30 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
                "uc_attention_bwd: output strides must be multiples of 4 elements");
     AttnBwdParams p;
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (const bf16_t*)O; p.dO = (const bf16_t*)dO;
-    p.LSE = LSE; p.delta = delta;
+    p.LSE = LSE; p.delta = delta; p.aux = delta;
+    p.nq_pad = (Nq + 127) / 128 * 128;
     p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
     p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
     p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh; p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh;
     p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh; p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.dk_sb = dk_sb; p.dk_sn = dk_sn;
     p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh; p.scale = scale;
-    p.rope_qpos = rope_qpos; p.rope_kpos = rope_kpos;
+    p.rope_qpos = rope_qpos; p.rope_kpos = rope_kpos; p.dbg = nullptr;
     p.rope_turn0 = rope_qpos ? (float)((double)rope_f0 / 6.283185307179586476925) : 0.f;
     p.rope_ratio = rope_qpos ? (float)pow((double)rope_base, -1.0 / 16.0) : 1.f;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * H * Nq;
     (void)total;      // (delta is computed by the dQ kernel since round 4; attn_delta_kernel remains for reference)
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((Nk + 127) / 128) * H * B)), dim3(256), 0, st, p);
+    // 64 keys per wave (attention_bwd64.h) when a 256-key workgroup is mostly real keys; the 32-key kernel otherwise
+    (void)uc_knobs();
+    const int k64 = g_uc_attn_bwd64.load();
+    const bool use64 = Nq > 64 && (k64 == 2 || (k64 == 1 && Nk >= 192 && ((Nk + 255) / 256) * 256 * 4 <= Nk * 5));
+    if (use64) {      // persistent: one workgroup per CU, workgroup g on XCD g % 8
+        const int64_t items = (int64_t)((Nk + 255) / 256) * H * B;
+        const int grid = (int)min((int64_t)(uc_num_cus() / 8 * 8), (items + 7) / 8 * 8);
+        hipLaunchKernelGGL(attn_bwd_dkv64_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    }
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((Nk + 127) / 128) * H * B)), dim3(256), 0, st, p);
     UC_CHECK_LAUNCH("uc_attention_bwd");
     return UC_OK;
 }

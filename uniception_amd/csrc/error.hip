@@ -31,6 +31,7 @@ std::atomic<int> g_uc_gemm_variant{-3};
 std::atomic<int> g_uc_gemm_stagger{-1};
 std::atomic<int> g_uc_attn_rs{UC_ATTN_RS_DEFAULT};
 std::atomic<int> g_uc_attn_p64{1};
+std::atomic<int> g_uc_attn_bwd64{1};
 std::atomic<int> g_uc_conv_rows{1};
 std::atomic<int> g_uc_small_m_split{2048};
 
@@ -65,6 +66,7 @@ const UcKnobs& uc_knobs() {
         g_uc_gemm_stagger.store(env_int("UC_GEMM_STAGGER", -1));
         g_uc_attn_rs.store(env_int("UC_ATTN_RS", UC_ATTN_RS_DEFAULT));
         g_uc_attn_p64.store(env_int("UC_ATTN_P64", 1));
+        g_uc_attn_bwd64.store(env_int("UC_ATTN_BWD64", 1));
         g_uc_conv_rows.store(env_int("UC_CONV_ROWS", 1));
         g_uc_small_m_split.store(env_int("UC_GEMM_SMALLM", 2048));
     });
@@ -86,6 +88,9 @@ extern "C" int uc_tuning_set(const char* name, int value) {
     } else if (!strcmp(name, "attn_p64")) {
         UC_REQUIRE(value >= 0 && value <= 2, "uc_tuning_set: attn_p64 must be 0 (never), 1 (policy) or 2 (wherever the shape allows) (got %d)", value);
         g_uc_attn_p64.store(value);
+    } else if (!strcmp(name, "attn_bwd64")) {
+        UC_REQUIRE(value >= 0 && value <= 2, "uc_tuning_set: attn_bwd64 must be 0 (never), 1 (policy) or 2 (always) (got %d)", value);
+        g_uc_attn_bwd64.store(value);
     } else if (!strcmp(name, "small_m_split")) {
         UC_REQUIRE(value >= 0, "uc_tuning_set: small_m_split is the smallest K a small-M launch splits in two for (0: never) (got %d)", value);
         g_uc_small_m_split.store(value);
@@ -93,7 +98,7 @@ extern "C" int uc_tuning_set(const char* name, int value) {
         UC_REQUIRE(value >= 0 && value <= 3, "uc_tuning_set: conv_rows must be 0 (implicit GEMM everywhere), 1 (row-walking kernels where they win), 2 (the 256-pixel row-walking kernel wherever the shape allows) or 3 (the eight-wave 512-pixel one wherever the shape allows) (got %d)", value);
         g_uc_conv_rows.store(value);
     } else {
-        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split, attn_p64, conv_rows, small_m_split; everything else is read from the environment once, see csrc/knobs.h)", name);
+        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split, attn_p64, attn_bwd64, conv_rows, small_m_split; everything else is read from the environment once, see csrc/knobs.h)", name);
         return UC_ERR_BAD_ARG;
     }
     return UC_OK;
@@ -106,6 +111,7 @@ extern "C" int uc_tuning_get(const char* name, int* value) {
     else if (!strcmp(name, "gemm_stagger")) *value = g_uc_gemm_stagger.load();
     else if (!strcmp(name, "attn_role_split")) *value = g_uc_attn_rs.load();
     else if (!strcmp(name, "attn_p64")) *value = g_uc_attn_p64.load();
+    else if (!strcmp(name, "attn_bwd64")) *value = g_uc_attn_bwd64.load();
     else if (!strcmp(name, "conv_rows")) *value = g_uc_conv_rows.load();
     else if (!strcmp(name, "small_m_split")) *value = g_uc_small_m_split.load();
     else { uc_set_error("uc_tuning_get: unknown knob '%s'", name); return UC_ERR_BAD_ARG; }

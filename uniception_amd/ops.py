@@ -1012,7 +1012,9 @@ def attention_bwd(q, k, v, o, do, lse, scale: float, out=None, rope=None):
         dq, dk, dv = out
         assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
         assert all(t.dtype == dt and t.stride(3) == 1 for t in out)
-    delta = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    # scratch: fp32 verification kernels [B,H,Nq]; bf16 kernels [B*H][2][Nq rounded up to 128] (ABI 13: the dQ kernel leaves -lse*log2(e)
+    # and -rowsum(dO*O) there as the dK / dV kernel's accumulator start values)
+    delta = torch.empty((B, H, Nq) if dt == torch.float32 else (B * H, 2, (Nq + 127) // 128 * 128), dtype=torch.float32, device=q.device)
     if rope is not None:
         assert dt == torch.bfloat16 and rope[0].dtype == torch.int64 and rope[1].dtype == torch.int64
         assert rope[0].is_contiguous() and rope[1].is_contiguous() and rope[0].numel() == 2 * B * Nq and rope[1].numel() == 2 * B * Nk
