@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libuc_hip.so")
 SOURCES = ["error.hip", "rope_norm.hip", "gemm.hip", "gemm_glds.hip", "gemm_glds_dense_bf16.hip", "gemm_glds_dense_f32.hip", "gemm_glds_dense_bs.hip", "gemm_glds_dense_all.hip", "gemm_glds_conv.hip", "gemm_glds_conv_f16.hip", "gemm_glds_dense_all_f16.hip", "gemm_tn.hip", "attention.hip", "attention_x3.hip", "attention_fp8.hip",
            "attention_bwd.hip", "elementwise.hip", "train.hip", "dpt_bwd.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-inline-asm"]
 
 
 def _read(path):

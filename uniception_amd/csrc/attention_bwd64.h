@@ -37,22 +37,32 @@
 __device__ __forceinline__ void b64_mfma_acc_a(float16_t& d, p64_bf16x8_t a, p64_bf16x8_t b) {       // accumulator in an AGPR block
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
 }
+// score chains: accumulator in VGPRs, the STATIONARY operand (K / V fragments) in accumulator registers (gfx90a+: an MFMA's A / B
+// operands may come from either file) — 64 VGPRs the vector work needs
+__device__ __forceinline__ void b64_mfma_first_b(float16_t& d, p64_bf16x8_t a, p64_bf16x8_t b, const float16_t& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+}
+__device__ __forceinline__ void b64_mfma_acc_b(float16_t& d, p64_bf16x8_t a, p64_bf16x8_t b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
 __device__ __forceinline__ float b64_mul(float a, float b) {
     float r;
     asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+typedef float b64_float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ b64_float2_t b64_pk_mul(b64_float2_t a, b64_float2_t b) {
+    b64_float2_t r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// LDS-DMA pieces with M0 declared clobbered (one wave per SIMD: every instruction is four cycles of the wave's issue time, and the
+// save / restore pair of p64_dma16 is two of five)
+__device__ __forceinline__ void b64_dma16(unsigned voff, p64_uint4_t srd, unsigned soff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" : : "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff) : "memory", "m0");
+}
 __device__ __forceinline__ void b64_dma4(unsigned voff, p64_uint4_t srd, unsigned soff, unsigned lds_byte_addr) {      // 64 lanes x 4 B
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 4\n\t"
-        "buffer_load_dword %1, %2, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff)
-        : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %3 offen lds" : : "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff) : "memory", "m0");
 }
 // the two transposing reads of one transposed A operand (see tr_operand): addresses a0 / a1 are the lane's, `imm` the slab offset
 template <int IMM>
@@ -87,26 +97,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
     const int nbh = p.B * p.H, nkt = (p.Nk + 255) >> 8;
     const int items_x = ((nbh - xcd + 7) >> 3) * nkt;
     if (slot_w >= items_x) return;          // (uniform per workgroup)
-    struct Item { unsigned long long qb, ob, ab, kb, vb; int b, h, key0; };
+    // (descriptors span the WHOLE tensors — the launcher checks that they fit 32-bit byte offsets — and an item is three byte offsets into
+    // them: a query tile past Nq then reads the next batch's rows instead of zeros, finite values that meet P = exp2(-1e30) = 0)
+    struct Item { unsigned oq, oo, oa; unsigned long long kb, vb; int b, h, key0; };
     auto make_item = [&](int j) -> Item {
         Item it;
         const int kq = j / nkt, kt = j - kq * nkt;
         const int bh = kq * 8 + xcd;
         it.b = bh / p.H;
         it.h = bh - it.b * p.H;
-        it.key0 = kt * 256 + wave * 64;
-        it.qb = (unsigned long long)(p.Q + (int64_t)it.b * p.q_sb + (int64_t)it.h * p.q_sh);
-        it.ob = (unsigned long long)(p.dO + (int64_t)it.b * p.o_sb + (int64_t)it.h * p.o_sh);
-        it.ab = (unsigned long long)(p.aux + (int64_t)bh * 2 * p.nq_pad);
+        it.key0 = __builtin_amdgcn_readfirstlane(kt * 256 + wave * 64);
+        // (readfirstlane: the integer division above runs on the vector unit, and everything derived from it would stay there)
+        it.b = __builtin_amdgcn_readfirstlane(it.b);
+        it.h = __builtin_amdgcn_readfirstlane(it.h);
+        it.oq = (unsigned)(((int64_t)it.b * p.q_sb + (int64_t)it.h * p.q_sh) * 2);
+        it.oo = (unsigned)(((int64_t)it.b * p.o_sb + (int64_t)it.h * p.o_sh) * 2);
+        it.oa = (unsigned)((int64_t)(it.b * p.H + it.h) * 2 * p.nq_pad * 4);
         it.kb = (unsigned long long)(p.K + (int64_t)it.b * p.k_sb + (int64_t)it.h * p.k_sh);
         it.vb = (unsigned long long)(p.V + (int64_t)it.b * p.v_sb + (int64_t)it.h * p.v_sh);
         return it;
     };
 
     // ---- the stream: per tile and wave 2 pieces of Q rows, 2 of dO rows (rows 16 w .. 16 w + 15), 1 of the scalars ----
-    const unsigned qbytes = (unsigned)((((int64_t)p.Nq - 1) * p.q_sn + 64) * 2);       // rows >= Nq read as zeros
-    const unsigned obytes = (unsigned)((((int64_t)p.Nq - 1) * p.o_sn + 64) * 2);
-    const unsigned abytes = (unsigned)(2 * p.nq_pad * 4);
+    const p64_uint4_t srd_q = p64_make_srd(p.Q, (unsigned)((((int64_t)p.B - 1) * p.q_sb + ((int64_t)p.H - 1) * p.q_sh + ((int64_t)p.Nq - 1) * p.q_sn + 64) * 2));
+    const p64_uint4_t srd_o = p64_make_srd(p.dO, (unsigned)((((int64_t)p.B - 1) * p.o_sb + ((int64_t)p.H - 1) * p.o_sh + ((int64_t)p.Nq - 1) * p.o_sn + 64) * 2));
+    const p64_uint4_t srd_a = p64_make_srd(p.aux, (unsigned)((int64_t)nbh * 2 * p.nq_pad * 4));
     unsigned voff_q[2], voff_o[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -119,25 +134,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
     const unsigned qstep = (unsigned)(64 * p.q_sn * 2), ostep = (unsigned)(64 * p.o_sn * 2);
     const unsigned q16 = (unsigned)(16 * p.q_sn * 2) * (unsigned)wave, o16 = (unsigned)(16 * p.o_sn * 2) * (unsigned)wave;
     const unsigned a_so = (unsigned)((wave & 1) * p.nq_pad * 4);
-    struct Pieces { p64_uint4_t srd_q, srd_o, srd_a; unsigned so_q, so_o, so_a, dst; };
+    struct Pieces { unsigned so_q, so_o, so_a, dst; };
     auto prep = [&](const Item& it, int t, int s) -> Pieces {
         Pieces pc;
-        pc.srd_q = p64_make_srd((const void*)it.qb, qbytes);
-        pc.srd_o = p64_make_srd((const void*)it.ob, obytes);
-        pc.srd_a = p64_make_srd((const void*)it.ab, abytes);
-        pc.so_q = (unsigned)t * qstep + q16;
-        pc.so_o = (unsigned)t * ostep + o16;
-        pc.so_a = a_so + (unsigned)t * 256u;
+        pc.so_q = it.oq + (unsigned)t * qstep + q16;
+        pc.so_o = it.oo + (unsigned)t * ostep + o16;
+        pc.so_a = it.oa + a_so + (unsigned)t * 256u;
         pc.dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(s * B64_SLOT) + (unsigned)wave * 2048u);
         return pc;
     };
     auto issue_piece = [&](const Pieces& pc, auto n_tag) __attribute__((always_inline)) {
         constexpr int n = decltype(n_tag)::value;
-        if constexpr (n == 0) p64_dma16(voff_q[0], pc.srd_q, pc.so_q, pc.dst);
-        else if constexpr (n == 1) p64_dma16(voff_q[1], pc.srd_q, pc.so_q, pc.dst + 1024);
-        else if constexpr (n == 2) p64_dma16(voff_o[0], pc.srd_o, pc.so_o, pc.dst + B64_TILE);
-        else if constexpr (n == 3) p64_dma16(voff_o[1], pc.srd_o, pc.so_o, pc.dst + B64_TILE + 1024);
-        else b64_dma4(voff_a, pc.srd_a, pc.so_a, pc.dst - (unsigned)wave * 2048u + B64_AUX_OFF + (unsigned)wave * 256u);
+        if constexpr (n == 0) b64_dma16(voff_q[0], srd_q, pc.so_q, pc.dst);
+        else if constexpr (n == 1) b64_dma16(voff_q[1], srd_q, pc.so_q, pc.dst + 1024);
+        else if constexpr (n == 2) b64_dma16(voff_o[0], srd_o, pc.so_o, pc.dst + B64_TILE);
+        else if constexpr (n == 3) b64_dma16(voff_o[1], srd_o, pc.so_o, pc.dst + B64_TILE + 1024);
+        else b64_dma4(voff_a, srd_a, pc.so_a, pc.dst - (unsigned)wave * 2048u + B64_AUX_OFF + (unsigned)wave * 256u);
     };
     auto issue_all = [&](const Pieces& pc) __attribute__((always_inline)) {
         issue_piece(pc, P64Int<0>()); issue_piece(pc, P64Int<1>()); issue_piece(pc, P64Int<2>()); issue_piece(pc, P64Int<3>());
@@ -180,8 +192,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
     float16_t dk[2][2], dv[2][2];          // [channel block db][key block kb], transposed: row = channel, column = key
     float16_t S[2], dP[2];                 // [key block]: rows = the block's 32 queries
     p64_bf16x8_t P[2][2][2], dS[2][2][2];  // [generation][key block][16-query slab]
-    p64_bf16x8_t F[4];                     // fragment ring: fragment m of a phase lives in F[m & 3] (the plan is in the phases' comments)
+    p64_bf16x8_t FA[8], F[4];              // row fragments of phase A, ring of transposed fragments of phase B (plans: the phases' comments)
     float16_t L, Dl;                       // the next block's start values
+    float e0 = 0.f, e1 = 0.f;              // the exponentials in flight between an "exp" slot and the next ("fin") slot
+    b64_float2_t dd = {0.f, 0.f};          // ... and the pair's products, converted in the exponential slot after
 
     // lane addresses inside the ring (advanced with the slots): row fragments, transposed fragments, start values
     const char* ka[4];
@@ -238,6 +252,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
                 P[1][kb][hf] = (p64_bf16x8_t)(0.f);       // generation 1 = "block -1"
                 dS[1][kb][hf] = (p64_bf16x8_t)(0.f);
             }
+        // the item's first phase A finishes "block -1"'s softmax (pairs 11..15, key block 1): exp2(-1e30) = 0, 0 * 0 = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[1][r] = -1e30f; dP[1][r] = 0.f; }
+        e0 = 0.f; e1 = 0.f;
+        dd = (b64_float2_t){0.f, 0.f};
     };
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -247,47 +266,101 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
     // block 0's start values and first fragments
     init_quad(cad, P64Int<0>()); init_quad(cad, P64Int<1>()); init_quad(cad, P64Int<2>()); init_quad(cad, P64Int<3>());
     init_quad(cad, P64Int<4>()); init_quad(cad, P64Int<5>()); init_quad(cad, P64Int<6>()); init_quad(cad, P64Int<7>());
-    F[0] = *reinterpret_cast<const p64_bf16x8_t*>(ka[0]);
-    F[1] = *reinterpret_cast<const p64_bf16x8_t*>(ka[0] + B64_TILE);
-    F[2] = *reinterpret_cast<const p64_bf16x8_t*>(ka[1]);
+    FA[0] = *reinterpret_cast<const p64_bf16x8_t*>(ka[0]);
+    FA[1] = *reinterpret_cast<const p64_bf16x8_t*>(ka[0] + B64_TILE);
+    FA[2] = *reinterpret_cast<const p64_bf16x8_t*>(ka[1]);
+    FA[3] = *reinterpret_cast<const p64_bf16x8_t*>(ka[1] + B64_TILE);
+    FA[4] = *reinterpret_cast<const p64_bf16x8_t*>(ka[2]);
+    FA[5] = *reinterpret_cast<const p64_bf16x8_t*>(ka[2] + B64_TILE);
 
-    // Fragment plan.  Phase A fragments a0..a7: a(2 st) = Q rows, a(2 st + 1) = dO rows of chunk pair st; used in slots 4 st + {0, 2} and
-    // 4 st + {1, 3}.  Phase B fragments b0..b7: pair p = 2 hf + db: b(2 p) = dO^T, b(2 p + 1) = Q^T of (16-query slab hf of the previous block,
-    // channel block db); used in slots 4 p + {0, 1} and 4 p + {2, 3}.  Fragment m sits in F[m & 3].  Loads (>= 4 slots ahead of the first use,
-    // behind the last use of the position's previous tenant): a3 A0, a4 A3, a5 A4, a6 A7, a7 A8, b0 A12, b1 A13, b2 A15, b3 B0, b4 B2, b5 B4,
-    // b6 B6, b7 B8, and the NEXT block's a0 B11, a1 B13, a2 B14.
-    //
-    // ---- phase A of query block qb of the current tile: slot 4 st + c; c = 0: S[0], 1: dP[0], 2: S[1], 3: dP[1] ----
-    //      beside them, from slot 8 (the first MFMAs have read L / Dl): the NEXT block's start values (nb_init), one read per slot; in the
-    //      odd block of a tile the five pieces of tile t + 2 ----
+    // The schedule of one 32-query block j (slots g = 0 .. 39 counted from its phase A; one MFMA per slot):
+    //   phase A, g = 0..15   g < 8: S[0] / dP[0] (key block 0: even / odd slots, chunk pair st = g >> 1), g >= 8: S[1] / dP[1]; the chains' first
+    //                        MFMAs take the block's start values L / Dl as C.  Row fragments FA[2 st] (Q rows), FA[2 st + 1] (dO rows): each
+    //                        feeds slots 2 st (+1) and 8 + 2 st (+1); FA[0..5] were read by the previous phase B (slots 10..15), FA[6..7] in g = 0, 1
+    //                        (six slots ahead of their first use: four were not enough — the row fragments' waits cost 17 % of the kernel).
+    //   phase B, g = 16..31  dV^T / dK^T of block j - 1 (fragment plan below) — unchanged by block j.
+    //   the block's softmax  runs at HALF density from g = 9 to g = 39 — under phase A's second half, phase B and the NEXT block's first 8
+    //                        slots: pair q (key block q >> 3, accumulator rows 2 (q & 7), + 1) has its two exponentials in slot 9 + 2 q and its
+    //                        two products and two conversions in the slot after (pairs 14, 15: slots 37, 38).  Key block 0's scores are
+    //                        complete at g = 7 and die at the next block's g = 0 (32); key block 1's are complete at g = 15 and die at 40.
+    //                        All 32 slots of a block then carry ~19 cycles of vector work beside their MFMA (32) instead of 16 slots carrying 45.
+    // Phase B fragments b0..b7: pair p = 2 hf + db: b(2 p) = dO^T, b(2 p + 1) = Q^T of (16-query slab hf of the previous block, channel block
+    // db); used in slots 4 p + {0, 1} and 4 p + {2, 3}; fragment m sits in F[m & 3]; loads b0 A12, b1 A13, b2 A15, b3 B0, b4 B2, b5 B4, b6 B6, b7 B8.
+    // (the product's conversion rides in the NEXT exponential slot: behind the packed multiply it costs a wait state, and with one wave
+    // per SIMD every instruction — an s_nop too — is four cycles of issue time)
+#ifndef B64_PKMUL
+#define B64_PKMUL 0     // (v_pk_mul_f32 is no bargain here: two v_mul_f32 are 8 % faster on the whole kernel — measured, tools/probes/run_b64.sh)
+#endif
+#ifndef B64_DEFER
+#define B64_DEFER 1
+#endif
+#ifndef B64_DBG
+#define B64_DBG 0       // probe builds, wrong results: 1 no softmax arithmetic, 2 no start-value reads, 4 no transposing reads, 8 no row-fragment reads in the phases, 16 no DMA pieces in the loop
+#endif
+    auto sm_cvt_ds = [&](auto qp_tag, auto gen_tag) __attribute__((always_inline)) {
+        constexpr int qp = decltype(qp_tag)::value, kbp = qp >> 3, ip = qp & 7, G = decltype(gen_tag)::value;
+        union { p64_bf16x8_t v; unsigned u[4]; } d;
+        d.v = dS[G][kbp][ip >> 2];
+        d.u[ip & 3] = p64_cvt_pk(dd.x, dd.y);
+        dS[G][kbp][ip >> 2] = d.v;
+    };
+    auto sm_exp = [&](auto q_tag, auto gen_tag) __attribute__((always_inline)) {       // gen: generation of pair q - 1 (pair 15 of the previous block for q = 0)
+        constexpr int q = decltype(q_tag)::value, kb = q >> 3, i = q & 7;
+        if constexpr (B64_DBG & 1) return;
+        // (conversion first: a vector instruction right behind a transcendental one costs a wait state)
+        if constexpr (B64_DEFER) sm_cvt_ds(P64Int<((q + 15) & 15)>(), gen_tag);
+        e0 = p64_exp2(S[kb][2 * i]);
+        e1 = p64_exp2(S[kb][2 * i + 1]);
+    };
+    auto sm_fin = [&](auto q_tag, auto gen_tag) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_tag)::value, kb = q >> 3, i = q & 7, G = decltype(gen_tag)::value;
+        if constexpr (B64_DBG & 1) return;
+        if constexpr (B64_PKMUL) dd = b64_pk_mul((b64_float2_t){e0, e1}, (b64_float2_t){dP[kb][2 * i], dP[kb][2 * i + 1]});
+        else { dd.x = b64_mul(e0, dP[kb][2 * i]); dd.y = b64_mul(e1, dP[kb][2 * i + 1]); }
+        union { p64_bf16x8_t v; unsigned u[4]; } a;
+        a.v = P[G][kb][i >> 2];
+        a.u[i & 3] = p64_cvt_pk(e0, e1);
+        P[G][kb][i >> 2] = a.v;
+        if constexpr (!B64_DEFER) sm_cvt_ds(q_tag, gen_tag);
+    };
+    // ---- phase A of query block qb of the current tile; beside it: the tail of the previous block's softmax (slots 0..7, generation
+    //      qb ^ 1), the head of this block's (slots 9..15, generation qb), from slot 10 the NEXT block's start values (nb_init: the first
+    //      MFMAs of key block 1 have read L / Dl in slots 8, 9), in the odd block of a tile the five pieces of tile t + 2 ----
     auto phase_a = [&](auto qb_tag, const char* nb_init, const Pieces& pc) __attribute__((always_inline)) {
         constexpr int qb = decltype(qb_tag)::value, pq = qb ^ 1;       // pq: the previous block's position in ITS tile (which tr0 / tr1 point at)
         auto slot = [&](auto k_tag) __attribute__((always_inline)) {
-            constexpr int k = decltype(k_tag)::value, st = k >> 2, c = k & 3;
-            if constexpr (k == 0) F[3] = *reinterpret_cast<const p64_bf16x8_t*>(ka[1] + qb * 4096 + B64_TILE);
-            if constexpr (k == 3) F[0] = *reinterpret_cast<const p64_bf16x8_t*>(ka[2] + qb * 4096);
-            if constexpr (k == 4) F[1] = *reinterpret_cast<const p64_bf16x8_t*>(ka[2] + qb * 4096 + B64_TILE);
-            if constexpr (k == 7) F[2] = *reinterpret_cast<const p64_bf16x8_t*>(ka[3] + qb * 4096);
-            if constexpr (k == 8) F[3] = *reinterpret_cast<const p64_bf16x8_t*>(ka[3] + qb * 4096 + B64_TILE);
-            if constexpr (k == 12) F[0] = b64_tr<B64_TILE + 4096 * pq>(tr0[0], tr1[0]);          // b0: dO^T, slab 2 pq, channel block 0
-            if constexpr (k == 13) F[1] = b64_tr<4096 * pq>(tr0[0], tr1[0]);                     // b1: Q^T,  slab 2 pq, channel block 0
-            if constexpr (k == 15) F[2] = b64_tr<B64_TILE + 4096 * pq>(tr0[1], tr1[1]);          // b2: dO^T, slab 2 pq, channel block 1
+            constexpr int k = decltype(k_tag)::value, st = (k & 7) >> 1, kb = k >> 3;
+            if constexpr (!(B64_DBG & 8) && k < 2) FA[6 + k] = *reinterpret_cast<const p64_bf16x8_t*>(ka[3] + qb * 4096 + (k & 1) * B64_TILE);
+            if constexpr (!(B64_DBG & 4) && k == 12) F[0] = b64_tr<B64_TILE + 4096 * pq>(tr0[0], tr1[0]);          // b0: dO^T, slab 2 pq, channel block 0
+            if constexpr (!(B64_DBG & 4) && k == 13) F[1] = b64_tr<4096 * pq>(tr0[0], tr1[0]);                     // b1: Q^T,  slab 2 pq, channel block 0
+            if constexpr (!(B64_DBG & 4) && k == 15) F[2] = b64_tr<B64_TILE + 4096 * pq>(tr0[1], tr1[1]);          // b2: dO^T, slab 2 pq, channel block 1
             if constexpr (qb == 1) {
-                if constexpr (k == 1) issue_piece(pc, P64Int<0>());
-                if constexpr (k == 2) issue_piece(pc, P64Int<1>());
-                if constexpr (k == 4) issue_piece(pc, P64Int<2>());
-                if constexpr (k == 5) issue_piece(pc, P64Int<3>());
-                if constexpr (k == 6) issue_piece(pc, P64Int<4>());
+                if constexpr (!(B64_DBG & 16) && k == 1) issue_piece(pc, P64Int<0>());
+                if constexpr (!(B64_DBG & 16) && k == 2) issue_piece(pc, P64Int<1>());
+                if constexpr (!(B64_DBG & 16) && k == 4) issue_piece(pc, P64Int<2>());
+                if constexpr (!(B64_DBG & 16) && k == 5) issue_piece(pc, P64Int<3>());
+                if constexpr (!(B64_DBG & 16) && k == 6) issue_piece(pc, P64Int<4>());
             }
-            if constexpr (k == 0) p64_mfma_first(S[0], F[0], kf[0][0], L);
-            else if constexpr (k == 1) p64_mfma_first(dP[0], F[1], vf[0][0], Dl);
-            else if constexpr (k == 2) p64_mfma_first(S[1], F[0], kf[1][0], L);
-            else if constexpr (k == 3) p64_mfma_first(dP[1], F[1], vf[1][0], Dl);
-            else if constexpr (c == 0) p64_mfma_acc(S[0], F[(2 * st) & 3], kf[0][st]);
-            else if constexpr (c == 1) p64_mfma_acc(dP[0], F[(2 * st + 1) & 3], vf[0][st]);
-            else if constexpr (c == 2) p64_mfma_acc(S[1], F[(2 * st) & 3], kf[1][st]);
-            else p64_mfma_acc(dP[1], F[(2 * st + 1) & 3], vf[1][st]);
-            if constexpr (k >= 8) init_quad(nb_init, P64Int<k - 8>());
+            if constexpr ((k & 7) == 0) b64_mfma_first_b(S[kb], FA[0], kf[kb][0], L);
+            else if constexpr ((k & 7) == 1) b64_mfma_first_b(dP[kb], FA[1], vf[kb][0], Dl);
+            else if constexpr ((k & 1) == 0) b64_mfma_acc_b(S[kb], FA[2 * st], kf[kb][st]);
+            else b64_mfma_acc_b(dP[kb], FA[2 * st + 1], vf[kb][st]);
+            // ---- vector work ----
+            if constexpr (k == 0) sm_fin(P64Int<11>(), P64Int<qb ^ 1>());
+            if constexpr (k == 1) sm_exp(P64Int<12>(), P64Int<qb ^ 1>());
+            if constexpr (k == 2) sm_fin(P64Int<12>(), P64Int<qb ^ 1>());
+            if constexpr (k == 3) sm_exp(P64Int<13>(), P64Int<qb ^ 1>());
+            if constexpr (k == 4) sm_fin(P64Int<13>(), P64Int<qb ^ 1>());
+            if constexpr (k == 5) sm_exp(P64Int<14>(), P64Int<qb ^ 1>());
+            if constexpr (k == 6) { sm_fin(P64Int<14>(), P64Int<qb ^ 1>()); sm_exp(P64Int<15>(), P64Int<qb ^ 1>()); }
+            if constexpr (k == 7) sm_fin(P64Int<15>(), P64Int<qb ^ 1>());
+            if constexpr (k == 9) sm_exp(P64Int<0>(), P64Int<qb ^ 1>());              // (converts the previous block's last product)
+            if constexpr (k >= 11 && (k & 1) == 1) sm_exp(P64Int<((k - 9) >> 1)>(), P64Int<qb>());
+            if constexpr (k >= 10 && (k & 1) == 0) sm_fin(P64Int<((k - 10) >> 1)>(), P64Int<qb>());
+            // ---- the next block's start values ----
+            if constexpr (!(B64_DBG & 2) && k >= 10 && k <= 13) init_quad(nb_init, P64Int<k - 10>());
+            if constexpr (!(B64_DBG & 2) && k == 14) { init_quad(nb_init, P64Int<4>()); init_quad(nb_init, P64Int<5>()); }
+            if constexpr (!(B64_DBG & 2) && k == 15) { init_quad(nb_init, P64Int<6>()); init_quad(nb_init, P64Int<7>()); }
             P64_PIN();
         };
         slot(P64Int<0>()); slot(P64Int<1>()); slot(P64Int<2>()); slot(P64Int<3>());
@@ -295,61 +368,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
         slot(P64Int<8>()); slot(P64Int<9>()); slot(P64Int<10>()); slot(P64Int<11>());
         slot(P64Int<12>()); slot(P64Int<13>()); slot(P64Int<14>()); slot(P64Int<15>());
     };
-    // ---- phase B behind phase A of block (t, ODD): dV^T / dK^T of the previous block (generation GR = ODD ^ 1 of P / dS; tile tr0 / tr1 point
-    //      at, slabs 2 pq, 2 pq + 1) beside this block's softmax (generation GW = ODD); the score registers are reloaded with the next
-    //      block's start values (nb_init) as the softmax lets go of them, the next block's first row fragments come from nb_rows ----
+    // ---- phase B behind phase A of block (t, ODD): dV^T / dK^T of the previous block (generation ODD ^ 1 of P / dS; tile tr0 / tr1 point
+    //      at, slabs 2 pq, 2 pq + 1) beside the middle of this block's softmax (generation ODD); the next block's first row fragments come
+    //      from nb_rows ----
     auto phase_b = [&](auto odd_tag, int nb_rows) __attribute__((always_inline)) {
         constexpr int ODD = decltype(odd_tag)::value, GW = ODD, GR = ODD ^ 1, pq = ODD ^ 1;
-        float e0 = 0.f, e1 = 0.f;
         auto slot = [&](auto k_tag) __attribute__((always_inline)) {
             constexpr int k = decltype(k_tag)::value, pp = k >> 2, c = k & 3, hf = pp >> 1, db = pp & 1;
-            if constexpr (k == 0) F[3] = b64_tr<4096 * pq>(tr0[1], tr1[1]);                          // b3: Q^T  slab 2 pq,     channel block 1
-            if constexpr (k == 2) F[0] = b64_tr<B64_TILE + 4096 * pq + 2048>(tr0[0], tr1[0]);        // b4: dO^T slab 2 pq + 1, channel block 0
-            if constexpr (k == 4) F[1] = b64_tr<4096 * pq + 2048>(tr0[0], tr1[0]);                   // b5: Q^T
-            if constexpr (k == 6) F[2] = b64_tr<B64_TILE + 4096 * pq + 2048>(tr0[1], tr1[1]);        // b6: dO^T slab 2 pq + 1, channel block 1
-            if constexpr (k == 8) F[3] = b64_tr<4096 * pq + 2048>(tr0[1], tr1[1]);                   // b7: Q^T
-            if constexpr (k == 11) F[0] = *reinterpret_cast<const p64_bf16x8_t*>(ka[0] + nb_rows);
-            if constexpr (k == 13) F[1] = *reinterpret_cast<const p64_bf16x8_t*>(ka[0] + nb_rows + B64_TILE);
-            if constexpr (k == 14) F[2] = *reinterpret_cast<const p64_bf16x8_t*>(ka[1] + nb_rows);
+            if constexpr (!(B64_DBG & 4) && k == 0) F[3] = b64_tr<4096 * pq>(tr0[1], tr1[1]);                          // b3: Q^T  slab 2 pq,     channel block 1
+            if constexpr (!(B64_DBG & 4) && k == 2) F[0] = b64_tr<B64_TILE + 4096 * pq + 2048>(tr0[0], tr1[0]);        // b4: dO^T slab 2 pq + 1, channel block 0
+            if constexpr (!(B64_DBG & 4) && k == 4) F[1] = b64_tr<4096 * pq + 2048>(tr0[0], tr1[0]);                   // b5: Q^T
+            if constexpr (!(B64_DBG & 4) && k == 6) F[2] = b64_tr<B64_TILE + 4096 * pq + 2048>(tr0[1], tr1[1]);        // b6: dO^T slab 2 pq + 1, channel block 1
+            if constexpr (!(B64_DBG & 4) && k == 8) F[3] = b64_tr<4096 * pq + 2048>(tr0[1], tr1[1]);                   // b7: Q^T
+            if constexpr (!(B64_DBG & 8) && k >= 10) FA[k - 10] = *reinterpret_cast<const p64_bf16x8_t*>(ka[(k - 10) >> 1] + nb_rows + ((k - 10) & 1) * B64_TILE);
             if constexpr (c == 0) b64_mfma_acc_a(dv[db][0], F[(2 * pp) & 3], P[GR][0][hf]);
             else if constexpr (c == 1) b64_mfma_acc_a(dv[db][1], F[(2 * pp) & 3], P[GR][1][hf]);
             else if constexpr (c == 2) b64_mfma_acc_a(dk[db][0], F[(2 * pp + 1) & 3], dS[GR][0][hf]);
             else b64_mfma_acc_a(dk[db][1], F[(2 * pp + 1) & 3], dS[GR][1][hf]);
-            // ---- vector work: finish the previous slot's pair, start this slot's ----
-            if constexpr (k > 0) {
-                constexpr int kp = k - 1, kbp = kp >> 3, ip = kp & 7;
-                const float d0 = b64_mul(e0, dP[kbp][2 * ip]), d1 = b64_mul(e1, dP[kbp][2 * ip + 1]);
-                union { p64_bf16x8_t v; unsigned u[4]; } a, d;
-                a.v = P[GW][kbp][ip >> 2];
-                a.u[ip & 3] = p64_cvt_pk(e0, e1);
-                P[GW][kbp][ip >> 2] = a.v;
-                d.v = dS[GW][kbp][ip >> 2];
-                d.u[ip & 3] = p64_cvt_pk(d0, d1);
-                dS[GW][kbp][ip >> 2] = d.v;
-            }
-            {
-                constexpr int kb = k >> 3, i = k & 7;
-                e0 = p64_exp2(S[kb][2 * i]);
-                e1 = p64_exp2(S[kb][2 * i + 1]);
-            }
+            if constexpr (k == 0) sm_fin(P64Int<3>(), P64Int<GW>());
+            else if constexpr (k & 1) sm_exp(P64Int<((k + 7) >> 1)>(), P64Int<GW>());
+            else sm_fin(P64Int<((k + 6) >> 1)>(), P64Int<GW>());
             P64_PIN();
         };
         slot(P64Int<0>()); slot(P64Int<1>()); slot(P64Int<2>()); slot(P64Int<3>());
         slot(P64Int<4>()); slot(P64Int<5>()); slot(P64Int<6>()); slot(P64Int<7>());
         slot(P64Int<8>()); slot(P64Int<9>()); slot(P64Int<10>()); slot(P64Int<11>());
         slot(P64Int<12>()); slot(P64Int<13>()); slot(P64Int<14>()); slot(P64Int<15>());
-        {   // the last pair
-            asm volatile("s_nop 0");                               // transcendental -> use
-            const float d0 = b64_mul(e0, dP[1][14]), d1 = b64_mul(e1, dP[1][15]);
-            union { p64_bf16x8_t v; unsigned u[4]; } a, d;
-            a.v = P[GW][1][1];
-            a.u[3] = p64_cvt_pk(e0, e1);
-            P[GW][1][1] = a.v;
-            d.v = dS[GW][1][1];
-            d.u[3] = p64_cvt_pk(d0, d1);
-            dS[GW][1][1] = d.v;
-        }
-        P64_PIN();
     };
     auto advance_tr = [&](int step) __attribute__((always_inline)) {
 #pragma unroll
@@ -363,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
         for (int t = 0; t < nt; ++t) {
             const int nstep = s_rd == 2 ? -2 * B64_SLOT : B64_SLOT;        // ring step current -> next tile
             const int pstep = s_rd == 0 ? -2 * B64_SLOT : B64_SLOT;        // ring step previous -> current tile
-            const int s_w = s_rd == 0 ? 2 : s_rd - 1;                      // the previous tile's slot: tile t + 2 of the stream lands there
+            const int s_w = __builtin_amdgcn_readfirstlane(s_rd == 0 ? 2 : s_rd - 1);      // the previous tile's slot: tile t + 2 of the stream lands there
             // (no next item: a harmless re-read into a slot nobody reads again)
             const Pieces pc = t + 2 < nt ? prep(cur, t + 2, s_w) : (has_next ? prep(nxt, t + 2 - nt, s_w) : prep(cur, nt - 1, s_w));
             B64_TS(0);
@@ -387,7 +431,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
             s_rd = s_rd == 2 ? 0 : s_rd + 1;
         }
         B64_TS(0);
-        // ---- the last block's dV^T / dK^T (tile nt - 1, slabs 2, 3; generation 1; tr0 / tr1 were advanced to that tile in its iteration) ----
+        // ---- the tail of the last block's softmax (pairs 11..15; in the stream it runs under the next block's first slots), then its
+        //      dV^T / dK^T (tile nt - 1, slabs 2, 3; generation 1; tr0 / tr1 were advanced to that tile in its iteration) ----
+        asm volatile("s_nop 0");
+        sm_fin(P64Int<11>(), P64Int<1>());
+        sm_exp(P64Int<12>(), P64Int<1>()); asm volatile("s_nop 0"); sm_fin(P64Int<12>(), P64Int<1>());
+        sm_exp(P64Int<13>(), P64Int<1>()); asm volatile("s_nop 0"); sm_fin(P64Int<13>(), P64Int<1>());
+        sm_exp(P64Int<14>(), P64Int<1>()); asm volatile("s_nop 0"); sm_fin(P64Int<14>(), P64Int<1>());
+        sm_exp(P64Int<15>(), P64Int<1>()); asm volatile("s_nop 0"); sm_fin(P64Int<15>(), P64Int<1>());
+        if constexpr (B64_DEFER) {
+            asm volatile("s_nop 1");
+            sm_cvt_ds(P64Int<15>(), P64Int<1>());
+        }
         p64_mfma_settle();
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
