@@ -34,19 +34,28 @@ int main(int argc, char** argv) {
     p.q_sh = p.k_sh = p.v_sh = p.o_sh = p.dq_sh = p.dk_sh = p.dv_sh = D;
     const unsigned items = (unsigned)(((N + 255) / 256) * H * B); const unsigned grid = std::min(argc > 4 ? (unsigned)atoi(argv[4]) : 256u, (items + 7) / 8 * 8);
     auto launch = [&] { hipLaunchKernelGGL(attn_bwd_dkv64_kernel, dim3(grid), dim3(256), 0, 0, p); };
+    float* dlse; CK(hipMalloc(&dlse, (size_t)B * H * N * 4));
+    { std::vector<float> l((size_t)B * H * N, 8.0f); CK(hipMemcpy(dlse, l.data(), l.size() * 4, hipMemcpyHostToDevice)); }
+    p.LSE = dlse;
+    const unsigned qitems = (unsigned)(((N + 255) / 256) * H * B), qgrid = std::min(256u, (qitems + 7) / 8 * 8);
+    auto launch_q = [&] { hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3(qgrid), dim3(256), 0, 0, p); };
+    auto launch_q_old = [&] { hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((N + 127) / 128) * H * B)), dim3(256), 0, 0, p); };
     auto launch_old = [&] { hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((N + 127) / 128) * H * B)), dim3(256), 0, 0, p); };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double fl = 4.0 * 2.0 * B * H * (double)N * N * D;
-    for (int which = 0; which < 2; ++which) {
-        for (int i = 0; i < 3; ++i) which ? launch() : launch_old();
+    for (int which = 0; which < 4; ++which) {
+        auto go = [&] { which == 0 ? launch_old() : which == 1 ? launch() : which == 2 ? launch_q_old() : launch_q(); };
+        for (int i = 0; i < 3; ++i) go();
         CK(hipDeviceSynchronize());
         const int iters = 20;
         CK(hipEventRecord(e0));
-        for (int i = 0; i < iters; ++i) which ? launch() : launch_old();
+        for (int i = 0; i < iters; ++i) go();
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double t = ms * 1e-3 / iters;
-        printf("B=%d H=%d N=%d %s: %.1f us  %.1f TFLOP/s executed (%.3f of 2500)\n", B, H, N, which ? "dkv64" : "dkv32", t * 1e6, fl / t / 1e12, fl / t / 2.5e15);
+        const double f2 = which < 2 ? fl : fl * 0.75;
+        const char* nm4[4] = {"dkv32", "dkv64", "dq32", "dq64"};
+        printf("B=%d H=%d N=%d %s: %.1f us  %.1f TFLOP/s executed (%.3f of 2500)\n", B, H, N, nm4[which], t * 1e6, f2 / t / 1e12, f2 / t / 2.5e15);
     }
 #ifdef B64_TIMING
     {

@@ -477,10 +477,17 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * H * Nq;
     (void)total;      // (delta is computed by the dQ kernel since round 4; attn_delta_kernel remains for reference)
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
-    // 64 keys per wave (attention_bwd64.h) when a 256-key workgroup is mostly real keys; the 32-key kernel otherwise
     (void)uc_knobs();
     const int k64 = g_uc_attn_bwd64.load();
+    const int64_t v_ext = ((int64_t)(B - 1) * v_sb + (int64_t)(H - 1) * v_sh + (int64_t)(Nk - 1) * v_sn + 64) * 2;
+    // 64 queries per wave (attention_bwd64.h) when a 256-query workgroup is mostly real queries; the 32-query kernel otherwise
+    const bool dq64 = Nk > 64 && v_ext < (int64_t)0xffffffffll && (k64 == 2 || (k64 == 1 && Nq >= 192 && ((Nq + 255) / 256) * 256 * 4 <= Nq * 5));
+    if (dq64) {
+        const int64_t items = (int64_t)((Nq + 255) / 256) * H * B;
+        const int grid = (int)min((int64_t)(uc_num_cus() / 8 * 8), (items + 7) / 8 * 8);
+        hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    } else hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
+    // 64 keys per wave (attention_bwd64.h) when a 256-key workgroup is mostly real keys; the 32-key kernel otherwise
     // (its Q / dO / scratch descriptors span the whole tensors: 32-bit byte offsets)
     const int64_t q_ext = ((int64_t)(B - 1) * q_sb + (int64_t)(H - 1) * q_sh + (int64_t)(Nq - 1) * q_sn + 64) * 2;
     const int64_t o_ext = ((int64_t)(B - 1) * o_sb + (int64_t)(H - 1) * o_sh + (int64_t)(Nq - 1) * o_sn + 64) * 2;

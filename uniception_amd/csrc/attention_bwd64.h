@@ -533,3 +533,391 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
     }
 #endif
 }
+
+// =====================================================================================================================================
+// attn_bwd_dq64_kernel — dQ with 64 queries per wave: the same construction turned around.  A wave owns 64 queries (two 32-query blocks);
+// K / V tiles of 64 keys stream through the ring; per 32-key granule
+//   phase A: 16 slots  S^T[qb] = K Q^T - lse2,  dP^T[qb] = V dO^T - delta   (swapped products: a query is a lane; the per-query scalars are
+//                      register blocks that hold the lane's value 16 times — built once per item)
+//   phase B:  8 slots  dQ^T[db][qb] += K^T dS^T of the PREVIOUS granule (K^T by transposing reads of the K tile)
+//   beside them the granule's softmax, one pair per slot from slot 9 of phase A to slot 2 of the next granule's: P = exp2(S^T),
+//   dS^T = P dP^T -> bf16 (P itself is not needed).
+// 48 MFMAs and 16 row + 16 transposing fragment reads per tile and wave (the 32-query kernel: 24 and 16 + 16).  The wave's stationary
+// operands (Q pre-multiplied by scale * log2(e), dO: B operands in accumulator registers), its dQ^T accumulators (accumulator registers)
+// and its per-query scalars come out of an LDS staging area that holds the NEXT item's Q / dO / O rows and LSE from the item's start;
+// delta = rowsum(dO * O) is computed there and left, with -lse2, in the scratch array for the dK / dV kernel.
+// Key rows beyond Nk read as ZEROS (per-(batch, head) descriptors): whatever their scores, they add K^T dS^T = 0 — no mask.
+#define D64_SLOT (2 * B64_TILE)
+#define D64_STAGE_OFF (3 * D64_SLOT)
+#define D64_STAGE_W (3 * B64_TILE + 256)         // per wave: Q rows | dO rows | O rows (the read-out's bounce area afterwards) | LSE[64]
+#define D64_LDS_BYTES (D64_STAGE_OFF + 4 * D64_STAGE_W)       // 145 KiB
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(AttnBwdParams p) {
+    __shared__ __attribute__((aligned(1024))) char smem[D64_LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const unsigned lds0 = (unsigned)(size_t)(ab_lds_ptr_t)smem;
+    const int nt = (p.Nk + 63) >> 6;
+
+    const int g = blockIdx.x, xcd = g & 7, slot_w = g >> 3, nslots = (int)(gridDim.x >> 3);
+    const int nbh = p.B * p.H, nqt = (p.Nq + 255) >> 8;
+    const int items_x = ((nbh - xcd + 7) >> 3) * nqt;
+    if (slot_w >= items_x) return;          // (uniform per workgroup)
+    struct Item { unsigned long long kb; unsigned ov; int b, h, q0; };
+    auto make_item = [&](int j) -> Item {
+        Item it;
+        const int kq = j / nqt, qt = j - kq * nqt;
+        const int bh = kq * 8 + xcd;
+        it.b = bh / p.H;
+        it.h = bh - it.b * p.H;
+        it.b = __builtin_amdgcn_readfirstlane(it.b);
+        it.h = __builtin_amdgcn_readfirstlane(it.h);
+        it.q0 = __builtin_amdgcn_readfirstlane(qt * 256 + wave * 64);
+        it.kb = (unsigned long long)(p.K + (int64_t)it.b * p.k_sb + (int64_t)it.h * p.k_sh);
+        it.ov = (unsigned)(((int64_t)it.b * p.v_sb + (int64_t)it.h * p.v_sh) * 2);
+        return it;
+    };
+
+    // ---- the stream: per tile and wave 2 pieces of K rows, 2 of V rows (rows 16 w .. 16 w + 15) ----
+    const unsigned kbytes = (unsigned)((((int64_t)p.Nk - 1) * p.k_sn + 64) * 2);        // key rows >= Nk read as zeros
+    const p64_uint4_t srd_v = p64_make_srd(p.V, (unsigned)((((int64_t)p.B - 1) * p.v_sb + ((int64_t)p.H - 1) * p.v_sh + ((int64_t)p.Nk - 1) * p.v_sn + 64) * 2));
+    unsigned voff_k[2], voff_v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = i * 8 + (lane >> 3);
+        const int cch = (lane & 7) ^ ((rr >> 1) & 7);
+        voff_k[i] = (unsigned)(((int64_t)rr * p.k_sn + cch * 8) * 2);
+        voff_v[i] = (unsigned)(((int64_t)rr * p.v_sn + cch * 8) * 2);
+    }
+    const unsigned kstep = (unsigned)(64 * p.k_sn * 2), vstep = (unsigned)(64 * p.v_sn * 2);
+    const unsigned k16 = (unsigned)(16 * p.k_sn * 2) * (unsigned)wave, v16 = (unsigned)(16 * p.v_sn * 2) * (unsigned)wave;
+    struct Pieces { p64_uint4_t srd_k; unsigned so_k, so_v, dst; };
+    auto prep = [&](const Item& it, int t, int s) -> Pieces {
+        Pieces pc;
+        pc.srd_k = p64_make_srd((const void*)it.kb, kbytes);
+        pc.so_k = (unsigned)t * kstep + k16;
+        pc.so_v = it.ov + (unsigned)t * vstep + v16;
+        pc.dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(s * D64_SLOT) + (unsigned)wave * 2048u);
+        return pc;
+    };
+    auto issue_piece = [&](const Pieces& pc, auto n_tag) __attribute__((always_inline)) {
+        constexpr int n = decltype(n_tag)::value;
+        if constexpr (n == 0) b64_dma16(voff_k[0], pc.srd_k, pc.so_k, pc.dst);
+        else if constexpr (n == 1) b64_dma16(voff_k[1], pc.srd_k, pc.so_k, pc.dst + 1024);
+        else if constexpr (n == 2) b64_dma16(voff_v[0], srd_v, pc.so_v, pc.dst + B64_TILE);
+        else b64_dma16(voff_v[1], srd_v, pc.so_v, pc.dst + B64_TILE + 1024);
+    };
+    auto issue_all = [&](const Pieces& pc) __attribute__((always_inline)) {
+        issue_piece(pc, P64Int<0>()); issue_piece(pc, P64Int<1>()); issue_piece(pc, P64Int<2>()); issue_piece(pc, P64Int<3>());
+    };
+    // the wave's 64 Q / dO / O rows and its 64 LSE values of an item into its staging area (query rows >= Nq read as zeros)
+    auto issue_stage = [&](const Item& it) {
+        const int64_t rows = min((int64_t)64, (int64_t)p.Nq - it.q0);
+        const bf16_t* qb = p.Q + (int64_t)it.b * p.q_sb + (int64_t)it.h * p.q_sh + (int64_t)it.q0 * p.q_sn;
+        const bf16_t* gb = p.dO + (int64_t)it.b * p.o_sb + (int64_t)it.h * p.o_sh + (int64_t)it.q0 * p.o_sn;
+        const bf16_t* ob = p.O + (int64_t)it.b * p.o_sb + (int64_t)it.h * p.o_sh + (int64_t)it.q0 * p.o_sn;
+        const float* lb = p.LSE + ((int64_t)it.b * p.H + it.h) * p.Nq + it.q0;
+        const p64_uint4_t srd_q = p64_make_srd(qb, rows > 0 ? (unsigned)(((rows - 1) * p.q_sn + 64) * 2) : 0u);
+        const p64_uint4_t srd_g = p64_make_srd(gb, rows > 0 ? (unsigned)(((rows - 1) * p.o_sn + 64) * 2) : 0u);
+        const p64_uint4_t srd_o = p64_make_srd(ob, rows > 0 ? (unsigned)(((rows - 1) * p.o_sn + 64) * 2) : 0u);
+        const p64_uint4_t srd_l = p64_make_srd(lb, rows > 0 ? (unsigned)(rows * 4) : 0u);
+        const unsigned dst = lds0 + (unsigned)(D64_STAGE_OFF + wave * D64_STAGE_W);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = i * 8 + (lane >> 3);
+            const int cch = (lane & 7) ^ ((rr >> 1) & 7);
+            const unsigned vq = (unsigned)(((int64_t)rr * p.q_sn + cch * 8) * 2), vo = (unsigned)(((int64_t)rr * p.o_sn + cch * 8) * 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                p64_dma16(vq, srd_q, (unsigned)((int64_t)(16 * k) * p.q_sn * 2), __builtin_amdgcn_readfirstlane(dst + k * 2048 + i * 1024));
+                p64_dma16(vo, srd_g, (unsigned)((int64_t)(16 * k) * p.o_sn * 2), __builtin_amdgcn_readfirstlane(dst + B64_TILE + k * 2048 + i * 1024));
+                p64_dma16(vo, srd_o, (unsigned)((int64_t)(16 * k) * p.o_sn * 2), __builtin_amdgcn_readfirstlane(dst + 2 * B64_TILE + k * 2048 + i * 1024));
+            }
+        }
+        b64_dma4((unsigned)lane * 4u, srd_l, 0u, __builtin_amdgcn_readfirstlane(dst + 3 * B64_TILE));
+    };
+
+    int j = slot_w;
+    Item cur = make_item(j);
+    Item nxt = cur;
+    bool has_next = j + nslots < items_x;
+    if (has_next) nxt = make_item(j + nslots);
+    issue_stage(cur);
+    issue_all(prep(cur, 0, 0));
+    issue_all(prep(cur, nt > 1 ? 1 : 0, 1));
+    {   // ring slot 2 is read as "the tile before tile 0" by the first phase B (beside dS = 0): finite data
+        uint4* z = reinterpret_cast<uint4*>(smem + 2 * D64_SLOT);
+#pragma unroll
+        for (int i = 0; i < B64_TILE / 16 / 256; ++i) z[i * 256 + tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    p64_bf16x8_t qf[2][4], dof[2][4];      // stationary B operands: lane query = qb * 32 + l31, channels 16 st + 8 hi .. + 7; Q carries scale * log2(e)
+    float16_t dq[2][2];                    // [channel block db][query block qb], transposed: row = channel, column = query
+    float16_t S[2], dP[2];                 // [query block]: rows = the granule's 32 keys, column = the lane's query
+    float16_t neg_lse[2], neg_dlt[2];      // the chains' start values: the lane's scalars, 16 times
+    p64_bf16x8_t dS[2][2][2];              // [generation][query block][16-key slab]
+    p64_bf16x8_t FA[8], F[4];
+    float e0 = 0.f, e1 = 0.f, d0 = 0.f, d1 = 0.f;
+
+    const char* ka[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) ka[st] = smem + bswz(l31, 2 * st + hi);
+    const char* tr0[2];
+    const char* tr1[2];
+    {
+        const int jj = lane & 15, piece = jj & 3;
+        const int row0 = 4 * (lane >> 5) + (jj >> 2), row1 = row0 + 8;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int chunk = ((db * 32 + (((lane >> 4) & 1) << 4)) >> 3) + (piece >> 1);
+            tr0[db] = smem + 2 * D64_SLOT + row0 * 128 + ((chunk ^ ((row0 >> 1) & 7)) << 4) + ((piece & 1) << 3);      // (starts at ring slot 2)
+            tr1[db] = smem + 2 * D64_SLOT + row1 * 128 + ((chunk ^ ((row1 >> 1) & 7)) << 4) + ((piece & 1) << 3);
+        }
+    }
+    int s_rd = 0;
+
+    // the wave's stationary operands and scalars out of its staging area (landed); delta and -lse2 into the scratch array
+    auto load_stationary = [&](const Item& it) __attribute__((always_inline)) {
+        const char* sq = smem + D64_STAGE_OFF + wave * D64_STAGE_W;
+        const float c = p.scale * 1.44269504088896340736f;
+        float* ax = p.aux + ((int64_t)it.b * p.H + it.h) * 2 * p.nq_pad;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float dlt = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                union { p64_bf16x8_t v; unsigned u[4]; } a;
+                a.v = *reinterpret_cast<const p64_bf16x8_t*>(sq + qb * 4096 + bswz(l31, 2 * st + hi));
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) a.u[q4] = pack_bf16x2(__uint_as_float(a.u[q4] << 16) * c, __uint_as_float(a.u[q4] & 0xffff0000u) * c);
+                qf[qb][st] = a.v;
+                const p64_bf16x8_t gf = *reinterpret_cast<const p64_bf16x8_t*>(sq + B64_TILE + qb * 4096 + bswz(l31, 2 * st + hi));
+                const p64_bf16x8_t of = *reinterpret_cast<const p64_bf16x8_t*>(sq + 2 * B64_TILE + qb * 4096 + bswz(l31, 2 * st + hi));
+                dof[qb][st] = gf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dlt = fmaf((float)of[e], (float)gf[e], dlt);
+            }
+            dlt += __shfl_xor(dlt, 32, 64);
+            const float lse2 = *reinterpret_cast<const float*>(sq + 3 * B64_TILE + (qb * 32 + l31) * 4) * 1.44269504088896340736f;
+            const int q = it.q0 + qb * 32 + l31;
+            if (hi == 0 && q < p.nq_pad) {      // (every query slot up to nq_pad gets its pair: the dK / dV kernel reads whole 64-query tiles of them)
+                ax[q] = q < p.Nq ? -lse2 : -1e30f;
+                ax[p.nq_pad + q] = q < p.Nq ? -dlt : 0.f;
+            }
+            float16_t nl, nd;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { nl[r] = -lse2; nd[r] = -dlt; }
+            asm volatile("" : "+v"(nl), "+v"(nd));      // opaque: a splat hipcc recognises is re-materialised (16 v_mov) per use
+            neg_lse[qb] = nl;
+            neg_dlt[qb] = nd;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) dq[i][k] = (float16_t)(0.f);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) dS[1][qb][hf] = (p64_bf16x8_t)(0.f);       // generation 1 = "granule -1"
+        // the item's first phase A finishes "granule -1"'s softmax (pairs 13..15, query block 1): exp2(-1e30) = 0, 0 * 0 = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[1][r] = -1e30f; dP[1][r] = 0.f; }
+        e0 = 0.f; e1 = 0.f; d0 = 0.f; d1 = 0.f;
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_stationary(cur);
+    if (has_next) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_stage(nxt);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) FA[m] = *reinterpret_cast<const p64_bf16x8_t*>(ka[m >> 1] + (m & 1) * B64_TILE);
+
+    // softmax pair q of a granule: query block q >> 3, accumulator rows 2 (q & 7), + 1 (keys).  A slot runs, in this order, the conversion of
+    // pair C's products (computed a slot earlier), the products of pair F (exponentials a slot earlier), the exponentials of pair E.
+    auto sm = [&](auto c_tag, auto f_tag, auto e_tag, auto gen_tag) __attribute__((always_inline)) {
+        constexpr int C = decltype(c_tag)::value, Fq = decltype(f_tag)::value, E = decltype(e_tag)::value, G = decltype(gen_tag)::value;
+        if constexpr (B64_DBG & 1) return;
+        if constexpr (C >= 0) {
+            union { p64_bf16x8_t v; unsigned u[4]; } d;
+            d.v = dS[G][C >> 3][(C & 7) >> 2];
+            d.u[C & 3] = p64_cvt_pk(d0, d1);
+            dS[G][C >> 3][(C & 7) >> 2] = d.v;
+        }
+        if constexpr (Fq >= 0) {
+            d0 = b64_mul(e0, dP[Fq >> 3][2 * (Fq & 7)]);
+            d1 = b64_mul(e1, dP[Fq >> 3][2 * (Fq & 7) + 1]);
+        }
+        if constexpr (E >= 0) {
+            e0 = p64_exp2(S[E >> 3][2 * (E & 7)]);
+            e1 = p64_exp2(S[E >> 3][2 * (E & 7) + 1]);
+        }
+    };
+    // ---- phase A of key granule kb of the current tile: slot k: query block k >> 3, chunk pair st = (k & 7) >> 1, even: S^T, odd: dP^T;
+    //      row fragments FA[2 st] (K rows), FA[2 st + 1] (V rows) were read by the previous phase B.  Beside it: the tail of the previous
+    //      granule's softmax (slots 0..3), the head of this one's (from slot 9), the first transposed fragments of phase B (slots 11, 13, 15),
+    //      in the odd granule of a tile the four pieces of tile t + 2 (slots 4..7) ----
+    auto phase_a = [&](auto kb_tag, const Pieces& pc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kb_tag)::value, pq = kb ^ 1;
+        typedef P64Int<-1> N_;
+        auto slot = [&](auto k_tag) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value, st = (k & 7) >> 1, qb = k >> 3;
+            if constexpr (!(B64_DBG & 4) && k == 11) F[0] = b64_tr<4096 * pq>(tr0[0], tr1[0]);            // slab 2 pq, channel block 0
+            if constexpr (!(B64_DBG & 4) && k == 13) F[1] = b64_tr<4096 * pq>(tr0[1], tr1[1]);            // slab 2 pq, channel block 1
+            if constexpr (!(B64_DBG & 4) && k == 15) F[2] = b64_tr<4096 * pq + 2048>(tr0[0], tr1[0]);     // slab 2 pq + 1, channel block 0
+            if constexpr (kb == 1 && !(B64_DBG & 16)) {
+                if constexpr (k == 4) issue_piece(pc, P64Int<0>());
+                if constexpr (k == 5) issue_piece(pc, P64Int<1>());
+                if constexpr (k == 6) issue_piece(pc, P64Int<2>());
+                if constexpr (k == 7) issue_piece(pc, P64Int<3>());
+            }
+            if constexpr ((k & 7) == 0) b64_mfma_first_b(S[qb], FA[0], qf[qb][0], neg_lse[qb]);
+            else if constexpr ((k & 7) == 1) b64_mfma_first_b(dP[qb], FA[1], dof[qb][0], neg_dlt[qb]);
+            else if constexpr ((k & 1) == 0) b64_mfma_acc_b(S[qb], FA[2 * st], qf[qb][st]);
+            else b64_mfma_acc_b(dP[qb], FA[2 * st + 1], dof[qb][st]);
+            if constexpr (k == 0) sm(P64Int<12>(), P64Int<13>(), P64Int<14>(), P64Int<kb ^ 1>());
+            if constexpr (k == 1) sm(P64Int<13>(), P64Int<14>(), P64Int<15>(), P64Int<kb ^ 1>());
+            if constexpr (k == 2) sm(P64Int<14>(), P64Int<15>(), N_(), P64Int<kb ^ 1>());
+            if constexpr (k == 3) sm(P64Int<15>(), N_(), N_(), P64Int<kb ^ 1>());
+            if constexpr (k == 9) sm(N_(), N_(), P64Int<0>(), P64Int<kb>());
+            if constexpr (k == 10) sm(N_(), P64Int<0>(), P64Int<1>(), P64Int<kb>());
+            if constexpr (k >= 11) sm(P64Int<k - 11>(), P64Int<k - 10>(), P64Int<k - 9>(), P64Int<kb>());
+            P64_PIN();
+        };
+        slot(P64Int<0>()); slot(P64Int<1>()); slot(P64Int<2>()); slot(P64Int<3>());
+        slot(P64Int<4>()); slot(P64Int<5>()); slot(P64Int<6>()); slot(P64Int<7>());
+        slot(P64Int<8>()); slot(P64Int<9>()); slot(P64Int<10>()); slot(P64Int<11>());
+        slot(P64Int<12>()); slot(P64Int<13>()); slot(P64Int<14>()); slot(P64Int<15>());
+    };
+    // ---- phase B behind phase A of granule kb: dQ^T += K^T dS^T of the previous granule (generation kb ^ 1; the tile tr0 / tr1 point at,
+    //      slabs 2 pq, 2 pq + 1): slot k: fragment k >> 1 = (slab hf, channel block db), query block k & 1; the next granule's row fragments,
+    //      one per slot, from nb_rows ----
+    auto phase_b = [&](auto kb_tag, int nb_rows) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kb_tag)::value, GR = kb ^ 1, pq = kb ^ 1;
+        typedef P64Int<-1> N_;
+        auto slot = [&](auto k_tag) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value, pp = k >> 1, hf = pp >> 1, db = pp & 1, qb = k & 1;
+            if constexpr (!(B64_DBG & 4) && k == 1) F[3] = b64_tr<4096 * pq + 2048>(tr0[1], tr1[1]);      // slab 2 pq + 1, channel block 1
+            if constexpr (!(B64_DBG & 8)) FA[k] = *reinterpret_cast<const p64_bf16x8_t*>(ka[k >> 1] + nb_rows + (k & 1) * B64_TILE);
+            b64_mfma_acc_a(dq[db][qb], F[pp], dS[GR][qb][hf]);
+            if constexpr (k == 0) sm(P64Int<5>(), P64Int<6>(), P64Int<7>(), P64Int<kb>());
+            if constexpr (k == 1) sm(P64Int<6>(), P64Int<7>(), N_(), P64Int<kb>());
+            if constexpr (k == 2) sm(P64Int<7>(), N_(), P64Int<8>(), P64Int<kb>());
+            if constexpr (k == 3) sm(N_(), P64Int<8>(), P64Int<9>(), P64Int<kb>());
+            if constexpr (k >= 4) sm(P64Int<k + 4>(), P64Int<k + 5>(), P64Int<k + 6>(), P64Int<kb>());
+            P64_PIN();
+        };
+        slot(P64Int<0>()); slot(P64Int<1>()); slot(P64Int<2>()); slot(P64Int<3>());
+        slot(P64Int<4>()); slot(P64Int<5>()); slot(P64Int<6>()); slot(P64Int<7>());
+    };
+    auto advance_tr = [&](int step) __attribute__((always_inline)) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { tr0[db] += step; tr1[db] += step; }
+    };
+
+    for (;;) {
+        for (int t = 0; t < nt; ++t) {
+            const int nstep = s_rd == 2 ? -2 * D64_SLOT : D64_SLOT;        // ring step current -> next tile
+            const int pstep = s_rd == 0 ? -2 * D64_SLOT : D64_SLOT;        // ring step previous -> current tile
+            const int s_w = __builtin_amdgcn_readfirstlane(s_rd == 0 ? 2 : s_rd - 1);
+            const Pieces pc = t + 2 < nt ? prep(cur, t + 2, s_w) : (has_next ? prep(nxt, t + 2 - nt, s_w) : prep(cur, nt - 1, s_w));
+            phase_a(P64Int<0>(), pc);
+            phase_b(P64Int<0>(), 4096);
+            advance_tr(pstep);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            phase_a(P64Int<1>(), pc);
+            phase_b(P64Int<1>(), nstep);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) ka[st] += nstep;
+            s_rd = s_rd == 2 ? 0 : s_rd + 1;
+        }
+        // ---- the tail of the last granule's softmax (generation 1), then its dQ^T (tile nt - 1, slabs 2, 3) ----
+        {
+            typedef P64Int<-1> N_;
+            asm volatile("s_nop 0");
+            sm(P64Int<12>(), P64Int<13>(), P64Int<14>(), P64Int<1>()); asm volatile("s_nop 0");
+            sm(P64Int<13>(), P64Int<14>(), P64Int<15>(), P64Int<1>()); asm volatile("s_nop 0");
+            sm(P64Int<14>(), P64Int<15>(), N_(), P64Int<1>()); asm volatile("s_nop 0");
+            sm(P64Int<15>(), N_(), N_(), P64Int<1>());
+        }
+        p64_mfma_settle();
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const p64_bf16x8_t tk = hf ? b64_tr<4096 + 2048>(tr0[db], tr1[db]) : b64_tr<4096>(tr0[db], tr1[db]);
+                b64_mfma_acc_a(dq[db][0], tk, dS[1][0][hf]);
+                b64_mfma_acc_a(dq[db][1], tk, dS[1][1][hf]);
+            }
+        p64_mfma_settle();
+
+        // ---- read-out: inverse RoPE, scale, bf16, bounced through the O rows of the staging area (delta of the NEXT item, which needs
+        //      them, is taken first: load_stationary below reads only Q and dO ... so the next item's O rows must be consumed before) ----
+        // (order: the next item's stationary operands are loaded BEFORE the bounce overwrites its O rows; the read-out values wait in registers)
+        float16_t out[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float16_t gq[2] = {dq[0][qb], dq[1][qb]};
+            if (p.rope_qpos) {
+                const int q = cur.q0 + qb * 32 + l31, qc = q < p.Nq ? q : p.Nq - 1;
+                ab_rope_inverse(gq, p.rope_qpos + ((int64_t)cur.b * p.Nq + qc) * 2, hi, p.rope_turn0, p.rope_ratio);
+            }
+            out[0][qb] = gq[0];
+            out[1][qb] = gq[1];
+        }
+        const Item done = cur;
+        const bool more = has_next;
+        if (more) {
+            j += nslots;
+            cur = nxt;
+            has_next = j + nslots < items_x;
+            if (has_next) nxt = make_item(j + nslots);
+            load_stationary(cur);                                   // (its staging pieces were issued an item ago and waited for by the tile loop's vmcnt(0))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staging area has been read
+        }
+        {
+            char* ob = smem + D64_STAGE_OFF + wave * D64_STAGE_W + 2 * B64_TILE;
+            const int64_t rows = min((int64_t)64, (int64_t)p.Nq - done.q0);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(out[db][qb][g4 * 4 + 0] * p.scale, out[db][qb][g4 * 4 + 1] * p.scale);
+                        pk.y = pack_bf16x2(out[db][qb][g4 * 4 + 2] * p.scale, out[db][qb][g4 * 4 + 3] * p.scale);
+                        *reinterpret_cast<uint2*>(ob + qb * 4096 + l31 * 128 + (((4 * db + g4) ^ (l31 & 7)) << 4) + hi * 8) = pk;
+                    }
+            uint4 rw[8];
+            {
+                const unsigned oa = lds0 + (unsigned)(D64_STAGE_OFF + wave * D64_STAGE_W + 2 * B64_TILE) + (unsigned)(lane >> 3) * 128u + ((unsigned)(lane & 7) << 4);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                             "ds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\tds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(rw[0]), "=&v"(rw[1]), "=&v"(rw[2]), "=&v"(rw[3]), "=&v"(rw[4]), "=&v"(rw[5]), "=&v"(rw[6]), "=&v"(rw[7])
+                             : "v"(oa) : "memory");
+            }
+            const bf16_t* gw = p.dQ + (int64_t)done.b * p.dq_sb + (int64_t)done.h * p.dq_sh + (int64_t)done.q0 * p.dq_sn;
+            const unsigned gbytes = rows > 0 ? (unsigned)(((rows - 1) * p.dq_sn + 64) * 2) : 0u;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gw, 0, (int)gbytes, 0x00020000);
+            const int R = lane >> 3;
+            const unsigned vo = (unsigned)(((int64_t)R * p.dq_sn + (((lane & 7) ^ (R & 7)) * 8)) * 2);
+            const unsigned o8 = (unsigned)(8 * p.dq_sn * 2);
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 d = {rw[ps].x, rw[ps].y, rw[ps].z, rw[ps].w};
+                __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)vo, (int)(ps * o8), 0);
+            }
+        }
+        if (!more) break;
+        if (has_next) issue_stage(nxt);         // (behind the bounce reads: lgkmcnt(0) inside the asm above)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
