@@ -250,6 +250,34 @@ def test_attention_backward_with_the_inverse_rope_inside(gpu):
         assert rel_l2(dq1.float().cpu(), dq0.float().cpu()) < 6e-3 and rel_l2(dk1.float().cpu(), dk0.float().cpu()) < 6e-3   # (one bf16 rounding instead of two)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 196, 196), (1, 2, 1024, 1024), (1, 2, 1370, 1370), (1, 1, 77, 130), (1, 2, 300, 1000), (2, 2, 1000, 300),
+                                       (3, 5, 256, 512), (20, 16, 512, 512)])
+def test_attention_backward_64_row_kernels_are_bitwise_the_32_row_kernels(gpu, B, H, Nq, Nk):
+    """attn_bwd_dq64_kernel / attn_bwd_dkv64_kernel (attention_bwd64.h; tuning knob attn_bwd64 = 2: wherever the shape allows) run the SAME
+    MFMA chains in the same order as the 32-row kernels (knob 0) — persistent workgroups, 64 rows per wave, hand-placed slots: every
+    bit of dQ, dK, dV must agree.  Shapes: ragged against the 64-row tiles and the 256-row workgroups, cross-attention both ways,
+    (batch, head) counts that are not multiples of the 8 XCDs, and more items than workgroups (20 x 16 x 2 = 640 > 256: item seams);
+    with and without the inverse RoPE in the epilogues, on strided views of one fused buffer."""
+    from uniception_amd import ops
+    g = torch.Generator().manual_seed(Nq * 13 + Nk)
+    q = torch.randn(B, Nq, 2, H, 64, generator=g).bfloat16().to(gpu)[:, :, 1]
+    kv = torch.randn(B, Nk, 2, H, 64, generator=g).bfloat16().to(gpu)
+    k, v = kv[:, :, 0], kv[:, :, 1]
+    do = torch.randn(B, Nq, H, 64, generator=g).bfloat16().to(gpu)
+    lse = torch.empty(B, H, Nq, dtype=torch.float32, device=gpu)
+    o = ops.attention(q, k, ops.vt_pack(v.contiguous()), 0.125, v_packed=True, lse=lse)
+    qpos = torch.randint(0, 40, (B * Nq, 2), generator=g).to(gpu)
+    kpos = torch.randint(0, 40, (B * Nk, 2), generator=g).to(gpu)
+    for rope in (None, (qpos, kpos, 100.0, 1.0)):
+        with ops.tuning("attn_bwd64", 0):
+            ref = ops.attention_bwd(q, k, v, o, do, lse, 0.125, rope=rope)
+        with ops.tuning("attn_bwd64", 2):
+            got = ops.attention_bwd(q, k, v, o, do, lse, 0.125, rope=rope)
+        for a, b, name in zip(got, ref, ("dq", "dk", "dv")):
+            assert torch.equal(a, b), f"{name} differs (rope={rope is not None}): max |diff| {float((a.float() - b.float()).abs().max())}"
+        assert all(bool(torch.isfinite(t.float()).all()) for t in got)
+
+
 # ------------------------------------------------------------------------------------------
 # DPT head backward helpers
 # ------------------------------------------------------------------------------------------

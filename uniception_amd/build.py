@@ -105,7 +105,8 @@ def check_glds4_agprs(fp=None, verbose=True):
       only while the compiler itself touches no AGPR in that kernel.  UC_GEMM_4WAVE=0 in the environment (the knob that keeps the
       kernel from ever being launched) skips this proof, so that a compiler that fails it still gets a usable library (ADVICE r4);
     * attn_bf16_p64_kernel places every MFMA through inline asm and guarantees the wait states to the readers IT places: it must
-      compile without scratch, register spills or AGPRs."""
+      compile without scratch, register spills or AGPRs; the 64-row attention backward kernels (attention_bwd64.h) likewise without
+      scratch or spills."""
     fp = fp or _fingerprint()
     mark = LIB + ".agpr"
     skip4 = os.environ.get("UC_GEMM_4WAVE", "") == "0"
@@ -140,9 +141,16 @@ def check_glds4_agprs(fp=None, verbose=True):
         if r["scratch"] != 0 or r["vgpr_spills"] != 0 or r["agprs"] != 0:
             raise RuntimeError(f"[uniception_amd.build] {name}: {r}: the persistent attention kernel must compile without scratch, spills or AGPRs "
                                "(a spill of an asm MFMA's result is read before it is written) — set UC_ATTN_P64=0 at run time and report")
+    b64 = chk.check_p64("attention_bwd.hip", "attn_bwd_d(kv|q)64_kernel")
+    if len(b64) < 2:
+        raise RuntimeError(f"[uniception_amd.build] found {len(b64)} 64-row attention backward kernels in attention_bwd.hip (expected 2)")
+    for name, r in b64.items():
+        if r["scratch"] != 0 or r["vgpr_spills"] != 0:
+            raise RuntimeError(f"[uniception_amd.build] {name}: {r}: the 64-row attention backward kernels must compile without scratch or spills "
+                               "(a spill of an asm MFMA's result is read before it is written) — set UC_ATTN_BWD64=0 at run time and report")
     if verbose:
         print(f"[uniception_amd.build] generated-code proofs: {n} gemm_bf16_glds4_kernel instantiations clean, {len(p64)} attn_bf16_p64_kernel "
-              "instantiations without scratch / spills / AGPRs", flush=True)
+              f"instantiations without scratch / spills / AGPRs, {len(b64)} 64-row attention backward kernels without scratch / spills", flush=True)
     if not skip4:
         with open(mark, "w") as f:
             f.write(fp)

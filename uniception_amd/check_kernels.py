@@ -9,6 +9,8 @@ build fingerprint; tools/check_glds4_agprs.py is the command-line front end).
    a reader of its result, and the kernel guarantees them by construction for the readers IT places — a compiler-generated spill of a
    score register right behind the MFMA that writes it would read garbage.  The kernel must therefore compile without any scratch
    (.private_segment_fixed_size 0, .vgpr_spill_count 0) and without AGPRs (a kernel that uses any gets its budget split 128 / 128).
+3. attn_bwd_dkv64_kernel / attn_bwd_dq64_kernel (attention_bwd64.h): the same construction at one wave per SIMD (accumulators and
+   stationary operands in AGPRs by design): no scratch, no spills to memory.
 """
 import os
 import re
@@ -52,13 +54,13 @@ def check(tu):
     return report
 
 
-def check_p64(tu="attention.hip"):
-    "{kernel name: {scratch bytes, vgpr spills, agprs}} of the attn_bf16_p64_kernel instantiations (code-object metadata of the device assembly)"
+def check_p64(tu="attention.hip", pattern="attn_bf16_p64_kernel"):
+    "{kernel name: {scratch bytes, vgpr spills, agprs}} of the kernels whose name contains `pattern` (code-object metadata of the device assembly)"
     txt = _device_asm(tu)
     report = {}
     # the amdhsa.kernels metadata: one YAML map per kernel
     for blk in re.split(r"\n  - (?=\.agpr_count:|\.args:)", txt):
-        m = re.search(r"\.name:\s+(\S*attn_bf16_p64_kernel\S*)", blk)
+        m = re.search(r"\.name:\s+(\S*" + pattern + r"\S*)", blk)
         if not m:
             continue
         def num(key):
