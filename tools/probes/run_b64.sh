@@ -8,5 +8,5 @@ for fl in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Wno-inline-asm $fl tools/probes/attn_bwd64_probe.hip -o /tmp/b64 || continue
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Wno-inline-asm -DB64_TIMING $fl tools/probes/attn_bwd64_probe.hip -o /tmp/b64t || continue
   for args in "128 16 1024" "16 16 4096"; do timeout 120 /tmp/b64 $args; done 2>&1 | grep -v "dkv32" | tee -a gpurun_out/b64_probe.txt
-  timeout 120 /tmp/b64t 128 16 1024 2>&1 | grep "wg    9" | tee -a gpurun_out/b64_probe.txt
+  timeout 120 /tmp/b64t 128 16 1024 2>&1 | grep "wg    9\|wg 9" | tee -a gpurun_out/b64_probe.txt
 done
