@@ -459,8 +459,18 @@ def test_gemm_small_m_fused_k_split(gpu, M, N, K):
         out = torch.empty(M, N, device=gpu, dtype=torch.float32)
         ops.gemm(a, w, b, residual=res32, out=out)          # (the stream's workspace is created outside the capture)
         torch.cuda.synchronize()
+        # (a capture belongs to a graph: ops.capture_scope(token) names it, fuse_ws_release(token) hands its buffers back — what
+        # uniception_amd.graphs does; a capture WITHOUT a scope has no owner for a hand-over buffer and runs unsplit: correct, other bits)
+        graph0 = torch.cuda.CUDAGraph()
+        out0 = torch.empty(M, N, device=gpu, dtype=torch.float32)
+        with torch.cuda.graph(graph0, stream=st):
+            ops.gemm(a, w, b, residual=res32, out=out0)
+        graph0.replay()
+        torch.cuda.synchronize()
+        with ops.tuning("small_m_split", 0):
+            assert torch.equal(out0, ops.gemm(a, w, b, residual=res32, out_dtype=torch.float32))
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=st):
+        with torch.cuda.graph(graph, stream=st), ops.capture_scope(0x7e57_0001):
             ops.gemm(a, w, b, residual=res32, out=out)
     for _ in range(3):
         out.zero_()
@@ -471,7 +481,7 @@ def test_gemm_small_m_fused_k_split(gpu, M, N, K):
     with torch.cuda.stream(st):
         out2 = torch.empty(M, N, device=gpu, dtype=torch.float32)
         graph2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph2, stream=st):
+        with torch.cuda.graph(graph2, stream=st), ops.capture_scope(0x7e57_0002):
             for _ in range(4):
                 ops.gemm(a, w, b, residual=res32, out=out2)
     torch.cuda.synchronize()
@@ -485,6 +495,9 @@ def test_gemm_small_m_fused_k_split(gpu, M, N, K):
             graph2.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, outs[0]) and torch.equal(out2, outs[0])
+    del graph, graph2
+    ops.fuse_ws_release(0x7e57_0001)
+    ops.fuse_ws_release(0x7e57_0002)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
