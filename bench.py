@@ -99,7 +99,7 @@ def roofline_pass(step_fn, v1, precision, steps):
             e0.record()
             out = fn(*args, **kw)
             e1.record()
-            fam, fl, by = work(out, *args, **kw)
+            fam, fl, by = work(out, *args, **{k_: v_ for k_, v_ in kw.items() if k_ != "out"})
             rec.setdefault(fam or family, []).append((e0, e1, fl, by))
             return out
         return wrapped
@@ -134,6 +134,18 @@ def roofline_pass(step_fn, v1, precision, steps):
         Nk = k.shape[1]
         return None, 4.0 * B_ * H_ * Nq * Nk * D_, nbytes(out) + 2.0 * q.element_size() * B_ * H_ * D_ * (Nq / 2 + Nk)   # Q + K + V read, O written
 
+    def attn_bwd_work(res, q, k, v, o, do, *args, **kw):     # the five algorithmic products (2.5 x the forward), whatever the kernels recompute
+        B_, Nq, H_, D_ = q.shape
+        Nk = k.shape[1]
+        return None, 10.0 * B_ * H_ * Nq * Nk * D_, nbytes(q, k, v, o, do, *res)
+
+    def gemm_tn_work(res, a, b, *args, **kw):                # weight gradients: sum over T tokens / output pixels of a[t,i] b[t,j]
+        T_, I_ = a.shape
+        conv = kw.get("conv")
+        J_ = 9 * b.shape[-1] if conv is not None else b.shape[1]
+        ws = res[0] if isinstance(res, tuple) else res
+        return ("conv3x3_wgrad" if conv is not None else "gemm_wgrad"), 2.0 * T_ * I_ * J_, nbytes(a, b, ws)
+
     def io_work(out, x, *args, **kw):
         outs = out if isinstance(out, (tuple, list)) else (out,)
         return None, 0.0, nbytes(x, *outs)
@@ -142,7 +154,9 @@ def roofline_pass(step_fn, v1, precision, steps):
             "bilinear_nhwc": ("bilinear", io_work), "pointmap_adaptor": ("adaptor", io_work), "adaptor_program": ("adaptor", io_work),
             "patch_gather": ("patch_gather", io_work), "convert": ("convert", io_work), "convt_scatter": ("convt_scatter", io_work),
             "pixel_shuffle": ("pixel_shuffle", io_work), "conv1x1_to4": ("conv1x1_to4", io_work), "layernorm": ("layernorm", io_work),
-            "nchw_to_nhwc": ("layout", io_work), "nhwc_to_nchw": ("layout", io_work)}
+            "nchw_to_nhwc": ("layout", io_work), "nhwc_to_nchw": ("layout", io_work),
+            # the training step's own families
+            "attention_bwd": ("attention_bwd", attn_bwd_work), "gemm_tn": ("gemm_wgrad", gemm_tn_work)}
     for name, (fam, work) in plan.items():
         saved[name] = getattr(ops, name)
         setattr(ops, name, bracket(fam, saved[name], work))
