@@ -20,6 +20,7 @@ import weakref
 from typing import Optional
 
 import torch
+import torch.nn as nn
 from torch.autograd import Function
 
 from . import engine, ops
@@ -238,6 +239,30 @@ def _bwd_rope(rope, qpos, kpos, dt):
     return (engine._pos2d(qpos), engine._pos2d(kpos), rope.base, rope.F0)
 
 
+def _norm_or_none(norm):
+    return None if norm is None or isinstance(norm, nn.Identity) else norm
+
+
+def _qknorm_fwd(view4, norm):
+    """qk_norm (utils/transformer_blocks.py:196-197, 229): LayerNorm over head_dim of a [B, N, H, Dh] view of q / k, BEFORE the positional
+    encoding -> contiguous [B, N, H, Dh] in the same dtype."""
+    if not isinstance(norm, nn.LayerNorm) or norm.weight is None or norm.bias is None:
+        raise UcHipError(f"qk_norm with {type(norm).__name__} has no HIP path (nn.LayerNorm with affine parameters only)")
+    pre = view4.contiguous()
+    Dh = pre.shape[-1]
+    return ops.layernorm(pre.view(-1, Dh), norm.weight.detach().float(), norm.bias.detach().float(), norm.eps, pre.dtype).view(pre.shape)
+
+
+def _qknorm_bwd(view4, norm, dn):
+    "(d view4 [contiguous], dgamma, dbeta) of _qknorm_fwd: uc_layernorm_bwd over B N H rows of head_dim (its 64-wide kernel)."
+    pre = view4.contiguous()
+    Dh = pre.shape[-1]
+    g = norm.weight.detach().float()
+    dg, db = torch.zeros_like(g), torch.zeros_like(g)
+    dpre = ops.layernorm_bwd(pre.view(-1, Dh), g, dn.contiguous().view(-1, Dh), norm.eps, dg, db)
+    return dpre.view(pre.shape), dg, db
+
+
 def _attention_fwd(q, k, v, scale, lse):
     if q.dtype == torch.bfloat16:
         if q.shape[-1] != 64:
@@ -367,7 +392,8 @@ class SelfAttnSubLayerFn(Function):
     """x + proj(SDPA(rope(q), rope(k), v)),  q,k,v = qkv(LN(x))   (blocks.py:105-125,154-158; transformer_blocks.py:214-260)."""
 
     @staticmethod
-    def forward(ctx, x2d, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None):
+    def forward(ctx, x2d, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None,
+                qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None):
         x2d = _c(x2d)
         M, C = x2d.shape
         Dh = C // H
@@ -376,7 +402,19 @@ class SelfAttnSubLayerFn(Function):
         h = ops.layernorm(x2d, g, bta, ln.eps, dt)
         wq, bq = engine.lin_weights(qkv, dt)
         wp, bp = engine.lin_weights(proj, dt) if gamma is None else engine.layerscale_lin_weights(proj, gamma, dt)
-        if dt == torch.bfloat16 and rope is not None:
+        qkn = None
+        if qn is not None or kn is not None:
+            # qk_norm: q / k are normalised over head_dim BEFORE the positional encoding — the unfused route (t keeps the RAW q | k | v;
+            # the normalised, rotated q / k the attention sees are saved next to it)
+            t = ops.gemm(h, wq, bq)
+            t5 = t.view(B, N, 3, H, Dh)
+            qx = _qknorm_fwd(t5[:, :, 0], qn) if qn is not None else t5[:, :, 0].contiguous()
+            kx = _qknorm_fwd(t5[:, :, 1], kn) if kn is not None else t5[:, :, 1].contiguous()
+            if rope is not None:
+                ops.rope_2d_(qx, pos.contiguous(), rope.base, rope.F0)
+                ops.rope_2d_(kx, pos.contiguous(), rope.base, rope.F0)
+            qkn = (qx, kx)
+        elif dt == torch.bfloat16 and rope is not None:
             if Dh != 64:
                 raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh})")
             t = ops.gemm(h, wq, bq, rope=engine._rope_epilogue(rope, engine._pos2d(pos), 2 * C))
@@ -388,18 +426,21 @@ class SelfAttnSubLayerFn(Function):
                 ops.rope_2d_(t5[:, :, 0], pos.contiguous(), rope.base, rope.F0)
                 ops.rope_2d_(t5[:, :, 1], pos.contiguous(), rope.base, rope.F0)
         lse = torch.empty((B, H, N), dtype=torch.float32, device=x2d.device)
-        o = _attention_fwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], scale, lse)
+        o = _attention_fwd(*(qkn if qkn is not None else (t5[:, :, 0], t5[:, :, 1])), t5[:, :, 2], scale, lse)
         out = ops.gemm(o.view(M, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
         # (gamma goes through save_for_backward: autograd's version check then catches an in-place edit between forward and backward)
-        ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0), *(() if gamma is None else (gamma,)))
-        ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None)
+        ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0), *(() if qkn is None else qkn),
+                              *(() if gamma is None else (gamma,)))
+        ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None, qn, kn, qkn is not None)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
         x2d, g, h, t, o, lse, pos, *rest = ctx.saved_tensors
+        ln, qkv, proj, B, N, H, rope, scale, dt, has_bq, has_bp, qn, kn, has_qkn = ctx.meta
+        qx, kx = (rest[0], rest[1]) if has_qkn else (None, None)
+        rest = rest[2:] if has_qkn else rest
         gamma = rest[0] if rest else None
-        ln, qkv, proj, B, N, H, rope, scale, dt, has_bq, has_bp = ctx.meta
         M, C = x2d.shape
         Dh = C // H
         dxo = _c(dxo)
@@ -415,24 +456,41 @@ class SelfAttnSubLayerFn(Function):
         dt3 = torch.empty_like(t)
         d5, t5 = dt3.view(B, N, 3, H, Dh), t.view(B, N, 3, H, Dh)
         fused_rope = _bwd_rope(rope, pos, pos, dt)      # (bf16: the inverse rotation of dq / dk rides in the backward kernels)
-        ops.attention_bwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale,
-                          out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]), rope=fused_rope)
-        if fused_rope is None:
-            _rope_inverse_(d5[:, :, 0], pos, rope)
-            _rope_inverse_(d5[:, :, 1], pos, rope)
+        dqn_w = dqn_b = dkn_w = dkn_b = None
+        if has_qkn:
+            dqx, dkx = torch.empty_like(qx), torch.empty_like(kx)
+            ops.attention_bwd(qx, kx, t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale, out=(dqx, dkx, d5[:, :, 2]), rope=fused_rope)
+            if fused_rope is None:
+                _rope_inverse_(dqx, pos, rope)
+                _rope_inverse_(dkx, pos, rope)
+            if qn is not None:
+                dqx, dqn_w, dqn_b = _qknorm_bwd(t5[:, :, 0], qn, dqx)
+            if kn is not None:
+                dkx, dkn_w, dkn_b = _qknorm_bwd(t5[:, :, 1], kn, dkx)
+            d5[:, :, 0].copy_(dqx)
+            d5[:, :, 1].copy_(dkx)
+        else:
+            ops.attention_bwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale,
+                              out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]), rope=fused_rope)
+            if fused_rope is None:
+                _rope_inverse_(d5[:, :, 0], pos, rope)
+                _rope_inverse_(d5[:, :, 1], pos, rope)
         dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * C)], bias_sink=[qkv.bias])
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db, sunk = _ln_grad_targets(ln, g)
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
         if sunk:
             dg = db = None
-        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10 + (dgamma,)
+        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10 + (dgamma, dqn_w, dqn_b, dkn_w, dkn_b, None, None)
 
 
-def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None):
-    "gamma: LayerScale on the sub-layer's output (x + gamma * proj(...)), or None."
+def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None, q_norm=None, k_norm=None):
+    """gamma: LayerScale on the sub-layer's output (x + gamma * proj(...)), or None.  q_norm / k_norm: the layer's qk_norm modules
+    (LayerNorm over head_dim before the positional encoding; nn.Identity / None: off)."""
+    qn, kn = _norm_or_none(q_norm), _norm_or_none(k_norm)
     return SelfAttnSubLayerFn.apply(x2d, ln.weight, ln.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, ln, qkv, proj,
-                                    B, N, H, rope, pos, scale, dt, gamma)
+                                    B, N, H, rope, pos, scale, dt, gamma, getattr(qn, "weight", None), getattr(qn, "bias", None),
+                                    getattr(kn, "weight", None), getattr(kn, "bias", None), qn, kn)
 
 
 @_sink_aware
@@ -441,7 +499,7 @@ class CrossAttnSubLayerFn(Function):
 
     @staticmethod
     def forward(ctx, x2d, y2d, ln_w, ln_b, lny_w, lny_b, wq_, bq_, wk_, bk_, wv_, bv_, wp_, bp_, ln, lny, projq, projk, projv, proj,
-                B, Nq, Nk, H, rope, qpos, kpos, scale, dt):
+                B, Nq, Nk, H, rope, qpos, kpos, scale, dt, qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None):
         x2d, y2d = _c(x2d), _c(y2d)
         Mq, C = x2d.shape
         Dh = C // H
@@ -457,7 +515,18 @@ class CrossAttnSubLayerFn(Function):
         wq, bq = engine.lin_weights(projq, dt)
         wkv, bkv = engine.kv_weights(projk, projv, dt)
         wp, bp = engine.lin_weights(proj, dt)
-        if dt == torch.bfloat16 and rope is not None:
+        qkn = None
+        if qn is not None or kn is not None:     # qk_norm: the unfused route (see SelfAttnSubLayerFn)
+            q = ops.gemm(hq, wq, bq)
+            kv = ops.gemm(hy, wkv, bkv)
+            q4, k4 = q.view(B, Nq, H, Dh), kv.view(B, Nk, 2, H, Dh)[:, :, 0]
+            qx = _qknorm_fwd(q4, qn) if qn is not None else q4.contiguous()
+            kx = _qknorm_fwd(k4, kn) if kn is not None else k4.contiguous()
+            if rope is not None:
+                ops.rope_2d_(qx, qpos.contiguous(), rope.base, rope.F0)
+                ops.rope_2d_(kx, kpos.contiguous(), rope.base, rope.F0)
+            qkn = (qx, kx)
+        elif dt == torch.bfloat16 and rope is not None:
             if Dh != 64:
                 raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh})")
             q = ops.gemm(hq, wq, bq, rope=engine._rope_epilogue(rope, engine._pos2d(qpos), C))
@@ -470,18 +539,19 @@ class CrossAttnSubLayerFn(Function):
                 ops.rope_2d_(kv.view(B, Nk, 2, H, Dh)[:, :, 0], kpos.contiguous(), rope.base, rope.F0)
         kv5 = kv.view(B, Nk, 2, H, Dh)
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=x2d.device)
-        o = _attention_fwd(q.view(B, Nq, H, Dh), kv5[:, :, 0], kv5[:, :, 1], scale, lse)
+        o = _attention_fwd(*(qkn if qkn is not None else (q.view(B, Nq, H, Dh), kv5[:, :, 0])), kv5[:, :, 1], scale, lse)
         out = ops.gemm(o.view(Mq, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
         e = torch.empty(0)
-        ctx.save_for_backward(x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos if qpos is not None else e, kpos if kpos is not None else e)
+        ctx.save_for_backward(x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos if qpos is not None else e, kpos if kpos is not None else e,
+                              *(() if qkn is None else qkn))
         ctx.meta = (ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt,
-                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None)
+                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None, qn, kn)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
-        x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos, kpos = ctx.saved_tensors
-        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp = ctx.meta
+        x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos, kpos, *qkn = ctx.saved_tensors
+        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp, qn, kn = ctx.meta
         Mq, C = x2d.shape
         Dh = C // H
         dxo = _c(dxo)
@@ -492,11 +562,26 @@ class CrossAttnSubLayerFn(Function):
         dkv = torch.empty_like(kv)
         kv5, dkv5 = kv.view(B, Nk, 2, H, Dh), dkv.view(B, Nk, 2, H, Dh)
         fused_rope = _bwd_rope(rope, qpos, kpos, dt)
-        ops.attention_bwd(q.view(B, Nq, H, Dh), kv5[:, :, 0], kv5[:, :, 1], o, do.view(B, Nq, H, Dh), lse, scale,
-                          out=(dq.view(B, Nq, H, Dh), dkv5[:, :, 0], dkv5[:, :, 1]), rope=fused_rope)
-        if fused_rope is None:
-            _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
-            _rope_inverse_(dkv5[:, :, 0], kpos, rope)
+        dqn_w = dqn_b = dkn_w = dkn_b = None
+        if qkn:
+            qx, kx = qkn
+            dqx, dkx = torch.empty_like(qx), torch.empty_like(kx)
+            ops.attention_bwd(qx, kx, kv5[:, :, 1], o, do.view(B, Nq, H, Dh), lse, scale, out=(dqx, dkx, dkv5[:, :, 1]), rope=fused_rope)
+            if fused_rope is None:
+                _rope_inverse_(dqx, qpos, rope)
+                _rope_inverse_(dkx, kpos, rope)
+            if qn is not None:
+                dqx, dqn_w, dqn_b = _qknorm_bwd(q.view(B, Nq, H, Dh), qn, dqx)
+            if kn is not None:
+                dkx, dkn_w, dkn_b = _qknorm_bwd(kv5[:, :, 0], kn, dkx)
+            dq.view(B, Nq, H, Dh).copy_(dqx)
+            dkv5[:, :, 0].copy_(dkx)
+        else:
+            ops.attention_bwd(q.view(B, Nq, H, Dh), kv5[:, :, 0], kv5[:, :, 1], o, do.view(B, Nq, H, Dh), lse, scale,
+                              out=(dq.view(B, Nq, H, Dh), dkv5[:, :, 0], dkv5[:, :, 1]), rope=fused_rope)
+            if fused_rope is None:
+                _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
+                _rope_inverse_(dkv5[:, :, 0], kpos, rope)
         # query side
         dWq, dbq = _wgrad(dq, hq, dt, has_bq, sink=[(projq.weight, 0, C)], bias_sink=[projq.bias])
         dhq = ops.gemm(dq, lin_weight_t(projq, dt))
@@ -519,14 +604,17 @@ class CrossAttnSubLayerFn(Function):
         dWk, dWv = (None, None) if dWkv is None else (dWkv[:C], dWkv[C:])
         dbk = dbkv[:C] if (has_bk and dbkv is not None) else None
         dbv = dbkv[C:] if (has_bv and dbkv is not None) else None
-        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbk, dWv, dbv, dWp, dbp) + (None,) * 15
+        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbk, dWv, dbv, dWp, dbp) + (None,) * 15 + (dqn_w, dqn_b, dkn_w, dkn_b, None, None)
 
 
 def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt):
     lw, lb = (lny.weight, lny.bias) if lny is not None else (None, None)
+    qn, kn = _norm_or_none(getattr(ca, "q_norm", None)), _norm_or_none(getattr(ca, "k_norm", None))
     return CrossAttnSubLayerFn.apply(x2d, y2d, ln.weight, ln.bias, lw, lb, ca.projq.weight, ca.projq.bias, ca.projk.weight,
                                      ca.projk.bias, ca.projv.weight, ca.projv.bias, ca.proj.weight, ca.proj.bias, ln, lny,
-                                     ca.projq, ca.projk, ca.projv, ca.proj, B, Nq, Nk, H, rope, qpos, kpos, scale, dt)
+                                     ca.projq, ca.projk, ca.projv, ca.proj, B, Nq, Nk, H, rope, qpos, kpos, scale, dt,
+                                     getattr(qn, "weight", None), getattr(qn, "bias", None), getattr(kn, "weight", None),
+                                     getattr(kn, "bias", None), qn, kn)
 
 
 @_sink_aware

@@ -158,6 +158,61 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const typename TX::s
     }
 }
 
+// C = 64 (round 5): LayerNorm over head_dim — qk_norm, utils/transformer_blocks.py:196-197 — has B N H rows of 64: 16 lanes x 4 channels
+// per row, four rows per wave and iteration (512 contiguous bytes per bf16 load), row sums over 16 lanes, dgamma / dbeta kept per lane
+// over the wave's rows and added once per block (the any-width kernel below would issue one atomic per ELEMENT on 64 addresses).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+template <typename TD, typename TX>
+__global__ __launch_bounds__(256) void layernorm64_bwd_kernel(const typename TX::storage* __restrict__ x, const float* __restrict__ gamma,
+                                                              const typename TD::storage* __restrict__ dy, typename TX::storage* __restrict__ dx,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, float eps) {
+    __shared__ float red[128];
+    const int lane = threadIdx.x & 63, sub = lane & 15, rg = lane >> 4;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    if (threadIdx.x < 128) red[threadIdx.x] = 0.f;
+    const float4_t g = *reinterpret_cast<const float4_t*>(gamma + 4 * sub);
+    float4_t dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r0 = wave_id * 4; r0 < rows; r0 += nwaves * 4) {
+        const int64_t row = r0 + rg;
+        const bool ok = row < rows;
+        float4_t v = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+        if (ok) { v = tr_load4<TX>(x + row * 64 + 4 * sub); d = tr_load4<TD>(dy + row * 64 + 4 * sub); }
+        const float mean = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        const float rstd = rsqrtf(row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 64.0f) + eps);
+        v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;                                     // xhat
+        dg.x += d.x * v.x; dg.y += d.y * v.y; dg.z += d.z * v.z; dg.w += d.w * v.w;
+        db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
+        d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;                                         // a = dy * gamma
+        const float s1 = row16_sum((d.x + d.y) + (d.z + d.w)) * (1.0f / 64.0f);
+        const float s2 = row16_sum((d.x * v.x + d.y * v.y) + (d.z * v.z + d.w * v.w)) * (1.0f / 64.0f);
+        if (ok) {
+            float4_t o;
+            o.x = rstd * (d.x - s1 - v.x * s2); o.y = rstd * (d.y - s1 - v.y * s2);
+            o.z = rstd * (d.z - s1 - v.z * s2); o.w = rstd * (d.w - s1 - v.w * s2);
+            tr_store4<TX>(dx + row * 64 + 4 * sub, o);
+        }
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {      // the wave's four row groups
+        dg.x += __shfl_xor(dg.x, o, 64); dg.y += __shfl_xor(dg.y, o, 64); dg.z += __shfl_xor(dg.z, o, 64); dg.w += __shfl_xor(dg.w, o, 64);
+        db.x += __shfl_xor(db.x, o, 64); db.y += __shfl_xor(db.y, o, 64); db.z += __shfl_xor(db.z, o, 64); db.w += __shfl_xor(db.w, o, 64);
+    }
+    __syncthreads();
+    if (rg == 0) {
+        atomicAdd(red + 4 * sub + 0, dg.x); atomicAdd(red + 4 * sub + 1, dg.y); atomicAdd(red + 4 * sub + 2, dg.z); atomicAdd(red + 4 * sub + 3, dg.w);
+        atomicAdd(red + 64 + 4 * sub + 0, db.x); atomicAdd(red + 64 + 4 * sub + 1, db.y); atomicAdd(red + 64 + 4 * sub + 2, db.z); atomicAdd(red + 64 + 4 * sub + 3, db.w);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsafeAtomicAdd(dgamma + threadIdx.x, red[threadIdx.x]);
+        unsafeAtomicAdd(dbeta + threadIdx.x, red[64 + threadIdx.x]);
+    }
+}
+
 // any width: one wavefront per row, three strided passes, per-element atomics for dgamma/dbeta (small models only)
 template <typename TD, typename TX = F32Tag>
 __global__ __launch_bounds__(256) void layernorm_bwd_generic_kernel(const typename TX::storage* __restrict__ x, const float* __restrict__ gamma,
@@ -207,6 +262,17 @@ extern "C" int uc_layernorm_bwd(const void* x, int x_dtype, const float* gamma, 
     hipStream_t st = (hipStream_t)stream;
     const int nv = C / 256;
     const bool xb = x_dtype == UC_BF16;
+    if (C == 64 && !dres && !dx_bf16) {
+        const unsigned g64 = (unsigned)min((int64_t)1024, ceil_div64(rows, 16));
+#define UC_LN64(TD_, TX_)                                                                                                               \
+        hipLaunchKernelGGL((layernorm64_bwd_kernel<TD_, TX_>), dim3(g64), dim3(256), 0, st, (const typename TX_::storage*)x, gamma,        \
+                           (const typename TD_::storage*)dy, (typename TX_::storage*)dx, dgamma, dbeta, rows, eps)
+        if (dy_dtype == UC_F32) { if (xb) UC_LN64(F32Tag, BF16Tag); else UC_LN64(F32Tag, F32Tag); }
+        else { if (xb) UC_LN64(BF16Tag, BF16Tag); else UC_LN64(BF16Tag, F32Tag); }
+#undef UC_LN64
+        UC_CHECK_LAUNCH("uc_layernorm_bwd");
+        return UC_OK;
+    }
     if (C % 256 != 0 || !(nv == 1 || nv == 2 || nv == 3 || nv == 4 || nv == 6 || nv == 8)) {
         const unsigned g = (unsigned)ceil_div64(rows, 4);
 #define UC_LNG(TD_, TX_)                                                                                                                \

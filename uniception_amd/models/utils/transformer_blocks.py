@@ -181,12 +181,11 @@ class SelfAttentionBlock(nn.Module):
         sa = self.attn
         _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
         if autograd.grad_needed(x2d, *self.parameters()):   # HIP forward + HIP backward sub-layers
-            if not isinstance(sa.q_norm, nn.Identity):
-                raise engine.UcHipError("qk_norm=True has no HIP backward: run these blocks under torch.no_grad()")
             g1 = None if isinstance(self.ls1, nn.Identity) else self.ls1.gamma       # LayerScale: folded weights forward, unfolded gradients
             g2 = None if isinstance(self.ls2, nn.Identity) else self.ls2.gamma
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, N, sa.num_heads, sa.custom_positional_encoding,
-                                              xpos, sa.scale * _softmax_scale_multiplier(sa, N), dt, gamma=g1)
+                                              xpos, sa.scale * _softmax_scale_multiplier(sa, N), dt, gamma=g1, q_norm=sa.q_norm,
+                                              k_norm=sa.k_norm)
             return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, gamma=g2)
         proj_wb = None if isinstance(self.ls1, nn.Identity) else engine.layerscale_lin_weights(sa.proj, self.ls1.gamma, dt)
         fc2_wb = None if isinstance(self.ls2, nn.Identity) else engine.layerscale_lin_weights(self.mlp.fc2, self.ls2.gamma, dt)
@@ -270,12 +269,9 @@ class CrossAttentionBlock(nn.Module):
         """Same three sub-layers as autograd Functions (HIP forward + HIP backward)."""
         sa, ca = self.attn, self.cross_attn
         _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, ca.attn_drop.p, ca.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
-        for m in (sa, ca):
-            if not isinstance(m.q_norm, nn.Identity):
-                raise engine.UcHipError("qk_norm=True has no HIP backward: run these blocks under torch.no_grad()")
         rope = self.custom_positional_encoding
         x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, Nx, sa.num_heads, rope, xpos,
-                                          sa.scale * _softmax_scale_multiplier(sa, Nx), dt)
+                                          sa.scale * _softmax_scale_multiplier(sa, Nx), dt, q_norm=sa.q_norm, k_norm=sa.k_norm)
         lny = None if isinstance(self.norm_y, nn.Identity) else self.norm_y
         x2d = autograd.cross_attn_sublayer(x2d, y2d, self.norm2, lny, ca, B, Nx, Ny, ca.num_heads, rope, xpos, ypos,
                                            ca.scale * _softmax_scale_multiplier(ca, Nx), dt)
