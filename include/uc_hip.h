@@ -440,6 +440,12 @@ int uc_colsum(const void* src, int dtype, int64_t M, int64_t N, int64_t ld, floa
 
 /* Activation backward: du = dg * act'(u), u = saved pre-activation (uc_gemm preact_out).  act: UC_ACT_GELU_ERF | UC_ACT_RELU. */
 int uc_act_bwd(const void* dg, const void* u, void* du, int dtype, int act, int64_t n, uc_stream_t stream);
+/* Dropout / DropPath in training (ABI 13; nn.Dropout, timm DropPath — reference blocks.py:64-86, 120-161, utils/transformer_blocks.py:145-208):
+ * out [rows, cols] = (residual +) x * (mask ? scale : 0).  mask: uint8, one per element (rows_per_mask == 0) or one per group of
+ * rows_per_mask consecutive rows (DropPath: rows_per_mask = tokens per sample).  x: fp32 / bf16; residual (optional) and out share
+ * out_dtype (fp32 / bf16); cols % 4 == 0.  Applied to the gradient (without residual) it is its own backward. */
+int uc_mask_scale(const void* x, int x_dtype, const unsigned char* mask, int64_t rows_per_mask, float scale, const void* residual,
+                  void* out, int out_dtype, int64_t rows, int cols, uc_stream_t stream);
 
 /* SwiGLU gate (DINOv2 giant's FFN; the hub's SwiGLUFFNFused, reference encoders/dinov2.py:68-84 loads it through torch.hub):
  * t [M, 2H] row-major = w12(x); g[m, j] = silu(t[m, j]) * t[m, H + j], g [M, H].  dtype UC_F32 | UC_BF16, H % 8 == 0. */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "uc_splitk_reduce": [vp, i32, i64, i64, vp, i32, vp],
     "uc_colsum": [vp, i32, i64, i64, i64, vp, vp],
     "uc_act_bwd": [vp, vp, vp, i32, i32, i64, vp],
+    "uc_mask_scale": [vp, i32, vp, i64, f32, vp, vp, i32, i64, i32, vp],
     "uc_swiglu": [vp, vp, i32, i64, i64, vp],
     "uc_swiglu_bwd": [vp, vp, vp, i32, i64, i64, vp],
     "uc_transpose2d": [vp, i32, vp, i32, vp, i64, i64, i64, vp],

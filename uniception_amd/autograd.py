@@ -239,6 +239,53 @@ def _bwd_rope(rope, qpos, kpos, dt):
     return (engine._pos2d(qpos), engine._pos2d(kpos), rope.base, rope.F0)
 
 
+class Drops:
+    """The dropout masks of ONE sub-layer call in training (uint8, 1 = keep; made by make_drops from PyTorch's generator, which owns the
+    RNG state): `out` = nn.Dropout on the sub-layer's output (proj_drop / the Mlp's drop2), `path` = DropPath on the sub-layer's branch
+    (one byte per sample), `mid` = the Mlp's drop1 on the hidden activation.  attn_drop (dropout of the attention probabilities inside
+    the flash kernels) is not supported."""
+    __slots__ = ("out", "out_scale", "path", "path_rows", "path_scale", "mid", "mid_scale")
+
+    def __init__(self):
+        self.out = self.path = self.mid = None
+        self.out_scale = self.path_scale = self.mid_scale = 1.0
+        self.path_rows = 0
+
+    @property
+    def has_out(self):
+        return self.out is not None or self.path is not None
+
+
+def make_drops(training: bool, device, B: int, N: int, C: int, p_out: float = 0.0, p_path: float = 0.0, hidden: int = 0,
+               p_mid: float = 0.0, scale_by_keep: bool = True):
+    """Drops for one sub-layer over [B * N, C] tokens, or None (eval mode / every rate 0).  Semantics: nn.Dropout (keep with
+    probability 1 - p, scale 1 / (1 - p)); timm's DropPath (per sample, scale 1 / keep when scale_by_keep)."""
+    if not training or (p_out <= 0.0 and p_path <= 0.0 and p_mid <= 0.0):
+        return None
+    d = Drops()
+    if p_out > 0.0:
+        d.out = (torch.rand((B * N, C), device=device) >= p_out).to(torch.uint8)
+        d.out_scale = 1.0 / (1.0 - p_out) if p_out < 1.0 else 0.0
+    if p_path > 0.0:
+        keep = 1.0 - p_path
+        d.path = (torch.rand((B,), device=device) < keep).to(torch.uint8)
+        d.path_rows = N
+        d.path_scale = 1.0 / keep if (scale_by_keep and keep > 0.0) else 1.0
+    if p_mid > 0.0:
+        d.mid = (torch.rand((B * N, hidden), device=device) >= p_mid).to(torch.uint8)
+        d.mid_scale = 1.0 / (1.0 - p_mid) if p_mid < 1.0 else 0.0
+    return d
+
+
+def _drop_out(f2d, drops, residual=None, out_dtype=None):
+    "residual + dropout(f) (+ DropPath): the output masks of `drops`, the residual add riding in the last pass."
+    steps = [(m, r, sc) for m, r, sc in ((drops.out, 0, drops.out_scale), (drops.path, drops.path_rows, drops.path_scale)) if m is not None]
+    for i, (m, r, sc) in enumerate(steps):
+        last = i == len(steps) - 1
+        f2d = ops.mask_scale(f2d, m, r, sc, residual if last else None, out_dtype if last else None)
+    return f2d
+
+
 def _norm_or_none(norm):
     return None if norm is None or isinstance(norm, nn.Identity) else norm
 
@@ -393,7 +440,7 @@ class SelfAttnSubLayerFn(Function):
 
     @staticmethod
     def forward(ctx, x2d, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None,
-                qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None):
+                qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None, drops=None):
         x2d = _c(x2d)
         M, C = x2d.shape
         Dh = C // H
@@ -427,17 +474,20 @@ class SelfAttnSubLayerFn(Function):
                 ops.rope_2d_(t5[:, :, 1], pos.contiguous(), rope.base, rope.F0)
         lse = torch.empty((B, H, N), dtype=torch.float32, device=x2d.device)
         o = _attention_fwd(*(qkn if qkn is not None else (t5[:, :, 0], t5[:, :, 1])), t5[:, :, 2], scale, lse)
-        out = ops.gemm(o.view(M, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
+        if drops is not None and drops.has_out:
+            out = _drop_out(ops.gemm(o.view(M, C), wp, bp), drops, x2d, x2d.dtype)
+        else:
+            out = ops.gemm(o.view(M, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
         # (gamma goes through save_for_backward: autograd's version check then catches an in-place edit between forward and backward)
         ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0), *(() if qkn is None else qkn),
                               *(() if gamma is None else (gamma,)))
-        ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None, qn, kn, qkn is not None)
+        ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None, qn, kn, qkn is not None, drops)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
         x2d, g, h, t, o, lse, pos, *rest = ctx.saved_tensors
-        ln, qkv, proj, B, N, H, rope, scale, dt, has_bq, has_bp, qn, kn, has_qkn = ctx.meta
+        ln, qkv, proj, B, N, H, rope, scale, dt, has_bq, has_bp, qn, kn, has_qkn, drops = ctx.meta
         qx, kx = (rest[0], rest[1]) if has_qkn else (None, None)
         rest = rest[2:] if has_qkn else rest
         gamma = rest[0] if rest else None
@@ -445,6 +495,8 @@ class SelfAttnSubLayerFn(Function):
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
+        if drops is not None and drops.has_out:
+            dyb = _drop_out(dyb, drops)
         dgamma = None
         if gamma is None:
             dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
@@ -481,16 +533,16 @@ class SelfAttnSubLayerFn(Function):
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
         if sunk:
             dg = db = None
-        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10 + (dgamma, dqn_w, dqn_b, dkn_w, dkn_b, None, None)
+        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10 + (dgamma, dqn_w, dqn_b, dkn_w, dkn_b, None, None, None)
 
 
-def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None, q_norm=None, k_norm=None):
+def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None, q_norm=None, k_norm=None, drops=None):
     """gamma: LayerScale on the sub-layer's output (x + gamma * proj(...)), or None.  q_norm / k_norm: the layer's qk_norm modules
     (LayerNorm over head_dim before the positional encoding; nn.Identity / None: off)."""
     qn, kn = _norm_or_none(q_norm), _norm_or_none(k_norm)
     return SelfAttnSubLayerFn.apply(x2d, ln.weight, ln.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, ln, qkv, proj,
                                     B, N, H, rope, pos, scale, dt, gamma, getattr(qn, "weight", None), getattr(qn, "bias", None),
-                                    getattr(kn, "weight", None), getattr(kn, "bias", None), qn, kn)
+                                    getattr(kn, "weight", None), getattr(kn, "bias", None), qn, kn, drops)
 
 
 @_sink_aware
@@ -499,7 +551,7 @@ class CrossAttnSubLayerFn(Function):
 
     @staticmethod
     def forward(ctx, x2d, y2d, ln_w, ln_b, lny_w, lny_b, wq_, bq_, wk_, bk_, wv_, bv_, wp_, bp_, ln, lny, projq, projk, projv, proj,
-                B, Nq, Nk, H, rope, qpos, kpos, scale, dt, qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None):
+                B, Nq, Nk, H, rope, qpos, kpos, scale, dt, qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None, drops=None):
         x2d, y2d = _c(x2d), _c(y2d)
         Mq, C = x2d.shape
         Dh = C // H
@@ -540,22 +592,27 @@ class CrossAttnSubLayerFn(Function):
         kv5 = kv.view(B, Nk, 2, H, Dh)
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=x2d.device)
         o = _attention_fwd(*(qkn if qkn is not None else (q.view(B, Nq, H, Dh), kv5[:, :, 0])), kv5[:, :, 1], scale, lse)
-        out = ops.gemm(o.view(Mq, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
+        if drops is not None and drops.has_out:
+            out = _drop_out(ops.gemm(o.view(Mq, C), wp, bp), drops, x2d, x2d.dtype)
+        else:
+            out = ops.gemm(o.view(Mq, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
         e = torch.empty(0)
         ctx.save_for_backward(x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos if qpos is not None else e, kpos if kpos is not None else e,
                               *(() if qkn is None else qkn))
         ctx.meta = (ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt,
-                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None, qn, kn)
+                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None, qn, kn, drops)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
         x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos, kpos, *qkn = ctx.saved_tensors
-        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp, qn, kn = ctx.meta
+        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp, qn, kn, drops = ctx.meta
         Mq, C = x2d.shape
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
+        if drops is not None and drops.has_out:
+            dyb = _drop_out(dyb, drops)
         dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
         do = ops.gemm(dyb, lin_weight_t(proj, dt))
         dq = torch.empty_like(q)
@@ -604,17 +661,17 @@ class CrossAttnSubLayerFn(Function):
         dWk, dWv = (None, None) if dWkv is None else (dWkv[:C], dWkv[C:])
         dbk = dbkv[:C] if (has_bk and dbkv is not None) else None
         dbv = dbkv[C:] if (has_bv and dbkv is not None) else None
-        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbk, dWv, dbv, dWp, dbp) + (None,) * 15 + (dqn_w, dqn_b, dkn_w, dkn_b, None, None)
+        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbk, dWv, dbv, dWp, dbp) + (None,) * 15 + (dqn_w, dqn_b, dkn_w, dkn_b, None, None, None)
 
 
-def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt):
+def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt, drops=None):
     lw, lb = (lny.weight, lny.bias) if lny is not None else (None, None)
     qn, kn = _norm_or_none(getattr(ca, "q_norm", None)), _norm_or_none(getattr(ca, "k_norm", None))
     return CrossAttnSubLayerFn.apply(x2d, y2d, ln.weight, ln.bias, lw, lb, ca.projq.weight, ca.projq.bias, ca.projk.weight,
                                      ca.projk.bias, ca.projv.weight, ca.projv.bias, ca.proj.weight, ca.proj.bias, ln, lny,
                                      ca.projq, ca.projk, ca.projv, ca.proj, B, Nq, Nk, H, rope, qpos, kpos, scale, dt,
                                      getattr(qn, "weight", None), getattr(qn, "bias", None), getattr(kn, "weight", None),
-                                     getattr(kn, "bias", None), qn, kn)
+                                     getattr(kn, "bias", None), qn, kn, drops)
 
 
 @_sink_aware
@@ -622,7 +679,7 @@ class MlpSubLayerFn(Function):
     """x + fc2(act(fc1(LN(x))))   (blocks.py:64-86,159; transformer_blocks.py:517-560)."""
 
     @staticmethod
-    def forward(ctx, x2d, ln_w, ln_b, w1_, b1_, w2_, b2_, ln, fc1, fc2, act, dt, gamma=None):
+    def forward(ctx, x2d, ln_w, ln_b, w1_, b1_, w2_, b2_, ln, fc1, fc2, act, dt, gamma=None, drops=None):
         x2d = _c(x2d)
         g, bta = engine.ln_params(ln)
         h = ops.layernorm(x2d, g, bta, ln.eps, dt)
@@ -630,18 +687,25 @@ class MlpSubLayerFn(Function):
         w2, b2 = engine.lin_weights(fc2, dt) if gamma is None else engine.layerscale_lin_weights(fc2, gamma, dt)
         u = torch.empty((x2d.shape[0], w1.shape[0]), dtype=dt, device=x2d.device)
         a = ops.gemm(h, w1, b1, act=act, preact_out=u)
-        out = ops.gemm(a, w2, b2, residual=x2d, out_dtype=x2d.dtype)
+        if drops is not None and drops.mid is not None:      # drop1: the hidden activation fc2 (and its weight gradient) sees
+            a = ops.mask_scale(a, drops.mid, 0, drops.mid_scale)
+        if drops is not None and drops.has_out:
+            out = _drop_out(ops.gemm(a, w2, b2), drops, x2d, x2d.dtype)
+        else:
+            out = ops.gemm(a, w2, b2, residual=x2d, out_dtype=x2d.dtype)
         ctx.save_for_backward(x2d, g, h, u, a, *(() if gamma is None else (gamma,)))
-        ctx.meta = (ln, fc1, fc2, act, dt, b1_ is not None, b2_ is not None)
+        ctx.meta = (ln, fc1, fc2, act, dt, b1_ is not None, b2_ is not None, drops)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
         x2d, g, h, u, a, *rest = ctx.saved_tensors
         gamma = rest[0] if rest else None
-        ln, fc1, fc2, act, dt, has_b1, has_b2 = ctx.meta
+        ln, fc1, fc2, act, dt, has_b1, has_b2, drops = ctx.meta
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
+        if drops is not None and drops.has_out:
+            dyb = _drop_out(dyb, drops)
         dgamma = None
         if gamma is None:
             dW2, db2 = _wgrad(dyb, a, dt, has_b2, sink=[(fc2.weight, 0, fc2.weight.shape[0])], bias_sink=[fc2.bias])
@@ -655,18 +719,20 @@ class MlpSubLayerFn(Function):
         else:
             da = ops.gemm(dyb, w2t)
             du = ops.act_bwd(da, u, act) if act != "none" else da
+        if drops is not None and drops.mid is not None:      # (elementwise factors commute: mask * act'(u) * da)
+            du = ops.mask_scale(du, drops.mid, 0, drops.mid_scale)
         dW1, db1 = _wgrad(du, h, dt, has_b1, sink=[(fc1.weight, 0, fc1.weight.shape[0])], bias_sink=[fc1.bias])
         dh = ops.gemm(du, lin_weight_t(fc1, dt))
         dg, db, sunk = _ln_grad_targets(ln, g)
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
         if sunk:
             dg = db = None
-        return (dx, dg, db, dW1, db1, dW2, db2) + (None,) * 5 + (dgamma,)
+        return (dx, dg, db, dW1, db1, dW2, db2) + (None,) * 5 + (dgamma, None)
 
 
-def mlp_sublayer(x2d, ln, fc1, fc2, act, dt, gamma=None):
-    "gamma: LayerScale on the sub-layer's output (x + gamma * fc2(...)), or None."
-    return MlpSubLayerFn.apply(x2d, ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln, fc1, fc2, act, dt, gamma)
+def mlp_sublayer(x2d, ln, fc1, fc2, act, dt, gamma=None, drops=None):
+    "gamma: LayerScale on the sub-layer's output (x + gamma * fc2(...)), or None.  drops: the call's dropout masks (make_drops) or None."
+    return MlpSubLayerFn.apply(x2d, ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln, fc1, fc2, act, dt, gamma, drops)
 
 
 @_sink_aware

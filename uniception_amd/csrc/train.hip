@@ -424,6 +424,53 @@ extern "C" int uc_act_bwd(const void* dg, const void* u, void* du, int dtype, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Dropout / DropPath in training (round 5; nn.Dropout on a sub-layer's output or hidden activation, timm's DropPath on the sub-layer's
+// branch — blocks.py:64-86, 120-161; transformer_blocks.py:145-208): out = (residual +) x * (mask ? scale : 0).  mask: one byte per
+// element (rows_per_mask == 0) or one byte per group of rows_per_mask consecutive rows (DropPath: one per sample).  The same kernel is
+// the backward (on the gradient, without residual).  HBM-bound; four elements per lane (cols % 4 == 0).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TX, typename TO>
+__global__ __launch_bounds__(256) void mask_scale_kernel(const typename TX::storage* __restrict__ x, const unsigned char* __restrict__ mask,
+                                                         const typename TO::storage* __restrict__ residual, typename TO::storage* __restrict__ out,
+                                                         int64_t n4, int cols4, int64_t rows_per_mask, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4_t v = tr_load4<TX>(x + i * 4);
+        float4_t m;
+        if (rows_per_mask > 0) {
+            const float k = mask[(i / cols4) / rows_per_mask] ? scale : 0.f;
+            m = (float4_t){k, k, k, k};
+        } else {
+            const unsigned w = *reinterpret_cast<const unsigned*>(mask + i * 4);
+            m = (float4_t){(w & 0xffu) ? scale : 0.f, (w & 0xff00u) ? scale : 0.f, (w & 0xff0000u) ? scale : 0.f, (w & 0xff000000u) ? scale : 0.f};
+        }
+        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        if (residual) {
+            const float4_t r = tr_load4<TO>(residual + i * 4);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        tr_store4<TO>(out + i * 4, v);
+    }
+}
+
+extern "C" int uc_mask_scale(const void* x, int x_dtype, const unsigned char* mask, int64_t rows_per_mask, float scale, const void* residual,
+                             void* out, int out_dtype, int64_t rows, int cols, uc_stream_t stream) {
+    UC_REQUIRE(x && mask && out && rows >= 0 && cols > 0 && cols % 4 == 0 && rows_per_mask >= 0, "uc_mask_scale: bad argument");
+    UC_REQUIRE((x_dtype == UC_F32 || x_dtype == UC_BF16) && (out_dtype == UC_F32 || out_dtype == UC_BF16), "uc_mask_scale: fp32 / bf16 tensors only");
+    if (rows == 0) return UC_OK;
+    const int64_t n4 = rows * (cols / 4);
+    const unsigned grid = (unsigned)min((int64_t)65536, ceil_div64(n4, 256));
+    hipStream_t st = (hipStream_t)stream;
+#define UC_MS(TX_, TO_)                                                                                                                   \
+    hipLaunchKernelGGL((mask_scale_kernel<TX_, TO_>), dim3(grid), dim3(256), 0, st, (const typename TX_::storage*)x, mask,                    \
+                       (const typename TO_::storage*)residual, (typename TO_::storage*)out, n4, cols / 4, rows_per_mask, scale)
+    if (x_dtype == UC_F32) { if (out_dtype == UC_F32) UC_MS(F32Tag, F32Tag); else UC_MS(F32Tag, BF16Tag); }
+    else { if (out_dtype == UC_F32) UC_MS(BF16Tag, F32Tag); else UC_MS(BF16Tag, BF16Tag); }
+#undef UC_MS
+    UC_CHECK_LAUNCH("uc_mask_scale");
+    return UC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // SwiGLU gate of DINOv2's giant FFN (the hub's SwiGLUFFNFused: x1, x2 = w12(x).chunk(2); w3(silu(x1) * x2)):
 //   forward   g[m, j] = silu(t[m, j]) * t[m, H + j]                                        t [M, 2H] -> g [M, H]
 //   backward  dt[m, j] = dg x2 s (1 + x1 (1 - s)),  dt[m, H + j] = dg x1 s,  s = sigmoid(x1)

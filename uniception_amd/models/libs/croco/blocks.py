@@ -40,7 +40,9 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
-        raise engine.UcHipError("DropPath with drop_prob > 0 in training mode is not supported by the HIP path")
+        # (in training the blocks apply it inside their sub-layer Functions: autograd.make_drops / uc_mask_scale)
+        raise engine.UcHipError("DropPath with drop_prob > 0 is applied by the blocks' training path; called on its own (or without "
+                                "gradients in train mode) it has no HIP form")
 
     def extra_repr(self):
         return f"drop_prob={round(self.drop_prob, 3):0.3f}"
@@ -49,6 +51,17 @@ class DropPath(nn.Module):
 def _check_no_dropout(module, *ps):
     if module.training and any(p > 0.0 for p in ps):
         raise engine.UcHipError("dropout > 0 in training mode is not supported by the HIP path")
+
+
+def _drop_path_rate(m):
+    "(rate, scale_by_keep) of a block's drop_path module (nn.Identity: 0)"
+    return (m.drop_prob, m.scale_by_keep) if isinstance(m, DropPath) else (0.0, True)
+
+
+def _check_attn_drop(module, p):
+    if module.training and p > 0.0:
+        raise engine.UcHipError("attn_drop > 0 in training mode is not supported by the HIP path (it would drop attention probabilities "
+                                "INSIDE the flash kernels; proj_drop, the Mlp's drop and DropPath are supported)")
 
 
 def _as_2d(x):
@@ -131,13 +144,19 @@ class Block(nn.Module):
 
     def forward_tokens(self, x2d, B, N, xpos, dt):
         """[B*N, C] residual stream in, new residual stream out (same dtype)."""
-        if isinstance(self.drop_path, DropPath):
-            self.drop_path(x2d)  # raises in training with rate > 0
         if autograd.grad_needed(x2d, *self.parameters()):
-            _check_no_dropout(self, self.attn.dropout_p, self.attn.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
+            # dropout (round 5): proj_drop / the Mlp's drops / DropPath as masks through the sub-layer Functions (autograd.make_drops)
+            _check_attn_drop(self, self.attn.dropout_p)
+            C = x2d.shape[1]
+            pp, sbk = _drop_path_rate(self.drop_path)
+            d1 = autograd.make_drops(self.training, x2d.device, B, N, C, p_out=self.attn.proj_drop.p, p_path=pp, scale_by_keep=sbk)
+            d2 = autograd.make_drops(self.training, x2d.device, B, N, C, p_out=self.mlp.drop2.p, p_path=pp, hidden=self.mlp.fc1.out_features,
+                                     p_mid=self.mlp.drop1.p, scale_by_keep=sbk)
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads,
-                                              self.attn.rope, xpos, self.attn.scale, dt)
-            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt)
+                                              self.attn.rope, xpos, self.attn.scale, dt, drops=d1)
+            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, drops=d2)
+        if isinstance(self.drop_path, DropPath):
+            self.drop_path(x2d)  # (train mode without gradients: raises at rate > 0)
         # LayerNorm -> GEMM pairs run fused when the stream carries its producer's bf16 twin + row statistics (engine.ln_operand)
         h, fold = engine.ln_operand(x2d, self.norm1, dt)
         x2d = self.attn._run(h, B, N, xpos, x2d, x2d.dtype, fold, True)

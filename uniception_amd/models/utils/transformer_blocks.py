@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import autograd, engine
-from ..libs.croco.blocks import DropPath, Mlp, _as_2d, _check_no_dropout, to_2tuple  # noqa: F401
+from ..libs.croco.blocks import DropPath, Mlp, _as_2d, _check_attn_drop, _check_no_dropout, _drop_path_rate, to_2tuple  # noqa: F401
 from .config import use_fused_attn
 
 
@@ -171,22 +171,28 @@ class SelfAttentionBlock(nn.Module):
 
     def forward_tokens(self, x2d, B, N, xpos, dt):
         """[B*N, C] fp32 residual stream in, new residual stream out; attention spans the N tokens of each of the B sequences."""
-        for dp in (self.drop_path1, self.drop_path2):
-            if isinstance(dp, DropPath) and dp.drop_prob > 0 and self.training:
-                raise engine.UcHipError("DropPath with drop_prob > 0 in training mode is not supported by the HIP path")
         if not isinstance(self.mlp, Mlp):
             raise engine.UcHipError("only the standard Mlp layer has a fused HIP pipeline")
         if self.custom_positional_encoding is not None:
             assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
         sa = self.attn
-        _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
         if autograd.grad_needed(x2d, *self.parameters()):   # HIP forward + HIP backward sub-layers
+            _check_attn_drop(self, sa.attn_drop.p)
+            C = x2d.shape[1]
+            (p1, k1), (p2, k2) = _drop_path_rate(self.drop_path1), _drop_path_rate(self.drop_path2)
+            d1 = autograd.make_drops(self.training, x2d.device, B, N, C, p_out=sa.proj_drop.p, p_path=p1, scale_by_keep=k1)
+            d2 = autograd.make_drops(self.training, x2d.device, B, N, C, p_out=self.mlp.drop2.p, p_path=p2, hidden=self.mlp.fc1.out_features,
+                                     p_mid=self.mlp.drop1.p, scale_by_keep=k2)
             g1 = None if isinstance(self.ls1, nn.Identity) else self.ls1.gamma       # LayerScale: folded weights forward, unfolded gradients
             g2 = None if isinstance(self.ls2, nn.Identity) else self.ls2.gamma
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, N, sa.num_heads, sa.custom_positional_encoding,
                                               xpos, sa.scale * _softmax_scale_multiplier(sa, N), dt, gamma=g1, q_norm=sa.q_norm,
-                                              k_norm=sa.k_norm)
-            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, gamma=g2)
+                                              k_norm=sa.k_norm, drops=d1)
+            return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, gamma=g2, drops=d2)
+        _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
+        for dp in (self.drop_path1, self.drop_path2):
+            if isinstance(dp, DropPath) and dp.drop_prob > 0 and self.training:
+                raise engine.UcHipError("DropPath with drop_prob > 0 in train mode without gradients has no HIP form")
         proj_wb = None if isinstance(self.ls1, nn.Identity) else engine.layerscale_lin_weights(sa.proj, self.ls1.gamma, dt)
         fc2_wb = None if isinstance(self.ls2, nn.Identity) else engine.layerscale_lin_weights(self.mlp.fc2, self.ls2.gamma, dt)
         h, fold = engine.ln_operand(x2d, self.norm1, dt)
@@ -239,9 +245,6 @@ class CrossAttentionBlock(nn.Module):
         for ls in (self.ls1, self.ls2, self.ls3):
             if not isinstance(ls, nn.Identity):
                 raise engine.UcHipError("LayerScale (init_values != None) is not supported by the HIP path")
-        for dp in (self.drop_path1, self.drop_path2, self.drop_path3):
-            if isinstance(dp, DropPath) and dp.drop_prob > 0 and self.training:
-                raise engine.UcHipError("DropPath with drop_prob > 0 in training mode is not supported by the HIP path")
         if not isinstance(self.mlp, Mlp):
             raise engine.UcHipError("only the standard Mlp layer has a fused HIP pipeline")
 
@@ -253,6 +256,9 @@ class CrossAttentionBlock(nn.Module):
             assert ypos is not None, "Positions of cross tokens (ypos) are a required input when using custom positional encoding"
         if autograd.grad_needed(x2d, y2d, *self.parameters()):
             return self._forward_tokens_train(x2d, y2d, B, Nx, Ny, xpos, ypos, dt)
+        for dp in (self.drop_path1, self.drop_path2, self.drop_path3):
+            if isinstance(dp, DropPath) and dp.drop_prob > 0 and self.training:
+                raise engine.UcHipError("DropPath with drop_prob > 0 in train mode without gradients has no HIP form")
         # LayerNorm -> GEMM pairs run fused when a stream carries its producer's bf16 twin + row statistics (engine.ln_operand)
         h, fold = engine.ln_operand(x2d, self.norm1, dt)
         x2d = self.attn._run(h, B, Nx, xpos, x2d, x2d.dtype, fold, True)
@@ -268,14 +274,20 @@ class CrossAttentionBlock(nn.Module):
     def _forward_tokens_train(self, x2d, y2d, B, Nx, Ny, xpos, ypos, dt):
         """Same three sub-layers as autograd Functions (HIP forward + HIP backward)."""
         sa, ca = self.attn, self.cross_attn
-        _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, ca.attn_drop.p, ca.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
+        _check_attn_drop(self, max(sa.attn_drop.p, ca.attn_drop.p))
+        C, dev = x2d.shape[1], x2d.device
+        (p1, k1), (p2, k2), (p3, k3) = (_drop_path_rate(m) for m in (self.drop_path1, self.drop_path2, self.drop_path3))
+        d1 = autograd.make_drops(self.training, dev, B, Nx, C, p_out=sa.proj_drop.p, p_path=p1, scale_by_keep=k1)
+        d2 = autograd.make_drops(self.training, dev, B, Nx, C, p_out=ca.proj_drop.p, p_path=p2, scale_by_keep=k2)
+        d3 = autograd.make_drops(self.training, dev, B, Nx, C, p_out=self.mlp.drop2.p, p_path=p3, hidden=self.mlp.fc1.out_features,
+                                 p_mid=self.mlp.drop1.p, scale_by_keep=k3)
         rope = self.custom_positional_encoding
         x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, Nx, sa.num_heads, rope, xpos,
-                                          sa.scale * _softmax_scale_multiplier(sa, Nx), dt, q_norm=sa.q_norm, k_norm=sa.k_norm)
+                                          sa.scale * _softmax_scale_multiplier(sa, Nx), dt, q_norm=sa.q_norm, k_norm=sa.k_norm, drops=d1)
         lny = None if isinstance(self.norm_y, nn.Identity) else self.norm_y
         x2d = autograd.cross_attn_sublayer(x2d, y2d, self.norm2, lny, ca, B, Nx, Ny, ca.num_heads, rope, xpos, ypos,
-                                           ca.scale * _softmax_scale_multiplier(ca, Nx), dt)
-        return autograd.mlp_sublayer(x2d, self.norm3, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt)
+                                           ca.scale * _softmax_scale_multiplier(ca, Nx), dt, drops=d2)
+        return autograd.mlp_sublayer(x2d, self.norm3, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, drops=d3)
 
     def forward(self, x, y, xpos=None, ypos=None):
         B, Nx, C = x.shape

@@ -881,6 +881,23 @@ def colsum_(src: torch.Tensor, out: torch.Tensor) -> None:
                                      _stream()), "uc_colsum")
 
 
+def mask_scale(x: torch.Tensor, mask: torch.Tensor, rows_per_mask: int, scale: float, residual: Optional[torch.Tensor] = None,
+               out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Dropout / DropPath (training): out [rows, cols] = (residual +) x * (mask ? scale : 0) (uc_mask_scale).  mask uint8: one per element
+    (rows_per_mask == 0) or one per group of rows_per_mask rows.  Its own backward when applied to the gradient without residual."""
+    _need_gpu(x, mask, residual)
+    assert x.dim() == 2 and x.is_contiguous() and mask.dtype == torch.uint8 and mask.is_contiguous() and x.shape[1] % 4 == 0
+    rows, cols = x.shape
+    assert mask.numel() == (x.numel() if rows_per_mask == 0 else (rows + rows_per_mask - 1) // rows_per_mask)
+    od = out_dtype or (residual.dtype if residual is not None else x.dtype)
+    if residual is not None:
+        assert residual.shape == x.shape and residual.is_contiguous() and residual.dtype == od
+    out = torch.empty((rows, cols), dtype=od, device=x.device)
+    _lib.check(_lib.load().uc_mask_scale(x.data_ptr(), _dt(x.dtype), mask.data_ptr(), int(rows_per_mask), float(scale), _p(residual),
+                                         out.data_ptr(), _dt(od), rows, cols, _stream()), "uc_mask_scale")
+    return out
+
+
 def act_bwd(dg: torch.Tensor, u: torch.Tensor, act: str) -> torch.Tensor:
     _need_gpu(dg, u)
     assert dg.is_contiguous() and u.is_contiguous() and dg.shape == u.shape and dg.dtype == u.dtype
