@@ -947,7 +947,8 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         } else
 #endif
         // persistent 64-queries-per-wave kernel (attention_p64.h) + its fix-up scan: 32-bit DMA offsets as above, at least two key
-        // tiles, and (policy) enough (batch, head, 256-query tile) items to give every one of 2 x 256 workgroups a few, a query count
+        // tiles, and (policy) enough (batch, head, 256-query tile) items — one per workgroup of the 2 x 256 (measured break-even: 384 items
+        // at 1024 keys, tools/bench_attention_ab.py; 256 items when an item is 64 key tiles long) —, a query count
         // that does not leave a quarter of the last tile empty.  (A wanted log-sum-exp is no obstacle: the kernel rounds scale * log2(e) * Q
         // to bf16, so its scores and LSE carry ~2^-9 of |q| |k| scale — and the backward's dQ kernel rounds Q the same way and recomputes
         // exactly these scores, the dK / dV kernel rounds K instead: the same noise class either way.)
@@ -955,7 +956,7 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
         const int64_t p64_items = (int64_t)B * H * ((Nq + 255) / 256);
         const int waste256 = (Nq + 255) / 256 * 256 - Nq;
         const bool p64_ok = dma_ok && p64_mode && Nk > 64 && p64_items < ((int64_t)1 << 28) && (int64_t)64 * q_sn * 2 < ((int64_t)1 << 31) && (int64_t)64 * o_sn * 2 < ((int64_t)1 << 31) &&
-                            (p64_mode == 2 || (p64_items >= 1024 && waste256 * 4 <= Nq));
+                            (p64_mode == 2 || ((p64_items >= 512 || (p64_items >= 256 && Nk >= 4096)) && waste256 * 4 <= Nq));
         if (p64_ok && !g_uc_attn_rs.load(std::memory_order_relaxed)) {
             AttnP64Params pp;
             pp.Q = Q; pp.K = K; pp.V = V; pp.O = O; pp.lse = lse; pp.B = B; pp.H = H; pp.Nq = Nq; pp.Nk = Nk;
