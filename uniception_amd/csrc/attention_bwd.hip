@@ -481,7 +481,7 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     const int k64 = g_uc_attn_bwd64.load();
     const int64_t v_ext = ((int64_t)(B - 1) * v_sb + (int64_t)(H - 1) * v_sh + (int64_t)(Nk - 1) * v_sn + 64) * 2;
     // 64 queries per wave (attention_bwd64.h) when a 256-query workgroup is mostly real queries; the 32-query kernel otherwise
-    const bool dq64 = Nk > 64 && v_ext < (int64_t)0xffffffffll && (k64 == 2 || (k64 == 1 && Nq >= 192 && ((Nq + 255) / 256) * 256 * 4 <= Nq * 5));
+    const bool dq64 = Nk > 64 && v_ext < (int64_t)0xffffffffll && (k64 == 2 || (k64 == 1 && Nq >= 192 && ((Nq + 255) / 256) * 256 * 3 <= Nq * 4));
     if (dq64) {
         const int64_t items = (int64_t)((Nq + 255) / 256) * H * B;
         const int grid = (int)min((int64_t)(uc_num_cus() / 8 * 8), (items + 7) / 8 * 8);
@@ -492,7 +492,7 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     const int64_t q_ext = ((int64_t)(B - 1) * q_sb + (int64_t)(H - 1) * q_sh + (int64_t)(Nq - 1) * q_sn + 64) * 2;
     const int64_t o_ext = ((int64_t)(B - 1) * o_sb + (int64_t)(H - 1) * o_sh + (int64_t)(Nq - 1) * o_sn + 64) * 2;
     const bool fits32 = q_ext < (int64_t)0xffffffffll && o_ext < (int64_t)0xffffffffll && (int64_t)B * H * 2 * p.nq_pad * 4 < (int64_t)0xffffffffll;
-    const bool use64 = Nq > 64 && fits32 && (k64 == 2 || (k64 == 1 && Nk >= 192 && ((Nk + 255) / 256) * 256 * 4 <= Nk * 5));
+    const bool use64 = Nq > 64 && fits32 && (k64 == 2 || (k64 == 1 && Nk >= 192 && ((Nk + 255) / 256) * 256 * 3 <= Nk * 4));
     if (use64) {      // persistent: one workgroup per CU, workgroup g on XCD g % 8
         const int64_t items = (int64_t)((Nk + 255) / 256) * H * B;
         const int grid = (int)min((int64_t)(uc_num_cus() / 8 * 8), (items + 7) / 8 * 8);
