@@ -153,3 +153,26 @@ def test_gradient_checkpointing_wraps_blocks_like_the_reference():
         assert not any(type(blk).__name__.startswith("Checkpointed") for blk in blocks_of(a))
     enc = encoder_factory("dinov2", name="d", size="small", with_registers=True, keep_first_n_layers=2, gradient_checkpointing=True)
     assert enc.gradient_checkpointing and all(type(b).__name__.startswith("Checkpointed") for b in enc.model.blocks)
+
+
+def test_dropout_masks_follow_nn_dropout_and_timm_droppath():
+    """autograd.make_drops (host logic of the training-time dropout): None in eval mode or at rate 0; element masks keep with
+    probability 1 - p and scale by 1 / (1 - p) (nn.Dropout); DropPath masks are one byte per SAMPLE, scale 1 / keep unless
+    scale_by_keep is off (timm); PyTorch's generator owns the state (same seed, same masks)."""
+    import torch
+    from uniception_amd import autograd
+    assert autograd.make_drops(False, "cpu", 2, 8, 16, p_out=0.5, p_path=0.5) is None
+    assert autograd.make_drops(True, "cpu", 2, 8, 16) is None
+    torch.manual_seed(3)
+    d = autograd.make_drops(True, "cpu", 64, 32, 64, p_out=0.25, p_path=0.5, hidden=128, p_mid=0.1)
+    assert d.out.shape == (64 * 32, 64) and d.out.dtype == torch.uint8 and abs(float(d.out.float().mean()) - 0.75) < 0.01
+    assert d.mid.shape == (64 * 32, 128) and abs(float(d.mid.float().mean()) - 0.9) < 0.01
+    assert d.path.shape == (64,) and d.path_rows == 32 and 0.2 < float(d.path.float().mean()) < 0.8
+    assert abs(d.out_scale - 1 / 0.75) < 1e-6 and abs(d.mid_scale - 1 / 0.9) < 1e-6 and d.path_scale == 2.0 and d.has_out
+    torch.manual_seed(3)
+    d2 = autograd.make_drops(True, "cpu", 64, 32, 64, p_out=0.25, p_path=0.5, hidden=128, p_mid=0.1)
+    assert torch.equal(d.out, d2.out) and torch.equal(d.path, d2.path) and torch.equal(d.mid, d2.mid)
+    d3 = autograd.make_drops(True, "cpu", 4, 8, 16, p_path=0.25, scale_by_keep=False)
+    assert d3.out is None and d3.mid is None and d3.path_scale == 1.0 and d3.has_out
+    d4 = autograd.make_drops(True, "cpu", 4, 8, 16, hidden=32, p_mid=0.5)
+    assert d4.mid is not None and not d4.has_out
