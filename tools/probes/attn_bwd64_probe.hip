@@ -61,16 +61,7 @@ int main(int argc, char** argv) {
     {
         unsigned long long* dd; const size_t nd = 65536 + 4 * (size_t)grid + 16;
         CK(hipMalloc(&dd, nd * 8)); CK(hipMemset(dd, 0, nd * 8));
-        p.dbg = dd; launch_q(); CK(hipDeviceSynchronize());
-        {
-            std::vector<unsigned long long> hq(8 * 256); CK(hipMemcpy(hq.data(), dd, hq.size() * 8, hipMemcpyDeviceToHost));
-            const char* nq[8] = {"prologue", "tile loop", "tail+dQ", "rope", "load_stationary", "bounce+stores", "issue_stage", "-"};
-            const int items_wg = (int)((qitems + qgrid - 1) / qgrid);
-            printf("  dq64 wg 9 (s_memtime ticks per item):");
-            for (int i = 0; i < 7; ++i) printf(" %s %.0f", nq[i], (double)hq[9 * 8 + i] / items_wg);
-            printf("\n");
-            CK(hipMemset(dd, 0, nd * 8));
-        }
+        p.dbg = dd;
         launch(); CK(hipDeviceSynchronize());
         std::vector<unsigned long long> hd(nd); CK(hipMemcpy(hd.data(), dd, nd * 8, hipMemcpyDeviceToHost));
         const char* nm[8] = {"loop-top", "A0", "B0", "wait+barrier", "A1", "B1", "prologue+seams", "tail+readout"};
