@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
     struct Pieces { unsigned so_q, so_o, so_a, dst; };
     auto prep = [&](const Item& it, int t, int s) -> Pieces {
         Pieces pc;
-        pc.so_q = it.oq + (unsigned)t * qstep + q16;
-        pc.so_o = it.oo + (unsigned)t * ostep + o16;
-        pc.so_a = it.oa + a_so + (unsigned)t * 256u;
+        pc.so_q = __builtin_amdgcn_readfirstlane(it.oq + (unsigned)t * qstep + q16);
+        pc.so_o = __builtin_amdgcn_readfirstlane(it.oo + (unsigned)t * ostep + o16);
+        pc.so_a = __builtin_amdgcn_readfirstlane(it.oa + a_so + (unsigned)t * 256u);
         pc.dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(s * B64_SLOT) + (unsigned)wave * 2048u);
         return pc;
     };
@@ -409,7 +409,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnBwdParams p)
             const int pstep = s_rd == 0 ? -2 * B64_SLOT : B64_SLOT;        // ring step previous -> current tile
             const int s_w = __builtin_amdgcn_readfirstlane(s_rd == 0 ? 2 : s_rd - 1);      // the previous tile's slot: tile t + 2 of the stream lands there
             // (no next item: a harmless re-read into a slot nobody reads again)
-            const Pieces pc = t + 2 < nt ? prep(cur, t + 2, s_w) : (has_next ? prep(nxt, t + 2 - nt, s_w) : prep(cur, nt - 1, s_w));
+            // (one prep on selected scalars: three inlined preps behind branches cost the wave's only issue stream ~300 cycles per tile)
+            const bool in_cur = t + 2 < nt, use_nxt = !in_cur && has_next;
+            Item src = cur;
+            src.oq = use_nxt ? nxt.oq : cur.oq;
+            src.oo = use_nxt ? nxt.oo : cur.oo;
+            src.oa = use_nxt ? nxt.oa : cur.oa;
+            const Pieces pc = prep(src, in_cur ? t + 2 : (use_nxt ? t + 2 - nt : nt - 1), s_w);
             B64_TS(0);
             phase_a(P64Int<0>(), cad + 128, pc);
             B64_TS(1);
@@ -597,8 +603,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(AttnBwdParams p) 
     auto prep = [&](const Item& it, int t, int s) -> Pieces {
         Pieces pc;
         pc.srd_k = p64_make_srd((const void*)it.kb, kbytes);
-        pc.so_k = (unsigned)t * kstep + k16;
-        pc.so_v = it.ov + (unsigned)t * vstep + v16;
+        pc.so_k = __builtin_amdgcn_readfirstlane((unsigned)t * kstep + k16);
+        pc.so_v = __builtin_amdgcn_readfirstlane(it.ov + (unsigned)t * vstep + v16);
         pc.dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(s * D64_SLOT) + (unsigned)wave * 2048u);
         return pc;
     };
