@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the `fwd_224` (224x224 pairs), `batch_sweep` (1 / 2 / 4 / 8 pairs), `other_configs` (BASELINE configs[3], [4]) and `train_step` (BASELINE configs[2]) legs of the default line")
+    ap.add_argument("--train-pairs", type=int, default=TRAIN_PAIRS, help="pairs per GPU of the `train_step` leg inside the forward line")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed steps of the `train_step` leg")
     ap.add_argument("--single-stream", action="store_true",
                     help="no two-stream execution of independent sub-graphs at large batch (engine.concurrent(False)): what the "
                          "roofline pass and the committed kernel profiles use — per-kernel durations are only defined without overlap")
@@ -521,9 +523,24 @@ def other_configs_leg(args, dev):
     return out
 
 
-def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3):
-    """BASELINE configs[2] inside the default line: forward + backward + (1-rank) gradient exchange + AdamW of the same ViT-L + DPT model
-    at 512x512, `pairs` pairs, `steps` individually fenced steps (median AND block mean reported), with its own dense-GEMM roofline."""
+def exchange_summary(stats, step_ms):
+    """The multi-GPU part of a training leg: what `GradientBuckets.comm_stats()` measured, in the names the line carries.
+    `rccl_ranks` is read back from the process group (dist.get_world_size()), not from --gpus."""
+    return {"rccl_ranks": stats["ranks"], "backend": stats["backend"], "buckets": stats["buckets"], "bucket_bytes": stats["bucket_bytes"],
+            "comm_ms_per_step": stats.get("comm_ms"), "exposed_comm_ms_per_step": stats.get("exposed_ms"),
+            "overlapped_frac": stats.get("overlapped_frac"), "busbw_GBps": stats.get("busbw_GBps"),
+            "exposed_frac_of_step": (round(stats["exposed_ms"] / step_ms, 4) if stats.get("exposed_ms") is not None and step_ms else None),
+            "steps_measured": stats["steps"],
+            "definition": "comm = sum over buckets of (all-reduce end - the point every producer of the bucket was done), events on the "
+                          "communication stream; exposed = what the compute stream waited for the exchange after the backward's last kernel"}
+
+
+def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3, rank=0, world=1):
+    """BASELINE configs[2] inside the default line: forward + backward + gradient exchange + AdamW of the same ViT-L + DPT model
+    at 512x512, `pairs` pairs per rank.  world == 1: `steps` individually fenced steps (median AND block mean reported), with its own
+    dense-GEMM roofline; the exchange is a no-op.  world > 1 (the driver's `bench.py --gpus N`): EVERY rank runs it — `Trainer` over the
+    RCCL group, parameters broadcast from rank 0, K steps between barrier + synchronize fences, max over ranks — and the leg reports
+    the bucketed all-reduce it ran (`exchange`: bucket count / bytes, communication per step, the part the backward did not hide)."""
     from uniception_amd import autograd, engine
     from uniception_amd.models.factory import DUSt3R
     from uniception_amd.training import Trainer
@@ -532,8 +549,9 @@ def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3):
     torch.manual_seed(0)
     m = DUSt3R(name="bench_train", img_size=(args.img, args.img), pred_head_type=args.head).to(dev).train()
     trainer = Trainer(m, lr=1e-5, weight_decay=0.05)
-    a1, a2 = make_views(pairs, args.img, args.img, 0, dev)
-    g = torch.Generator().manual_seed(2000)
+    trainer.broadcast_parameters(0)
+    a1, a2 = make_views(pairs, args.img, args.img, rank, dev)
+    g = torch.Generator().manual_seed(2000 + rank)
     gt1 = torch.randn(pairs, args.img, args.img, 3, generator=g).to(dev)
     gt2 = torch.randn(pairs, args.img, args.img, 3, generator=g).to(dev)
 
@@ -546,21 +564,34 @@ def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3):
         trainer.step()
         return loss.detach()
     step(); step()
-    dt, st = timed_each(step, steps)
-    loss = step()
+    exchange = None
+    if world > 1:
+        from uniception_amd.distributed import max_over_ranks
+        trainer.enable_comm_timing(True)
+        dt, loss = timed(step, steps, world)
+        dt = max_over_ranks(dt, dev)
+        st = {"n": steps, "reported": "K steps between barrier + synchronize fences, max over ranks"}
+        exchange = exchange_summary(trainer.comm_stats(), dt / steps * 1e3)
+        trainer.enable_comm_timing(False)
+    else:
+        dt, st = timed_each(step, steps)
+        loss = step()
     assert torch.isfinite(loss).all()
-    pps = pairs * steps / dt
+    pps = world * pairs * steps / dt
     gf = gflop_enc_dec(args.img)
     out = {"workload": f"BASELINE configs[2]: ViT-L/16 + 12-block decoder + {args.head} head, {args.img}x{args.img} pairs, forward + backward + AdamW, "
-                       "synthetic pointmap targets, 1 rank (the gradient exchange is a no-op at world 1)",
-           "pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": pairs, "timing": st,
+                       "synthetic pointmap targets, " + ("1 rank (the gradient exchange is a no-op at world 1)" if world == 1 else
+                                                         f"{world} ranks (replicated model, bucketed in-place gradient all-reduce, weak scaling)"),
+           "pairs_per_s": round(pps, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_gpu": pairs, "n_gpus": world, "timing": st,
            "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
            "heads": engine.train_head_dtype_name() if hasattr(engine, "train_head_dtype_name") else "bf16 kernels (forward and backward)",
            "streams": "2 (encoder views, decoder branches, heads: forward and backward)" if (engine.CONCURRENT and engine.TRAIN_CONCURRENT) else "1",
            "residual_stream": "bf16 (the reference's stream under autocast)" if engine._bf16_train_stream else "fp32",
-           "enc_dec_mfma_frac_lower_bound": round(pps * gf * 3 / 1e3 / PEAK_BF16_TFLOPS, 4),
+           "enc_dec_mfma_frac_lower_bound": round(pps / world * gf * 3 / 1e3 / PEAK_BF16_TFLOPS, 4),
            "note": "fraction = pairs/s x 3 x forward enc+dec flops / peak: charges heads, optimizer and the whole step to the enc+dec flops"}
-    if not args.no_roofline:
+    if exchange is not None:
+        out["exchange"] = exchange
+    if not args.no_roofline and world == 1:
         with engine.concurrent(False):
             step()      # (untimed: the first single-stream step after two-stream ones draws fresh blocks from hipMalloc — inside the brackets otherwise)
             torch.cuda.synchronize()
@@ -602,10 +633,31 @@ def launch_check(rank, world):
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
     dt = max_over_ranks(time.perf_counter() - t0)
+    line = {"launch_check": True, "n_gpus": world, "max_rank_s": round(dt, 4), "note": "control flow only: not a measurement"}
     if world > 1:
+        # the exchange the N > 1 line reports, on a toy CPU model: the same FlatParameters / GradientBuckets / comm_stats /
+        # exchange_summary code the GPU ranks run (Trainer's optimizer kernel needs a GPU; the bucketed all-reduce does not)
+        from uniception_amd.training import FlatParameters, GradientBuckets
+        torch.manual_seed(3)
+        toy = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.GELU(), torch.nn.Linear(32, 32), torch.nn.GELU(), torch.nn.Linear(32, 3))
+        flat = FlatParameters(toy, 2048)
+        buckets = GradientBuckets(flat)
+        buckets.enable_comm_timing(True)
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 + rank))
+        ts = time.perf_counter()
+        for _ in range(2):
+            flat.zero_grad()
+            buckets.start_step()
+            toy(x).square().mean().backward()
+            buckets.finish()
+        step_ms = (time.perf_counter() - ts) / 2 * 1e3
+        line["rccl_ranks"] = dist.get_world_size()
+        line["backend"] = dist.get_backend()
+        line["train_step"] = {"workload": "toy CPU model over gloo: the exchange code path only", "n_gpus": world,
+                              "exchange": exchange_summary(buckets.comm_stats(), step_ms)}
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "max_rank_s": round(dt, 4), "note": "control flow only: not a measurement"}), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -720,6 +772,8 @@ def main():
     for _ in range(args.warmup):
         step()
 
+    if args.mode == "train" and world > 1:
+        trainer.enable_comm_timing(True)
     dt, out = timed(step, args.steps, world)
     if world > 1:
         from uniception_amd.distributed import max_over_ranks
@@ -760,6 +814,17 @@ def main():
         "enc_dec_gflop_per_pair": round(gflop_pair, 1),
         "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
     }
+    if world > 1:
+        # the multi-GPU line measures the multi-GPU design: forward pairs/s above is weak scaling with no data-path
+        # collective; the bucketed gradient all-reduce only exists in the training step, so at N > 1 EVERY rank also runs it
+        line["rccl_ranks"] = dist.get_world_size()
+        line["backend"] = dist.get_backend()
+        if not fwd:
+            line["exchange"] = exchange_summary(trainer.comm_stats(), dt / args.steps * 1e3)
+        elif not args.no_extra_legs and args.precision == "bf16" and not args.graph:
+            del out
+            leg = train_step_leg(args, dev, pairs=args.train_pairs, steps=args.train_steps, rank=rank, world=world)
+            line["train_step"] = leg
     if share:
         line["config"]["shared_gpu_dry_run"] = "ranks share devices, gloo process group: control-flow check only, not a measurement"
     if rank == 0 and world == 1 and not fwd and not args.no_roofline and args.precision == "bf16":
@@ -784,7 +849,7 @@ def main():
             line["fwd_224"] = fwd_224_leg(args, dev)
             line["batch_sweep"] = batch_sweep(model, [1, 2, 4, 8], args, dev)      # the reference harness's own sizes (profile_dust3r.py:12-46)
             line["other_configs"] = other_configs_leg(args, dev)
-            line["train_step"] = train_step_leg(args, dev)
+            line["train_step"] = train_step_leg(args, dev, pairs=args.train_pairs, steps=args.train_steps)
         if args.sweep and "batch_sweep" not in line:
             line["batch_sweep"] = batch_sweep(model, [int(x) for x in args.sweep.split(",")], args, dev)
         if not args.no_cpu_baseline:

@@ -133,3 +133,23 @@ def test_four_wave_gemm_hands_its_accumulators_over_in_untouched_agprs():
     assert open(B.LIB + ".agpr").read().strip() == B.loaded_fingerprint()
     gen = subprocess.run([sys.executable, os.path.join(ROOT, "uniception_amd", "csrc", "gen", "gen_glds4_loop.py")], capture_output=True, text=True, check=True).stdout
     assert gen == open(os.path.join(ROOT, "uniception_amd", "csrc", "gemm_glds4_loop.inc")).read(), "regenerate gemm_glds4_loop.inc"
+
+
+def test_package_reaches_no_vendor_blas():
+    """nothing in the package may compute a matrix product through PyTorch (rocBLAS / hipBLASLt behind `@`, mm, linear,
+    einsum ...), not even in one-time weight preparation — every product is a uc_hip kernel or an elementwise pass.  Static check over the
+    package sources (tools/ are offline utilities that compare against torch on purpose)."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uniception_amd")
+    pat = re.compile(r"(\s@\s|torch\.(mm|matmul|bmm|addmm|einsum|mv|baddbmm)\(|\.(matmul|mm|bmm|mv)\(|F\.linear\(|F\.conv2d\(|F\.scaled_dot_product_attention\()")
+    hits = []
+    for d, _, files in os.walk(root):
+        if os.sep + "tools" in d:
+            continue
+        for f in files:
+            if f.endswith(".py"):
+                for i, line in enumerate(open(os.path.join(d, f)), 1):
+                    code = line.split("#")[0]
+                    if pat.search(code) and not code.lstrip().startswith(('"', "'")):
+                        hits.append(f"{os.path.relpath(os.path.join(d, f), root)}:{i}: {line.strip()}")
+    assert not hits, hits

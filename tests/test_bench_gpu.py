@@ -25,9 +25,16 @@ def _bench(args, extra_env=None):
 @pytest.mark.parametrize("mode", ["fwd", "train"])
 def test_bench_two_ranks_from_plain_python(gpu, mode):
     line = _bench(["--gpus", "2", "--mode", mode, "--pairs", "1", "--img", "224", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-                   "--no-reference-policy", "--no-roofline"], {"UNICEPTION_AMD_BENCH_SHARE_GPU": "1"})
+                   "--no-reference-policy", "--no-roofline", "--train-pairs", "1", "--train-steps", "1"], {"UNICEPTION_AMD_BENCH_SHARE_GPU": "1"})
     assert line["n_gpus"] == 2 and line["config"]["global_pairs_per_step"] == 2 and line["scaling"] == "weak"
     assert line["value"] > 0 and "shared_gpu_dry_run" in line["config"]
+    # at N > 1 the line carries the exchange it ran — in the forward line through the `train_step` leg every rank runs
+    assert line["rccl_ranks"] == 2
+    ex = line["train_step"]["exchange"] if mode == "fwd" else line["exchange"]
+    assert ex["rccl_ranks"] == 2 and ex["buckets"] >= 1 and sum(ex["bucket_bytes"]) > 4 * 300e6
+    assert ex["comm_ms_per_step"] > 0 and ex["exposed_comm_ms_per_step"] >= 0 and ex["steps_measured"] >= 1
+    if mode == "fwd":
+        assert line["train_step"]["n_gpus"] == 2 and line["train_step"]["pairs_per_s"] > 0
 
 
 @pytest.mark.gpu

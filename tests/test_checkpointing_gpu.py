@@ -132,3 +132,46 @@ def test_dinov2_encoder_checkpointed_equal_plain(gpu, mode):
     _same(res[False], res[True], "dinov2")
     print(f"\n[checkpointing {mode}] dinov2: held {res[False][3] / 2**20:.1f} MiB plain, {res[True][3] / 2**20:.1f} MiB checkpointed")
     assert res[True][3] < 0.7 * res[False][3]
+
+
+@pytest.mark.parametrize("kind", ["self", "cross"])
+def test_checkpointed_block_with_random_masks_equals_the_plain_block_under_the_same_seed(gpu, kind):
+    """proj_drop / the Mlp's drop / DropPath draw masks from PyTorch's generator in every forward, so a checkpointed block's
+    re-computation has to see the generator state of its first forward (the reference's `checkpoint(..., use_reentrant=False)` keeps
+    `preserve_rng_state=True`, encoders/base.py:139-152).  A wrapped block and the same block unwrapped, seeded alike, must produce the
+    same output and the same gradients; with the state NOT restored the recomputed activations belong to other masks than the ones the
+    saved ctx applies."""
+    import copy
+    from uniception_amd import engine
+    from uniception_amd.models.utils.checkpointing import has_random_masks, wrap_module_with_gradient_checkpointing
+    from uniception_amd.models.utils.transformer_blocks import CrossAttentionBlock, SelfAttentionBlock
+    from tests.helpers import rel_l2
+    B, N, Ny, C, H = 3, 40, 24, 128, 2
+    torch.manual_seed(11)
+    kw = dict(dim=C, num_heads=H, qkv_bias=True, proj_drop=0.2, drop_path=0.3)
+    plain = (SelfAttentionBlock(**kw) if kind == "self" else CrossAttentionBlock(**kw)).to(gpu).train()
+    ck = wrap_module_with_gradient_checkpointing(copy.deepcopy(plain))
+    assert has_random_masks(plain) and not has_random_masks(SelfAttentionBlock(dim=C, num_heads=H))
+    x0 = torch.randn(B, N, C, device=gpu)
+    y0 = torch.randn(B, Ny, C, device=gpu)
+    w = torch.randn(B, N, C, device=gpu)
+    res = []
+    for blk in (plain, ck):
+        x = x0.clone().requires_grad_(True)
+        y = y0.clone().requires_grad_(True)
+        torch.manual_seed(1234)
+        with engine.precision("fp32"):
+            # two blocks' worth of generator use between the forward and the backward: the recomputation must not see the advanced state
+            out = blk(x) if kind == "self" else blk(x, y)
+            _ = torch.rand(1000, device=gpu)
+            (out.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), x.grad.clone(), y.grad.clone() if kind == "cross" else None,
+                    {k: p.grad.clone() for k, p in blk.named_parameters()}))
+    (o0, gx0, gy0, p0), (o1, gx1, gy1, p1) = res
+    assert torch.equal(o0, o1)
+    assert rel_l2(gx1.double().cpu(), gx0.double().cpu()) < 1e-5
+    if kind == "cross":
+        assert rel_l2(gy1.double().cpu(), gy0.double().cpu()) < 1e-5
+    for k in p0:
+        assert rel_l2(p1[k].double().cpu(), p0[k].double().cpu()) < 1e-5, k

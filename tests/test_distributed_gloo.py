@@ -227,6 +227,14 @@ def test_bench_self_launches_two_ranks_from_plain_python():
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["launch_check"] is True
     assert lines[0]["max_rank_s"] >= 0.02          # the slowest rank's time (rank 1 sleeps 20 ms)
+    # the N > 1 line reports the gradient exchange it ran — ranks read back from the process group, bucket count and
+    # bytes, communication per step and the part the backward did not hide (same GradientBuckets.comm_stats / exchange_summary code as
+    # the GPU ranks' `train_step` leg; here over gloo on a toy model)
+    assert lines[0]["rccl_ranks"] == 2 and lines[0]["backend"] == "gloo"
+    ex = lines[0]["train_step"]["exchange"]
+    assert ex["rccl_ranks"] == 2 and ex["buckets"] == len(ex["bucket_bytes"]) >= 2 and sum(ex["bucket_bytes"]) >= 4 * (6 * 32 + 32 * 32 + 32 * 3)
+    assert ex["steps_measured"] == 2 and ex["comm_ms_per_step"] > 0 and ex["exposed_comm_ms_per_step"] >= 0
+    assert ex["exposed_comm_ms_per_step"] <= ex["comm_ms_per_step"] * 1.5 + 1.0 and ex["busbw_GBps"] is not None
 
 
 def test_bench_rejects_a_world_size_that_contradicts_gpus():

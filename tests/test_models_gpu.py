@@ -274,7 +274,7 @@ def test_bench_sized_batch_reproduces_the_golden_pair_to_the_bit(gpu):
     from uniception_amd import ops
     # (three default choices follow the number of tiles of a launch, i.e. the batch size, and each changes a summation order: the small-M
     #  path sums K >= 2048 in two halves, a 3x3 conv with fewer eight-wave row tiles than CUs stays on the implicit-GEMM kernel, and an
-    #  attention call with fewer than 1024 (batch, head, 256-query) items stays on the eight-wave kernel.
+    #  attention call with fewer than 512 (batch, head, 256-query) items stays on the eight-wave kernel.
     #  Pinned — small_m_split 0, conv_rows 3: the eight-wave conv kernel, attn_p64 2: the persistent attention kernel wherever the shape
     #  allows — a pair's bits do not depend on its batch)
     with ops.tuning("small_m_split", 0), ops.tuning("conv_rows", 3), ops.tuning("attn_p64", 2):

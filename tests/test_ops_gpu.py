@@ -738,7 +738,9 @@ def test_attention_persistent_kernel_score_range(gpu, case):
     assert (out.cpu().float() - ref).abs().max() < 6.5e-2       # (two bf16 output steps at |o| < 8)
     assert rel_l2(out.cpu().float(), ref) < 8e-3
     # (Q is pre-multiplied by scale * log2(e) and re-rounded to bf16 inside the kernel: against a key 16 x a query, |q| |k| scale ~ 130 nats,
-    #  every score carries ~5e-4 of that — the launcher keeps calls that want the log-sum-exp on the eight-wave kernel for this reason)
+    #  every score carries ~5e-4 of that.  Training's LSE calls DO take this kernel under the default policy (uc_attention_fwd has no lse
+    #  gate): the backward kernels re-round scale * log2(e) * Q the same way, so the P they rebuild from this LSE sums to one — the
+    #  gradient is that of the re-rounded Q; INTEGRATION.md §3 states the accepted LSE noise)
     assert (lse.cpu() - ref_lse).abs().max() < 0.12
 
 

@@ -194,13 +194,38 @@ def _rccl_worker(rank, world, port, out_path, mode):
         tr = Trainer(model, lr=2e-3, weight_decay=0.05, bucket_bytes=1 << 20, force_collectives=True)
         assert tr.buckets.active and len(tr.buckets.buckets) > 1 and len(tr.buckets._hooks) == len(tr.flat.order)
         issued = []
+        tr.enable_comm_timing(True)      # (bench.py's multi-GPU line: events around every bucket's ncclAllReduce on the communication stream)
         for _ in range(2):
             tr.zero_grad()
             _loss(model, imgs, gts, mode).backward()
             issued.append(tr.buckets._next)           # buckets launched by hooks DURING the backward
             tr.step()
+        stats = tr.comm_stats()
+        # ---- plain DistributedDataParallel over the same modules: the Functions hand ordinary gradients to
+        # autograd when no Trainer owns them, so DDP's reducer sees every parameter.  One rank: the all-reduce is the identity and the
+        # gradients must equal a bare backward's.  Single-stream training: DDP's bucket copies are not ordered against side streams.
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from uniception_amd import autograd as uc_autograd, engine
+        uc_autograd.set_grad_sink(False)
+        prev_tc, engine.TRAIN_CONCURRENT = engine.TRAIN_CONCURRENT, False
+        try:
+            m2, _ = build_case_model("tiny_linear")
+            m2 = m2.to(dev).train()
+            _loss(m2, imgs, gts, mode).backward()
+            bare = {k: p.grad.detach().clone() for k, p in m2.named_parameters() if p.grad is not None}
+            m2.zero_grad(set_to_none=True)
+            ddp = DDP(m2, device_ids=[0], find_unused_parameters=True)
+            with engine.precision(mode):
+                r1, r2 = ddp(imgs[0], imgs[1], {})
+                (uc_autograd.conf_loss(r1["pts3d"], r1["conf"], gts[0])
+                 + uc_autograd.conf_loss(r2["pts3d_in_other_view"], r2["conf"], gts[1])).backward()
+            torch.cuda.synchronize()
+            ddp_grads = {k: p.grad.detach().cpu() for k, p in m2.named_parameters() if p.grad is not None}
+            bare = {k: v.cpu() for k, v in bare.items()}
+        finally:
+            engine.TRAIN_CONCURRENT = prev_tc
         torch.save({"params": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "issued": issued,
-                    "nbuckets": len(tr.buckets.buckets)}, out_path)
+                    "nbuckets": len(tr.buckets.buckets), "stats": stats, "ddp": ddp_grads, "bare": bare}, out_path)
     finally:
         dist.destroy_process_group()
 
@@ -215,6 +240,14 @@ def test_one_rank_rccl_exchange_step(gpu, tmp_path, mode):
     mp.spawn(_rccl_worker, args=(1, port, out_path, mode), nprocs=1, join=True)
     got = torch.load(out_path)
     assert got["issued"][0] >= got["nbuckets"] - 1, "hooks must launch the collectives during the backward, not finish()"
+    st = got["stats"]
+    assert st["ranks"] == 1 and st["backend"] == "nccl" and st["buckets"] == got["nbuckets"] == len(st["bucket_bytes"]) and st["steps"] == 2
+    assert st["comm_ms"] > 0 and 0 <= st["exposed_ms"] and st["overlapped_frac"] is not None
+    print(f"\n[1-rank RCCL exchange, {mode}] {st['buckets']} buckets, comm {st['comm_ms']} ms / step, exposed {st['exposed_ms']} ms")
+    assert got["ddp"].keys() == got["bare"].keys() and len(got["ddp"]) > 10
+    worst_ddp = max(rel_l2(got["ddp"][k], got["bare"][k]) for k in got["bare"] if float(got["bare"][k].norm()) > 0)
+    print(f"[DistributedDataParallel vs bare backward, {mode}] worst gradient deviation {worst_ddp:.2e}")
+    assert worst_ddp < (1e-5 if mode == "fp32" else 1e-2)
     model, c = build_case_model("tiny_linear")
     model = model.to(gpu).train()
     imgs = [t.to(gpu) for t in case_images(c)]

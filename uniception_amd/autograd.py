@@ -264,17 +264,44 @@ def make_drops(training: bool, device, B: int, N: int, C: int, p_out: float = 0.
         return None
     d = Drops()
     if p_out > 0.0:
-        d.out = (torch.rand((B * N, C), device=device) >= p_out).to(torch.uint8)
+        d.out = torch.empty((B * N, C), dtype=torch.uint8, device=device).bernoulli_(1.0 - p_out)
         d.out_scale = 1.0 / (1.0 - p_out) if p_out < 1.0 else 0.0
     if p_path > 0.0:
         keep = 1.0 - p_path
-        d.path = (torch.rand((B,), device=device) < keep).to(torch.uint8)
+        d.path = torch.empty((B,), dtype=torch.uint8, device=device).bernoulli_(keep)
         d.path_rows = N
         d.path_scale = 1.0 / keep if (scale_by_keep and keep > 0.0) else 1.0
     if p_mid > 0.0:
-        d.mid = (torch.rand((B * N, hidden), device=device) >= p_mid).to(torch.uint8)
+        d.mid = torch.empty((B * N, hidden), dtype=torch.uint8, device=device).bernoulli_(1.0 - p_mid)
         d.mid_scale = 1.0 / (1.0 - p_mid) if p_mid < 1.0 else 0.0
     return d
+
+
+def _drops_saved(drops):
+    """(mask tensors, spec) of a call's Drops: the masks go through ctx.save_for_backward — visible to checkpoint's saved-tensor hooks
+    (dropped with the other activations of a checkpointed block and re-drawn from the restored generator state) and covered by
+    autograd's version check; ctx.meta keeps only the scales."""
+    if drops is None:
+        return (), None
+    masks = tuple(m for m in (drops.out, drops.path, drops.mid) if m is not None)
+    return masks, (drops.out is not None, drops.out_scale, drops.path is not None, drops.path_rows, drops.path_scale,
+                   drops.mid is not None, drops.mid_scale)
+
+
+def _drops_restore(spec, saved):
+    "(Drops or None, the saved tensors without the trailing masks): inverse of _drops_saved in a backward."
+    if spec is None:
+        return None, tuple(saved)
+    n = int(spec[0]) + int(spec[2]) + int(spec[5])
+    masks, saved = list(saved[len(saved) - n:]), tuple(saved[:len(saved) - n])
+    d = Drops()
+    if spec[0]:
+        d.out, d.out_scale = masks.pop(0), spec[1]
+    if spec[2]:
+        d.path, d.path_rows, d.path_scale = masks.pop(0), spec[3], spec[4]
+    if spec[5]:
+        d.mid, d.mid_scale = masks.pop(0), spec[6]
+    return d, saved
 
 
 def _drop_out(f2d, drops, residual=None, out_dtype=None):
@@ -479,15 +506,17 @@ class SelfAttnSubLayerFn(Function):
         else:
             out = ops.gemm(o.view(M, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
         # (gamma goes through save_for_backward: autograd's version check then catches an in-place edit between forward and backward)
+        masks, dspec = _drops_saved(drops)
         ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0), *(() if qkn is None else qkn),
-                              *(() if gamma is None else (gamma,)))
-        ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None, qn, kn, qkn is not None, drops)
+                              *(() if gamma is None else (gamma,)), *masks)
+        ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None, qn, kn, qkn is not None, dspec)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
-        x2d, g, h, t, o, lse, pos, *rest = ctx.saved_tensors
-        ln, qkv, proj, B, N, H, rope, scale, dt, has_bq, has_bp, qn, kn, has_qkn, drops = ctx.meta
+        ln, qkv, proj, B, N, H, rope, scale, dt, has_bq, has_bp, qn, kn, has_qkn, dspec = ctx.meta
+        drops, saved = _drops_restore(dspec, ctx.saved_tensors)
+        x2d, g, h, t, o, lse, pos, *rest = saved
         qx, kx = (rest[0], rest[1]) if has_qkn else (None, None)
         rest = rest[2:] if has_qkn else rest
         gamma = rest[0] if rest else None
@@ -597,16 +626,18 @@ class CrossAttnSubLayerFn(Function):
         else:
             out = ops.gemm(o.view(Mq, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
         e = torch.empty(0)
+        masks, dspec = _drops_saved(drops)
         ctx.save_for_backward(x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos if qpos is not None else e, kpos if kpos is not None else e,
-                              *(() if qkn is None else qkn))
+                              *(() if qkn is None else qkn), *masks)
         ctx.meta = (ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt,
-                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None, qn, kn, drops)
+                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None, qn, kn, dspec)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
-        x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos, kpos, *qkn = ctx.saved_tensors
-        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp, qn, kn, drops = ctx.meta
+        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp, qn, kn, dspec = ctx.meta
+        drops, saved = _drops_restore(dspec, ctx.saved_tensors)
+        x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos, kpos, *qkn = saved
         Mq, C = x2d.shape
         Dh = C // H
         dxo = _c(dxo)
@@ -693,15 +724,17 @@ class MlpSubLayerFn(Function):
             out = _drop_out(ops.gemm(a, w2, b2), drops, x2d, x2d.dtype)
         else:
             out = ops.gemm(a, w2, b2, residual=x2d, out_dtype=x2d.dtype)
-        ctx.save_for_backward(x2d, g, h, u, a, *(() if gamma is None else (gamma,)))
-        ctx.meta = (ln, fc1, fc2, act, dt, b1_ is not None, b2_ is not None, drops)
+        masks, dspec = _drops_saved(drops)
+        ctx.save_for_backward(x2d, g, h, u, a, *(() if gamma is None else (gamma,)), *masks)
+        ctx.meta = (ln, fc1, fc2, act, dt, b1_ is not None, b2_ is not None, dspec)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
-        x2d, g, h, u, a, *rest = ctx.saved_tensors
+        ln, fc1, fc2, act, dt, has_b1, has_b2, dspec = ctx.meta
+        drops, saved = _drops_restore(dspec, ctx.saved_tensors)
+        x2d, g, h, u, a, *rest = saved
         gamma = rest[0] if rest else None
-        ln, fc1, fc2, act, dt, has_b1, has_b2, drops = ctx.meta
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
         if drops is not None and drops.has_out:

@@ -492,7 +492,11 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     const int64_t q_ext = ((int64_t)(B - 1) * q_sb + (int64_t)(H - 1) * q_sh + (int64_t)(Nq - 1) * q_sn + 64) * 2;
     const int64_t o_ext = ((int64_t)(B - 1) * o_sb + (int64_t)(H - 1) * o_sh + (int64_t)(Nq - 1) * o_sn + 64) * 2;
     const bool fits32 = q_ext < (int64_t)0xffffffffll && o_ext < (int64_t)0xffffffffll && (int64_t)B * H * 2 * p.nq_pad * 4 < (int64_t)0xffffffffll;
-    const bool use64 = Nq > 64 && fits32 && (k64 == 2 || (k64 == 1 && Nk >= 192 && ((Nk + 255) / 256) * 256 * 3 <= Nk * 4));
+    // query rows past Nq of a (batch, head) are read through those descriptors and must be FINITE (their P is exp2(-1e30 + s) = 0): true
+    // when the next batch's rows follow directly (or the tensor ends: zero fill), not when a strided view leaves a gap of foreign memory
+    // between batches — such views take the 32-key kernel, whose loads are bounded per (batch, head)
+    const bool rows_follow = B == 1 || (q_sb == (int64_t)Nq * q_sn && o_sb == (int64_t)Nq * o_sn);
+    const bool use64 = Nq > 64 && fits32 && rows_follow && (k64 == 2 || (k64 == 1 && Nk >= 192 && ((Nk + 255) / 256) * 256 * 3 <= Nk * 4));
     if (use64) {      // persistent: one workgroup per CU, workgroup g on XCD g % 8
         const int64_t items = (int64_t)((Nk + 255) / 256) * H * B;
         const int grid = (int)min((int64_t)(uc_num_cus() / 8 * 8), (items + 7) / 8 * 8);

@@ -468,7 +468,7 @@ def _fold_ln(w: torch.Tensor, b: Optional[torch.Tensor], ln: nn.LayerNorm, dtype
     """(W * gamma in dtype, b + W beta fp32, row sums of the ROUNDED W * gamma fp32): LN(x) W^T + b = rstd (x W'^T - mean colsum) + b'."""
     w32 = w.detach().float()
     wf = (w32 * ln.weight.detach().float()[None, :]).to(dtype).contiguous()
-    bias = w32 @ ln.bias.detach().float()
+    bias = (w32 * ln.bias.detach().float()[None, :]).sum(1)      # (one-time weight prep; an elementwise product + row sum, not a vendor-BLAS gemv)
     if b is not None:
         bias = bias + b.detach().float()
     return wf, bias.contiguous(), wf.float().sum(1).contiguous()

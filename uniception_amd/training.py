@@ -20,6 +20,7 @@ communication stream, from which the collective is launched.  xGMI rings are per
 and applies uc_adamw with grad_scale = 1/world_size (the mean).
 """
 import contextlib
+import time
 from typing import List
 
 import torch
@@ -113,6 +114,10 @@ class GradientBuckets:
         self._comm_stream = torch.cuda.Stream(device=flat.grad.device) if flat.grad.is_cuda else None
         self._main_stream = torch.cuda.current_stream(flat.grad.device) if flat.grad.is_cuda else None   # re-recorded by start_step()
         self._hooks = []
+        # communication timing (bench.py's multi-GPU line): off by default — events only when asked for
+        self.measure = False
+        self._timing: List = []            # per finished step: (bwd_done, comm_done, [(start, end, bytes)]) events / host seconds
+        self._step_marks: List = []
         if self.active:
             for n, p in flat.order:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(n)))
@@ -172,8 +177,14 @@ class GradientBuckets:
                 self._comm_stream.wait_stream(s)
             g.record_stream(self._comm_stream)
             with torch.cuda.stream(self._comm_stream):
+                if self.measure:           # the point where the collective MAY start: every producer of the bucket is behind it
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record(self._comm_stream)
+                    self._step_marks.append([ev0, None, (hi - lo) * g.element_size()])
                 self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
+            if self.measure:
+                self._step_marks.append([time.perf_counter(), None, (hi - lo) * g.element_size()])
             self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self) -> None:
@@ -181,14 +192,76 @@ class GradientBuckets:
         sequence on every rank — and wait for everything."""
         if not self.active:
             return
+        cuda = self._comm_stream is not None
+        bwd_done = None
+        if self.measure:
+            if cuda:
+                # "the backward is over" = the last kernel of the main stream AND of every side stream a forked branch's backward ran on
+                from . import engine
+                cur = torch.cuda.current_stream(self.flat.grad.device)
+                for s in engine.all_side_streams(self.flat.grad.device):
+                    cur.wait_stream(s)
+                bwd_done = torch.cuda.Event(enable_timing=True)
+                bwd_done.record(cur)
+            else:
+                bwd_done = time.perf_counter()
         for b in range(self._next, len(self.buckets)):
             self._issue(b)
         self._next = len(self.buckets)
-        for h in self.handles:
-            h.wait()
-        if self._comm_stream is not None:
+        if cuda:
+            # the waits run on the communication stream (it then holds every collective's end: an event after a wait is that
+            # collective's completion time), and the compute stream joins the communication stream once
+            with torch.cuda.stream(self._comm_stream):
+                for i, h in enumerate(self.handles):
+                    h.wait()
+                    if self.measure and i < len(self._step_marks):
+                        ev1 = torch.cuda.Event(enable_timing=True)
+                        ev1.record(self._comm_stream)
+                        self._step_marks[i][1] = ev1
             torch.cuda.current_stream(self.flat.grad.device).wait_stream(self._comm_stream)
+        else:
+            for i, h in enumerate(self.handles):
+                h.wait()
+                if self.measure and i < len(self._step_marks):
+                    self._step_marks[i][1] = time.perf_counter()
+        if self.measure:
+            if cuda:
+                comm_done = torch.cuda.Event(enable_timing=True)
+                comm_done.record(torch.cuda.current_stream(self.flat.grad.device))
+            else:
+                comm_done = time.perf_counter()
+            self._timing.append((bwd_done, comm_done, self._step_marks))
+            self._step_marks = []
         self.handles = []
+
+    def enable_comm_timing(self, on: bool = True) -> None:
+        "Record, from the next step on, when each bucket's collective may start / has ended and when the backward / the exchange end."
+        self.measure = bool(on) and self.active
+        self._timing, self._step_marks = [], []
+
+    def comm_stats(self) -> dict:
+        """Per-step averages over the steps finished since enable_comm_timing(): `comm_ms` = sum over buckets of (collective end −
+        the point it could start), `exposed_ms` = what the compute stream waited for the exchange AFTER the backward's last kernel
+        (communication not hidden under the backward), `overlapped_frac` = 1 − exposed / comm.  Synchronizes the device."""
+        world = self.world
+        out = {"ranks": world, "backend": (dist.get_backend(self.pg) if (dist.is_available() and dist.is_initialized()) else None),
+               "buckets": len(self.buckets), "bucket_bytes": [(hi - lo) * self.flat.grad.element_size() for lo, hi in self.buckets],
+               "steps": len(self._timing)}
+        if not self._timing:
+            return out
+        cuda = self._comm_stream is not None
+        if cuda:
+            torch.cuda.synchronize(self.flat.grad.device)
+        el = (lambda a, b: a.elapsed_time(b)) if cuda else (lambda a, b: (b - a) * 1e3)
+        comm = [sum(el(m[0], m[1]) for m in marks if m[1] is not None) for _b, _c, marks in self._timing]
+        exposed = [max(0.0, el(b, c)) for b, c, _m in self._timing]
+        out["comm_ms"] = round(sum(comm) / len(comm), 3)
+        out["exposed_ms"] = round(sum(exposed) / len(exposed), 3)
+        out["overlapped_frac"] = round(1.0 - out["exposed_ms"] / out["comm_ms"], 4) if out["comm_ms"] > 0 else None
+        total = sum(out["bucket_bytes"])
+        # ring all-reduce moves 2 (n-1)/n of the buffer per rank: the bus bandwidth the exchange ran at while it was on the wire
+        out["busbw_GBps"] = round(2.0 * (world - 1) / max(world, 1) * total / (out["comm_ms"] * 1e-3) / 1e9, 2) if out["comm_ms"] > 0 else None
+        return out
 
 
 class Trainer:
@@ -209,6 +282,13 @@ class Trainer:
     @property
     def world_size(self) -> int:
         return self.buckets.world
+
+    def enable_comm_timing(self, on: bool = True) -> None:
+        self.buckets.enable_comm_timing(on)
+
+    def comm_stats(self) -> dict:
+        "GradientBuckets.comm_stats(): bucket count / bytes, per-step communication time and the part the backward did not hide."
+        return self.buckets.comm_stats()
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world_size > 1:
