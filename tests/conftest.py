@@ -35,4 +35,5 @@ def _automatic_gemm_variant():
         ops.tuning_set("gemm_stagger", -1)
         ops.tuning_set("attn_role_split", ATTN_RS_DEFAULT)
         ops.tuning_set("conv_rows", 1)
+        ops.tuning_set("conv_rows_flat", 1)
         ops.tuning_set("small_m_split", 2048)

@@ -555,12 +555,20 @@ def test_conv3x3_row_walking_kernel(gpu, dtype, geom):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("geom", [(8, 128, 128, 64, 128), (1, 256, 512, 64, 128), (2, 256, 256, 128, 128), (1, 128, 1024, 64, 128), (1, 512, 128, 64, 256),
-                                  (3, 192, 256, 64, 128)])
+                                  (3, 192, 256, 64, 128),
+                                  # round 6, the FLAT form (rows that do not tile 512 pixels; tiles of 512 consecutive pixels): the DINOv2-518
+                                  # head's 148 / 296 / 592-wide maps, the 224 x 224 head's 56 / 112 / 224, the 64^2 level, a 17-wide odd map
+                                  # whose 1700 pixels leave a ragged last tile and put several images into one tile
+                                  (2, 148, 148, 64, 128), (1, 37, 296, 128, 128), (1, 30, 592, 64, 128), (3, 56, 56, 64, 128), (2, 112, 112, 64, 256),
+                                  (1, 224, 224, 64, 128), (4, 64, 64, 64, 128), (5, 20, 17, 64, 128)])
 def test_conv3x3_eight_wave_row_walking_kernel(gpu, dtype, geom):
     """conv3x3_rows8_kernel (512 pixels x 128 output channels per workgroup, eight waves of 128 x 64, 32-channel super-steps of three
     taps, register-prefetched fragments): same contract as the implicit-GEMM kernel — against torch's conv on the same rounded
     operands; tiles of one, two and four image-row segments, two tiles per image row (W = 1024), image borders, several images,
-    ReLU on load, bias + ReLU, two residuals, fp32 output, two column tiles, the fused 1x1 tail, bf16 and fp16 operands."""
+    ReLU on load, bias + ReLU, two residuals, fp32 output, two column tiles, the fused 1x1 tail, bf16 and fp16 operands.
+    Round 6: any width from 16 pixels and any pixel count through the kernel's flat form (edge columns zeroed in registers, the
+    vertical padding by the DMA's zero fill, the last tile by the epilogues' row bound); `conv_rows_flat` 0 keeps those maps on the
+    implicit-GEMM kernel (same products, another summation order)."""
     from uniception_amd import ops
     B, H, W, Cin, Cout = geom
     g = torch.Generator().manual_seed(B * H + W + Cin + 1)
@@ -589,6 +597,11 @@ def test_conv3x3_eight_wave_row_walking_kernel(gpu, dtype, geom):
         outs[mode] = ops.gemm(xg, w_r, bias.to(gpu), conv=(B, H, W, Cin, 1), out_dtype=torch.float32)
     assert rel_l2(outs[3], outs[0]) < 2e-6 and not torch.equal(outs[3], outs[0])
     ops.tuning_set("conv_rows", 3)
+    flat = not (W >= 128 and (W % 512 == 0 or 512 % W == 0) and H % max(1, 512 // W) == 0 and (B * H * W) % 512 == 0)
+    if flat:      # the knob that keeps such maps off the kernel: then this IS the implicit-GEMM launch
+        with ops.tuning("conv_rows_flat", 0):
+            off = ops.gemm(xg, w_r, bias.to(gpu), conv=(B, H, W, Cin, 1), out_dtype=torch.float32)
+        assert torch.equal(off, outs[0])
     if Cout == 128 and dtype == torch.bfloat16:
         w4 = torch.randn(4, 128, generator=g) / math.sqrt(128)
         b4 = torch.randn(4, generator=g)

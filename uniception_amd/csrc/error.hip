@@ -33,6 +33,7 @@ std::atomic<int> g_uc_attn_rs{UC_ATTN_RS_DEFAULT};
 std::atomic<int> g_uc_attn_p64{1};
 std::atomic<int> g_uc_attn_bwd64{1};
 std::atomic<int> g_uc_conv_rows{1};
+std::atomic<int> g_uc_conv_rows_flat{1};
 std::atomic<int> g_uc_small_m_split{2048};
 
 static int env_int(const char* name, int dflt) {
@@ -68,6 +69,7 @@ const UcKnobs& uc_knobs() {
         g_uc_attn_p64.store(env_int("UC_ATTN_P64", 1));
         g_uc_attn_bwd64.store(env_int("UC_ATTN_BWD64", 1));
         g_uc_conv_rows.store(env_int("UC_CONV_ROWS", 1));
+        g_uc_conv_rows_flat.store(env_int("UC_CONV_ROWS_FLAT", 1));
         g_uc_small_m_split.store(env_int("UC_GEMM_SMALLM", 2048));
     });
     return g_knobs;
@@ -97,8 +99,11 @@ extern "C" int uc_tuning_set(const char* name, int value) {
     } else if (!strcmp(name, "conv_rows")) {
         UC_REQUIRE(value >= 0 && value <= 3, "uc_tuning_set: conv_rows must be 0 (implicit GEMM everywhere), 1 (row-walking kernels where they win), 2 (the 256-pixel row-walking kernel wherever the shape allows) or 3 (the eight-wave 512-pixel one wherever the shape allows) (got %d)", value);
         g_uc_conv_rows.store(value);
+    } else if (!strcmp(name, "conv_rows_flat")) {
+        UC_REQUIRE(value == 0 || value == 1, "uc_tuning_set: conv_rows_flat must be 0 (the eight-wave row kernel only on maps whose rows tile 512 pixels) or 1 (its flat form on every other map too) (got %d)", value);
+        g_uc_conv_rows_flat.store(value);
     } else {
-        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split, attn_p64, attn_bwd64, conv_rows, small_m_split; everything else is read from the environment once, see csrc/knobs.h)", name);
+        uc_set_error("uc_tuning_set: unknown knob '%s' (run-time switchable: gemm_variant, gemm_stagger, attn_role_split, attn_p64, attn_bwd64, conv_rows, conv_rows_flat, small_m_split; everything else is read from the environment once, see csrc/knobs.h)", name);
         return UC_ERR_BAD_ARG;
     }
     return UC_OK;
@@ -113,6 +118,7 @@ extern "C" int uc_tuning_get(const char* name, int* value) {
     else if (!strcmp(name, "attn_p64")) *value = g_uc_attn_p64.load();
     else if (!strcmp(name, "attn_bwd64")) *value = g_uc_attn_bwd64.load();
     else if (!strcmp(name, "conv_rows")) *value = g_uc_conv_rows.load();
+    else if (!strcmp(name, "conv_rows_flat")) *value = g_uc_conv_rows_flat.load();
     else if (!strcmp(name, "small_m_split")) *value = g_uc_small_m_split.load();
     else { uc_set_error("uc_tuning_get: unknown knob '%s'", name); return UC_ERR_BAD_ARG; }
     return UC_OK;

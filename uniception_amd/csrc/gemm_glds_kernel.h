@@ -2227,7 +2227,40 @@ static void launch_conv_rows(GldsParams p, hipStream_t st) {
 //   the 16 rows of a fragment by kx, row segments by two halo pixels each).
 //   Accumulator layout = the eight-wave GEMM's (FA = 8): the shared epilogues apply; the fused 1x1 tail drains a 128-row wave tile
 //   as two 64-row halves.
-template <int EPI, bool F16, bool RELU_A>
+//
+//   FLAT (round 6): maps whose rows do NOT tile 512 pixels (148 / 296 / 592-wide: the DINOv2-518 head; 56 / 112 / 224: 224 x 224 pairs; any
+//   pixel count).  A tile is 512 CONSECUTIVE output pixels of the flattened (image, y, x) order — whole or partial rows, across
+//   image borders, the last tile masked by the epilogues' row bound — and the slab of kernel row ky is the 514 consecutive INPUT pixels
+//   m0 + (ky - 1) W - 1 ... : tap (ky, kx) of output pixel o is input pixel o + (ky - 1) W + (kx - 1) of the same flat order, so the
+//   fragment of tap kx is again the slab shifted by kx rows, with no per-segment halo.  What the flat order gets wrong is the PADDING:
+//   vertically (the pixel W back / ahead of an image's first / last row belongs to the neighbouring image) the DMA zero-fills a slab
+//   row whose OWN pixel (y', x') has y' - (ky - 1) outside the map — every use of that row by an existing output with the tap inside
+//   its row is then right; horizontally (kx = 0 at x = 0, kx = 2 at x = W - 1 read the neighbouring ROW's edge pixel, which other
+//   outputs need as it is) the fragment's lanes of those pixels are zeroed in registers.  Which of a wave's 128 pixels sit in column 0 /
+//   W - 1 is wave-uniform: two 128-bit maps in 8 SGPRs (16 lane masks in SGPR pairs is more scalar state than the kernel has room for:
+//   the allocator then hands an inline-asm "s" operand a VGPR); per fragment of the kx = 0 and kx = 2 units the 16-bit slice is
+//   replicated over the four 16-lane groups into VCC (4 scalar instructions) and four v_cndmask_b32 zero the lanes — about what
+//   the ReLU-on-load form already spends there.  (volatile: hoisted out of the loop the sixteen masks would be live SGPR pairs again.)
+template <int SLICE>
+__device__ __forceinline__ bf16x8_t glds_zero_edge_lanes(bf16x8_t v, unsigned map_dword) {
+    uint4 q = __builtin_bit_cast(uint4, v);
+    unsigned t;
+    asm volatile(
+        "s_bfe_u32 %4, %5, %6\n\t"
+        "s_mul_i32 %4, %4, 0x10001\n\t"
+        "s_mov_b32 vcc_lo, %4\n\t"
+        "s_mov_b32 vcc_hi, %4\n\t"
+        "v_cndmask_b32_e64 %0, %0, 0, vcc\n\t"
+        "v_cndmask_b32_e64 %1, %1, 0, vcc\n\t"
+        "v_cndmask_b32_e64 %2, %2, 0, vcc\n\t"
+        "v_cndmask_b32_e64 %3, %3, 0, vcc"
+        : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "=&s"(t)
+        : "s"(map_dword), "n"((16 * SLICE) | (16 << 16))
+        : "vcc");
+    return __builtin_bit_cast(bf16x8_t, q);
+}
+
+template <int EPI, bool F16, bool RELU_A, bool FLAT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
     constexpr int BM_ = 512, BN_ = 128, ROWB = 64, NPIECE = 33, SLAB_BYTES = NPIECE * 1024, WT_BYTES = 3 * BN_ * ROWB;
     constexpr int WT0 = 0, SLAB0 = 2 * WT_BYTES;              // LDS image: weights[2] | slab[2]
@@ -2255,12 +2288,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
 
     // ---- tile geometry (wave-uniform): R row segments of seg pixels, first at (image row id rowid0 = b * H + oy0, ox0) ----
     const int W_ = p.cW, H_ = p.cH, Cin = p.cCin;
-    const int seg = min(BM_, W_), R = BM_ / seg, segp = seg + 2;
+    const int seg = FLAT ? BM_ : min(BM_, W_), R = BM_ / seg, segp = seg + 2;
     const unsigned rowid0 = uc_div((unsigned)m0, p.dWo);
     const int ox0 = (int)((unsigned)m0 - rowid0 * (unsigned)W_);
     const unsigned b0 = uc_div(rowid0, p.dHo);
     const int oy0 = (int)(rowid0 - b0 * (unsigned)H_);
-    const unsigned long long pa = (unsigned long long)(p.A + (((int64_t)rowid0 - 1) * W_ + (ox0 - 1)) * Cin);
+    // slab row 0 of kernel row 0: segmented form = pixel (row above the tile's first, one left of its first column); flat form = flat
+    // pixel m0 - W - 1.  (Either may lie before the tensor: lanes that would read there are masked — the descriptor base is only an origin.)
+    const unsigned long long pa = FLAT ? (unsigned long long)(p.A + ((int64_t)m0 - 1 - W_) * Cin)
+                                       : (unsigned long long)(p.A + (((int64_t)rowid0 - 1) * W_ + (ox0 - 1)) * Cin);
     const unsigned long long pw = (unsigned long long)(p.W + n0 * p.K);
     const uint4_t srd_a = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
     const uint4_t srd_w = (uint4_t){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pw), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(pw >> 32) & 0xffffu)), 0xffffff00u, 0x00020000u};
@@ -2271,15 +2307,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
     for (int q = 0; q < 5; ++q) {
         const int row = (wave + 8 * q) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ glds_swz<32>(row);
-        const int rr = row / segp, xs = row - rr * segp;             // (division by a wave-uniform value, once per tile)
-        const int ix = ox0 - 1 + xs;
-        // (launcher: 32-bit windows, pixel and channel counts below 2^24: 24-bit multiplies — the 32-bit product of a v_mad_u64_u32
-        //  lives in a register PAIR for the whole loop)
-        sl_off[q] = (__umul24(__umul24((unsigned)rr, (unsigned)W_) + (unsigned)xs, (unsigned)Cin) + (unsigned)c * 8u) * 2u;
-        asm volatile("" : "+v"(sl_off[q]));
-        if (rr < R && ix >= 0 && ix < W_ && (q < 4 || wave == 0)) {
+        if constexpr (FLAT) {
+            sl_off[q] = (__umul24((unsigned)row, (unsigned)Cin) + (unsigned)c * 8u) * 2u;
+            asm volatile("" : "+v"(sl_off[q]));
+            const int g = (int)m0 - 1 + row;                          // the slab row's own pixel (kernel row 1), flat; M < 2^30 (launcher)
+            if (row < BM_ + 2 && g >= 0 && (int64_t)g < p.M && (q < 4 || wave == 0)) {
+                const unsigned rid = uc_div((unsigned)g, p.dWo);      // image row id b * H + y
+                const int yg = (int)(rid - uc_div(rid, p.dHo) * (unsigned)H_);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) sl_mask |= ((unsigned)(oy0 + rr + ky - 1) < (unsigned)H_ ? 1u : 0u) << (3 * q + ky);
+                for (int ky = 0; ky < 3; ++ky) sl_mask |= ((unsigned)(yg + ky - 1) < (unsigned)H_ ? 1u : 0u) << (3 * q + ky);
+            }
+        } else {
+            const int rr = row / segp, xs = row - rr * segp;             // (division by a wave-uniform value, once per tile)
+            const int ix = ox0 - 1 + xs;
+            // (launcher: 32-bit windows, pixel and channel counts below 2^24: 24-bit multiplies — the 32-bit product of a v_mad_u64_u32
+            //  lives in a register PAIR for the whole loop)
+            sl_off[q] = (__umul24(__umul24((unsigned)rr, (unsigned)W_) + (unsigned)xs, (unsigned)Cin) + (unsigned)c * 8u) * 2u;
+            asm volatile("" : "+v"(sl_off[q]));
+            if (rr < R && ix >= 0 && ix < W_ && (q < 4 || wave == 0)) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) sl_mask |= ((unsigned)(oy0 + rr + ky - 1) < (unsigned)H_ ? 1u : 0u) << (3 * q + ky);
+            }
         }
     }
     unsigned w_off;
@@ -2290,7 +2338,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
         asm volatile("" : "+v"(w_off));
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
-    const unsigned wave0_exec = (unsigned)__builtin_amdgcn_readfirstlane(wave == 0 ? -1 : 0);      // both halves of the fifth slot's EXEC
+    // both halves of the fifth slot's EXEC.  (Scalar by construction: as `readfirstlane(wave == 0 ? -1 : 0)` hipcc drops the readfirstlane
+    //  of a value it knows to be uniform, may still SELECT it on the vector unit, and then hands the VGPR to the asm's "s" operand.)
+    unsigned wave0_exec;
+    asm volatile("s_cmp_eq_u32 %1, 0\n\ts_cselect_b32 %0, -1, 0" : "=s"(wave0_exec) : "s"(wave) : "scc");
     const int nch = Cin / 32;
     const int S = 3 * nch;                                   // super-steps, even (launcher)
     // piece j = 0..7 of super-step s -> buffer pair b: slab pieces q = j (j < 5), weight pieces of tap kx = j - 5
@@ -2317,9 +2368,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
     int a_off[3];
     {
         const int mi = wr * 128;
-        const int base = mi + 2 * (mi / seg) + frow;
+        const int base = mi + 2 * (mi / seg) + frow;             // (flat form: seg = 512, no halo rows between segments)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) a_off[kx] = SLAB0 + (base + kx) * ROWB + ((fk ^ glds_swz<32>(base + kx)) << 4);
+    }
+    // flat form: which of the wave's 128 pixels sit in column 0 / W - 1 (bit 16 i + frow of a 128-bit map; W >= 16: launcher)
+    unsigned edge0[4] = {0u, 0u, 0u, 0u}, edge2[4] = {0u, 0u, 0u, 0u};
+    if constexpr (FLAT) {
+        const unsigned tp = (unsigned)m0 + (unsigned)(wr * 128 + frow);
+        int x = (int)(tp - uc_div(tp, p.dWo) * (unsigned)W_);
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            edge0[i >> 1] |= ((unsigned)__ballot(x == 0) & 0xffffu) << (16 * (i & 1));
+            edge2[i >> 1] |= ((unsigned)__ballot(x == W_ - 1) & 0xffffu) << (16 * (i & 1));
+            x += 16;
+            if (x >= W_) x -= W_;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            edge0[d] = (unsigned)__builtin_amdgcn_readfirstlane((int)edge0[d]);
+            edge2[d] = (unsigned)__builtin_amdgcn_readfirstlane((int)edge2[d]);
+        }
     }
     const int w_lane = WT0 + (wc * 64 + frow) * ROWB + ((fk ^ glds_swz<32>(frow)) << 4);
 
@@ -2336,19 +2405,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
     auto rd_w = [&](int b, int kx, int j) __attribute__((always_inline)) {
         return *reinterpret_cast<const bf16x8_t*>(smem + w_lane + (b * WT_BYTES + kx * (BN_ * ROWB) + j * 16 * ROWB));
     };
-    auto mma_row = [&](int i, bf16x8_t (&wv)[4]) __attribute__((always_inline)) {
+    auto mma_row = [&](int i, bf16x8_t (&wv)[4], auto ckx) __attribute__((always_inline)) {      // ckx: the tap column these MFMAs belong to
         bf16x8_t av = a[i];
         if constexpr (RELU_A) av = __builtin_bit_cast(bf16x8_t, glds_relu_bf16x8(__builtin_bit_cast(uint4, av)));
+        if constexpr (FLAT && decltype(ckx)::value == 0) av = (i & 1) ? glds_zero_edge_lanes<1>(av, edge0[i >> 1]) : glds_zero_edge_lanes<0>(av, edge0[i >> 1]);
+        if constexpr (FLAT && decltype(ckx)::value == 2) av = (i & 1) ? glds_zero_edge_lanes<1>(av, edge2[i >> 1]) : glds_zero_edge_lanes<0>(av, edge2[i >> 1]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = glds_mfma<F16>(wv[j], av, acc[i][j]);
     };
+    constexpr std::integral_constant<int, 0> KX0{};
+    constexpr std::integral_constant<int, 1> KX1{};
+    constexpr std::integral_constant<int, 2> KX2{};
     // one unit: MFMAs on (a, wcur) while the next unit's fragments stream into (a, wnext); the scheduling fences keep every refill of
     // a[i] behind the MFMAs that read the old a[i] (hoisted, both generations are live and the loop spills)
     auto unit = [&](bf16x8_t (&wcur)[4], bf16x8_t (&wnext)[4], int nb, int nkx, auto dma) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < FA; ++i) {
-            mma_row(i, wcur);
+            if (nkx == 1) mma_row(i, wcur, KX0); else mma_row(i, wcur, KX1);      // (nkx = the tap column being LOADED: the MFMAs are one behind)
             __builtin_amdgcn_sched_barrier(0);
             if (i == 0) {
 #pragma unroll
@@ -2394,7 +2468,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
         auto unit2a = [&](bf16x8_t (&wcur)[4]) __attribute__((always_inline)) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mma_row(i, wcur);
+            for (int i = 0; i < 4; ++i) mma_row(i, wcur, KX2);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto unit2b = [&](bf16x8_t (&wcur)[4], bf16x8_t (&wnext)[4], int nb, auto dma) __attribute__((always_inline)) {
@@ -2406,7 +2480,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 4; i < FA; ++i) {
-                mma_row(i, wcur);
+                mma_row(i, wcur, KX2);
                 __builtin_amdgcn_sched_barrier(0);
                 a[i] = rd_a(nb, 0, i);
                 dma(i - 4);
@@ -2439,7 +2513,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
     unit(w, wn, 1, 2, no_dma);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < FA; ++i) mma_row(i, wn);
+    for (int i = 0; i < FA; ++i) mma_row(i, wn, KX2);
 
 #if defined(__HIP_DEVICE_COMPILE__)
     const __attribute__((opencl_constant)) GldsParams* kp =
@@ -2455,13 +2529,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows8_kernel(GldsParams p) {
 
 // shapes the eight-wave row-walking kernel takes: stride 1, whole 64-channel chunks (an even number of 32-channel super-steps), 128-column
 // tiles, maps 128 .. wide whose rows tile 512 pixels exactly (a tile = whole row segments of one image), 32-bit source windows
-static inline bool conv_rows8_ok(const GldsParams& p) {
-    if (p.a_mode != UC_A_CONV3X3 || p.cStride != 1 || p.cCin % 64 != 0 || p.N % 128 != 0 || p.split_k > 1) return false;
+// returns 0: not a shape of this kernel; 1: the segmented form (rows tile 512 pixels: no register masks); 2: the flat form (round 6: any
+// map at least 16 wide, any pixel count — tiles of 512 consecutive pixels, the last one masked)
+static inline int conv_rows8_ok(const GldsParams& p) {
+    if (p.a_mode != UC_A_CONV3X3 || p.cStride != 1 || p.cCin % 64 != 0 || p.N % 128 != 0 || p.split_k > 1) return 0;
     const int W = p.cW, H = p.cH;
-    if (W < 128 || !(W % 512 == 0 || 512 % W == 0)) return false;
-    const int R = W >= 512 ? 1 : 512 / W;
-    if (H % R != 0 || p.M % 512 != 0) return false;
-    return ((int64_t)(R + 3) * W + 4) * p.cCin * 2 < ((int64_t)1 << 31) && p.N * p.K * 2 < ((int64_t)1 << 31) && p.M < ((int64_t)1 << 30);
+    if (p.N * p.K * 2 >= ((int64_t)1 << 31) || p.M >= ((int64_t)1 << 30)) return 0;
+    if (W >= 128 && (W % 512 == 0 || 512 % W == 0)) {
+        const int R = W >= 512 ? 1 : 512 / W;
+        if (H % R == 0 && p.M % 512 == 0 && ((int64_t)(R + 3) * W + 4) * p.cCin * 2 < ((int64_t)1 << 31)) return 1;
+    }
+    if (W < 16 || g_uc_conv_rows_flat.load(std::memory_order_relaxed) == 0) return 0;
+    return ((int64_t)(530 + 2 * W) * p.cCin * 2 < ((int64_t)1 << 31)) ? 2 : 0;
 }
 
 // where the eight-wave form is routed by default: everywhere its shape rules allow — measured ahead of both other forms on every
@@ -2471,7 +2550,8 @@ static inline bool conv_rows8_wins(const GldsParams&) { return true; }
 
 template <int EPI, bool F16>
 static void launch_conv_rows8(GldsParams p, hipStream_t st) {
-    p.tiles_m = (int)(p.M / 512);
+    const bool flat = conv_rows8_ok(p) == 2;
+    p.tiles_m = (int)((p.M + 511) / 512);
     p.tiles_n = (int)(p.N / 128);
     p.dNwg = uc_make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
     p.dPerGroup = uc_make_fastdiv((unsigned)(p.group_m * p.tiles_n));
@@ -2485,9 +2565,14 @@ static void launch_conv_rows8(GldsParams p, hipStream_t st) {
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
     };
-    static bool set0 = false, set1 = false;
-    if constexpr (EPI == GLDS_EPI_RES16) launch(conv3x3_rows8_kernel<EPI, F16, false>, set0);      // (glds_launch_conv_res16: no ReLU on load)
-    else if (p.relu_a) launch(conv3x3_rows8_kernel<EPI, F16, true>, set1);
+    static bool set0 = false, set1 = false, set2 = false, set3 = false;
+    if constexpr (EPI == GLDS_EPI_RES16) {      // (glds_launch_conv_res16: no ReLU on load)
+        if (flat) launch(conv3x3_rows8_kernel<EPI, F16, false, true>, set2);
+        else launch(conv3x3_rows8_kernel<EPI, F16, false>, set0);
+    } else if (flat) {
+        if (p.relu_a) launch(conv3x3_rows8_kernel<EPI, F16, true, true>, set3);
+        else launch(conv3x3_rows8_kernel<EPI, F16, false, true>, set2);
+    } else if (p.relu_a) launch(conv3x3_rows8_kernel<EPI, F16, true>, set1);
     else launch(conv3x3_rows8_kernel<EPI, F16, false>, set0);
 }
 
@@ -2505,7 +2590,7 @@ template <bool F16>
 static bool glds_launch_conv_res16(const GldsParams& p, int variant, hipStream_t st) {
     if (!glds_res16_ok(p)) return false;
     const int rows_mode = g_uc_conv_rows.load(std::memory_order_relaxed);
-    if (conv_rows8_ok(p) && (rows_mode == 3 || (rows_mode == 1 && conv_rows8_wins(p) && (p.M / 512) * (p.N / 128) >= 256))) {
+    if (conv_rows8_ok(p) && (rows_mode == 3 || (rows_mode == 1 && conv_rows8_wins(p) && ((p.M + 511) / 512) * (p.N / 128) >= 256))) {
         launch_conv_rows8<GLDS_EPI_RES16, F16>(p, st);
         return true;
     }
@@ -2534,7 +2619,7 @@ static void glds_launch_variants(const GldsParams& p, int variant, hipStream_t s
         // conv_rows 3: the eight-wave 512-pixel form wherever the shape allows; 1 (default): where it wins
         // (fewer tiles than CUs: the latency-regime variants below — unless forced: conv_rows 3 makes the kernel choice, and with it the
         //  summation order, independent of the batch size)
-        if (conv_rows8_ok(p) && (rows_mode == 3 || (rows_mode == 1 && conv_rows8_wins(p) && (p.M / 512) * (p.N / 128) >= 256))) {
+        if (conv_rows8_ok(p) && (rows_mode == 3 || (rows_mode == 1 && conv_rows8_wins(p) && ((p.M + 511) / 512) * (p.N / 128) >= 256))) {
             launch_conv_rows8<EPI, F16>(p, st);
             return;
         }

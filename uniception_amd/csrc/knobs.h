@@ -40,6 +40,7 @@ extern std::atomic<int> g_uc_gemm_variant;   // UC_GEMM_VARIANT: -3 automatic, -
 extern std::atomic<int> g_uc_gemm_stagger;   // UC_GEMM_STAGGER: -1 launcher policy, >= 0 ticks per phase group
 extern std::atomic<int> g_uc_small_m_split;  // UC_GEMM_SMALLM: small-M path of the dense GEMM — smallest K for which a launch on <= half the CUs splits K in two inside the kernel (default 2048: K = 1024 is level, 3072 / 4096 gain 26-28 %; 0: never, and a pair's bits then do not depend on its batch size)
 extern std::atomic<int> g_uc_conv_rows;      // UC_CONV_ROWS: row-walking 3x3 conv kernels: 0 never, 1 where they win, 2 the 256-pixel kernel wherever the shape allows, 3 the eight-wave 512-pixel kernel wherever the shape allows
+extern std::atomic<int> g_uc_conv_rows_flat; // UC_CONV_ROWS_FLAT: the eight-wave row kernel's flat form (tiles of 512 consecutive pixels, edge lanes zeroed in registers) for maps whose rows do not tile 512 pixels: 1 (default) / 0
 extern std::atomic<int> g_uc_attn_p64;       // UC_ATTN_P64: persistent 64-queries-per-wave bf16 attention (attention_p64.h): 0 never, 1 where the launch has enough items (default), 2 wherever the shape allows
 extern std::atomic<int> g_uc_attn_bwd64;     // UC_ATTN_BWD64: 64-rows-per-wave attention backward kernels (attention_bwd64.h): 0 never, 1 where a workgroup's rows are mostly real (default), 2 always
 extern std::atomic<int> g_uc_attn_rs;        // UC_ATTN_RS: eight-wave bf16 attention as role-split segments (matrix beside vector on every SIMD): 0 / 1

@@ -47,7 +47,7 @@ def _p(t: Optional[torch.Tensor]):
 def tuning_set(name: str, value: int) -> None:
     """Run-time switchable tuning knobs of libuc_hip.so (uc_tuning_set): "gemm_variant" (-3 automatic, -1 register-staged kernel,
     0..3 / 6 / 7 tile variants of the direct-to-LDS bf16 GEMM), "gemm_stagger" (-1 launcher policy), "attn_role_split", "attn_p64" (persistent 64-queries-per-wave attention forward: 0 never, 1 policy, 2 wherever the shape allows), "attn_bwd64" (64-rows-per-wave attention backward kernels: 0 never, 1 policy, 2 wherever the shape allows; bitwise the same results), "conv_rows" (row-walking 3x3
-    conv kernels: 0 never, 1 where they win, 2 the 256-pixel one wherever the shape allows, 3 the eight-wave 512-pixel one wherever the shape allows), "small_m_split" (smallest K for which a dense launch on at most half
+    conv kernels: 0 never, 1 where they win, 2 the 256-pixel one wherever the shape allows, 3 the eight-wave 512-pixel one wherever the shape allows), "conv_rows_flat" (1: the eight-wave kernel's flat form also takes maps whose rows do not tile 512 pixels; 0: those stay on the implicit-GEMM kernel), "small_m_split" (smallest K for which a dense launch on at most half
     the CUs splits K in two inside the kernel; 0: never — results are then bit-identical across batch sizes).  Every value selects a correct
     kernel; everything else the library reads from the environment, once (csrc/knobs.h)."""
     _lib.check(_lib.load().uc_tuning_set(name.encode(), int(value)), f"uc_tuning_set({name})")
