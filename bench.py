@@ -380,20 +380,44 @@ def timed(step, steps, world):
     return time.perf_counter() - t0, out
 
 
+def _host_events():
+    "Counters whose change inside a timed step names a one-time stall: caching-allocator traffic to the driver and Python's cyclic GC."
+    import gc
+    ms = torch.cuda.memory_stats() if torch.cuda.is_available() else {}
+    return {"device_allocs": ms.get("num_device_alloc", 0), "device_frees": ms.get("num_device_free", 0),
+            "alloc_retries": ms.get("num_alloc_retries", 0), "gc_gen2": gc.get_stats()[2]["collections"]}
+
+
 def timed_each(step, steps):
-    """The legs beside the headline: every step fenced and timed on its own.  Returns (median * steps, stats) where stats carries the
-    sorted step times, their MEDIAN (what the legs' pairs/s and enc_dec_mfma_frac are computed from: a block of K steps right after a
-    model switch now and then contains one ~250-ms host-side stall — DESIGN.md section 7) AND the block mean over the same steps
-    (what the headline's contract — K steps between two fences — would have read), so the two are comparable."""
-    ts = []
+    """The legs beside the headline: every step fenced and timed on its own; the MEAN over the K steps is reported (the headline's
+    contract, and the reference harness's `blocked_autorange().mean`, utils/profile.py:4-6), the median and the sorted times beside it.
+    Round 5 reported medians because a block of K steps right after a model switch now and then contained one step 60-250 ms long.
+    Root cause (round 6, `stall_events`: per-step deltas of the caching allocator's hipMalloc / hipFree counts and of Python's
+    generation-2 collections): see DESIGN.md section 7 — the legs now collect garbage and settle the allocator BEFORE their timed
+    steps (`settle()`), so the mean is the number."""
+    ts, evs = [], []
     for _ in range(steps):
+        e0 = _host_events()
         d1, _ = timed(step, 1, 1)
+        e1 = _host_events()
         ts.append(d1)
+        evs.append({k: e1[k] - e0[k] for k in e0 if e1[k] != e0[k]})
     mean = sum(ts) / len(ts)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    return med * steps, {"n": steps, "ms_per_step_median": round(med * 1e3, 2), "ms_per_step_block_mean": round(mean * 1e3, 2),
-                         "ms_per_step_sorted": [round(t * 1e3, 1) for t in ts], "reported": "median"}
+    order = sorted(ts)
+    med = order[len(order) // 2]
+    st = {"n": steps, "ms_per_step_mean": round(mean * 1e3, 2), "ms_per_step_median": round(med * 1e3, 2),
+          "ms_per_step_in_order": [round(t * 1e3, 1) for t in ts], "reported": "mean"}
+    if any(evs):
+        st["stall_events"] = evs
+    return mean * steps, st
+
+
+def settle():
+    """Before a leg's timed steps: run Python's cyclic collector now (modules of the previous leg die in reference cycles: collected
+    later, inside somebody's timed step, their tensors go back to the caching allocator mid-step) and let queued frees land."""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 def reference_policy_legs(model, v1, v2, args, dev):
@@ -418,6 +442,7 @@ def reference_policy_legs(model, v1, v2, args, dev):
 
     def leg(f, n, extra):
         f(); f()          # (the first call of a shape runs its fork points one after the other)
+        settle()
         dt, st = timed_each(f, n)
         e = {"pairs_per_s": round(args.pairs * n / dt, 2), "ms_per_step": round(dt / n * 1e3, 2), "pairs_per_gpu": args.pairs, "timing": st}
         e.update(extra)
@@ -427,7 +452,7 @@ def reference_policy_legs(model, v1, v2, args, dev):
         lin = DUSt3R(name="bench_linear", img_size=(args.img, args.img), pred_head_type="linear").to(dev).eval()
         e, pps = leg(fwd(v1, v2, "bf16", lin), steps, {})
         e["enc_dec_mfma_frac"] = round(pps * gflop_enc_dec(args.img) / 1e3 / PEAK_BF16_TFLOPS, 4)
-        e["enc_dec_mfma_frac_from"] = "median step time x SURVEY section 8d flops per pair"
+        e["enc_dec_mfma_frac_from"] = "mean step time x SURVEY section 8d flops per pair"
         out["enc_dec_linear_head"] = e
         del lin          # (no torch.cuda.empty_cache() here or anywhere between legs: on some boxes of the pool the leg that runs on freshly
                          #  hipMalloc'ed blocks reads 15-25 % low — 345 instead of 470 pairs/s for this one, 213 instead of 248 for the next —
@@ -465,7 +490,8 @@ def fwd_224_leg(args, dev, pairs_list=(64, 256)):
                 return m(a1, a2)
         f(); f(); f()
         n = 5
-        dt, st = timed_each(f, n)     # (median of fenced steps, like every leg beside the headline: a new model's first steps carry a one-time host stall)
+        settle()
+        dt, st = timed_each(f, n)
         pps = b * n / dt
         out["by_pairs_per_gpu"].append({"pairs_per_gpu": b, "pairs_per_s": round(pps, 1), "ms_per_step": round(dt / n * 1e3, 3), "timing": st,
                                         "enc_dec_gflop_per_pair": round(gf, 1),
@@ -494,6 +520,7 @@ def other_configs_leg(args, dev):
                 return m(a1, a2)
         f(); f(); f()
         n = 5
+        settle()
         dt, st = timed_each(f, n)
         pps = pairs * n / dt
         del a1, a2
@@ -574,6 +601,7 @@ def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3, rank=0, world=1):
         exchange = exchange_summary(trainer.comm_stats(), dt / steps * 1e3)
         trainer.enable_comm_timing(False)
     else:
+        settle()
         dt, st = timed_each(step, steps)
         loss = step()
     assert torch.isfinite(loss).all()

@@ -51,8 +51,10 @@ const char* uc_last_error(void);
  *       block-major [N/64][M][2] instead of [M][N/64][2]; uc_gemm_desc gained fuse_ws (caller-provided hand-over buffer of the
  *       small-M path, uc_gemm_fuse_ws_bytes): the library no longer allocates.
  *   12: uc_swiglu / uc_swiglu_bwd added (DINOv2 giant's SwiGLU FFN); tuning knob conv_rows takes 3 (eight-wave row-walking 3x3
- *       convolution wherever the shape allows). */
-#define UC_ABI_VERSION 13
+ *       convolution wherever the shape allows).
+ *   14 (round 6): attention dropout — uc_attention_fwd_drop, uc_attention_bwd_drop, uc_attention_bwd_f32_drop, uc_attention_drop_mask
+ *       added; tuning knob conv_rows_flat. */
+#define UC_ABI_VERSION 14
 int uc_abi_version(void);
 /* "release" (the shipped library: no diagnostics compiled in) or "diag" (-DUC_DIAG: UC_GEMM_DBG / UC_ATTN_DBG / UC_GEMM_TRACE honoured). */
 const char* uc_build_flavor(void);
@@ -532,6 +534,37 @@ int uc_dilate_nhwc(const void* src, void* dst, int dtype, int B, int h, int w, i
  * (dfeat = 0 where feat <= 0): the regressor's conv3x3 -> ReLU -> conv1x1 tail without a mask pass of its own. */
 int uc_conv1x1_to4_bwd(const void* feat, int dtype, const float* w, const float* dout, void* dfeat, float* dw, float* db,
                        int64_t npix, int Cin, int relu_mask, uc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Attention dropout (training with attn_drop > 0; replaces nn.Dropout on the softmax probabilities / the dropout_p of the fused SDPA in
+ * /root/reference/uniception/models/utils/transformer_blocks.py:198, 245, 251, 374, 380 and libs/croco/blocks.py:98-125).
+ * No mask is stored: whether probability (b, h, q, k) is kept is a counter-based hash of (seed, b * H + h, q, k) against
+ * round(drop_p * 2^32), evaluated identically by the forward kernel, by both backward kernels (which rebuild P from the LSE) and by
+ * uc_attention_drop_mask.  O = (P o mask / (1 - drop_p)) V; the LSE written is that of the undropped scores.  drop_p in [0, 1).
+ * ---------------------------------------------------------------------------------- */
+/* uc_attention_fwd's argument list + (drop_p, seed).  bf16 (packed VT, head_dim 64) and fp32 (row-major V, head_dim <= 64). */
+int uc_attention_fwd_drop(const void* Q, const void* K, const void* V, void* O, int dtype, int v_layout, int B, int H, int Nq,
+                          int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                          int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,
+                          float* lse, float drop_p, unsigned long long seed, uc_stream_t stream);
+/* uc_attention_bwd's argument list + the forward's (drop_p, seed); O is the forward's (dropped) output. */
+int uc_attention_bwd_drop(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                          void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb, int64_t q_sn,
+                          int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                          int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb,
+                          int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
+                          const int64_t* rope_qpos, const int64_t* rope_kpos, float rope_base, float rope_f0, float drop_p,
+                          unsigned long long seed, uc_stream_t stream);
+/* uc_attention_bwd_f32's argument list + the forward's (drop_p, seed). */
+int uc_attention_bwd_f32_drop(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                              const float* LSE, float* dQ, float* dK, float* dV, float* delta, int B, int H, int Nq, int Nk,
+                              int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                              int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                              int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
+                              int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, float drop_p, unsigned long long seed,
+                              uc_stream_t stream);
+/* The keep mask those kernels apply, as bytes [B, H, Nq, Nk] (1 = kept): for reference implementations and tests. */
+int uc_attention_drop_mask(void* mask, int B, int H, int Nq, int Nk, float drop_p, unsigned long long seed, uc_stream_t stream);
 
 /* fp32 verification-mode attention backward: same math, row-major fp32 operands (head_dim D <= 64), no packed
  * transposes needed.  delta fp32 [B,H,Nq] is scratch. */

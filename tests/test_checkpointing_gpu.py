@@ -148,7 +148,7 @@ def test_checkpointed_block_with_random_masks_equals_the_plain_block_under_the_s
     from tests.helpers import rel_l2
     B, N, Ny, C, H = 3, 40, 24, 128, 2
     torch.manual_seed(11)
-    kw = dict(dim=C, num_heads=H, qkv_bias=True, proj_drop=0.2, drop_path=0.3)
+    kw = dict(dim=C, num_heads=H, qkv_bias=True, proj_drop=0.2, drop_path=0.3, attn_drop=0.1)      # (attn_drop: its seed comes from the CPU generator)
     plain = (SelfAttentionBlock(**kw) if kind == "self" else CrossAttentionBlock(**kw)).to(gpu).train()
     ck = wrap_module_with_gradient_checkpointing(copy.deepcopy(plain))
     assert has_random_masks(plain) and not has_random_masks(SelfAttentionBlock(dim=C, num_heads=H))

@@ -477,3 +477,61 @@ def test_swiglu_gate_and_its_backward(gpu, dtype, tol, M, H):
     assert rel_l2(dt.double().cpu(), td.grad) < tol
     with pytest.raises(Exception):
         ops.swiglu(torch.zeros(4, 12, device=gpu))       # H = 6: not a multiple of 8
+
+
+@pytest.mark.parametrize("dtype,B,H,Nq,Nk,D", [(torch.bfloat16, 2, 3, 200, 136, 64), (torch.bfloat16, 1, 2, 128, 64, 64), (torch.bfloat16, 2, 2, 70, 300, 64),
+                                             (torch.float32, 2, 2, 100, 77, 64), (torch.float32, 1, 3, 33, 50, 32)])
+def test_attention_with_dropout_forward_and_backward(gpu, dtype, B, H, Nq, Nk, D):
+    """uc_attention_fwd_drop / uc_attention_bwd_drop / uc_attention_bwd_f32_drop against fp32 PyTorch autograd over
+    softmax(S) o mask / (1 - p) @ V with the mask uc_attention_drop_mask reports: output, LSE (of the UNdropped scores), dQ, dK, dV;
+    ragged query and key counts, strided q / k / v views, the inverse RoPE riding in the bf16 backward as without dropout."""
+    from uniception_amd import ops
+    p, seed = 0.3, 0x1234_5678_9ABC_DEF1
+    g = torch.Generator().manual_seed(Nq * 13 + Nk)
+    qkv = torch.randn(B, max(Nq, Nk), 3, H, D, generator=g).to(dtype)
+    q, k, v = qkv[:, :Nq, 0], qkv[:, :Nk, 1], qkv[:, :Nk, 2]
+    do = torch.randn(B, Nq, H, D, generator=g).to(dtype)
+    scale = D ** -0.5
+    dev = qkv.to(gpu)
+    qd, kd, vd = dev[:, :Nq, 0], dev[:, :Nk, 1], dev[:, :Nk, 2]
+    mask = ops.attention_drop_mask(B, H, Nq, Nk, p, seed, gpu)
+    assert abs(float(mask.float().mean()) - (1 - p)) < 0.02
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qf, kf) * scale
+    pr = s.softmax(-1) * mask.cpu().float() / (1 - p)
+    o_ref = torch.einsum("bhqk,bkhd->bqhd", pr, vf)
+    o_ref.backward(do.float())
+    lse = torch.empty(B, H, Nq, dtype=torch.float32, device=gpu)
+    bf = dtype == torch.bfloat16
+    o = ops.attention(qd, kd, ops.vt_pack(vd) if bf else vd, scale, v_packed=bf, lse=lse, dropout=(p, seed))
+    assert rel_l2(o.cpu().float(), o_ref.detach()) < (8e-3 if bf else 3e-6)
+    assert float((lse.cpu() - s.detach().logsumexp(-1)).abs().max()) < (2e-3 if bf else 1e-5)
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, o, do.to(gpu), lse, scale, dropout=(p, seed))
+    tol = 1.5e-2 if bf else 1e-5
+    assert rel_l2(dv.cpu().float(), vf.grad) < tol
+    assert rel_l2(dq.cpu().float(), qf.grad) < tol
+    assert rel_l2(dk.cpu().float(), kf.grad) < tol
+    # another seed is another mask; p = 0 is the plain kernel
+    o2 = ops.attention(qd, kd, ops.vt_pack(vd) if bf else vd, scale, v_packed=bf, dropout=(p, seed + 1))
+    assert rel_l2(o2.float(), o.float()) > 0.1
+    o0 = ops.attention(qd, kd, ops.vt_pack(vd) if bf else vd, scale, v_packed=bf, dropout=(0.0, seed))
+    assert torch.equal(o0, ops.attention(qd, kd, ops.vt_pack(vd) if bf else vd, scale, v_packed=bf))
+
+
+def test_attention_dropout_mask_statistics(gpu):
+    """The counter-based keep function: keep rate 1 - p per (batch, head) and per key column, no correlation between neighbouring
+    queries / keys / heads, a different mask per seed."""
+    from uniception_amd import ops
+    B, H, Nq, Nk = 2, 4, 512, 384
+    for p in (0.1, 0.5):
+        m = ops.attention_drop_mask(B, H, Nq, Nk, p, 42, gpu).float()
+        sd = (p * (1 - p)) ** 0.5                     # (bounds: 5 standard deviations of a mean over that many Bernoulli draws)
+        assert float((m.mean((2, 3)) - (1 - p)).abs().max()) < 5 * sd / (Nq * Nk) ** 0.5
+        assert float((m.mean((0, 1, 2)) - (1 - p)).abs().max()) < 5 * sd / (B * H * Nq) ** 0.5
+        assert float((m.mean((0, 1, 3)) - (1 - p)).abs().max()) < 5 * sd / (B * H * Nk) ** 0.5
+        c = m - m.mean()
+        var = float((c * c).mean())
+        for a, b in ((c[:, :, :-1], c[:, :, 1:]), (c[:, :, :, :-1], c[:, :, :, 1:]), (c[:, :-1], c[:, 1:]), (c[:1], c[1:])):
+            assert abs(float((a * b).mean())) / var < 0.01
+        m2 = ops.attention_drop_mask(B, H, Nq, Nk, p, 43, gpu).float()
+        assert abs(float(((m - m.mean()) * (m2 - m2.mean())).mean())) / var < 0.01

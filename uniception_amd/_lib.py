@@ -17,6 +17,7 @@ UC_ACT_NONE, UC_ACT_GELU_ERF, UC_ACT_RELU = 0, 1, 2
 UC_V_ROWMAJOR, UC_V_PACKED_T = 0, 1
 
 i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+u64 = C.c_uint64
 
 
 class UcHipError(RuntimeError):
@@ -106,12 +107,16 @@ SIGNATURES = {
     "uc_dilate_nhwc": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "uc_conv1x1_to4_bwd": [vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "uc_attention_bwd_f32": [vp] * 10 + [i32] * 5 + [i64] * 21 + [f32, vp],
+    "uc_attention_fwd_drop": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [i64] * 12 + [f32, vp, f32, u64, vp],
+    "uc_attention_bwd_drop": [vp] * 10 + [i32] * 4 + [i64] * 21 + [f32, vp, vp, f32, f32, f32, u64, vp],
+    "uc_attention_bwd_f32_drop": [vp] * 10 + [i32] * 5 + [i64] * 21 + [f32, f32, u64, vp],
+    "uc_attention_drop_mask": [vp, i32, i32, i32, i32, f32, u64, vp],
 }
 
 _lib = None
 
 
-ABI_VERSION = 13   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
+ABI_VERSION = 14   # UC_ABI_VERSION of include/uc_hip.h this binding was written against
 
 
 def load():

@@ -337,12 +337,23 @@ def _qknorm_bwd(view4, norm, dn):
     return dpre.view(pre.shape), dg, db
 
 
-def _attention_fwd(q, k, v, scale, lse):
+def _attention_fwd(q, k, v, scale, lse, dropout=None):
     if q.dtype == torch.bfloat16:
         if q.shape[-1] != 64:
             raise UcHipError(f"bf16 attention needs head_dim 64 (got {q.shape[-1]})")
-        return ops.attention(q, k, ops.vt_pack(v), scale, v_packed=True, lse=lse)
-    return ops.attention(q, k, v, scale, lse=lse)
+        return ops.attention(q, k, ops.vt_pack(v), scale, v_packed=True, lse=lse, dropout=dropout)
+    return ops.attention(q, k, v, scale, lse=lse, dropout=dropout)
+
+
+def attn_dropout(training: bool, p: float):
+    """(p, seed) for a sub-layer's attention dropout, or None (eval mode / rate 0).  The seed comes from PyTorch's CPU generator —
+    torch.manual_seed reproduces it, and a checkpointed block's re-computation draws the same one (preserve_rng_state) — and keys the
+    counter-based mask the forward and backward kernels evaluate (uc_attention_fwd_drop)."""
+    if not training or p <= 0.0:
+        return None
+    if p >= 1.0:
+        raise UcHipError("attn_drop must be below 1")
+    return (float(p), int(torch.randint(0, 2 ** 62, (1,)).item()))
 
 
 # =================================================================================================================
@@ -467,7 +478,7 @@ class SelfAttnSubLayerFn(Function):
 
     @staticmethod
     def forward(ctx, x2d, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None,
-                qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None, drops=None):
+                qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None, drops=None, adrop=None):
         x2d = _c(x2d)
         M, C = x2d.shape
         Dh = C // H
@@ -500,7 +511,7 @@ class SelfAttnSubLayerFn(Function):
                 ops.rope_2d_(t5[:, :, 0], pos.contiguous(), rope.base, rope.F0)
                 ops.rope_2d_(t5[:, :, 1], pos.contiguous(), rope.base, rope.F0)
         lse = torch.empty((B, H, N), dtype=torch.float32, device=x2d.device)
-        o = _attention_fwd(*(qkn if qkn is not None else (t5[:, :, 0], t5[:, :, 1])), t5[:, :, 2], scale, lse)
+        o = _attention_fwd(*(qkn if qkn is not None else (t5[:, :, 0], t5[:, :, 1])), t5[:, :, 2], scale, lse, adrop)
         if drops is not None and drops.has_out:
             out = _drop_out(ops.gemm(o.view(M, C), wp, bp), drops, x2d, x2d.dtype)
         else:
@@ -510,6 +521,7 @@ class SelfAttnSubLayerFn(Function):
         ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0), *(() if qkn is None else qkn),
                               *(() if gamma is None else (gamma,)), *masks)
         ctx.meta = (ln, qkv, proj, B, N, H, rope, scale, dt, b_qkv is not None, b_proj is not None, qn, kn, qkn is not None, dspec)
+        ctx.adrop = adrop
         return out
 
     @staticmethod
@@ -540,7 +552,8 @@ class SelfAttnSubLayerFn(Function):
         dqn_w = dqn_b = dkn_w = dkn_b = None
         if has_qkn:
             dqx, dkx = torch.empty_like(qx), torch.empty_like(kx)
-            ops.attention_bwd(qx, kx, t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale, out=(dqx, dkx, d5[:, :, 2]), rope=fused_rope)
+            ops.attention_bwd(qx, kx, t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale, out=(dqx, dkx, d5[:, :, 2]), rope=fused_rope,
+                              dropout=ctx.adrop)
             if fused_rope is None:
                 _rope_inverse_(dqx, pos, rope)
                 _rope_inverse_(dkx, pos, rope)
@@ -552,7 +565,7 @@ class SelfAttnSubLayerFn(Function):
             d5[:, :, 1].copy_(dkx)
         else:
             ops.attention_bwd(t5[:, :, 0], t5[:, :, 1], t5[:, :, 2], o, do.view(B, N, H, Dh), lse, scale,
-                              out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]), rope=fused_rope)
+                              out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]), rope=fused_rope, dropout=ctx.adrop)
             if fused_rope is None:
                 _rope_inverse_(d5[:, :, 0], pos, rope)
                 _rope_inverse_(d5[:, :, 1], pos, rope)
@@ -562,16 +575,16 @@ class SelfAttnSubLayerFn(Function):
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)
         if sunk:
             dg = db = None
-        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10 + (dgamma, dqn_w, dqn_b, dkn_w, dkn_b, None, None, None)
+        return (dx, dg, db, dWq, dbq, dWp, dbp) + (None,) * 10 + (dgamma, dqn_w, dqn_b, dkn_w, dkn_b, None, None, None, None)
 
 
-def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None, q_norm=None, k_norm=None, drops=None):
+def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=None, q_norm=None, k_norm=None, drops=None, attn_drop=None):
     """gamma: LayerScale on the sub-layer's output (x + gamma * proj(...)), or None.  q_norm / k_norm: the layer's qk_norm modules
-    (LayerNorm over head_dim before the positional encoding; nn.Identity / None: off)."""
+    (LayerNorm over head_dim before the positional encoding; nn.Identity / None: off).  attn_drop: (p, seed) from attn_dropout, or None."""
     qn, kn = _norm_or_none(q_norm), _norm_or_none(k_norm)
     return SelfAttnSubLayerFn.apply(x2d, ln.weight, ln.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, ln, qkv, proj,
                                     B, N, H, rope, pos, scale, dt, gamma, getattr(qn, "weight", None), getattr(qn, "bias", None),
-                                    getattr(kn, "weight", None), getattr(kn, "bias", None), qn, kn, drops)
+                                    getattr(kn, "weight", None), getattr(kn, "bias", None), qn, kn, drops, attn_drop)
 
 
 @_sink_aware
@@ -580,7 +593,8 @@ class CrossAttnSubLayerFn(Function):
 
     @staticmethod
     def forward(ctx, x2d, y2d, ln_w, ln_b, lny_w, lny_b, wq_, bq_, wk_, bk_, wv_, bv_, wp_, bp_, ln, lny, projq, projk, projv, proj,
-                B, Nq, Nk, H, rope, qpos, kpos, scale, dt, qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None, drops=None):
+                B, Nq, Nk, H, rope, qpos, kpos, scale, dt, qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None, drops=None,
+                gamma=None, adrop=None):
         x2d, y2d = _c(x2d), _c(y2d)
         Mq, C = x2d.shape
         Dh = C // H
@@ -595,7 +609,7 @@ class CrossAttnSubLayerFn(Function):
             hy = y2d if y2d.dtype == dt else ops.convert(y2d, dt)
         wq, bq = engine.lin_weights(projq, dt)
         wkv, bkv = engine.kv_weights(projk, projv, dt)
-        wp, bp = engine.lin_weights(proj, dt)
+        wp, bp = engine.lin_weights(proj, dt) if gamma is None else engine.layerscale_lin_weights(proj, gamma, dt)
         qkn = None
         if qn is not None or kn is not None:     # qk_norm: the unfused route (see SelfAttnSubLayerFn)
             q = ops.gemm(hq, wq, bq)
@@ -620,7 +634,8 @@ class CrossAttnSubLayerFn(Function):
                 ops.rope_2d_(kv.view(B, Nk, 2, H, Dh)[:, :, 0], kpos.contiguous(), rope.base, rope.F0)
         kv5 = kv.view(B, Nk, 2, H, Dh)
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=x2d.device)
-        o = _attention_fwd(*(qkn if qkn is not None else (q.view(B, Nq, H, Dh), kv5[:, :, 0])), kv5[:, :, 1], scale, lse)
+        o = _attention_fwd(*(qkn if qkn is not None else (q.view(B, Nq, H, Dh), kv5[:, :, 0])), kv5[:, :, 1], scale, lse, adrop)
+        ctx.adrop = adrop
         if drops is not None and drops.has_out:
             out = _drop_out(ops.gemm(o.view(Mq, C), wp, bp), drops, x2d, x2d.dtype)
         else:
@@ -628,24 +643,33 @@ class CrossAttnSubLayerFn(Function):
         e = torch.empty(0)
         masks, dspec = _drops_saved(drops)
         ctx.save_for_backward(x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos if qpos is not None else e, kpos if kpos is not None else e,
-                              *(() if qkn is None else qkn), *masks)
+                              *(() if qkn is None else qkn), *(() if gamma is None else (gamma,)), *masks)
         ctx.meta = (ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt,
-                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None, qn, kn, dspec)
+                    bq_ is not None, bk_ is not None, bv_ is not None, bp_ is not None, qn, kn, dspec, qkn is not None)
         return out
 
     @staticmethod
     def backward(ctx, dxo):
-        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp, qn, kn, dspec = ctx.meta
+        ln, lny, projq, projk, projv, proj, B, Nq, Nk, H, rope, scale, dt, has_bq, has_bk, has_bv, has_bp, qn, kn, dspec, has_qkn = ctx.meta
         drops, saved = _drops_restore(dspec, ctx.saved_tensors)
-        x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos, kpos, *qkn = saved
+        x2d, y2d, g, gy, hq, hy, q, kv, o, lse, qpos, kpos, *rest = saved
+        qkn = rest[:2] if has_qkn else []
+        rest = rest[2:] if has_qkn else rest
+        gamma = rest[0] if rest else None
         Mq, C = x2d.shape
         Dh = C // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
         if drops is not None and drops.has_out:
             dyb = _drop_out(dyb, drops)
-        dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
-        do = ops.gemm(dyb, lin_weight_t(proj, dt))
+        dgamma = None
+        if gamma is None:
+            dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
+            do = ops.gemm(dyb, lin_weight_t(proj, dt))
+        else:       # LayerScale folded into proj: gradient of the folded weight, unfolded into d W, d b, d gamma
+            dWp, dbp = _wgrad(dyb, o.view(Mq, C), dt, has_bp)
+            dWp, dbp, dgamma = _unfold_layerscale(proj, gamma, dWp, dbp)
+            do = ops.gemm(dyb, _folded_weight_t(proj, gamma, dt))
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         kv5, dkv5 = kv.view(B, Nk, 2, H, Dh), dkv.view(B, Nk, 2, H, Dh)
@@ -654,7 +678,8 @@ class CrossAttnSubLayerFn(Function):
         if qkn:
             qx, kx = qkn
             dqx, dkx = torch.empty_like(qx), torch.empty_like(kx)
-            ops.attention_bwd(qx, kx, kv5[:, :, 1], o, do.view(B, Nq, H, Dh), lse, scale, out=(dqx, dkx, dkv5[:, :, 1]), rope=fused_rope)
+            ops.attention_bwd(qx, kx, kv5[:, :, 1], o, do.view(B, Nq, H, Dh), lse, scale, out=(dqx, dkx, dkv5[:, :, 1]), rope=fused_rope,
+                              dropout=ctx.adrop)
             if fused_rope is None:
                 _rope_inverse_(dqx, qpos, rope)
                 _rope_inverse_(dkx, kpos, rope)
@@ -666,7 +691,7 @@ class CrossAttnSubLayerFn(Function):
             dkv5[:, :, 0].copy_(dkx)
         else:
             ops.attention_bwd(q.view(B, Nq, H, Dh), kv5[:, :, 0], kv5[:, :, 1], o, do.view(B, Nq, H, Dh), lse, scale,
-                              out=(dq.view(B, Nq, H, Dh), dkv5[:, :, 0], dkv5[:, :, 1]), rope=fused_rope)
+                              out=(dq.view(B, Nq, H, Dh), dkv5[:, :, 0], dkv5[:, :, 1]), rope=fused_rope, dropout=ctx.adrop)
             if fused_rope is None:
                 _rope_inverse_(dq.view(B, Nq, H, Dh), qpos, rope)
                 _rope_inverse_(dkv5[:, :, 0], kpos, rope)
@@ -692,17 +717,18 @@ class CrossAttnSubLayerFn(Function):
         dWk, dWv = (None, None) if dWkv is None else (dWkv[:C], dWkv[C:])
         dbk = dbkv[:C] if (has_bk and dbkv is not None) else None
         dbv = dbkv[C:] if (has_bv and dbkv is not None) else None
-        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbk, dWv, dbv, dWp, dbp) + (None,) * 15 + (dqn_w, dqn_b, dkn_w, dkn_b, None, None, None)
+        return (dx, dy, dg, db, dgy, dby, dWq, dbq, dWk, dbk, dWv, dbv, dWp, dbp) + (None,) * 15 + (dqn_w, dqn_b, dkn_w, dkn_b, None, None, None,
+                                                                                                      dgamma, None)
 
 
-def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt, drops=None):
+def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt, drops=None, gamma=None, attn_drop=None):
     lw, lb = (lny.weight, lny.bias) if lny is not None else (None, None)
     qn, kn = _norm_or_none(getattr(ca, "q_norm", None)), _norm_or_none(getattr(ca, "k_norm", None))
     return CrossAttnSubLayerFn.apply(x2d, y2d, ln.weight, ln.bias, lw, lb, ca.projq.weight, ca.projq.bias, ca.projk.weight,
                                      ca.projk.bias, ca.projv.weight, ca.projv.bias, ca.proj.weight, ca.proj.bias, ln, lny,
                                      ca.projq, ca.projk, ca.projv, ca.proj, B, Nq, Nk, H, rope, qpos, kpos, scale, dt,
                                      getattr(qn, "weight", None), getattr(qn, "bias", None), getattr(kn, "weight", None),
-                                     getattr(kn, "bias", None), qn, kn, drops)
+                                     getattr(kn, "bias", None), qn, kn, drops, gamma, attn_drop)
 
 
 @_sink_aware

@@ -32,6 +32,7 @@ struct AttnParams {
     float* lse;   // optional [B,H,Nq]: log-sum-exp of the scaled scores (saved for the backward)
     uc_fastdiv dGroup, dNq, dH;   // exact fast division by 8*nq, nq, H (workgroup -> (query tile, batch, head) in the DMA kernel)
     int prio_young;               // eight-wave workgroups: s_setprio 1 for waves 4-7 (the younger half loses every VALU arbitration to the older one)
+    UcDropout drop;               // attention dropout (uc_attention_fwd_drop; thr 0 elsewhere)
 };
 
 #define KV_TILE 64
@@ -47,6 +48,10 @@ __device__ __forceinline__ int vt_key_of_pos(int pp) {
 
 // the body of attn_bf16_kernel for the 128 queries from q0w of (batch b, head h): also what attn_bf16_fixup_kernel recomputes a
 // flagged block of the persistent kernel with (attention_p64.h)
+// DROP: attention dropout (training with attn_drop > 0): the row sum — the softmax's normalisation — takes every probability, the
+// P^T operand of O^T += V^T P^T only the kept ones, scaled by 1 / (1 - p): O = (P o mask / (1 - p)) V, the reference's
+// attn_drop(softmax(...)) @ v.  The LSE is that of the undropped scores.
+template <bool DROP = false>
 __device__ __forceinline__ void attn_bf16_body(const AttnParams& p, const int b, const int h, const int q0w, char* smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -124,6 +129,8 @@ __device__ __forceinline__ void attn_bf16_body(const AttnParams& p, const int b,
     float m_run = -1e30f;   // running max of raw scores (shared by the lane pair)
     float l_run = 0.f;      // lane-partial running sum
     const float c = p.scale * 1.44269504088896340736f;  // scale * log2(e)
+    unsigned dk1 = 0, dk2 = 0;
+    if constexpr (DROP) uc_drop_keys(p.drop, (unsigned)(b * p.H + h), dk1, dk2);
 
     const int nt = (p.Nk + KV_TILE - 1) / KV_TILE;
     ATT_STAGE_LOAD(0);
@@ -190,6 +197,11 @@ __device__ __forceinline__ void attn_bf16_body(const AttnParams& p, const int b,
                 for (int j = 0; j < 8; ++j) {
                     e[j] = __builtin_amdgcn_exp2f(fmaf(s[kb][hf * 8 + j], c, -mc));
                     psum += e[j];
+                    if constexpr (DROP) {
+                        const int r = hf * 8 + j;
+                        const unsigned key = (unsigned)(k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                        e[j] = uc_drop_hash(dk1, dk2, (unsigned)(q0 + l31), key) >= p.drop.thr ? e[j] * p.drop.keep_scale : 0.f;
+                    }
                 }
                 union { bf16x8_t v; unsigned u[4]; } pk;
 #pragma unroll
@@ -235,6 +247,10 @@ __device__ __forceinline__ void attn_bf16_body(const AttnParams& p, const int b,
 __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE_BYTES];  // 2 stages x (K tile + VT tile)
     attn_bf16_body(p, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x * 128, smem);
+}
+__global__ __launch_bounds__(256) void attn_bf16_drop_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * ATT_TILE_BYTES];
+    attn_bf16_body<true>(p, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x * 128, smem);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -834,7 +850,7 @@ extern "C" int uc_vt_pack(const void* V, void* VT, int B, int H, int Nk, int D, 
 // ---------------------------------------------------------------------------------------
 #define F32_KT 32
 
-template <int DMAX>
+template <int DMAX, bool DROP = false>
 __global__ __launch_bounds__(128) void attn_f32_kernel(AttnParams p) {
     __shared__ float Ks[F32_KT][DMAX];
     __shared__ float Vs[F32_KT][DMAX];
@@ -852,6 +868,8 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(AttnParams p) {
         acc[d] = 0.f;
     }
     float m_run = -INFINITY, l_run = 0.f;
+    unsigned dk1 = 0, dk2 = 0;
+    if constexpr (DROP) uc_drop_keys(p.drop, (unsigned)(b * p.H + h), dk1, dk2);
     for (int k0 = 0; k0 < p.Nk; k0 += F32_KT) {
         __syncthreads();
         for (int idx = threadIdx.x; idx < F32_KT * DMAX; idx += blockDim.x) {
@@ -879,8 +897,9 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(AttnParams p) {
         for (int d = 0; d < DMAX; ++d) acc[d] *= alpha;
 #pragma unroll
         for (int kk = 0; kk < F32_KT; ++kk) {
-            const float pw = (k0 + kk < p.Nk) ? expf(s[kk] - m_new) : 0.f;
+            float pw = (k0 + kk < p.Nk) ? expf(s[kk] - m_new) : 0.f;
             l_run += pw;
+            if constexpr (DROP) pw = uc_drop_hash(dk1, dk2, (unsigned)q, (unsigned)(k0 + kk)) >= p.drop.thr ? pw * p.drop.keep_scale : 0.f;
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) acc[d] = fmaf(pw, Vs[kk][d], acc[d]);
         }
@@ -894,6 +913,77 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(AttnParams p) {
         for (int d = 0; d < DMAX; ++d)
             if (d < D) op[d] = acc[d] * inv;
     }
+}
+
+// keep mask of uc_attention_fwd_drop / uc_attention_bwd_drop as bytes [B, H, Nq, Nk] (1 = kept): what a reference implementation
+// multiplies the probabilities with (tests), evaluated by the same function as the kernels
+__global__ void attn_drop_mask_kernel(unsigned char* mask, int H, int Nq, int Nk, int64_t total, UcDropout d) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % Nk);
+    const int q = (int)((idx / Nk) % Nq);
+    const unsigned bh = (unsigned)(idx / ((int64_t)Nk * Nq));
+    unsigned k1, k2;
+    uc_drop_keys(d, bh, k1, k2);
+    mask[idx] = uc_drop_hash(k1, k2, (unsigned)q, (unsigned)k) >= d.thr ? 1 : 0;
+}
+
+extern "C" int uc_attention_drop_mask(void* mask, int B, int H, int Nq, int Nk, float drop_p, unsigned long long seed, uc_stream_t stream) {
+    UC_REQUIRE(mask && B > 0 && H > 0 && Nq > 0 && Nk > 0, "uc_attention_drop_mask: bad arguments");
+    UC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "uc_attention_drop_mask: drop_p must be in [0, 1) (got %g)", (double)drop_p);
+    const int64_t total = (int64_t)B * H * Nq * Nk;
+    hipLaunchKernelGGL(attn_drop_mask_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned char*)mask, H, Nq, Nk, total, uc_make_dropout(drop_p, seed));
+    UC_CHECK_LAUNCH("uc_attention_drop_mask");
+    return UC_OK;
+}
+
+// Attention forward with dropout of the probabilities (training, attn_drop > 0): the argument list of uc_attention_fwd + (drop_p, seed).
+// bf16: the register-staged 128-query kernel with the mask applied between the softmax and the second product; fp32: the verification
+// kernel.  drop_p == 0 is uc_attention_fwd.
+extern "C" int uc_attention_fwd_drop(const void* Q, const void* K, const void* V, void* O, int dtype, int v_layout,
+                                     int B, int H, int Nq, int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                                     int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                                     int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale, float* lse, float drop_p,
+                                     unsigned long long seed, uc_stream_t stream) {
+    UC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "uc_attention_fwd_drop: drop_p must be in [0, 1) (got %g)", (double)drop_p);
+    if (drop_p == 0.f)
+        return uc_attention_fwd(Q, K, V, O, dtype, v_layout, B, H, Nq, Nk, D, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh,
+                                scale, lse, stream);
+    UC_REQUIRE(Q && K && V && O, "uc_attention_fwd_drop: null pointer");
+    UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && D > 0, "uc_attention_fwd_drop: bad shape");
+    UC_REQUIRE(H <= 65535 && B <= 65535, "uc_attention_fwd_drop: B and H must fit a grid dimension");
+    AttnParams p;
+    p.Q = Q; p.K = K; p.V = V; p.O = O; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.D = D;
+    p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
+    p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
+    p.npad = (Nk + 63) / 64 * 64;
+    p.scale = scale;
+    p.lse = lse;
+    p.prio_young = 0;
+    p.drop = uc_make_dropout(drop_p, seed);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UC_BF16) {
+        UC_REQUIRE(D == 64, "uc_attention_fwd_drop(bf16): head_dim must be 64 (got %d)", D);
+        UC_REQUIRE(v_layout == UC_V_PACKED_T, "uc_attention_fwd_drop(bf16): V must be in the packed VT layout (uc_vt_pack)");
+        UC_REQUIRE(q_sb % 8 == 0 && q_sn % 8 == 0 && q_sh % 8 == 0 && k_sb % 8 == 0 && k_sn % 8 == 0 && k_sh % 8 == 0,
+                   "uc_attention_fwd_drop(bf16): Q/K strides must be multiples of 8 elements");
+        UC_REQUIRE(o_sb % 4 == 0 && o_sn % 4 == 0 && o_sh % 4 == 0, "uc_attention_fwd_drop(bf16): O strides must be multiples of 4");
+        UC_REQUIRE(((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)O % 8 == 0),
+                   "uc_attention_fwd_drop(bf16): pointer alignment");
+        hipLaunchKernelGGL(attn_bf16_drop_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, st, p);
+    } else if (dtype == UC_F32) {
+        UC_REQUIRE(v_layout == UC_V_ROWMAJOR, "uc_attention_fwd_drop(f32): V must be row-major");
+        UC_REQUIRE(D <= 64, "uc_attention_fwd_drop(f32): head_dim must be <= 64 (got %d)", D);
+        const dim3 grid((Nq + 127) / 128, H, B);
+        if (D <= 32) hipLaunchKernelGGL((attn_f32_kernel<32, true>), grid, dim3(128), 0, st, p);
+        else hipLaunchKernelGGL((attn_f32_kernel<64, true>), grid, dim3(128), 0, st, p);
+    } else {
+        uc_set_error("uc_attention_fwd_drop: unsupported dtype %d", dtype);
+        return UC_ERR_BAD_ARG;
+    }
+    UC_CHECK_LAUNCH("uc_attention_fwd_drop");
+    return UC_OK;
 }
 
 extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, void* O, int dtype, int v_layout,
@@ -911,6 +1001,7 @@ extern "C" int uc_attention_fwd(const void* Q, const void* K, const void* V, voi
     p.scale = scale;
     p.lse = lse;
     p.prio_young = uc_knobs().attn_prio;
+    p.drop = uc_make_dropout(0.f, 0ull);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UC_BF16) {
         UC_REQUIRE(D == 64, "uc_attention_fwd(bf16): head_dim must be 64 (got %d)", D);

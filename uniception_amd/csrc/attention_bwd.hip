@@ -43,6 +43,7 @@ struct AttnBwdParams {
     float rope_turn0;           // F0 / (2 pi): rotation per unit position of channel 0, in turns
     float rope_ratio;           // base^(-1/16)
     unsigned long long* dbg;    // probe builds (-DB64_TIMING): per-workgroup cycle stamps
+    UcDropout drop;             // attention dropout (uc_attention_bwd_drop; thr 0 elsewhere): the forward's mask, re-evaluated
 };
 
 #define TB (64 * 128)   // bytes of one 64-row tile
@@ -160,6 +161,10 @@ __device__ __forceinline__ void ab_xcd_order(int w, int nt, int nbh, int& tile, 
     else { const int rem = w - (nbh / 8) * 8 * nt; bh = (nbh / 8) * 8 + rem / nt; tile = rem % nt; }
 }
 
+// DROP (attention dropout, uc_attention_bwd_drop): the forward computed O = P' V with P' = P o mask / (1 - p).  dV = P'^T dO;
+// dP' = dO V^T; dP = dP' o mask / (1 - p); dS = P o (dP - delta) with delta = rowsum(dP o P) = rowsum(dP' o P') = rowsum(dO o O) as
+// without dropout.  The accumulator chain that starts at -delta holds dP' - delta: dS = P ((acc + delta) m - delta), m = mask / (1 - p).
+template <bool DROP = false>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem_all[4 * TB];   // 2 stages x (K rows | V rows), filled by LDS-DMA
     const int tid = threadIdx.x;
@@ -220,6 +225,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
         }
     }
 
+    unsigned dk1 = 0, dk2 = 0;
+    if constexpr (DROP) uc_drop_keys(p.drop, (unsigned)(b * p.H + h), dk1, dk2);
     float16_t dq[2];
     dq[0] = (float16_t)(0.f);
     dq[1] = (float16_t)(0.f);
@@ -267,6 +274,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
                     const int r = hf * 8 + j;
                     float pv = __builtin_amdgcn_exp2f(s[r]);
                     if (tail && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Nk) pv = 0.f;   // ragged last tile only (uniform test first)
+                    if constexpr (DROP) {
+                        const unsigned key = (unsigned)(k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                        const float m = uc_drop_hash(dk1, dk2, (unsigned)(q0 + l31), key) >= p.drop.thr ? p.drop.keep_scale : 0.f;
+                        e[j] = pv * __builtin_fmaf(dp[r] + dlt, m, -dlt);
+                    } else
                     e[j] = pv * dp[r];
                 }
                 union { bf16x8_t v; unsigned u[4]; } pk;
@@ -302,6 +314,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdParams p) {
 // =================================================================================================================
 // dK, dV
 // =================================================================================================================
+template <bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem_all[4 * TB + 1024];   // 2 stages x (Q rows | dO rows) + 2 x (lse2[64] delta[64])
     const int tid = threadIdx.x;
@@ -344,6 +357,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     float16_t dk[2], dv[2];
     dk[0] = (float16_t)(0.f); dk[1] = (float16_t)(0.f);
     dv[0] = (float16_t)(0.f); dv[1] = (float16_t)(0.f);
+    unsigned dk1 = 0, dk2 = 0;
+    if constexpr (DROP) uc_drop_keys(p.drop, (unsigned)(b * p.H + h), dk1, dk2);
 
     int r_off[4];
 #pragma unroll
@@ -378,13 +393,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             // accumulator row r = query qb*32 + (r & 3) + 8 (r >> 2) + 4 hi: registers 4k .. 4k+3 = one 16-byte LDS read
-            float16_t s, dp;
+            float16_t s, dp, ndl;       // (ndl: the rows' -delta once more, for the dropout form of dS)
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 const float4_t l4 = *reinterpret_cast<const float4_t*>(s_lse + qb * 32 + 8 * k4 + 4 * hi);
                 const float4_t d4 = *reinterpret_cast<const float4_t*>(s_dl + qb * 32 + 8 * k4 + 4 * hi);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) { s[4 * k4 + jj] = l4[jj]; dp[4 * k4 + jj] = d4[jj]; }
+                for (int jj = 0; jj < 4; ++jj) { s[4 * k4 + jj] = l4[jj]; dp[4 * k4 + jj] = d4[jj]; if constexpr (DROP) ndl[4 * k4 + jj] = d4[jj]; }
             }
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
@@ -401,8 +416,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
                 for (int j8 = 0; j8 < 8; ++j8) {
                     const int r = hf * 8 + j8;
                     const float pv = __builtin_amdgcn_exp2f(s[r]);
+                    if constexpr (DROP) {
+                        const unsigned qq = (unsigned)(q0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                        const float m = uc_drop_hash(dk1, dk2, qq, (unsigned)(key0 + l31)) >= p.drop.thr ? p.drop.keep_scale : 0.f;
+                        pe[j8] = pv * m;                                             // P' for dV
+                        de[j8] = pv * __builtin_fmaf(dp[r] - ndl[r], m, ndl[r]);     // P ((acc + delta) m - delta), ndl = -delta
+                    } else {
                     pe[j8] = pv;
                     de[j8] = pv * dp[r];
+                    }
                 }
                 union { bf16x8_t v; unsigned u[4]; } a, d2;
 #pragma unroll
@@ -446,12 +468,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 
 #include "attention_bwd64.h"
 
-extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-                                void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb,
-                                int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
-                                int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh,
-                                int64_t dk_sb, int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
-                                const int64_t* rope_qpos, const int64_t* rope_kpos, float rope_base, float rope_f0, uc_stream_t stream) {
+static int attention_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                              void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb,
+                              int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
+                              int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh,
+                              int64_t dk_sb, int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
+                              const int64_t* rope_qpos, const int64_t* rope_kpos, float rope_base, float rope_f0, const UcDropout& drop,
+                              uc_stream_t stream) {
     UC_REQUIRE(Q && K && V && O && dO && LSE && dQ && dK && dV && delta, "uc_attention_bwd: null pointer");
     UC_REQUIRE((rope_qpos == nullptr) == (rope_kpos == nullptr), "uc_attention_bwd: rope_qpos and rope_kpos go together");
     UC_REQUIRE(!rope_qpos || (rope_base > 0.f && rope_f0 != 0.f), "uc_attention_bwd: the inverse RoPE needs base > 0 and F0 != 0");
@@ -474,7 +497,14 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
     p.rope_qpos = rope_qpos; p.rope_kpos = rope_kpos; p.dbg = nullptr;
     p.rope_turn0 = rope_qpos ? (float)((double)rope_f0 / 6.283185307179586476925) : 0.f;
     p.rope_ratio = rope_qpos ? (float)pow((double)rope_base, -1.0 / 16.0) : 1.f;
+    p.drop = drop;
     hipStream_t st = (hipStream_t)stream;
+    if (drop.thr) {      // attention dropout: the 32-row kernels with the forward's mask re-evaluated per element
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((unsigned)(((Nk + 127) / 128) * H * B)), dim3(256), 0, st, p);
+        UC_CHECK_LAUNCH("uc_attention_bwd_drop");
+        return UC_OK;
+    }
     const int64_t total = (int64_t)B * H * Nq;
     (void)total;      // (delta is computed by the dQ kernel since round 4; attn_delta_kernel remains for reference)
     (void)uc_knobs();
@@ -486,7 +516,7 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
         const int64_t items = (int64_t)((Nq + 255) / 256) * H * B;
         const int grid = (int)min((int64_t)(uc_num_cus() / 8 * 8), (items + 7) / 8 * 8);
         hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
-    } else hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
+    } else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)(((Nq + 127) / 128) * H * B)), dim3(256), 0, st, p);
     // 64 keys per wave (attention_bwd64.h) when a 256-key workgroup is mostly real keys; the 32-key kernel otherwise
     // (its Q / dO / scratch descriptors span the whole tensors: 32-bit byte offsets)
     const int64_t q_ext = ((int64_t)(B - 1) * q_sb + (int64_t)(H - 1) * q_sh + (int64_t)(Nq - 1) * q_sn + 64) * 2;
@@ -502,9 +532,35 @@ extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, con
         const int grid = (int)min((int64_t)(uc_num_cus() / 8 * 8), (items + 7) / 8 * 8);
         hipLaunchKernelGGL(attn_bwd_dkv64_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     }
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((Nk + 127) / 128) * H * B)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((unsigned)(((Nk + 127) / 128) * H * B)), dim3(256), 0, st, p);
     UC_CHECK_LAUNCH("uc_attention_bwd");
     return UC_OK;
+}
+
+extern "C" int uc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb,
+                                int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
+                                int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh,
+                                int64_t dk_sb, int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
+                                const int64_t* rope_qpos, const int64_t* rope_kpos, float rope_base, float rope_f0, uc_stream_t stream) {
+    return attention_bwd_impl(Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh,
+                              o_sb, o_sn, o_sh, dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh, scale, rope_qpos, rope_kpos,
+                              rope_base, rope_f0, uc_make_dropout(0.f, 0ull), stream);
+}
+
+// Backward of uc_attention_fwd_drop: uc_attention_bwd's arguments + the forward's (drop_p, seed).  O is the forward's (dropped) output,
+// LSE that of the undropped scores.
+extern "C" int uc_attention_bwd_drop(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                     void* dQ, void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int64_t q_sb,
+                                     int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
+                                     int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh,
+                                     int64_t dk_sb, int64_t dk_sn, int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale,
+                                     const int64_t* rope_qpos, const int64_t* rope_kpos, float rope_base, float rope_f0, float drop_p,
+                                     unsigned long long seed, uc_stream_t stream) {
+    UC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "uc_attention_bwd_drop: drop_p must be in [0, 1) (got %g)", (double)drop_p);
+    return attention_bwd_impl(Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh,
+                              o_sb, o_sn, o_sh, dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh, scale, rope_qpos, rope_kpos,
+                              rope_base, rope_f0, uc_make_dropout(drop_p, seed), stream);
 }
 
 // =================================================================================================================
@@ -518,6 +574,7 @@ struct AttnBwdF32Params {
     int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
     int64_t dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh;
     float scale;
+    UcDropout drop;      // thr 0: none (a run-time test in these verification kernels)
 };
 
 #define BF_T 32
@@ -558,6 +615,8 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(AttnBwdF32Params p
     }
     const float lse = p.LSE[((int64_t)b * p.H + h) * p.Nq + qc];
     const float dlt = p.delta[((int64_t)b * p.H + h) * p.Nq + qc];
+    unsigned dk1 = 0, dk2 = 0;
+    if (p.drop.thr) uc_drop_keys(p.drop, (unsigned)(b * p.H + h), dk1, dk2);
     for (int k0 = 0; k0 < p.Nk; k0 += BF_T) {
         __syncthreads();
         for (int idx = threadIdx.x; idx < BF_T * DMAX; idx += blockDim.x) {
@@ -576,6 +635,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(AttnBwdF32Params p
                 dp = fmaf(dor[d], Vs[kk][d], dp);
             }
             const float pw = expf(s * p.scale - lse);
+            if (p.drop.thr) dp *= uc_drop_hash(dk1, dk2, (unsigned)qc, (unsigned)(k0 + kk)) >= p.drop.thr ? p.drop.keep_scale : 0.f;   // dP = dP' o mask / (1 - p)
             const float ds = pw * (dp - dlt);
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) acc[d] = fmaf(ds, Ks[kk][d], acc[d]);
@@ -611,6 +671,8 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(AttnBwdF32Params 
         dk[d] = 0.f;
         dv[d] = 0.f;
     }
+    unsigned dk1 = 0, dk2 = 0;
+    if (p.drop.thr) uc_drop_keys(p.drop, (unsigned)(b * p.H + h), dk1, dk2);
     for (int q0 = 0; q0 < p.Nq; q0 += BF_T) {
         __syncthreads();
         for (int idx = threadIdx.x; idx < BF_T * DMAX; idx += blockDim.x) {
@@ -634,10 +696,16 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(AttnBwdF32Params 
                 dp = fmaf(Ds[qq][d], vr[d], dp);
             }
             const float pw = expf(s * p.scale - Ls[qq]);
+            float pdrop = pw;                                     // P' = P o mask / (1 - p) for dV
+            if (p.drop.thr) {
+                const float m = uc_drop_hash(dk1, dk2, (unsigned)(q0 + qq), (unsigned)kc) >= p.drop.thr ? p.drop.keep_scale : 0.f;
+                pdrop *= m;
+                dp *= m;
+            }
             const float ds = pw * (dp - Dl[qq]);
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) {
-                dv[d] = fmaf(pw, Ds[qq][d], dv[d]);
+                dv[d] = fmaf(pdrop, Ds[qq][d], dv[d]);
                 dk[d] = fmaf(ds, Qs[qq][d], dk[d]);
             }
         }
@@ -654,12 +722,13 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(AttnBwdF32Params 
     }
 }
 
-extern "C" int uc_attention_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO,
-                                    const float* LSE, float* dQ, float* dK, float* dV, float* delta, int B, int H, int Nq,
-                                    int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
-                                    int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
-                                    int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn,
-                                    int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream) {
+static int attention_bwd_f32_impl(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                                  const float* LSE, float* dQ, float* dK, float* dV, float* delta, int B, int H, int Nq,
+                                  int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
+                                  int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
+                                  int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn,
+                                  int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, const UcDropout& drop,
+                                  uc_stream_t stream) {
     UC_REQUIRE(Q && K && V && O && dO && LSE && dQ && dK && dV && delta, "uc_attention_bwd_f32: null pointer");
     UC_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && D > 0 && D <= 64 && B <= 65535 && H <= 65535, "uc_attention_bwd_f32: bad shape (head_dim <= 64)");
     AttnBwdF32Params p;
@@ -668,6 +737,7 @@ extern "C" int uc_attention_bwd_f32(const float* Q, const float* K, const float*
     p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh; p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh;
     p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh; p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.dk_sb = dk_sb; p.dk_sn = dk_sn;
     p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh; p.scale = scale;
+    p.drop = drop;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * H * Nq;
     hipLaunchKernelGGL(attn_delta_f32_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, p);
@@ -680,4 +750,29 @@ extern "C" int uc_attention_bwd_f32(const float* Q, const float* K, const float*
     }
     UC_CHECK_LAUNCH("uc_attention_bwd_f32");
     return UC_OK;
+}
+
+extern "C" int uc_attention_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                                    const float* LSE, float* dQ, float* dK, float* dV, float* delta, int B, int H, int Nq,
+                                    int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
+                                    int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
+                                    int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn,
+                                    int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, uc_stream_t stream) {
+    return attention_bwd_f32_impl(Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh,
+                                  o_sb, o_sn, o_sh, dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh, scale,
+                                  uc_make_dropout(0.f, 0ull), stream);
+}
+
+// fp32 backward of uc_attention_fwd_drop (verification mode): uc_attention_bwd_f32's arguments + the forward's (drop_p, seed)
+extern "C" int uc_attention_bwd_f32_drop(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                                         const float* LSE, float* dQ, float* dK, float* dV, float* delta, int B, int H, int Nq,
+                                         int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
+                                         int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
+                                         int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, int64_t dk_sb, int64_t dk_sn,
+                                         int64_t dk_sh, int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, float drop_p,
+                                         unsigned long long seed, uc_stream_t stream) {
+    UC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "uc_attention_bwd_f32_drop: drop_p must be in [0, 1) (got %g)", (double)drop_p);
+    return attention_bwd_f32_impl(Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh,
+                                  o_sb, o_sn, o_sh, dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh, scale,
+                                  uc_make_dropout(drop_p, seed), stream);
 }

@@ -180,6 +180,47 @@ __device__ __forceinline__ float2 uc_ln_merge_row(const float2* __restrict__ p, 
     return make_float2(mu, 1.0f / sqrtf(uc_ln_tree16(s) / cnt + eps));
 }
 
+// ---- attention dropout (attn_drop > 0 in training; reference: utils/transformer_blocks.py:198, 245, 251, 374, 380 — nn.Dropout on the
+// softmax probabilities, or dropout_p of the fused SDPA) ----
+// The keep decision of element (batch b, head h, query q, key k) is a COUNTER-BASED function of (seed, b * H + h, q, k): no mask is
+// stored — the forward kernel, both backward kernels (which rebuild P) and uc_attention_drop_mask evaluate the same function, whatever
+// their tile shapes (a lane of the forward / dQ kernels holds four consecutive KEYS of a query, a lane of the dK / dV kernel four
+// consecutive QUERIES of a key: a generator that yields groups of outputs would fit one of them).  Two murmur3-style rounds over the
+// two 32-bit words (q + key word 1, k + key word 2), then the murmur3 finaliser; the per-(seed, b, h) key words are mixed on the
+// device from the 64-bit seed.  keep <=> hash >= thr, thr = round(p * 2^32): P(keep) = 1 - p to 2^-32.
+struct UcDropout {
+    unsigned thr;          // 0: no dropout
+    unsigned seed_lo, seed_hi;
+    float keep_scale;      // 1 / (1 - p)
+};
+__host__ __device__ __forceinline__ unsigned uc_fmix32(unsigned y) {
+    y ^= y >> 16; y *= 0x85EBCA6Bu; y ^= y >> 13; y *= 0xC2B2AE35u; y ^= y >> 16;
+    return y;
+}
+// the two key words of one (batch, head)
+__host__ __device__ __forceinline__ void uc_drop_keys(const UcDropout& d, unsigned bh, unsigned& k1, unsigned& k2) {
+    k1 = uc_fmix32(d.seed_lo ^ (bh * 0x9E3779B1u) ^ 0x3C6EF372u);
+    k2 = uc_fmix32(d.seed_hi + bh * 0x7F4A7C15u + 0xDAA66D2Bu);
+}
+__host__ __device__ __forceinline__ unsigned uc_drop_hash(unsigned k1, unsigned k2, unsigned q, unsigned k) {
+    unsigned x = (q + k1) * 0xCC9E2D51u;
+    x = (x << 15) | (x >> 17);
+    x *= 0x1B873593u;
+    x ^= (k + k2) * 0x85EBCA6Bu;
+    x = (x << 13) | (x >> 19);
+    x = x * 5u + 0xE6546B64u;
+    return uc_fmix32(x);
+}
+static inline UcDropout uc_make_dropout(float p, unsigned long long seed) {
+    UcDropout d;
+    double t = (double)p * 4294967296.0;
+    d.thr = p <= 0.f ? 0u : (t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)(t + 0.5));
+    d.seed_lo = (unsigned)(seed & 0xFFFFFFFFull);
+    d.seed_hi = (unsigned)(seed >> 32);
+    d.keep_scale = p < 1.f ? 1.0f / (1.0f - p) : 0.f;
+    return d;
+}
+
 // compute units of the current device (persistent kernels launch one workgroup per CU)
 static inline int uc_num_cus() {
     static int n = [] {

@@ -736,8 +736,9 @@ def _attention_generic(q, k, v, scale):
 def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk: int, projq: nn.Linear, projk: nn.Linear,
                     projv: nn.Linear, proj: nn.Linear, num_heads: int, rope, qpos, kpos, scale: float,
                     residual: Optional[torch.Tensor], out_dtype: torch.dtype, fold_q=None, fold_kv=None,
-                    emit_ln: bool = False, q_norm=None, k_norm=None, hv2d: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    emit_ln: bool = False, q_norm=None, k_norm=None, hv2d: Optional[torch.Tensor] = None, proj_wb=None) -> torch.Tensor:
     """fold_q / fold_kv: from ln_operand for the query / key-value streams (see self_attention).
+    proj_wb: optional prepared (W, b) overriding proj's own (a LayerScale folded in).
     q_norm / k_norm: the layer's qk_norm modules.  hv2d: the VALUE tokens when they are not the key tokens
     (utils/transformer_blocks.py:341-348: projk(key), projv(value) — two GEMMs instead of the fused [Wk; Wv] one)."""
     dtype = hq2d.dtype
@@ -745,14 +746,14 @@ def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk
     Dh = Cd // num_heads
     if hv2d is not None or _has_norm(q_norm, k_norm):
         return _cross_attention_unfused(hq2d, hkv2d, hv2d, B, Nq, Nk, projq, projk, projv, proj, num_heads, rope, qpos, kpos, scale,
-                                        residual, out_dtype, fold_q, fold_kv, emit_ln, q_norm, k_norm)
+                                        residual, out_dtype, fold_q, fold_kv, emit_ln, q_norm, k_norm, proj_wb)
     wq, bq, lnq = _folded(projq, fold_q, dtype)
     if fold_kv is None:
         (wkv, bkv), lnkv = kv_weights(projk, projv, dtype), None
     else:
         wkv, bkv, cskv = ln_kv_weights(projk, projv, fold_kv[1], dtype)
         lnkv = (fold_kv[0], cskv)
-    wp, bp = lin_weights(proj, dtype)
+    wp, bp = proj_wb if proj_wb is not None else lin_weights(proj, dtype)
     native = rope is None or is_native_rope(rope)
     if dtype == torch.bfloat16 and Dh == 64 and native and _fp8_attention():
         epq = _rope_epilogue(rope, _pos2d(qpos), Cd) if rope is not None else None
@@ -782,7 +783,7 @@ def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk
 
 
 def _cross_attention_unfused(hq2d, hk2d, hv2d, B, Nq, Nk, projq, projk, projv, proj, num_heads, rope, qpos, kpos, scale, residual,
-                             out_dtype, fold_q, fold_k, emit_ln, q_norm, k_norm):
+                             out_dtype, fold_q, fold_k, emit_ln, q_norm, k_norm, proj_wb=None):
     """CrossAttention with options the fused pipeline does not carry: qk_norm (LayerNorm of q / k over head_dim before the positional
     encoding) and value tokens that are not the key tokens.  q, k, v from three GEMMs (the query / key LayerNorm folds still apply),
     uc_layernorm for the norms, uc_rope2d in place, attention on row-major V."""
@@ -809,7 +810,7 @@ def _cross_attention_unfused(hq2d, hk2d, hv2d, B, Nq, Nk, projq, projk, projv, p
     if o is None:
         q, k = _apply_rope(rope, q, k, qpos, kpos)
         o = _attention_generic(q, k, v, scale)
-    wp, bp = lin_weights(proj, dtype)
+    wp, bp = proj_wb if proj_wb is not None else lin_weights(proj, dtype)
     emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cd)
     return ops.gemm(o.reshape(B * Nq, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 

@@ -59,9 +59,9 @@ def _drop_path_rate(m):
 
 
 def _check_attn_drop(module, p):
-    if module.training and p > 0.0:
-        raise engine.UcHipError("attn_drop > 0 in training mode is not supported by the HIP path (it would drop attention probabilities "
-                                "INSIDE the flash kernels; proj_drop, the Mlp's drop and DropPath are supported)")
+    "Kept for callers outside the blocks: attention dropout runs inside the sub-layer Functions since round 6 (autograd.attn_dropout)."
+    if module.training and p > 0.0 and not torch.is_grad_enabled():
+        raise engine.UcHipError("attn_drop > 0 in train mode without gradients has no HIP form (the inference kernels apply no dropout)")
 
 
 def _as_2d(x):
@@ -86,9 +86,9 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features, bias=bias[1])
         self.drop2 = nn.Dropout(drop_probs[1])
 
-    def _run(self, h2d, residual, out_dtype, fold=None, emit_ln=False):
+    def _run(self, h2d, residual, out_dtype, fold=None, emit_ln=False, fc2_wb=None):
         _check_no_dropout(self, self.drop1.p, self.drop2.p)
-        return engine.mlp(h2d, self.fc1, self.fc2, engine.act_name(self.act), residual, out_dtype, fold=fold, emit_ln=emit_ln)
+        return engine.mlp(h2d, self.fc1, self.fc2, engine.act_name(self.act), residual, out_dtype, fc2_wb=fc2_wb, fold=fold, emit_ln=emit_ln)
 
     def forward(self, x):
         engine.require_inference(x, self.fc1.weight)
@@ -146,14 +146,14 @@ class Block(nn.Module):
         """[B*N, C] residual stream in, new residual stream out (same dtype)."""
         if autograd.grad_needed(x2d, *self.parameters()):
             # dropout (round 5): proj_drop / the Mlp's drops / DropPath as masks through the sub-layer Functions (autograd.make_drops)
-            _check_attn_drop(self, self.attn.dropout_p)
+            ad = autograd.attn_dropout(self.training, self.attn.dropout_p)      # (round 6: inside the attention kernels, forward and backward)
             C = x2d.shape[1]
             pp, sbk = _drop_path_rate(self.drop_path)
             d1 = autograd.make_drops(self.training, x2d.device, B, N, C, p_out=self.attn.proj_drop.p, p_path=pp, scale_by_keep=sbk)
             d2 = autograd.make_drops(self.training, x2d.device, B, N, C, p_out=self.mlp.drop2.p, p_path=pp, hidden=self.mlp.fc1.out_features,
                                      p_mid=self.mlp.drop1.p, scale_by_keep=sbk)
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, self.attn.qkv, self.attn.proj, B, N, self.attn.num_heads,
-                                              self.attn.rope, xpos, self.attn.scale, dt, drops=d1)
+                                              self.attn.rope, xpos, self.attn.scale, dt, drops=d1, attn_drop=ad)
             return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, drops=d2)
         if isinstance(self.drop_path, DropPath):
             self.drop_path(x2d)  # (train mode without gradients: raises at rate > 0)

@@ -26,6 +26,8 @@ def has_random_masks(module: nn.Module) -> bool:
             return True
         if float(getattr(m, "drop_prob", 0.0) or 0.0) > 0.0:          # DropPath (libs/croco/blocks.py, timm-style)
             return True
+        if float(getattr(m, "dropout_p", 0.0) or 0.0) > 0.0:          # CroCo Attention's attn_drop rate
+            return True
     return False
 
 

@@ -59,13 +59,14 @@ class Attention(nn.Module):
         self.base_token_count_for_entropy_scaling = base_token_count_for_entropy_scaling
         self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
 
-    def _run(self, h2d, B, N, xpos, residual, out_dtype, fold=None, emit_ln=False):
+    def _run(self, h2d, B, N, xpos, residual, out_dtype, fold=None, emit_ln=False, proj_wb=None):
         _check_no_dropout(self, self.attn_drop.p, self.proj_drop.p)
         if self.custom_positional_encoding is not None:
             assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
         scale = self.scale * _softmax_scale_multiplier(self, N)
         return engine.self_attention(h2d, B, N, self.qkv, self.proj, self.num_heads, self.custom_positional_encoding, xpos,
-                                     scale, residual, out_dtype, fold=fold, emit_ln=emit_ln, q_norm=self.q_norm, k_norm=self.k_norm)
+                                     scale, residual, out_dtype, proj_wb=proj_wb, fold=fold, emit_ln=emit_ln, q_norm=self.q_norm,
+                                     k_norm=self.k_norm)
 
     def forward(self, x: torch.Tensor, xpos: torch.Tensor = None) -> torch.Tensor:
         engine.require_inference(x, self.qkv.weight)
@@ -103,7 +104,8 @@ class CrossAttention(nn.Module):
         self.base_token_count_for_entropy_scaling = base_token_count_for_entropy_scaling
         self.entropy_scaling_growth_factor = entropy_scaling_growth_factor
 
-    def _run(self, hq2d, hkv2d, B, Nq, Nk, qpos, kpos, residual, out_dtype, fold_q=None, fold_kv=None, emit_ln=False, hv2d=None):
+    def _run(self, hq2d, hkv2d, B, Nq, Nk, qpos, kpos, residual, out_dtype, fold_q=None, fold_kv=None, emit_ln=False, hv2d=None,
+             proj_wb=None):
         _check_no_dropout(self, self.attn_drop.p, self.proj_drop.p)
         if self.custom_positional_encoding is not None:
             assert qpos is not None, "Positions of queries (qpos) are a required input when using custom positional encoding"
@@ -111,7 +113,8 @@ class CrossAttention(nn.Module):
         scale = self.scale * _softmax_scale_multiplier(self, Nq)
         return engine.cross_attention(hq2d, hkv2d, B, Nq, Nk, self.projq, self.projk, self.projv, self.proj, self.num_heads,
                                       self.custom_positional_encoding, qpos, kpos, scale, residual, out_dtype,
-                                      fold_q=fold_q, fold_kv=fold_kv, emit_ln=emit_ln, q_norm=self.q_norm, k_norm=self.k_norm, hv2d=hv2d)
+                                      fold_q=fold_q, fold_kv=fold_kv, emit_ln=emit_ln, q_norm=self.q_norm, k_norm=self.k_norm, hv2d=hv2d,
+                                      proj_wb=proj_wb)
 
     def forward(self, query, key, value, qpos=None, kpos=None):
         engine.require_inference(query, key, value, self.projq.weight)
@@ -130,8 +133,9 @@ class CrossAttention(nn.Module):
 
 
 class LayerScale(nn.Module):
-    """Per-channel scale; parameter container only.  SelfAttentionBlock folds it into the preceding linear's weights
-    (gamma * (x W^T + b) = x (gamma W)^T + gamma b: no kernel work); CrossAttentionBlock requires init_values=None (as DUSt3R uses)."""
+    """Per-channel scale; parameter container only.  The blocks fold it into the preceding linear's weights
+    (gamma * (x W^T + b) = x (gamma W)^T + gamma b: no kernel work); in training the folded weight's gradient is unfolded into
+    d W, d b and d gamma (autograd._unfold_layerscale).  SelfAttentionBlock since round 2, CrossAttentionBlock since round 6."""
 
     def __init__(self, dim: int, init_values: float = 1e-5, inplace: bool = False):
         super().__init__()
@@ -177,7 +181,7 @@ class SelfAttentionBlock(nn.Module):
             assert xpos is not None, "Positions of tokens (xpos) are a required input when using custom positional encoding"
         sa = self.attn
         if autograd.grad_needed(x2d, *self.parameters()):   # HIP forward + HIP backward sub-layers
-            _check_attn_drop(self, sa.attn_drop.p)
+            ad = autograd.attn_dropout(self.training, sa.attn_drop.p)       # (round 6: inside the attention kernels, forward and backward)
             C = x2d.shape[1]
             (p1, k1), (p2, k2) = _drop_path_rate(self.drop_path1), _drop_path_rate(self.drop_path2)
             d1 = autograd.make_drops(self.training, x2d.device, B, N, C, p_out=sa.proj_drop.p, p_path=p1, scale_by_keep=k1)
@@ -187,7 +191,7 @@ class SelfAttentionBlock(nn.Module):
             g2 = None if isinstance(self.ls2, nn.Identity) else self.ls2.gamma
             x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, N, sa.num_heads, sa.custom_positional_encoding,
                                               xpos, sa.scale * _softmax_scale_multiplier(sa, N), dt, gamma=g1, q_norm=sa.q_norm,
-                                              k_norm=sa.k_norm, drops=d1)
+                                              k_norm=sa.k_norm, drops=d1, attn_drop=ad)
             return autograd.mlp_sublayer(x2d, self.norm2, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, gamma=g2, drops=d2)
         _check_no_dropout(self, sa.attn_drop.p, sa.proj_drop.p, self.mlp.drop1.p, self.mlp.drop2.p)
         for dp in (self.drop_path1, self.drop_path2):
@@ -241,10 +245,11 @@ class CrossAttentionBlock(nn.Module):
         self.ls3 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
         self.drop_path3 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
+    def _gammas(self):
+        "LayerScale parameters of the three sub-layers (None where init_values was None)."
+        return tuple(None if isinstance(ls, nn.Identity) else ls.gamma for ls in (self.ls1, self.ls2, self.ls3))
+
     def _check_supported(self):
-        for ls in (self.ls1, self.ls2, self.ls3):
-            if not isinstance(ls, nn.Identity):
-                raise engine.UcHipError("LayerScale (init_values != None) is not supported by the HIP path")
         if not isinstance(self.mlp, Mlp):
             raise engine.UcHipError("only the standard Mlp layer has a fused HIP pipeline")
 
@@ -260,21 +265,26 @@ class CrossAttentionBlock(nn.Module):
             if isinstance(dp, DropPath) and dp.drop_prob > 0 and self.training:
                 raise engine.UcHipError("DropPath with drop_prob > 0 in train mode without gradients has no HIP form")
         # LayerNorm -> GEMM pairs run fused when a stream carries its producer's bf16 twin + row statistics (engine.ln_operand)
+        g1, g2, g3 = self._gammas()        # LayerScale (utils/transformer_blocks.py:584-647): folded into proj / fc2, no kernel work
+        wb1 = None if g1 is None else engine.layerscale_lin_weights(self.attn.proj, g1, dt)
+        wb2 = None if g2 is None else engine.layerscale_lin_weights(self.cross_attn.proj, g2, dt)
+        wb3 = None if g3 is None else engine.layerscale_lin_weights(self.mlp.fc2, g3, dt)
         h, fold = engine.ln_operand(x2d, self.norm1, dt)
-        x2d = self.attn._run(h, B, Nx, xpos, x2d, x2d.dtype, fold, True)
+        x2d = self.attn._run(h, B, Nx, xpos, x2d, x2d.dtype, fold, True, proj_wb=wb1)
         if isinstance(self.norm_y, nn.Identity):
             yn, fold_y = (y2d if y2d.dtype == dt else engine.ops.convert(y2d, dt)), None
         else:
             yn, fold_y = engine.ln_operand(y2d, self.norm_y, dt)
         h, fold = engine.ln_operand(x2d, self.norm2, dt)
-        x2d = self.cross_attn._run(h, yn, B, Nx, Ny, xpos, ypos, x2d, x2d.dtype, fold, fold_y, True)
+        x2d = self.cross_attn._run(h, yn, B, Nx, Ny, xpos, ypos, x2d, x2d.dtype, fold, fold_y, True, proj_wb=wb2)
         h, fold = engine.ln_operand(x2d, self.norm3, dt)
-        return self.mlp._run(h, x2d, x2d.dtype, fold, True)
+        return self.mlp._run(h, x2d, x2d.dtype, fold, True, fc2_wb=wb3)
 
     def _forward_tokens_train(self, x2d, y2d, B, Nx, Ny, xpos, ypos, dt):
         """Same three sub-layers as autograd Functions (HIP forward + HIP backward)."""
         sa, ca = self.attn, self.cross_attn
-        _check_attn_drop(self, max(sa.attn_drop.p, ca.attn_drop.p))
+        ad1 = autograd.attn_dropout(self.training, sa.attn_drop.p)          # (round 6: inside the attention kernels, forward and backward)
+        ad2 = autograd.attn_dropout(self.training, ca.attn_drop.p)
         C, dev = x2d.shape[1], x2d.device
         (p1, k1), (p2, k2), (p3, k3) = (_drop_path_rate(m) for m in (self.drop_path1, self.drop_path2, self.drop_path3))
         d1 = autograd.make_drops(self.training, dev, B, Nx, C, p_out=sa.proj_drop.p, p_path=p1, scale_by_keep=k1)
@@ -282,12 +292,14 @@ class CrossAttentionBlock(nn.Module):
         d3 = autograd.make_drops(self.training, dev, B, Nx, C, p_out=self.mlp.drop2.p, p_path=p3, hidden=self.mlp.fc1.out_features,
                                  p_mid=self.mlp.drop1.p, scale_by_keep=k3)
         rope = self.custom_positional_encoding
+        g1, g2, g3 = self._gammas()
         x2d = autograd.self_attn_sublayer(x2d, self.norm1, sa.qkv, sa.proj, B, Nx, sa.num_heads, rope, xpos,
-                                          sa.scale * _softmax_scale_multiplier(sa, Nx), dt, q_norm=sa.q_norm, k_norm=sa.k_norm, drops=d1)
+                                          sa.scale * _softmax_scale_multiplier(sa, Nx), dt, gamma=g1, q_norm=sa.q_norm, k_norm=sa.k_norm,
+                                          drops=d1, attn_drop=ad1)
         lny = None if isinstance(self.norm_y, nn.Identity) else self.norm_y
         x2d = autograd.cross_attn_sublayer(x2d, y2d, self.norm2, lny, ca, B, Nx, Ny, ca.num_heads, rope, xpos, ypos,
-                                           ca.scale * _softmax_scale_multiplier(ca, Nx), dt, drops=d2)
-        return autograd.mlp_sublayer(x2d, self.norm3, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, drops=d3)
+                                           ca.scale * _softmax_scale_multiplier(ca, Nx), dt, gamma=g2, drops=d2, attn_drop=ad2)
+        return autograd.mlp_sublayer(x2d, self.norm3, self.mlp.fc1, self.mlp.fc2, engine.act_name(self.mlp.act), dt, gamma=g3, drops=d3)
 
     def forward(self, x, y, xpos=None, ypos=None):
         B, Nx, C = x.shape

@@ -587,9 +587,11 @@ def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt8: torch.Tensor, scale: fl
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, v_packed: bool = False,
-              out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None, dropout=None) -> torch.Tensor:
     """q [B,Nq,H,D], k [B,Nk,H,D] strided views (stride(3)==1); v same, or packed VT [B,H,D,Npad] when v_packed.
-    Returns O [B,Nq,H,D] contiguous (== [B,Nq,H*D])."""
+    Returns O [B,Nq,H,D] contiguous (== [B,Nq,H*D]).
+    dropout = (p, seed): dropout of the attention probabilities inside the kernel (uc_attention_fwd_drop: a counter-based keep
+    function of (seed, batch, head, query, key); attention_drop_mask materialises it; the backward takes the same pair)."""
     _need_gpu(q, k, v)
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
@@ -602,6 +604,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, v
     else:
         assert v.stride(3) == 1
         vs = (v.stride(0), v.stride(1), v.stride(2))
+    if dropout is not None and float(dropout[0]) > 0.0:
+        _lib.check(_lib.load().uc_attention_fwd_drop(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _dt(q.dtype), UC_V_PACKED_T if v_packed else UC_V_ROWMAJOR,
+            B, H, Nq, Nk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), vs[0], vs[1], vs[2],
+            out.stride(0), out.stride(1), out.stride(2), float(scale), _p(lse), float(dropout[0]), int(dropout[1]), _stream()),
+            "uc_attention_fwd_drop")
+        return out
     _lib.check(_lib.load().uc_attention_fwd(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _dt(q.dtype), UC_V_PACKED_T if v_packed else UC_V_ROWMAJOR,
         B, H, Nq, Nk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), vs[0], vs[1], vs[2],
@@ -1006,8 +1015,17 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, l
                                     float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream()), "uc_adamw")
 
 
-def attention_bwd(q, k, v, o, do, lse, scale: float, out=None, rope=None):
+def attention_drop_mask(B: int, H: int, Nq: int, Nk: int, p: float, seed: int, device) -> torch.Tensor:
+    "uint8 [B,H,Nq,Nk] keep mask (1 = kept) of attention(..., dropout=(p, seed)): the function the kernels evaluate, for references."
+    mask = torch.empty((B, H, Nq, Nk), dtype=torch.uint8, device=device)
+    _need_gpu(mask)
+    _lib.check(_lib.load().uc_attention_drop_mask(mask.data_ptr(), B, H, Nq, Nk, float(p), int(seed), _stream()), "uc_attention_drop_mask")
+    return mask
+
+
+def attention_bwd(q, k, v, o, do, lse, scale: float, out=None, rope=None, dropout=None):
     """q,o,do [B,Nq,H,64]; k,v [B,Nk,H,64] bf16 views (unit last stride); lse fp32 [B,H,Nq].
+    dropout = the forward's (p, seed) when it dropped attention probabilities (the kernels re-evaluate the mask).
     Returns dq, dk, dv ([B,N,H,64] bf16): fresh contiguous tensors, or the three views passed as `out`
     (e.g. slices of one fused dqkv buffer).
     rope = (qpos int64 [B*Nq,2], kpos int64 [B*Nk,2], base, F0) (bf16 only): q and k were RoPE-rotated before the forward; dq / dk come
@@ -1035,6 +1053,27 @@ def attention_bwd(q, k, v, o, do, lse, scale: float, out=None, rope=None):
     if rope is not None:
         assert dt == torch.bfloat16 and rope[0].dtype == torch.int64 and rope[1].dtype == torch.int64
         assert rope[0].is_contiguous() and rope[1].is_contiguous() and rope[0].numel() == 2 * B * Nq and rope[1].numel() == 2 * B * Nk
+    drop = dropout is not None and float(dropout[0]) > 0.0
+    if dt == torch.float32 and drop:
+        _lib.check(_lib.load().uc_attention_bwd_f32_drop(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+            dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk, D,
+            q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
+            o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1),
+            dk.stride(2), dv.stride(0), dv.stride(1), dv.stride(2), float(scale), float(dropout[0]), int(dropout[1]), _stream()),
+            "uc_attention_bwd_f32_drop")
+        return dq, dk, dv
+    if drop:
+        _lib.check(_lib.load().uc_attention_bwd_drop(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Nq, Nk,
+            q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
+            o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1), dk.stride(2),
+            dv.stride(0), dv.stride(1), dv.stride(2), float(scale),
+            _p(rope[0]) if rope is not None else None, _p(rope[1]) if rope is not None else None,
+            float(rope[2]) if rope is not None else 0.0, float(rope[3]) if rope is not None else 0.0,
+            float(dropout[0]), int(dropout[1]), _stream()), "uc_attention_bwd_drop")
+        return dq, dk, dv
     if dt == torch.float32:
         _lib.check(_lib.load().uc_attention_bwd_f32(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(),
