@@ -129,20 +129,35 @@ def _qk_norm(t: Tensor, sd: SD, prefix: str) -> Tensor:
     return F.layer_norm(t, (t.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
 
 
-def self_attention(x: Tensor, pos: Optional[Tensor], sd: SD, prefix: str, num_heads: int, base: float) -> Tensor:
-    """qkv -> [q_norm, k_norm] -> RoPE(q), RoPE(k) -> SDPA -> proj (libs/croco/blocks.py:105-129; utils/transformer_blocks.py:219-256).
-    Wqkv rows: [0:D]=Q, [D:2D]=K, [2D:3D]=V, head-major.  pos None: no positional encoding."""
+def q_scaling(n_tokens: int, scalable_softmax: bool = False, entropy_scaling: bool = False, base_token_count: int = 444,
+              growth_factor: float = 1.4) -> float:
+    """The reference's optional scalings of q after the positional encoding (utils/transformer_blocks.py:231-241, 360-370):
+    scalable softmax q * log(N), entropy scaling q * sqrt(growth * log(N) / log(base count)); N = the QUERY count."""
+    import math
+    m = 1.0
+    if scalable_softmax:
+        m *= math.log(n_tokens)
+    if entropy_scaling:
+        m *= math.sqrt(growth_factor * math.log(n_tokens) / math.log(base_token_count))
+    return m
+
+
+def self_attention(x: Tensor, pos: Optional[Tensor], sd: SD, prefix: str, num_heads: int, base: float, q_scale: float = 1.0) -> Tensor:
+    """qkv -> [q_norm, k_norm] -> RoPE(q), RoPE(k) -> [q * q_scale] -> SDPA -> proj (libs/croco/blocks.py:105-129;
+    utils/transformer_blocks.py:219-256).  Wqkv rows: [0:D]=Q, [D:2D]=K, [2D:3D]=V, head-major.  pos None: no positional encoding."""
     B, N, Cd = x.shape
     qkv = linear(x, sd, prefix + ".qkv").view(B, N, 3, num_heads, Cd // num_heads).permute(2, 0, 3, 1, 4)
     q, k, v = _qk_norm(qkv[0], sd, prefix + ".q_norm"), _qk_norm(qkv[1], sd, prefix + ".k_norm"), qkv[2]
     if pos is not None:
         q, k = rope2d(q, pos, base), rope2d(k, pos, base)
+    if q_scale != 1.0:
+        q = q * q_scale
     o = sdpa(q, k, v).transpose(1, 2).reshape(B, N, Cd)
     return linear(o, sd, prefix + ".proj")
 
 
 def cross_attention(xq: Tensor, y: Tensor, qpos: Optional[Tensor], kpos: Optional[Tensor], sd: SD, prefix: str, num_heads: int,
-                    base: float, value: Optional[Tensor] = None) -> Tensor:
+                    base: float, value: Optional[Tensor] = None, q_scale: float = 1.0) -> Tensor:
     """projq/projk/projv, [q_norm, k_norm], RoPE on q (own positions) and k (other view's), SDPA, proj
     (utils/transformer_blocks.py:345-386).  value: the value tokens when they are not the key tokens y (:341-348)."""
     B, Nq, Cd = xq.shape
@@ -154,6 +169,8 @@ def cross_attention(xq: Tensor, y: Tensor, qpos: Optional[Tensor], kpos: Optiona
     q, k = _qk_norm(q, sd, prefix + ".q_norm"), _qk_norm(k, sd, prefix + ".k_norm")
     if qpos is not None:
         q, k = rope2d(q, qpos, base), rope2d(k, kpos, base)
+    if q_scale != 1.0:
+        q = q * q_scale
     o = sdpa(q, k, v).transpose(1, 2).reshape(B, Nq, Cd)
     return linear(o, sd, prefix + ".proj")
 

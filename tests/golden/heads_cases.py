@@ -73,3 +73,20 @@ def dpt_grad_weight(name, shape):
     import torch
     g = torch.Generator().manual_seed(sum(map(ord, name)) + 2027)
     return torch.randn(*shape, generator=g)
+
+
+# use_bn=True (round 6, tests/golden/dpt_bn.npz from make_golden_dpt_bn.py): eval-mode BatchNorm inside the DPT head's residual conv
+# units and the segmentation processor
+DPT_BN_DOUBLE = dict(input_feature_dims=[128, 192], layer_dims=[32, 64], feature_dim=32, grid=(5, 7), B=2)
+DPT_BN_SEG = dict(input_feature_dim=32, output_dim=5, hidden_dim=16, feat_hw=(24, 40), target=(35, 61), B=2)
+
+
+def bn_buffers_(sd):
+    "After the name-keyed filler: make every BatchNorm's running statistics those of a plausible trained layer (positive variances)."
+    for k, v in sd.items():
+        if k.endswith("running_var"):
+            v.copy_(v.abs() * 0.5 + 0.25)
+        elif k.endswith("running_mean"):
+            v.mul_(0.3)
+        elif k.endswith("num_batches_tracked"):
+            v.fill_(100)

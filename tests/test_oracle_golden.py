@@ -96,3 +96,23 @@ def test_oracle_attention_options_match_reference_golden():
         ref = torch.from_numpy(z[name + "/out"])
         err = float((out - ref).norm() / ref.norm())
         assert err < 2e-5, (name, err)
+
+
+def test_oracle_q_scalings_match_reference_golden():
+    """`use_scalable_softmax` / `use_entropy_scaling` (utils/transformer_blocks.py:231-241, 360-370): the oracle's q_scaling against outputs
+    of the reference's Attention / CrossAttention with those options (tests/golden/attn_scale_opts.npz, make_golden_attn_scale.py)."""
+    import numpy as np
+    from tests.golden.attn_opts_cases import SCALE_CASES, make_inputs
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "attn_scale_opts.npz"))
+    for name, c in SCALE_CASES.items():
+        sd = {"l." + k[len(name) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "/sd/")}
+        ins = make_inputs(c)
+        qs = O.q_scaling(c["gh"] * c["gw"], c["scalable"], c["entropy"])
+        if c["kind"] == "self":
+            out = O.self_attention(ins["x"], ins["xpos"] if c["rope"] else None, sd, "l", c["heads"], 100.0, q_scale=qs)
+        else:
+            out = O.cross_attention(ins["q"], ins["k"], ins["qpos"] if c["rope"] else None, ins["kpos"] if c["rope"] else None, sd, "l",
+                                    c["heads"], 100.0, q_scale=qs)
+        ref = torch.from_numpy(z[name + "/out"])
+        err = float((out - ref).norm() / ref.norm())
+        assert err < 2e-5, (name, err)

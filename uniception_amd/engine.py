@@ -501,6 +501,19 @@ def conv3x3_weights(conv: nn.Conv2d, dtype: torch.dtype):
                              _f32c(conv.bias)))
 
 
+def conv3x3_bn_weights(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype: torch.dtype):
+    """conv3x3 -> BatchNorm2d in EVAL mode (running statistics) as one convolution: with s = gamma / sqrt(var + eps),
+    BN(conv(x)) = conv_{W s}(x) + (beta + (b - mean) s) — the DPT head's `use_bn=True` residual conv units
+    (libs/croco/dpt_block.py:125-176).  Same layout as conv3x3_weights."""
+    def build():
+        s = (bn.weight.detach().float() if bn.weight is not None else torch.ones_like(bn.running_var)) / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w = (conv.weight.detach().float() * s[:, None, None, None]).permute(0, 2, 3, 1).reshape(conv.out_channels, -1).to(dtype).contiguous()
+        b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(s)
+        beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(s)
+        return w, (beta + (b0 - bn.running_mean.detach().float()) * s).contiguous()
+    return prepared(conv, ("c3bn", dtype), (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var), build)
+
+
 def convt_weights(ct: nn.ConvTranspose2d, dtype: torch.dtype):
     """ConvTranspose2d(k=s): weight [Cin,Cout,k,k] -> GEMM weight [(u,v,o), Cin]; bias repeated per (u,v)."""
     k = ct.kernel_size[0]
@@ -872,13 +885,19 @@ def conv1x1(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
 
 
 def conv3x3(x: torch.Tensor, conv: nn.Conv2d, relu_in: bool = False, act=None, residual: Optional[torch.Tensor] = None,
-            residual2: Optional[torch.Tensor] = None, grad_mask_cell=None) -> torch.Tensor:
+            residual2: Optional[torch.Tensor] = None, grad_mask_cell=None, bn: Optional[nn.BatchNorm2d] = None) -> torch.Tensor:
+    """bn: a BatchNorm2d applied to the convolution's output BEFORE act / the residuals, folded into its weights (eval mode only)."""
+    if bn is not None and (bn.training or bn.running_mean is None):
+        raise UcHipError("BatchNorm in the DPT head runs folded into its convolution: eval mode with running statistics only "
+                         "(batch statistics in training have no HIP path)")
     if _train(x, conv.weight, residual, residual2):
+        if bn is not None:
+            raise UcHipError("BatchNorm in the DPT head has no HIP backward (use_bn=True models run in inference only)")
         from . import autograd
         return autograd.conv3x3(x, conv, relu_in, act, residual, residual2, grad_mask_cell)
     B, H, W, Cin = x.shape
     s = conv.stride[0]
-    w, b = conv3x3_weights(conv, x.dtype)
+    w, b = conv3x3_weights(conv, x.dtype) if bn is None else conv3x3_bn_weights(conv, bn, x.dtype)
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     r1 = None if residual is None else residual.reshape(-1, residual.shape[-1])
     r2 = None if residual2 is None else residual2.reshape(-1, residual2.shape[-1])

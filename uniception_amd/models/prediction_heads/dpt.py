@@ -172,12 +172,10 @@ class DPTSegmentationProcessor(nn.Module):
         super().__init__(*args, **kwargs)
         if hidden_dim is None:
             hidden_dim = input_feature_dim
-        if use_bn:
-            raise engine.UcHipError("BatchNorm in the DPT head is not supported by the HIP path (use_bn=False)")
         self.output_dim = output_dim
         self.conv = nn.Sequential(
             nn.Conv2d(input_feature_dim, hidden_dim, kernel_size=3, padding=1, bias=False),
-            nn.Identity(),
+            nn.BatchNorm2d(hidden_dim) if use_bn else nn.Identity(),      # (dpt.py:346; eval mode: folded into the convolution, round 6)
             nn.ReLU(True),
             nn.Dropout(0.1, False),
             nn.Conv2d(hidden_dim, output_dim, kernel_size=1),
@@ -196,7 +194,8 @@ class DPTSegmentationProcessor(nn.Module):
         dt = engine.head_dtype()
         last = self.conv[4]
         train = engine._train(x, self.conv[0].weight, last.weight)
-        x = engine.conv3x3(engine.bchw_to_nhwc(x, dt), self.conv[0], act="relu")
+        bn = self.conv[1] if isinstance(self.conv[1], nn.BatchNorm2d) else None
+        x = engine.conv3x3(engine.bchw_to_nhwc(x, dt), self.conv[0], act="relu", bn=bn)
         cpad = (self.output_dim + 7) // 8 * 8       # output channels padded with zero rows to the 8-channel granule of the NHWC kernels
         if train:
             y = autograd.padded_conv1x1(x, last, dt, cpad)
