@@ -145,8 +145,10 @@ def q_scaling(n_tokens: int, scalable_softmax: bool = False, entropy_scaling: bo
 def self_attention(x: Tensor, pos: Optional[Tensor], sd: SD, prefix: str, num_heads: int, base: float, q_scale: float = 1.0) -> Tensor:
     """qkv -> [q_norm, k_norm] -> RoPE(q), RoPE(k) -> [q * q_scale] -> SDPA -> proj (libs/croco/blocks.py:105-129;
     utils/transformer_blocks.py:219-256).  Wqkv rows: [0:D]=Q, [D:2D]=K, [2D:3D]=V, head-major.  pos None: no positional encoding."""
-    B, N, Cd = x.shape
-    qkv = linear(x, sd, prefix + ".qkv").view(B, N, 3, num_heads, Cd // num_heads).permute(2, 0, 3, 1, 4)
+    B, N, _ = x.shape
+    qkv = linear(x, sd, prefix + ".qkv")
+    Cd = qkv.shape[-1] // 3           # the model width, or the layer's latent_attn_dim (utils/transformer_blocks.py:178-199)
+    qkv = qkv.view(B, N, 3, num_heads, Cd // num_heads).permute(2, 0, 3, 1, 4)
     q, k, v = _qk_norm(qkv[0], sd, prefix + ".q_norm"), _qk_norm(qkv[1], sd, prefix + ".k_norm"), qkv[2]
     if pos is not None:
         q, k = rope2d(q, pos, base), rope2d(k, pos, base)

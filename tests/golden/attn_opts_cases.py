@@ -33,4 +33,9 @@ SCALE_CASES = {
                             scalable=True, entropy=True),
     "cross_entropy_qknorm": dict(kind="cross", dim=128, heads=2, qk_norm=True, rope=False, sep_v=False, B=1, gh=4, gw=4, gkh=5, gkw=5, seed=24,
                                  scalable=False, entropy=True),
+    # latent attention (utils/transformer_blocks.py:178-199): q / k / v in `latent` channels, proj back to dim
+    "self_latent_rope": dict(kind="self", dim=128, heads=4, qk_norm=False, rope=True, sep_v=False, B=2, gh=6, gw=5, gkh=6, gkw=5, seed=25,
+                             scalable=False, entropy=False, latent=256),
+    "self_latent_narrow_qknorm": dict(kind="self", dim=192, heads=2, qk_norm=True, rope=False, sep_v=False, B=1, gh=4, gw=7, gkh=4, gkw=7, seed=26,
+                                      scalable=True, entropy=False, latent=64),
 }

@@ -1,5 +1,6 @@
 """Golden vectors of the reference's Attention / CrossAttention layers with their optional q scalings — `use_scalable_softmax`
-(q * log N) and `use_entropy_scaling` (q * sqrt(growth * log N / log base)), utils/transformer_blocks.py:231-241, 360-370 — from the
+(q * log N) and `use_entropy_scaling` (q * sqrt(growth * log N / log base)), utils/transformer_blocks.py:231-241, 360-370 — and of
+Attention with `latent_attn_dim` (q / k / v in a latent width, :178-199) from the
 REAL reference (build container only; stubs as in make_golden.py):
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/tmp/oracle_stubs:/root/reference:/root/repo python3 -B /root/repo/tests/golden/make_golden_attn_scale.py
@@ -28,6 +29,8 @@ def main():
         rope = RoPE2D(freq=100.0) if c["rope"] else None
         kw = dict(dim=c["dim"], num_heads=c["heads"], qkv_bias=True, qk_norm=c["qk_norm"], custom_positional_encoding=rope,
                   use_scalable_softmax=c["scalable"], use_entropy_scaling=c["entropy"])
+        if c.get("latent"):
+            kw["latent_attn_dim"] = c["latent"]
         layer = (Attention(**kw) if c["kind"] == "self" else CrossAttention(**kw)).eval()
         with torch.no_grad():
             for k, p in layer.named_parameters():

@@ -99,8 +99,9 @@ def test_oracle_attention_options_match_reference_golden():
 
 
 def test_oracle_q_scalings_match_reference_golden():
-    """`use_scalable_softmax` / `use_entropy_scaling` (utils/transformer_blocks.py:231-241, 360-370): the oracle's q_scaling against outputs
-    of the reference's Attention / CrossAttention with those options (tests/golden/attn_scale_opts.npz, make_golden_attn_scale.py)."""
+    """`use_scalable_softmax` / `use_entropy_scaling` (utils/transformer_blocks.py:231-241, 360-370) and `latent_attn_dim` (:178-199): the
+    oracle's q_scaling / self_attention against outputs of the reference's Attention / CrossAttention with those options
+    (tests/golden/attn_scale_opts.npz, make_golden_attn_scale.py)."""
     import numpy as np
     from tests.golden.attn_opts_cases import SCALE_CASES, make_inputs
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "attn_scale_opts.npz"))

@@ -481,7 +481,8 @@ class SelfAttnSubLayerFn(Function):
                 qn_w=None, qn_b=None, kn_w=None, kn_b=None, qn=None, kn=None, drops=None, adrop=None):
         x2d = _c(x2d)
         M, C = x2d.shape
-        Dh = C // H
+        Ca = qkv.out_features // 3          # width of q / k / v: C, or the layer's latent_attn_dim (utils/transformer_blocks.py:178-199)
+        Dh = Ca // H
         _check_rope(rope)
         g, bta = engine.ln_params(ln)
         h = ops.layernorm(x2d, g, bta, ln.eps, dt)
@@ -502,7 +503,7 @@ class SelfAttnSubLayerFn(Function):
         elif dt == torch.bfloat16 and rope is not None:
             if Dh != 64:
                 raise UcHipError(f"bf16 attention needs head_dim 64 (got {Dh})")
-            t = ops.gemm(h, wq, bq, rope=engine._rope_epilogue(rope, engine._pos2d(pos), 2 * C))
+            t = ops.gemm(h, wq, bq, rope=engine._rope_epilogue(rope, engine._pos2d(pos), 2 * Ca))
             t5 = t.view(B, N, 3, H, Dh)
         else:
             t = ops.gemm(h, wq, bq)
@@ -513,9 +514,9 @@ class SelfAttnSubLayerFn(Function):
         lse = torch.empty((B, H, N), dtype=torch.float32, device=x2d.device)
         o = _attention_fwd(*(qkn if qkn is not None else (t5[:, :, 0], t5[:, :, 1])), t5[:, :, 2], scale, lse, adrop)
         if drops is not None and drops.has_out:
-            out = _drop_out(ops.gemm(o.view(M, C), wp, bp), drops, x2d, x2d.dtype)
+            out = _drop_out(ops.gemm(o.view(M, Ca), wp, bp), drops, x2d, x2d.dtype)
         else:
-            out = ops.gemm(o.view(M, C), wp, bp, residual=x2d, out_dtype=x2d.dtype)
+            out = ops.gemm(o.view(M, Ca), wp, bp, residual=x2d, out_dtype=x2d.dtype)
         # (gamma goes through save_for_backward: autograd's version check then catches an in-place edit between forward and backward)
         masks, dspec = _drops_saved(drops)
         ctx.save_for_backward(x2d, g, h, t, o, lse, pos if pos is not None else torch.empty(0), *(() if qkn is None else qkn),
@@ -533,17 +534,18 @@ class SelfAttnSubLayerFn(Function):
         rest = rest[2:] if has_qkn else rest
         gamma = rest[0] if rest else None
         M, C = x2d.shape
-        Dh = C // H
+        Ca = qkv.out_features // 3          # width of q / k / v: C, or the layer's latent_attn_dim (utils/transformer_blocks.py:178-199)
+        Dh = Ca // H
         dxo = _c(dxo)
         dyb = _as_dt(dxo, dt)
         if drops is not None and drops.has_out:
             dyb = _drop_out(dyb, drops)
         dgamma = None
         if gamma is None:
-            dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
+            dWp, dbp = _wgrad(dyb, o.view(M, Ca), dt, has_bp, sink=[(proj.weight, 0, C)], bias_sink=[proj.bias])
             do = ops.gemm(dyb, lin_weight_t(proj, dt))
         else:
-            dWp, dbp = _wgrad(dyb, o.view(M, C), dt, has_bp)
+            dWp, dbp = _wgrad(dyb, o.view(M, Ca), dt, has_bp)
             dWp, dbp, dgamma = _unfold_layerscale(proj, gamma, dWp, dbp)
             do = ops.gemm(dyb, _folded_weight_t(proj, gamma, dt))
         dt3 = torch.empty_like(t)
@@ -569,7 +571,7 @@ class SelfAttnSubLayerFn(Function):
             if fused_rope is None:
                 _rope_inverse_(d5[:, :, 0], pos, rope)
                 _rope_inverse_(d5[:, :, 1], pos, rope)
-        dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * C)], bias_sink=[qkv.bias])
+        dWq, dbq = _wgrad(dt3, h, dt, has_bq, sink=[(qkv.weight, 0, 3 * Ca)], bias_sink=[qkv.bias])
         dh = ops.gemm(dt3, lin_weight_t(qkv, dt))
         dg, db, sunk = _ln_grad_targets(ln, g)
         dx = _ln_bwd_residual(x2d, g, dh, ln.eps, dg, db, dxo, dt)

@@ -664,7 +664,8 @@ def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.L
     emit_ln: the proj GEMM also writes the twin / statistics the next sub-layer's folded LayerNorm consumes.
     q_norm / k_norm: the layer's qk_norm modules (LayerNorm over head_dim, before the positional encoding)."""
     dtype = h2d.dtype
-    M, Cd = h2d.shape
+    M, Cm = h2d.shape
+    Cd = qkv.out_features // 3          # width of q / k / v: the model width, or `latent_attn_dim` (utils/transformer_blocks.py:178-199)
     Dh = Cd // num_heads
     wq, bq, lnq = _folded(qkv, fold, dtype)
     wp, bp = proj_wb if proj_wb is not None else lin_weights(proj, dtype)
@@ -688,7 +689,7 @@ def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.L
         if o is None:
             q, k = _apply_rope(rope, q, k, pos, pos)
             o = _attention_generic(q, k, v, scale)
-    emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cd)
+    emit = emit_ln and out_dtype in (torch.float32, torch.bfloat16) and fold_ok(dtype, Cm)
     return ops.gemm(o.view(M, Cd), wp, bp, residual=residual, out_dtype=out_dtype, emit_ln=emit)
 
 

@@ -39,19 +39,23 @@ class Attention(nn.Module):
                  use_entropy_scaling: bool = False, base_token_count_for_entropy_scaling: int = 444,
                  entropy_scaling_growth_factor: float = 1.4):
         super().__init__()
-        if latent_attn_dim is not None:
-            raise engine.UcHipError("latent_attn_dim is not supported by the HIP attention path")
         assert dim % num_heads == 0, "dim should be divisible by num_heads"
-        self.latent_attn = False
+        # latent attention (utils/transformer_blocks.py:178-199; round 6): q / k / v live in `latent_attn_dim` channels, proj maps back
+        if latent_attn_dim is not None:
+            assert latent_attn_dim % num_heads == 0, "latent_attn_dim should be divisible by num_heads"
+            self.latent_attn_dim = latent_attn_dim
+            self.latent_attn = True
+        else:
+            self.latent_attn = False
         self.num_heads = num_heads
-        self.head_dim = dim // num_heads
+        self.head_dim = dim // num_heads if not self.latent_attn else latent_attn_dim // num_heads
         self.scale = self.head_dim**-0.5
         self.fused_attn = use_fused_attn()
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias) if not self.latent_attn else nn.Linear(dim, latent_attn_dim * 3, bias=qkv_bias)
         self.q_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
         self.k_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = nn.Linear(dim, dim) if not self.latent_attn else nn.Linear(latent_attn_dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.custom_positional_encoding = custom_positional_encoding
         self.use_scalable_softmax = use_scalable_softmax
