@@ -219,3 +219,46 @@ def test_fp32_class_heads_in_training_track_the_reference_closer_than_bf16_heads
           f"fp32-class heads: loss {loss_f:.4f}, heads {ef['heads']:.2e} transformer {ef['transformer']:.2e} (reference loss {float(gold['loss']):.4f})")
     assert ef["heads"] < 0.6 * eb["heads"] and ef["transformer"] < eb["transformer"]
     assert abs(loss_f - float(gold["loss"])) < abs(loss_b - float(gold["loss"]))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gradient_with_respect_to_the_input_images(gpu, mode):
+    """VERDICT r5 missing #5: d loss / d image — free under the reference's autograd — through the whole two-view model: the patch
+    embedding's backward returns d cols = d tok . W scattered back over the (non-overlapping) patches.  Against autograd over the CPU
+    oracle with the images requiring grad: fp32 mode <= 1e-3 (the north-star bar), bf16 mode cosine > 0.995."""
+    from oracle import dust3r_oracle as O
+    from uniception_amd import autograd, engine
+    model, c = build_case_model("tiny_linear")
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    img1, img2 = case_images(c)
+    gt1, gt2 = grad_targets(c)
+    i1, i2 = img1.clone().requires_grad_(True), img2.clone().requires_grad_(True)
+
+    def ref_loss(pts, conf, gt):
+        cf = conf[..., 0]
+        return (cf * (pts - gt).norm(dim=-1)).mean() - 0.2 * cf.log().mean()
+
+    o1, o2 = O.dust3r_forward(sd, i1, i2, head=c["head"], enc_depth=c["enc_depth"], enc_heads=c["enc_heads"],
+                              dec_depth=c["dec_depth"], dec_heads=c["dec_heads"], patch_size=c["patch"], indices=tuple(c["indices"]))
+    (ref_loss(o1["pts3d"], o1["conf"], gt1) + ref_loss(o2["pts3d_in_other_view"], o2["conf"], gt2)).backward()
+    model = model.to(gpu).train()
+    g1, g2 = img1.to(gpu).requires_grad_(True), img2.to(gpu).requires_grad_(True)
+    with engine.precision(mode):
+        r1, r2 = model(g1, g2, {})
+        loss = autograd.conf_loss(r1["pts3d"], r1["conf"], gt1.to(gpu)) + autograd.conf_loss(r2["pts3d_in_other_view"], r2["conf"], gt2.to(gpu))
+    loss.backward()
+    assert g1.grad is not None and g2.grad is not None and g1.grad.shape == img1.shape
+    for got, want in ((g1.grad, i1.grad), (g2.grad, i2.grad)):
+        got = got.float().cpu()
+        err = rel_l2(got, want)
+        cos = float((got.double() * want.double()).sum() / (got.double().norm() * want.double().norm()))
+        print(f"\n[{mode}] d loss / d image: rel-L2 {err:.2e}, cosine {cos:.6f}")
+        assert (err < 1e-3) if mode == "fp32" else (cos > 0.995)
+    # frozen patch embedding, gradient for the image only: the weight gradient is skipped, the image's still flows
+    model.zero_grad(set_to_none=True)
+    model.encoder.patch_embed.proj.requires_grad_(False)
+    g1.grad = None
+    with engine.precision(mode):
+        r1, r2 = model(g1, g2, {})
+        autograd.conf_loss(r1["pts3d"], r1["conf"], gt1.to(gpu)).backward()
+    assert g1.grad is not None and model.encoder.patch_embed.proj.weight.grad is None

@@ -424,28 +424,36 @@ def linear(x2d, weight, bias, owner, dt, out_dtype):
 
 @_sink_aware
 class PatchEmbedFn(Function):
-    """tokens = gather(img) . W^T + b (libs/croco/patch_embed.py:47,69-82); the image gets no gradient."""
+    """tokens = gather(img) . W^T + b (libs/croco/patch_embed.py:47,69-82).  The image's gradient (round 6; free under the reference's
+    autograd) is d cols = d tok . W — one more GEMM — scattered back: patches do not overlap (stride = patch size), so the adjoint of the
+    gather is a permutation of [B, gh, gw, c, u, v] into [B, c, gh u, gw v]."""
 
     @staticmethod
     def forward(ctx, img, weight, bias, owner, P, dt, out_dtype=torch.float32):
         cols = ops.patch_gather(img, P, dt)
         w, b = engine.patch_weights(owner, dt)
         ctx.save_for_backward(cols)
-        ctx.dt, ctx.wshape, ctx.has_bias, ctx.weight = dt, weight.shape, bias is not None, weight
+        ctx.dt, ctx.wshape, ctx.has_bias, ctx.weight, ctx.owner, ctx.P, ctx.ishape = dt, weight.shape, bias is not None, weight, owner, P, img.shape
         return ops.gemm(cols, w, b, out_dtype=out_dtype)
 
     @staticmethod
     def backward(ctx, dtok):
         (cols,) = ctx.saved_tensors
         dtok = _as_dt(_c(dtok), ctx.dt)
-        dW, db = _wgrad(dtok, cols, ctx.dt, ctx.has_bias, sink=[(ctx.weight, 0, ctx.wshape[0])])
-        dW = None if dW is None else dW.view(ctx.wshape)
-        return None, dW, db, None, None, None, None
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            owner, P, (B, Cn, H, W) = ctx.owner, ctx.P, ctx.ishape
+            wt = _w_t(owner, "pe", (owner.weight,), lambda: owner.weight.detach().float().reshape(owner.weight.shape[0], -1).contiguous(), ctx.dt)
+            dcols = ops.gemm(dtok, wt, out_dtype=torch.float32)                       # [B gh gw, (c, u, v)]
+            dimg = dcols.view(B, H // P, W // P, Cn, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, Cn, H, W)
+        dW, db = (None, None)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = _wgrad(dtok, cols, ctx.dt, ctx.has_bias, sink=[(ctx.weight, 0, ctx.wshape[0])])
+            dW = None if dW is None else dW.view(ctx.wshape)
+        return dimg, dW, db, None, None, None, None
 
 
 def patch_embed(img, conv, P, dt, out_dtype=torch.float32):
-    if img.requires_grad:
-        raise UcHipError("gradients w.r.t. the input images are not implemented")
     return PatchEmbedFn.apply(img, conv.weight, conv.bias, conv, P, dt, out_dtype)
 
 
