@@ -156,7 +156,9 @@ def test_gemm_bf16_rope_and_vt_epilogue(gpu):
     """Fused QKV epilogue: RoPE on q,k columns, V written in the packed VT layout."""
     from uniception_amd import ops
     B, h, w, H = 2, 5, 7, 3   # N = 35 tokens: not a multiple of 16 -> general VT path
-    for (h, w) in [(5, 7), (8, 8)]:  # (8,8): N = 64, aligned fast path
+    # (8,8): N = 64, aligned fast path; (14,14) = the 196 tokens of a 224 x 224 view and (6,6): multiples of 4 but not of 16 — the
+    # quad-store path (round 6), wave tiles straddling image borders
+    for (h, w) in [(5, 7), (8, 8), (14, 14), (6, 6)]:
         N = h * w
         Cd = H * 64
         g = torch.Generator().manual_seed(6)

@@ -274,7 +274,11 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
         // acc[i][j][r]: token row m = wave_m + 16i + 4g + r, channel column wave_n + 16j + frow
         const int head = (int)((wave_n - p.vt_col0) >> 6);
         const int nheads = (int)((p.N - p.vt_col0) >> 6);
-        const bool aligned = (p.vt_ntok & 15) == 0;
+        // token counts that are multiples of 4 (round 6: 196 tokens of a 224 x 224 view; before: multiples of 16 only): the four rows
+        // mb .. mb + 3 of a lane (mb is a multiple of 4) are one image's aligned token quad, i.e. four CONSECUTIVE positions of the
+        // permuted 16-key group — one 8-byte store per channel, four lanes filling 32 contiguous bytes of a channel row, instead of
+        // sixteen 2-byte stores (the 224 x 224 forward's QKV / KV GEMMs ran at 0.21-0.31 of peak on that path)
+        const bool aligned = (p.vt_ntok & 3) == 0;
         float bcol[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bcol[j] = bias_of(j);
@@ -286,7 +290,8 @@ __device__ __forceinline__ void glds_epilogue_vt(glds_pe_t p, float4_t (&acc)[FA
                 if (mb >= p.M) continue;
                 const int b = (int)(mb / p.vt_ntok);
                 const int tok = (int)(mb % p.vt_ntok);
-                const int pos = (tok & ~15) + ((g & 1) << 3) + ((g >> 1) << 2);
+                const int qi = (tok & 15) >> 2;                      // the quad's index inside its 16-key group (uc_vt_perm)
+                const int pos = (tok & ~15) + ((qi & 1) << 3) + ((qi >> 1) << 2);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int d = 16 * j + frow;

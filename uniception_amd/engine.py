@@ -656,6 +656,10 @@ def _has_norm(*norms) -> bool:
     return any(n is not None and not isinstance(n, nn.Identity) for n in norms)
 
 
+# token counts that are not multiples of 4: V row-major out of the QKV / KV GEMM + uc_vt_pack instead of the element-wise VT epilogue
+VT_PACK_ODD: bool = os.environ.get("UNICEPTION_AMD_VT_PACK_ODD", "1") != "0"
+
+
 def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.Linear, num_heads: int, rope, pos,
                    scale: float, residual: Optional[torch.Tensor], out_dtype: torch.dtype, proj_wb=None, fold=None,
                    emit_ln: bool = False, q_norm=None, k_norm=None) -> torch.Tensor:
@@ -674,6 +678,13 @@ def self_attention(h2d: torch.Tensor, B: int, N: int, qkv: nn.Linear, proj: nn.L
         ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
         t5 = ops.gemm(h2d, wq, bq, rope=ep, ln=lnq).view(B, N, 3, num_heads, Dh)
         o = ops.attention_fp8(t5[:, :, 0], t5[:, :, 1], ops.vt_pack_fp8(t5[:, :, 2]), scale)
+    elif dtype == torch.bfloat16 and Dh == 64 and native and N % 4 != 0 and VT_PACK_ODD:
+        # token counts that are not multiples of 4 (DINOv2: 1370 / 1369 tokens): the QKV GEMM's packed-VT epilogue would store such
+        # V tiles element by element (2-byte stores: its launches ran at 0.20-0.31 of peak) — V leaves the GEMM row-major through the
+        # plain 16-byte drain and one uc_vt_pack pass (HBM-bound, ~5 TB/s) re-lays it out
+        ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
+        t5 = ops.gemm(h2d, wq, bq, rope=ep, ln=lnq).view(B, N, 3, num_heads, Dh)
+        o = ops.attention(t5[:, :, 0], t5[:, :, 1], ops.vt_pack(t5[:, :, 2]), scale, v_packed=True)
     elif dtype == torch.bfloat16 and Dh == 64 and native:
         vt = ops.vt_buffer(B, num_heads, N, h2d.device)
         ep = _rope_epilogue(rope, _pos2d(pos), 2 * Cd) if rope is not None else None
@@ -775,6 +786,12 @@ def cross_attention(hq2d: torch.Tensor, hkv2d: torch.Tensor, B: int, Nq: int, Nk
         q = ops.gemm(hq2d, wq, bq, rope=epq, ln=lnq).view(B, Nq, num_heads, Dh)
         kv5 = ops.gemm(hkv2d, wkv, bkv, rope=epk, ln=lnkv).view(B, Nk, 2, num_heads, Dh)
         o = ops.attention_fp8(q, kv5[:, :, 0], ops.vt_pack_fp8(kv5[:, :, 1]), scale)
+    elif dtype == torch.bfloat16 and Dh == 64 and native and Nk % 4 != 0 and VT_PACK_ODD:      # (see self_attention)
+        epq = _rope_epilogue(rope, _pos2d(qpos), Cd) if rope is not None else None
+        epk = _rope_epilogue(rope, _pos2d(kpos), Cd) if rope is not None else None
+        q = ops.gemm(hq2d, wq, bq, rope=epq, ln=lnq).view(B, Nq, num_heads, Dh)
+        kv5 = ops.gemm(hkv2d, wkv, bkv, rope=epk, ln=lnkv).view(B, Nk, 2, num_heads, Dh)
+        o = ops.attention(q, kv5[:, :, 0], ops.vt_pack(kv5[:, :, 1]), scale, v_packed=True)
     elif dtype == torch.bfloat16 and Dh == 64 and native:
         vt = ops.vt_buffer(B, num_heads, Nk, hq2d.device)
         epq = _rope_epilogue(rope, _pos2d(qpos), Cd) if rope is not None else None
