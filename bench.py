@@ -416,6 +416,8 @@ def settle():
     """Before a leg's timed steps: run Python's cyclic collector now (modules of the previous leg die in reference cycles: collected
     later, inside somebody's timed step, their tensors go back to the caching allocator mid-step) and let queued frees land."""
     import gc
+    if os.environ.get("UNICEPTION_AMD_BENCH_NO_SETTLE", "0") == "1":      # (A/B of the root cause: profiles/r6_*stall*)
+        return
     gc.collect()
     torch.cuda.synchronize()
 
