@@ -23,7 +23,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md §Chip-level parameters)
 PEAK_HBM_GBS = 8000.0      # HBM3E peak (same guide)
-PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r6_pmc_traffic.json"
 FWD_PAIRS = 128            # pairs per GPU per forward step: 56 GB; 64 -> 96 -> 128 pairs measured +0.7 / +0.9 % (same box), 256: see DESIGN section 7
 TRAIN_PAIRS = 64           # pairs per GPU per training step: 216 GB of the 288 GB at 512x512 with DPT heads (32: 96-98 pairs/s, 64: 100-101, 80: 101.9 at 267 GB)
 
@@ -853,7 +853,10 @@ def main():
             line["exchange"] = exchange_summary(trainer.comm_stats(), dt / args.steps * 1e3)
         elif not args.no_extra_legs and args.precision == "bf16" and not args.graph:
             del out
-            leg = train_step_leg(args, dev, pairs=args.train_pairs, steps=args.train_steps, rank=rank, world=world)
+            try:
+                leg = train_step_leg(args, dev, pairs=args.train_pairs, steps=args.train_steps, rank=rank, world=world)
+            except Exception as e:      # (the forward's line must survive a failure of the extra leg: reported, not raised)
+                leg = {"error": f"{type(e).__name__}: {e}"[:500], "n_gpus": world}
             line["train_step"] = leg
     if share:
         line["config"]["shared_gpu_dry_run"] = "ranks share devices, gloo process group: control-flow check only, not a measurement"

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 root=$(pwd)
 out=gpurun_out/prof_$tag
 bash tools/profile_round.sh $tag pmc > /dev/null 2>&1
-cp $out/${tag}_pmc_traffic.json profiles/r5_pmc_traffic.json
+cp $out/${tag}_pmc_traffic.json profiles/r6_pmc_traffic.json
 rm -rf $out/trace $out/pmc_*
 python bench.py --steps 20 --warmup 3 > $out/${tag}_bench_forward_pairs128.json 2> $out/bench_forward.err
 cat $out/${tag}_bench_forward_pairs128.json

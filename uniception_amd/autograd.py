@@ -457,6 +457,72 @@ def patch_embed(img, conv, P, dt, out_dtype=torch.float32):
     return PatchEmbedFn.apply(img, conv.weight, conv.bias, conv, P, dt, out_dtype)
 
 
+# =================================================================================================================
+# Attention alone, and the UNFUSED sub-layers built from it: training through a FOREIGN positional-encoding callable (round 6; free
+# under the reference's autograd: custom_positional_encoding is any callable of (tokens [B, H, N, Dh], positions),
+# utils/transformer_blocks.py:226-229, 352-356).  The callable runs as ordinary PyTorch code between HIP Functions — LayerNorm, the
+# QKV / q / kv linears, attention forward + backward, the output projection — and PyTorch's autograd differentiates it.
+# =================================================================================================================
+class AttentionFn(Function):
+    "o = softmax(scale q k^T) v for [B, N, H, Dh] views; backward = uc_attention_bwd from the saved log-sum-exp."
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, adrop=None):
+        q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
+        B, Nq, H, _ = q.shape
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        o = _attention_fwd(q, k, v, scale, lse, adrop)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale, ctx.adrop = scale, adrop
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do).to(q.dtype), lse, ctx.scale, dropout=ctx.adrop)
+        return dq, dk, dv, None, None
+
+
+def attention(q, k, v, scale, attn_drop=None):
+    return AttentionFn.apply(q, k, v, scale, attn_drop)
+
+
+def _foreign_rope(rope, t4, pos):
+    "the reference's call: rope(tokens [B, H, N, Dh], positions) (utils/transformer_blocks.py:228-229) on a [B, N, H, Dh] view"
+    return rope(t4.transpose(1, 2), pos).transpose(1, 2)
+
+
+def self_attn_sublayer_unfused(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, drops=None, attn_drop=None):
+    """x + proj(SDPA(rope(q), rope(k), v)) with a foreign `rope` callable: HIP Functions around PyTorch-differentiated rope calls."""
+    M, C = x2d.shape
+    Ca = qkv.out_features // 3
+    h = layer_norm(x2d, ln, dt)
+    t5 = linear(h, qkv.weight, qkv.bias, qkv, dt, dt).view(B, N, 3, H, Ca // H)
+    q, k = _foreign_rope(rope, t5[:, :, 0], pos), _foreign_rope(rope, t5[:, :, 1], pos)
+    o = attention(q.to(dt), k.to(dt), t5[:, :, 2], scale, attn_drop)
+    f = linear(o.reshape(M, Ca), proj.weight, proj.bias, proj, dt, x2d.dtype)
+    if drops is not None and drops.has_out:
+        raise UcHipError("dropout of the sub-layer output next to a foreign positional-encoding callable has no HIP path")
+    return x2d + f
+
+
+def cross_attn_sublayer_unfused(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt, drops=None, attn_drop=None):
+    "the cross-attention sub-layer of CrossAttentionBlock with a foreign `rope` callable (see self_attn_sublayer_unfused)"
+    Mq, C = x2d.shape
+    Dh = C // H
+    hq = layer_norm(x2d, ln, dt)
+    hy = layer_norm(y2d, lny, dt) if lny is not None else convert(y2d, dt)
+    q = linear(hq, ca.projq.weight, ca.projq.bias, ca.projq, dt, dt).view(B, Nq, H, Dh)
+    k = linear(hy, ca.projk.weight, ca.projk.bias, ca.projk, dt, dt).view(B, Nk, H, Dh)
+    v = linear(hy, ca.projv.weight, ca.projv.bias, ca.projv, dt, dt).view(B, Nk, H, Dh)
+    q, k = _foreign_rope(rope, q, qpos), _foreign_rope(rope, k, kpos)
+    o = attention(q.to(dt), k.to(dt), v, scale, attn_drop)
+    f = linear(o.reshape(Mq, C), ca.proj.weight, ca.proj.bias, ca.proj, dt, x2d.dtype)
+    if drops is not None and drops.has_out:
+        raise UcHipError("dropout of the sub-layer output next to a foreign positional-encoding callable has no HIP path")
+    return x2d + f
+
+
 # LayerScale behind a sub-layer's output linear (DINOv2 blocks, SelfAttentionBlock(init_values=...)): the forward runs the linear with
 # the folded weights W_f = gamma[:,None] W, b_f = gamma b (engine.layerscale_lin_weights — zero kernel work); the backward takes the
 # gradients of the FOLDED parameters from the usual weight-gradient GEMM and unfolds them:
@@ -592,6 +658,10 @@ def self_attn_sublayer(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, gamma=
     """gamma: LayerScale on the sub-layer's output (x + gamma * proj(...)), or None.  q_norm / k_norm: the layer's qk_norm modules
     (LayerNorm over head_dim before the positional encoding; nn.Identity / None: off).  attn_drop: (p, seed) from attn_dropout, or None."""
     qn, kn = _norm_or_none(q_norm), _norm_or_none(k_norm)
+    if rope is not None and not engine.is_native_rope(rope):      # a foreign positional-encoding callable: the unfused route
+        if gamma is not None or qn is not None or kn is not None:
+            raise UcHipError("LayerScale / qk_norm next to a foreign positional-encoding callable have no HIP training path")
+        return self_attn_sublayer_unfused(x2d, ln, qkv, proj, B, N, H, rope, pos, scale, dt, drops, attn_drop)
     return SelfAttnSubLayerFn.apply(x2d, ln.weight, ln.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, ln, qkv, proj,
                                     B, N, H, rope, pos, scale, dt, gamma, getattr(qn, "weight", None), getattr(qn, "bias", None),
                                     getattr(kn, "weight", None), getattr(kn, "bias", None), qn, kn, drops, attn_drop)
@@ -734,6 +804,10 @@ class CrossAttnSubLayerFn(Function):
 def cross_attn_sublayer(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt, drops=None, gamma=None, attn_drop=None):
     lw, lb = (lny.weight, lny.bias) if lny is not None else (None, None)
     qn, kn = _norm_or_none(getattr(ca, "q_norm", None)), _norm_or_none(getattr(ca, "k_norm", None))
+    if rope is not None and not engine.is_native_rope(rope):      # a foreign positional-encoding callable: the unfused route
+        if gamma is not None or qn is not None or kn is not None:
+            raise UcHipError("LayerScale / qk_norm next to a foreign positional-encoding callable have no HIP training path")
+        return cross_attn_sublayer_unfused(x2d, y2d, ln, lny, ca, B, Nq, Nk, H, rope, qpos, kpos, scale, dt, drops, attn_drop)
     return CrossAttnSubLayerFn.apply(x2d, y2d, ln.weight, ln.bias, lw, lb, ca.projq.weight, ca.projq.bias, ca.projk.weight,
                                      ca.projk.bias, ca.projv.weight, ca.projv.bias, ca.proj.weight, ca.proj.bias, ln, lny,
                                      ca.projq, ca.projk, ca.projv, ca.proj, B, Nq, Nk, H, rope, qpos, kpos, scale, dt,
