@@ -176,3 +176,54 @@ def test_dropout_masks_follow_nn_dropout_and_timm_droppath():
     assert d3.out is None and d3.mid is None and d3.path_scale == 1.0 and d3.has_out
     d4 = autograd.make_drops(True, "cpu", 4, 8, 16, hidden=32, p_mid=0.5)
     assert d4.mid is not None and not d4.has_out
+
+
+def test_round6_host_logic_of_the_training_options():
+    """Host side of the options round 6 closed: the masks' save / restore round trip of the sub-layer Functions (they travel through
+    save_for_backward, the scales through ctx.meta), attention-dropout seeds from PyTorch's generator (reproducible under manual_seed,
+    None in eval mode / at rate 0), which blocks make a checkpoint keep the generator state, and the constructor surface of
+    latent_attn_dim / LayerScale in the cross-attention block / use_bn heads (the reference's state_dict keys)."""
+    import torch
+    from uniception_amd import autograd
+    from uniception_amd.models.prediction_heads.dpt import DPTFeature, DPTSegmentationProcessor
+    from uniception_amd.models.utils.checkpointing import has_random_masks
+    from uniception_amd.models.utils.transformer_blocks import Attention, CrossAttentionBlock, SelfAttentionBlock
+    torch.manual_seed(5)
+    d = autograd.make_drops(True, "cpu", 4, 8, 16, p_out=0.25, p_path=0.5, hidden=32, p_mid=0.1)
+    masks, spec = autograd._drops_saved(d)
+    assert len(masks) == 3 and all(m.dtype == torch.uint8 for m in masks)
+    x = torch.zeros(3)
+    back, rest = autograd._drops_restore(spec, (x, x, *masks))
+    assert rest == (x, x) and torch.equal(back.out, d.out) and torch.equal(back.path, d.path) and torch.equal(back.mid, d.mid)
+    assert (back.out_scale, back.path_rows, back.path_scale, back.mid_scale) == (d.out_scale, d.path_rows, d.path_scale, d.mid_scale)
+    assert autograd._drops_saved(None) == ((), None) and autograd._drops_restore(None, (x,)) == (None, (x,))
+    d_path = autograd.make_drops(True, "cpu", 4, 8, 16, p_path=0.5)
+    m2, s2 = autograd._drops_saved(d_path)
+    b2, r2 = autograd._drops_restore(s2, (x, *m2))
+    assert len(m2) == 1 and b2.out is None and b2.mid is None and torch.equal(b2.path, d_path.path) and r2 == (x,)
+    # attention dropout: (p, seed) drawn from the CPU generator
+    assert autograd.attn_dropout(False, 0.3) is None and autograd.attn_dropout(True, 0.0) is None
+    torch.manual_seed(9)
+    a = autograd.attn_dropout(True, 0.3)
+    torch.manual_seed(9)
+    b = autograd.attn_dropout(True, 0.3)
+    c = autograd.attn_dropout(True, 0.3)
+    assert a == b and a[0] == 0.3 and 0 <= a[1] < 2 ** 62 and c[1] != a[1]
+    with pytest.raises(UcHipError):
+        autograd.attn_dropout(True, 1.0)
+    # which blocks consume the generator
+    assert not has_random_masks(SelfAttentionBlock(dim=64, num_heads=1))
+    for kw in (dict(proj_drop=0.1), dict(attn_drop=0.1), dict(drop_path=0.1)):
+        assert has_random_masks(SelfAttentionBlock(dim=64, num_heads=1, **kw)), kw
+        assert has_random_masks(CrossAttentionBlock(dim=64, num_heads=1, **kw)), kw
+    # constructor surface: the reference's parameter shapes / state_dict keys
+    att = Attention(128, latent_attn_dim=256, num_heads=4, qkv_bias=True)
+    assert att.qkv.weight.shape == (768, 128) and att.proj.weight.shape == (128, 256) and att.head_dim == 64 and att.scale == 64 ** -0.5
+    blk = CrossAttentionBlock(dim=64, num_heads=1, init_values=0.1)
+    assert {"ls1.gamma", "ls2.gamma", "ls3.gamma"} <= set(blk.state_dict()) and blk._gammas()[0] is blk.ls1.gamma
+    assert CrossAttentionBlock(dim=64, num_heads=1)._gammas() == (None, None, None)
+    seg = DPTSegmentationProcessor(32, 5, hidden_dim=16, use_bn=True)
+    assert {"conv.1.running_mean", "conv.1.weight"} <= set(seg.state_dict()) and seg.conv[0].bias is None
+    feat = DPTFeature(patch_size=16, hooks=[0, 1, 2, 3], input_feature_dims=[32, 32, 32, 32], layer_dims=[16, 32, 64, 64], feature_dim=32, use_bn=True)
+    keys = set(feat.state_dict())
+    assert any(k.endswith("refinenet1.resConfUnit1.bn1.running_var") for k in keys) and not any(k.endswith("resConfUnit1.conv1.bias") for k in keys)
