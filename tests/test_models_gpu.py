@@ -309,3 +309,34 @@ def test_bf16_mode_with_an_fp32_residual_stream(gpu, name):
         rep[on] = r
     keys = sorted(rep[True])
     print(f"\n[bf16 stream vs fp32 stream] {name}: " + ", ".join(f"{k}={rep[True][k]:.1e}/{rep[False][k]:.1e}" for k in keys))
+
+
+def test_round6_shape_routes_inside_the_model_at_224(gpu):
+    """The two routes round 6 added, inside the factory ViT-L + DPT model at 224 x 224 (196 tokens per view: the packed-VT epilogue's
+    token-quad stores; 56 / 112 / 224-wide head maps: the eight-wave 3x3 kernel's FLAT form once a launch has a CU's worth of tiles)
+    against the routes they replace, same weights, same pairs, bf16 transformer + TF32-class heads: `conv_rows_flat` 0 (implicit-GEMM
+    convolutions: the same products in another summation order) and the fp32 verification mode as the reference for both."""
+    from uniception_amd import engine, ops
+    from uniception_amd.models.factory import DUSt3R
+    torch.manual_seed(0)
+    model = DUSt3R(name="t224", img_size=(224, 224), pred_head_type="dpt").to(gpu).eval()
+    g = torch.Generator().manual_seed(5)
+    B = 6       # 6 pairs: the 224 x 224 128 -> 128 convolution of a head is 6 x 98 = 588 tiles of 512 pixels (>= 256: the default route)
+    v1 = {"img": torch.randn(B, 3, 224, 224, generator=g).to(gpu), "instance": [str(i) for i in range(B)], "data_norm_type": "dust3r"}
+    v2 = {"img": torch.randn(B, 3, 224, 224, generator=g).to(gpu), "instance": [str(100 + i) for i in range(B)], "data_norm_type": "dust3r"}
+
+    def run(mode):
+        with torch.no_grad(), engine.precision(mode):
+            r1, r2 = model(v1, v2)
+        torch.cuda.synchronize()
+        return torch.cat([r1["pts3d"].float().flatten(), r1["conf"].float().flatten(), r2["pts3d_in_other_view"].float().flatten()])
+    flat = run("bf16")
+    with ops.tuning("conv_rows_flat", 0):
+        implicit = run("bf16")
+    exact = run("fp32")
+    assert torch.isfinite(flat).all()
+    e_routes = rel_l2(flat, implicit)
+    e_flat, e_impl = rel_l2(flat, exact), rel_l2(implicit, exact)
+    print(f"\n[224 x 224, 6 pairs] flat vs implicit-GEMM convolutions {e_routes:.2e}; vs fp32 mode: flat {e_flat:.2e}, implicit {e_impl:.2e}")
+    assert not torch.equal(flat, implicit) and e_routes < 2e-3          # (fp16 maps: one rounding step of difference here and there)
+    assert e_flat < 3e-2 and abs(e_flat - e_impl) < 3e-3                # the bf16 mode's distance to the exact arithmetic, either route
