@@ -29,6 +29,17 @@ rm -rf gpurun_out/pmc_attn
 python tools/bench_model_gemms2.py 128 auto,2,6,7 enc,dec 0.4 > $out/${tag}_model_gemm_shapes.txt 2>&1
 python tools/bench_attention_ab.py > $out/${tag}_attention_ab_same_box.txt 2>&1
 python tools/bench_attention_bwd.py > $out/${tag}_attention_bwd.txt 2>&1
+# round 6: kernel traces of the two other north-star forwards (224 x 224 at 256 pairs, DINOv2-518 at 32 pairs), single stream
+base="--steps 3 --warmup 2 --single-stream --no-cpu-baseline --no-roofline --no-reference-policy --no-extra-legs"
+for cfg in "224_pairs256:--img 224 --pairs 256" "dinov2_518_pairs32:--encoder dinov2 --pairs 32"; do
+  name=${cfg%%:*}; flags=${cfg#*:}
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $root/$out/t_$name -o t_$name -- python $root/bench.py $flags $base) > $out/trace_$name.log 2>&1
+  db=$(ls $out/t_$name/*/*_results.db $out/t_$name/*_results.db 2>/dev/null | head -1)
+  python tools/rocpd_stats.py $db > $out/${tag}_forward_kernel_stats_$name.md
+  python tools/rocpd_dispatches.py $db > $out/${tag}_forward_dispatches_$name.txt
+  rm -rf $out/t_$name
+done
+python tools/bench_conv_flat.py > $out/${tag}_conv_flat_ab.txt 2>&1
 if [ -x tools/_bin/dma_seg ]; then ./tools/_bin/dma_seg > $out/${tag}_probe_dma_seg.txt 2>&1; fi
 if [ -x tools/_bin/mfma_valu ]; then ./tools/_bin/mfma_valu > $out/${tag}_probe_mfma_valu.txt 2>&1; fi
 exit 0
