@@ -392,9 +392,10 @@ def timed_each(step, steps):
     """The legs beside the headline: every step fenced and timed on its own; the MEAN over the K steps is reported (the headline's
     contract, and the reference harness's `blocked_autorange().mean`, utils/profile.py:4-6), the median and the sorted times beside it.
     Round 5 reported medians because a block of K steps right after a model switch now and then contained one step 60-250 ms long.
-    Root cause (round 6, `stall_events`: per-step deltas of the caching allocator's hipMalloc / hipFree counts and of Python's
-    generation-2 collections): see DESIGN.md section 7 — the legs now collect garbage and settle the allocator BEFORE their timed
-    steps (`settle()`), so the mean is the number."""
+    Round 6 attached `stall_events` (per-step deltas of the caching allocator's hipMalloc / hipFree counts and of Python's
+    generation-2 collections) and a `settle()` (collect + synchronize) before every leg's timed steps: over 4 full runs no step of any
+    leg deviates 1 % from its median, with or without the settle — the stall was not reproduced and is not root-caused (DESIGN.md
+    section 0, row 8); the mean is the number."""
     ts, evs = [], []
     for _ in range(steps):
         e0 = _host_events()
@@ -430,7 +431,7 @@ def reference_policy_legs(model, v1, v2, args, dev):
     (engine.precision("bf16x3"): split-operand GEMMs / convolutions / attention products on the matrix pipe) — the mode that meets
     the 1e-3 / 1e-2 gate (tests/test_precision_modes_gpu.py) — at the headline batch; (c) the encoder + decoder alone (linear
     head, 0.15 % of the FLOPs), the quantity the 40 % MFMA target is defined on; (d) the headline forward with an fp32 residual
-    stream instead of the reference's bf16 one.  Every leg: steps fenced one by one, median AND block mean reported (timed_each)."""
+    stream instead of the reference's bf16 one.  Every leg: steps fenced one by one, the MEAN reported (median beside it: timed_each)."""
     from uniception_amd import engine
     from uniception_amd.models.factory import DUSt3R
     out = {}
@@ -506,7 +507,7 @@ def fwd_224_leg(args, dev, pairs_list=(64, 256)):
 def other_configs_leg(args, dev):
     """BASELINE configs[3] and [4] inside the default line (round 5): DINOv2 ViT-L/14 at 518x518 (32 pairs) and the ViT-L/16 model at
     1024x1024 (8 pairs) with bf16 AND e4m3 attention — forward, bf16 transformer, the headline's head policy; five fenced steps each
-    (median and block mean); `enc_dec_mfma_frac_lower_bound` = all-in pairs/s x the encoder + decoder flops of SURVEY section 8d over
+    (mean reported, median beside it); `enc_dec_mfma_frac_lower_bound` = all-in pairs/s x the encoder + decoder flops of SURVEY section 8d over
     the bf16 peak (the heads' time is in the denominator, their flops are not in the numerator)."""
     from uniception_amd import engine
     from uniception_amd.models.encoders import encoder_factory
@@ -566,7 +567,7 @@ def exchange_summary(stats, step_ms):
 
 def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3, rank=0, world=1):
     """BASELINE configs[2] inside the default line: forward + backward + gradient exchange + AdamW of the same ViT-L + DPT model
-    at 512x512, `pairs` pairs per rank.  world == 1: `steps` individually fenced steps (median AND block mean reported), with its own
+    at 512x512, `pairs` pairs per rank.  world == 1: `steps` individually fenced steps (mean reported, median beside it), with its own
     dense-GEMM roofline; the exchange is a no-op.  world > 1 (the driver's `bench.py --gpus N`): EVERY rank runs it — `Trainer` over the
     RCCL group, parameters broadcast from rank 0, K steps between barrier + synchronize fences, max over ranks — and the leg reports
     the bucketed all-reduce it ran (`exchange`: bucket count / bytes, communication per step, the part the backward did not hide)."""
