@@ -9,6 +9,18 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 pairs, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4, int(sys.argv[2]) if len(sys.argv) > 2 else 30
 model = DUSt3R(name="soak", img_size=(512, 512), pred_head_type="dpt").to(dev).train()
+# SOAK_DROP=p (round 6): every dropout of the transformer blocks at rate p — proj_drop / Mlp drops (uc_mask_scale) and attn_drop (the
+# attention kernels' counter-based mask, forward and backward) — at the full model's shapes (1024 tokens, 16 / 12 heads)
+drop = float(os.environ.get("SOAK_DROP", "0"))
+if drop > 0:
+    n = 0
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = drop
+            n += 1
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = drop
+    print(f"dropout {drop} on {n} Dropout modules", flush=True)
 tr = Trainer(model, lr=3e-5, weight_decay=0.05)
 g = torch.Generator().manual_seed(1)
 v1 = {"img": torch.randn(pairs, 3, 512, 512, generator=g).to(dev), "instance": [str(i) for i in range(pairs)], "data_norm_type": "dust3r"}
