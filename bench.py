@@ -630,6 +630,31 @@ def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3, rank=0, world=1):
         roof["traffic"], roof["traffic_source"] = None, "not collected for the training step"
         out["roofline"] = roof
         out["roofline_families"] = fams
+    if world == 1 and not args.no_reference_policy and pairs >= 4:
+        # VERDICT r5 #4e: the reference trains its heads in fp32 (TF32 under allow_tf32, libs/croco/blocks.py:15; dust3r.py:288-309) —
+        # the same step with fp32-class heads (fp32 tensors, split bf16 operands forward and backward) beside the bf16-head step, both at
+        # a quarter of the leg's batch (fp32 head maps + their split copies of the full batch do not fit beside the step's other tensors)
+        import contextlib
+        try:
+            del a1, a2, gt1, gt2
+            torch.cuda.empty_cache()
+            b = max(1, pairs // 4)
+            a1, a2 = make_views(b, args.img, args.img, rank, dev)
+            g2 = torch.Generator().manual_seed(3000 + rank)
+            gt1 = torch.randn(b, args.img, args.img, 3, generator=g2).to(dev)
+            gt2 = torch.randn(b, args.img, args.img, 3, generator=g2).to(dev)
+            pol = {"pairs_per_gpu": b, "note": "same model and trainer, a quarter of the leg's batch; mean of 2 fenced steps after 2 warm-up steps"}
+            for name, mode in (("bf16_heads", None), ("fp32class_heads", "fp32")):
+                with (engine.head_precision(mode) if mode else contextlib.nullcontext()):
+                    step(); step()
+                    settle()
+                    d2, t2 = timed_each(step, 2)
+                    pol[name] = {"pairs_per_s": round(b * 2 / d2, 2), "ms_per_step": round(d2 / 2 * 1e3, 2), "heads": engine.train_head_dtype_name(), "timing": t2}
+                torch.cuda.empty_cache()
+            pol["fp32class_over_bf16_heads"] = round(pol["fp32class_heads"]["pairs_per_s"] / pol["bf16_heads"]["pairs_per_s"], 4)
+            out["reference_policy_heads"] = pol
+        except Exception as e:      # (an extra leg must not take the line down: reported)
+            out["reference_policy_heads"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     del trainer, m, a1, a2, gt1, gt2
     torch.cuda.empty_cache()
     return out

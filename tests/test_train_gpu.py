@@ -262,3 +262,45 @@ def test_gradient_with_respect_to_the_input_images(gpu, mode):
         r1, r2 = model(g1, g2, {})
         autograd.conf_loss(r1["pts3d"], r1["conf"], gt1.to(gpu)).backward()
     assert g1.grad is not None and model.encoder.patch_embed.proj.weight.grad is None
+
+
+def test_backward_outside_the_precision_scope_runs_the_forwards_arithmetic(gpu):
+    """Round 6: `loss.backward()` is normally called OUTSIDE `engine.precision(...)` — the autograd engine runs the Functions' backward
+    with no scope in force.  The fp32-class head policy decides per call how an fp32-operand GEMM runs (split-operand bf16x3 MFMA next
+    to a bf16 transformer, the exact VALU kernel otherwise): the Functions now record the forward's choice and apply it in their
+    backward, so the step is the same wherever backward is called from (it used to fall to the exact kernels: 14x the bf16-head step
+    at bench sizes)."""
+    from uniception_amd import autograd, engine, ops
+    name = "tiny_dpt"
+    seen = []
+    real = ops.fp32_matmul_hook
+
+    def run(inside):
+        model, c = build_case_model(name)
+        model = model.to(gpu).train()
+        img1, img2 = (t.to(gpu) for t in case_images(c))
+        gt1, gt2 = (t.to(gpu) for t in grad_targets(c))
+        with engine.head_precision("fp32"):
+            with engine.precision("bf16"):
+                r1, r2 = model(img1, img2, {})
+                loss = autograd.conf_loss(r1["pts3d"], r1["conf"], gt1, 0.2) + autograd.conf_loss(r2["pts3d_in_other_view"], r2["conf"], gt2, 0.2)
+                if inside:
+                    loss.backward()
+            if not inside:
+                def spy():
+                    m = real()
+                    seen.append(m)
+                    return m
+                ops.fp32_matmul_hook = spy
+                try:
+                    loss.backward()
+                finally:
+                    ops.fp32_matmul_hook = real
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    la, ga = run(True)
+    lb, gb = run(False)
+    assert abs(la - lb) < 1e-5 * abs(la) and ga.keys() == gb.keys()      # (the loss is summed with fp32 atomics: last-digit differences run to run)
+    assert seen and set(seen) == {"bf16x3"}, set(seen)          # every fp32 GEMM of the backward ran the forward's way
+    for k in ga:
+        assert rel_l2(gb[k].double().cpu(), ga[k].double().cpu()) < 1e-5, k

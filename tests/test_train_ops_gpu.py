@@ -81,6 +81,18 @@ def test_transpose2d(gpu, R, S, src, dst):
     assert torch.equal(y.cpu(), x.t().contiguous().to(dst))
 
 
+def test_transpose2d_of_a_map_with_more_than_four_million_rows(gpu):
+    """Round 6: a [16 x 512 x 512 pixels, C] gradient map has 65 536 row tiles of 64 — one more than grid.y takes; the longer tile axis
+    rides on grid.x now (the fp32-class heads' training step at bench sizes failed with 'too many rows')."""
+    from uniception_amd import ops
+    R, S = 65536 * 64 + 70, 8
+    x = torch.arange(R * S, device=gpu, dtype=torch.float32).view(R, S) % 1021
+    y = ops.transpose2d(x, torch.bfloat16)
+    assert y.shape == (S, R) and torch.equal(y, x.t().contiguous().to(torch.bfloat16))
+    z = ops.transpose2d(x[:300].t().contiguous(), torch.float32)           # the other orientation: few rows, the long axis in S
+    assert torch.equal(z, x[:300])
+
+
 @pytest.mark.parametrize("P,Cout,h,w", [(16, 4, 3, 5), (14, 4, 2, 2), (2, 3, 4, 4)])
 def test_pixel_unshuffle_is_inverse_of_pixel_shuffle(gpu, P, Cout, h, w):
     from uniception_amd import ops

@@ -83,16 +83,23 @@ def _sink_aware(cls):
 
     def forward(ctx, *args, **kw):
         ctx._uc_sink_ok = _sink_fwd_ok[0]
+        # how fp32-operand GEMMs ran in this forward (exact VALU kernel / split-operand bf16x3 MFMA: engine._fp32_matmul).  The backward
+        # is called by the autograd engine OUTSIDE the caller's engine.precision(...) scope, where the policy would read "exact": the
+        # fp32-class heads' training step ran 86 % of its time in gemm_f32_kernel (round 6, 14x the bf16-head step) — the backward now
+        # runs its fp32 GEMMs the way the forward did
+        ctx._uc_mm = ops.fp32_matmul_hook()
         return fwd(ctx, *args, **kw)
 
     def backward(ctx, *grads):
         global _grad_sink_gate
         prev = _grad_sink_gate
         _grad_sink_gate = getattr(ctx, "_uc_sink_ok", True)
+        prev_mm, engine._mm_override = engine._mm_override, getattr(ctx, "_uc_mm", None)
         try:
             return bwd(ctx, *grads)
         finally:
             _grad_sink_gate = prev
+            engine._mm_override = prev_mm
     cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
     return cls
 

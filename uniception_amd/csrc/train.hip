@@ -554,9 +554,11 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void transpose64_kernel(const typename TI::storage* __restrict__ src,
                                                           typename TO::storage* __restrict__ dst,
                                                           typename TO::storage* __restrict__ copy, int64_t R, int64_t S,
-                                                          int64_t ld_dst) {
+                                                          int64_t ld_dst, int rows_on_x) {
     __shared__ float tile[64][65];
-    const int64_t s0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+    // (the longer tile axis rides on grid.x, whose limit is 2^31 - 1: a [4 M pixels, C] gradient map has 65 536 row tiles — one more
+    //  than grid.y takes; round 6: the fp32-class heads' training step at bench sizes)
+    const int64_t s0 = (int64_t)(rows_on_x ? blockIdx.y : blockIdx.x) * 64, r0 = (int64_t)(rows_on_x ? blockIdx.x : blockIdx.y) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -580,12 +582,14 @@ extern "C" int uc_transpose2d(const void* src, int sd, void* dst, int dd, void* 
                               int64_t ld_dst, uc_stream_t stream) {
     UC_REQUIRE(src && dst && R > 0 && S > 0, "uc_transpose2d: bad argument");
     UC_REQUIRE(ld_dst >= R && ld_dst < R + 64, "uc_transpose2d: ld_dst must be in [R, R+64)");
-    UC_REQUIRE((ld_dst + 63) / 64 <= 65535, "uc_transpose2d: too many rows");
-    dim3 grid((unsigned)ceil_div64(S, 64), (unsigned)ceil_div64(ld_dst, 64));
+    const int64_t tiles_s = ceil_div64(S, 64), tiles_r = ceil_div64(ld_dst, 64);
+    const int rows_on_x = tiles_r > tiles_s;
+    UC_REQUIRE(std::min(tiles_s, tiles_r) <= 65535 && std::max(tiles_s, tiles_r) < ((int64_t)1 << 31), "uc_transpose2d: matrix exceeds the launch grid");
+    dim3 grid((unsigned)(rows_on_x ? tiles_r : tiles_s), (unsigned)(rows_on_x ? tiles_s : tiles_r));
     hipStream_t st = (hipStream_t)stream;
-    if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<BF16Tag, BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, (bf16_t*)rowmajor_copy, R, S, ld_dst);
-    else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((transpose64_kernel<F32Tag, F32Tag>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, (float*)rowmajor_copy, R, S, ld_dst);
-    else if (sd == UC_F32 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<F32Tag, BF16Tag>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, (bf16_t*)rowmajor_copy, R, S, ld_dst);
+    if (sd == UC_BF16 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<BF16Tag, BF16Tag>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, (bf16_t*)rowmajor_copy, R, S, ld_dst, rows_on_x);
+    else if (sd == UC_F32 && dd == UC_F32) hipLaunchKernelGGL((transpose64_kernel<F32Tag, F32Tag>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, (float*)rowmajor_copy, R, S, ld_dst, rows_on_x);
+    else if (sd == UC_F32 && dd == UC_BF16) hipLaunchKernelGGL((transpose64_kernel<F32Tag, BF16Tag>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, (bf16_t*)rowmajor_copy, R, S, ld_dst, rows_on_x);
     else { uc_set_error("uc_transpose2d: unsupported dtypes %d -> %d", sd, dd); return UC_ERR_BAD_ARG; }
     UC_CHECK_LAUNCH("uc_transpose2d");
     return UC_OK;

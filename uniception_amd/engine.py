@@ -91,8 +91,13 @@ def head_precision(mode: str):
         set_head_precision(prev)
 
 
+_mm_override: Optional[str] = None      # set by the autograd Functions around their backward: the mode their forward ran in
+
+
 def _fp32_matmul() -> str:
     """How an fp32-operand GEMM runs right now (hook of ops.gemm)."""
+    if _mm_override is not None:
+        return _mm_override
     if _forced_x3:
         return "bf16x3"
     if _head_mode == "fp32" and compute_dtype() == torch.bfloat16:
