@@ -18,5 +18,5 @@ with engine.head_precision("fp32"):
         with engine.precision("bf16"):
             r1, r2 = m(v1, v2)
             loss = autograd.conf_loss(r1["pts3d"], r1["conf"], gt1) + autograd.conf_loss(r2["pts3d_in_other_view"], r2["conf"], gt2)
-        loss.backward(); tr.step()
+        loss.backward(); tr.step()      # (backward OUTSIDE engine.precision: what callers do)
 torch.cuda.synchronize()

@@ -47,6 +47,16 @@ def _split_k(I: int, J: int, T: int) -> int:
     return max(1, min(T // 512, 256 // tiles))
 
 
+def _split_k_x3(I: int, J: int, T: int, dt) -> int:
+    """split_k of an fp32 weight-gradient GEMM on the split-operand (bf16x3) route: its output is a few 128 x 128 tiles and its
+    reduction runs over every token / pixel (x3) — unsplit, the fp32-class heads' 3x3 weight gradients ran on 9 CUs for 44 ms.
+    1 on the exact-fp32 route (the verification kernel has no split form)."""
+    if dt != torch.float32 or ops.fp32_matmul_hook() != "bf16x3":
+        return 1
+    tiles = ((I + 127) // 128) * ((J + 127) // 128)
+    return max(1, min(T // 1024, 256 // max(tiles, 1), 64))
+
+
 def _tn_ok(*ts) -> bool:
     return all(t.dtype == torch.bfloat16 and t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.shape[-1] % 8 == 0
                and (t.dim() != 2 or t.stride(0) % 8 == 0) for t in ts)
@@ -162,8 +172,10 @@ def _wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dt: torch.dtype, bias: bool = 
                     ops.splitk_reduce(ws[:, r0:r1], out=p.grad.view(r1 - r0, K), accumulate=True)
                 return None, db
             return _reduce_slabs(ws), db
-    dW = ops.gemm(_tp(_c(dy2d), dt), _tp(_c(x2d), dt), out_dtype=torch.float32)
-    return dW, (_colsum(_c(dy2d)) if bias else None)
+    aT, bT = _tp(_c(dy2d), dt), _tp(_c(x2d), dt)
+    sk = _split_k_x3(aT.shape[0], bT.shape[0], aT.shape[1], dt)
+    dW = ops.gemm(aT, bT, out_dtype=torch.float32, split_k=sk)
+    return (dW if sk <= 1 else _reduce_slabs(dW)), (_colsum(_c(dy2d)) if bias else None)
 
 
 def _wgrad_conv(dz: torch.Tensor, x: torch.Tensor, stride: int, relu_in: bool, bias: bool = False):
@@ -177,8 +189,10 @@ def _wgrad_conv(dz: torch.Tensor, x: torch.Tensor, stride: int, relu_in: bool, b
             ws, cs = ops.gemm_tn(dz2, x, split_k=sk, conv=(stride, relu_in), colsum=True)
             return _reduce_slabs(ws), _reduce_slabs(cs.unsqueeze(1)).reshape(-1)
         return _reduce_slabs(ops.gemm_tn(dz2, x, split_k=sk, conv=(stride, relu_in))), None
-    dW = ops.gemm(_tp(dz2, x.dtype), ops.im2col_t(x, stride, relu_in, KPAD), out_dtype=torch.float32)
-    return dW, (_colsum(dz2) if bias else None)
+    aT, bT = _tp(dz2, x.dtype), ops.im2col_t(x, stride, relu_in, KPAD)
+    sk = _split_k_x3(aT.shape[0], bT.shape[0], aT.shape[1], x.dtype)
+    dW = ops.gemm(aT, bT, out_dtype=torch.float32, split_k=sk)
+    return (dW if sk <= 1 else _reduce_slabs(dW)), (_colsum(dz2) if bias else None)
 
 
 # bf16 twins of residual-stream gradients: uc_layernorm_bwd writes a bf16 copy of the dx it produces; the sub-layer that

@@ -321,13 +321,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     assert a.dtype == w.dtype and w.is_contiguous() and w.dim() == 2
     cd = _dt(a.dtype)
     N, K = w.shape
-    if (cd == UC_F32 and fp32_matmul_hook() == "bf16x3" and rope is None and vt is None and preact_out is None and split_k <= 1
+    if (cd == UC_F32 and fp32_matmul_hook() == "bf16x3" and rope is None and vt is None and preact_out is None
+            and (split_k <= 1 or (conv is None and bias is None and act in (None, "none") and residual is None and not relu_a))
             and dact is None and ln is None and not emit_ln and (K // (9 if conv is not None else 1)) % 8 == 0 and a.is_contiguous()):
         # fp32-class product on the bf16 matrix pipe: [hi | hi | lo] rows against [Wh | Wl | Wh] weights (uc_split_bf16x3)
+        # (split_k > 1, round 6: the weight gradients of the fp32-class heads — a handful of output tiles, millions of reduction steps —
+        #  return fp32 slabs [split_k, M, N] like the bf16 path's)
         a3 = split_bf16x3(a, relu=relu_a)
         conv3 = None if conv is None else (conv[0], conv[1], conv[2], 3 * conv[3], conv[4])
         return gemm(a3, split_weight_bf16x3(w, 9 if conv is not None else 1), bias, act=act, residual=residual, residual2=residual2,
-                    out_dtype=out_dtype or torch.float32, out=out, conv=conv3, tail=tail)
+                    out_dtype=out_dtype or torch.float32, out=out, conv=conv3, tail=tail, split_k=split_k)
     d = GemmDesc()
     d.compute_dtype = cd
     d.relu_a = 1 if relu_a else 0
