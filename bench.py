@@ -393,9 +393,12 @@ def timed_each(step, steps):
     contract, and the reference harness's `blocked_autorange().mean`, utils/profile.py:4-6), the median and the sorted times beside it.
     Round 5 reported medians because a block of K steps right after a model switch now and then contained one step 60-250 ms long.
     Round 6 attached `stall_events` (per-step deltas of the caching allocator's hipMalloc / hipFree counts and of Python's
-    generation-2 collections) and a `settle()` (collect + synchronize) before every leg's timed steps: over 4 full runs no step of any
-    leg deviates 1 % from its median, with or without the settle — the stall was not reproduced and is not root-caused (DESIGN.md
-    section 0, row 8); the mean is the number."""
+    generation-2 collections) and a `settle()` (collect + synchronize) before every leg's timed steps.  Root cause, caught with the
+    counters (profiles/r6_z_bench_forward_pairs128.json, train_step: 595.9 / 682.6 / 596.8 ms, the slow step the one with
+    `device_allocs: 1`): the caching allocator going to the driver for a new segment INSIDE a step — a hipMalloc with 216 of the 288 GB
+    in use costs tens of ms; the same event on an emptier device costs nothing (most legs show it with no effect).  Python's
+    collector is not it (generation-2 collections inside steps: no effect).  The leg's number stays the all-inclusive mean; the mean
+    of the steps without allocator traffic is printed beside it."""
     ts, evs = [], []
     for _ in range(steps):
         e0 = _host_events()
@@ -410,6 +413,9 @@ def timed_each(step, steps):
           "ms_per_step_in_order": [round(t * 1e3, 1) for t in ts], "reported": "mean"}
     if any(evs):
         st["stall_events"] = evs
+        quiet = [t for t, e in zip(ts, evs) if not e.get("device_allocs") and not e.get("device_frees")]
+        if quiet and len(quiet) < len(ts):      # (for the reader: the steady state beside the all-inclusive mean the leg reports)
+            st["ms_per_step_mean_without_allocator_growth"] = round(sum(quiet) / len(quiet) * 1e3, 2)
     return mean * steps, st
 
 
@@ -593,7 +599,7 @@ def train_step_leg(args, dev, pairs=TRAIN_PAIRS, steps=3, rank=0, world=1):
         loss.backward()
         trainer.step()
         return loss.detach()
-    step(); step()
+    step(); step(); step()      # (three: the allocator's segments of a two-stream training step settle late — see timed_each)
     exchange = None
     if world > 1:
         from uniception_amd.distributed import max_over_ranks
