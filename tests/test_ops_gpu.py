@@ -58,6 +58,27 @@ def test_rope2d_contiguous(gpu, dtype, tol, shape):
     assert rel_l2(t.cpu().float(), tok.float()) < 2 * tol
 
 
+def test_rope2d_against_the_references_compiled_cpu_loop(gpu):
+    """uc_rope2d (the curope drop-in) against the REFERENCE'S OWN code: curope.cpp compiled from /root/reference in the build container
+    into oracle/_ref/curope_ref.so (oracle/build_ref.py; it travels to the GPU box with the snapshot) — `rope_2d` on CPU tensors is
+    its `rope_2d_cpu` loop (curope.cpp:11-46).  Forward and inverse rotation, random (non-grid) positions, 64- and 32-wide heads."""
+    from oracle import build_ref
+    from uniception_amd import ops
+    ref = build_ref.load()
+    if ref is None:
+        pytest.skip("oracle/_ref/curope_ref.so is not in this snapshot")
+    g = torch.Generator().manual_seed(4)
+    for (B, N, H, D) in ((2, 77, 3, 64), (1, 200, 2, 32)):
+        t = torch.randn(B, N, H, D, generator=g)
+        pos = torch.randint(0, 64, (B, N, 2), generator=g)
+        for fwd in (1.0, -1.0):
+            want = t.clone()
+            ref.rope_2d(want, pos, 100.0, fwd)
+            got = t.to(gpu)
+            ops.rope_2d_(got, pos.to(gpu), 100.0, fwd)
+            assert float((got.cpu() - want).abs().max()) < 2e-5, (B, N, H, D, fwd)
+
+
 def test_rope2d_strided_qkv_view(gpu):
     """q and k views of a fused qkv buffer rotated in place; v untouched (blocks.py:105-114)."""
     from uniception_amd import ops

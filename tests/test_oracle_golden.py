@@ -117,3 +117,26 @@ def test_oracle_q_scalings_match_reference_golden():
         ref = torch.from_numpy(z[name + "/out"])
         err = float((out - ref).norm() / ref.norm())
         assert err < 2e-5, (name, err)
+
+
+def test_oracle_rope_matches_the_references_own_compiled_cpu_loop():
+    """oracle/_ref/curope_ref.so = the reference's curope.cpp compiled from where it lies (oracle/build_ref.py): its `rope_2d` on CPU
+    tensors runs `rope_2d_cpu` (curope.cpp:11-46), the loop the CUDA kernel mirrors.  The oracle's rope2d — and through it every
+    golden fixture that involves RoPE — against it: forward and the inverse rotation (fwd = -1), 32- and 64-wide heads."""
+    from oracle import build_ref
+    build_ref.build(verbose=False)
+    ref = build_ref.load()
+    if ref is None:
+        pytest.skip("oracle/_ref/curope_ref.so not built (no /root/reference here)")
+    g = torch.Generator().manual_seed(3)
+    for (B, N, H, D) in ((2, 35, 3, 64), (1, 128, 2, 32)):
+        t = torch.randn(B, N, H, D, generator=g)
+        pos = torch.randint(0, 64, (B, N, 2), generator=g)
+        for fwd in (1.0, -1.0):
+            want = t.clone()
+            ref.rope_2d(want, pos, 100.0, fwd)                     # in place, [B, N, H, D]
+            got = O.rope2d(t.transpose(1, 2), pos, 100.0, fwd).transpose(1, 2)
+            assert float((got - want).abs().max()) < 2e-5, (B, N, H, D, fwd)
+    back = want.clone()
+    ref.rope_2d(back, pos, 100.0, 1.0)                             # the inverse of the inverse
+    assert float((back - t).abs().max()) < 2e-5
