@@ -140,3 +140,14 @@ def test_oracle_rope_matches_the_references_own_compiled_cpu_loop():
     back = want.clone()
     ref.rope_2d(back, pos, 100.0, 1.0)                             # the inverse of the inverse
     assert float((back - t).abs().max()) < 2e-5
+
+
+def test_fullsize_oracle_fixture_equals_the_reference_at_1024():
+    """tests/golden/fullsize.npz (oracle outputs of config 5 at 1024 x 1024 on every 16th pixel) against fullsize_ref.npz — the REAL
+    reference's factory model run at that size by make_golden_fullsize_ref.py: data replay, < 2e-5 (observed 6.5e-7)."""
+    import numpy as np
+    d = os.path.join(os.path.dirname(__file__), "golden")
+    a, b = np.load(os.path.join(d, "fullsize.npz")), np.load(os.path.join(d, "fullsize_ref.npz"))
+    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
+        o, r = torch.from_numpy(a["c5_" + k]), torch.from_numpy(b["c5ref_" + k])
+        assert o.shape == r.shape and float((o - r).norm() / r.norm()) < 2e-5, k
