@@ -151,3 +151,20 @@ def test_fullsize_oracle_fixture_equals_the_reference_at_1024():
     for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
         o, r = torch.from_numpy(a["c5_" + k]), torch.from_numpy(b["c5ref_" + k])
         assert o.shape == r.shape and float((o - r).norm() / r.norm()) < 2e-5, k
+
+
+def test_factory_fixture_intermediates_were_confirmed_by_the_reference():
+    """tests/golden/factory_intermediates_ref.json (make_golden_factory_intermediates.py): the intermediates stored in the two factory
+    fixtures — encoder features, decoder finals / takes, DPT feature maps, decoded channels — against forward hooks on the REAL
+    reference's own sub-modules: every entry below 2e-5 (observed <= 8.6e-7), every stored intermediate covered."""
+    import json
+    import numpy as np
+    d = os.path.join(os.path.dirname(__file__), "golden")
+    rep = json.load(open(os.path.join(d, "factory_intermediates_ref.json")))["cases"]
+    assert set(rep) == {"vitl_linear_224", "vitl_dpt_512"}
+    for name, entries in rep.items():
+        z = np.load(os.path.join(d, name + ".npz"))
+        stored = {k.rsplit("__", 1)[0] for k in z.files if k.endswith("__samples")} - {"pts3d_1", "conf_1", "pts3d_2", "conf_2"}
+        assert stored == set(entries), (name, stored ^ set(entries))
+        for k, e in entries.items():
+            assert e["samples_rel_l2"] < 2e-5 and e["norm_rel_diff"] < 2e-5, (name, k, e)
